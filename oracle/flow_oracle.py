@@ -1,0 +1,392 @@
+"""ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU restatement (torch, dtype-generic fp32/fp64) of the reference's SO(3) normalizing-flow density path.
+Only tests/, __graft_entry__.smoke() and bench.py's ``cpu_baseline`` leg may import this module; the shipped
+package ``rotationnormflow_amd`` never does (its ops raise if the HIP library is missing).
+
+Parity pinning: the reference holds no tests or golden vectors for this path, so the oracle is
+pinned against outputs of the reference itself, generated in the build container by tests/golden/make_golden.py
+(which imports /root/reference with the stand-ins under oracle/stubs/) and committed under tests/golden/*.npz;
+tests/test_oracle_golden.py checks every fixture.  The one third-party boundary (pytorch3d 0.7.5 quaternion
+conversions, source absent) is restated from its published semantics -- "parity unpinned" there, see DESIGN.md.
+
+The formulas deliberately follow the reference step by step (3-D Moebius map, explicit [K,3,3] Jacobian, 15-step
+bisection) rather than the closed forms the HIP kernels use, so that kernel-vs-oracle agreement is a real check.
+
+All citations are relative to /root/reference/.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import torch
+
+TWO_PI = 2.0 * math.pi
+
+# flow/flow.py:13-15 -- (x-column, y-column, z-column) per exchange count mod 6
+PERMUTE_ROWS = ((0, 1, 2), (1, 2, 0), (2, 0, 1), (0, 1, 2), (1, 2, 0), (2, 0, 1))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# layer list (flow/flow.py:19-51, flow/mobiusflow.py:7-14, flow/affineflow.py:5-73 -- 16Trans family only)
+# --------------------------------------------------------------------------------------------------------------
+def _affine_kind(cfg, first_layer_condition=False):
+    """Subset of get_affine (flow/affineflow.py:5-73) covering the non-LU 4x4 quaternion-affine family."""
+    if getattr(cfg, "lu", 0):
+        raise NotImplementedError("oracle covers lu=0 only")
+    rot = cfg.rot
+    if first_layer_condition and rot == "16UnTrans":           # affineflow.py:7-11
+        return "cond16"
+    if cfg.condition:
+        if rot == "16Trans":                                    # affineflow.py:16-20
+            return "cond16"
+        if rot == "16UnTrans":                                  # affineflow.py:21-25
+            return "uncond16"
+    else:
+        if rot == "16Trans":                                    # affineflow.py:50-54
+            return "uncond16"
+    if rot in ("36Trans", "9TransLSVD", "9TransRSVD", "9TransLSmith", "9TransRSmith", "16Rot", "16UnRot"):
+        raise NotImplementedError(f"oracle does not restate rot={rot!r}")
+    return None                                                 # affineflow.py:45-46,72-73
+
+
+def feature_dim_of(cfg):
+    """flow/flow.py:29-34."""
+    if not cfg.condition:
+        return 0
+    fd = 32 if cfg.feature_dim is None else cfg.feature_dim
+    if getattr(cfg, "embedding", 0):
+        fd += cfg.embedding_dim
+    return fd
+
+
+def layer_kinds(cfg):
+    """Ordered list of layer kinds ('mobius' | 'uncond16' | 'cond16'), index = position in Flow.layers."""
+    kinds = []
+    if cfg.last_affine:                                         # flow.py:37-39 (appended unguarded)
+        k = _affine_kind(cfg, first_layer_condition=True)
+        if k is None:
+            raise TypeError("reference would append None here and fail at the first call (flow.py:38,65)")
+        kinds.append(k)
+    for i in range(cfg.layers):                                 # flow.py:41-48
+        if getattr(cfg, "dist", "mobiusflow") != "noflow":
+            kinds.append("mobius")
+        k = _affine_kind(cfg)
+        if k is not None and (i != cfg.layers - 1 or cfg.first_affine):
+            kinds.append(k)
+    return kinds
+
+
+def state_shapes(cfg):
+    """{state-dict key: shape} the reference's Flow(cfg).state_dict() holds."""
+    fd = feature_dim_of(cfg)
+    K = cfg.segments
+    shapes = {}
+
+    def mlp(prefix, ni, no):
+        shapes[f"{prefix}.fc_first.weight"] = (64, ni)
+        shapes[f"{prefix}.fc_first.bias"] = (64,)
+        for j in (1, 3, 5):
+            shapes[f"{prefix}.layers.{j}.weight"] = (64, 64)
+            shapes[f"{prefix}.layers.{j}.bias"] = (64,)
+        shapes[f"{prefix}.fc_last.weight"] = (no, 64)
+        shapes[f"{prefix}.fc_last.bias"] = (no,)
+
+    for i, kind in enumerate(layer_kinds(cfg)):
+        if kind == "mobius":
+            mlp(f"layers.{i}.conditioner", 3 + (fd if cfg.condition else 0), 4 * K)
+        elif kind == "uncond16":
+            shapes[f"layers.{i}.mat"] = (1, 4, 4)
+        elif kind == "cond16":
+            mlp(f"layers.{i}.net", fd, 16)
+    return shapes
+
+
+# --------------------------------------------------------------------------------------------------------------
+# conditioner MLP (flow/condition.py:24-30)
+# --------------------------------------------------------------------------------------------------------------
+def conditioner(x, p, prefix):
+    lin = torch.nn.functional.linear
+    x0 = lin(x, p[f"{prefix}.fc_first.weight"], p[f"{prefix}.fc_first.bias"])
+    h = x0
+    for j in (1, 3, 5):                                         # ReLU, Linear pairs (condition.py:15-20)
+        h = lin(torch.relu(h), p[f"{prefix}.layers.{j}.weight"], p[f"{prefix}.layers.{j}.bias"])
+    h = torch.relu(x0 + h)                                      # condition.py:29
+    return lin(h, p[f"{prefix}.fc_last.weight"], p[f"{prefix}.fc_last.bias"])
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Moebius coupling layer (flow/mobiusflow.py)
+# --------------------------------------------------------------------------------------------------------------
+def _h(z, w):
+    """mobiusflow.py:17-24.  z [N,3], w [N,K,3] -> [N,K,3]."""
+    wn = torch.norm(w, dim=-1, keepdim=True)
+    d = z[:, None, :] - w
+    return (1 - wn ** 2) / (torch.norm(d, dim=-1, keepdim=True) ** 2) * d - w
+
+
+def _wrapped_angle(hz, r, v):
+    """atan2(h.v, h.r) mapped to [0, 2pi)  (mobiusflow.py:94-99, 234-239)."""
+    ang = torch.atan2(torch.einsum("nki,ni->nk", hz, v), torch.einsum("nki,ni->nk", hz, r))
+    return torch.where(ang >= 0, ang, ang + TWO_PI)
+
+
+def _segment_params(cond_in, y, p, prefix, K):
+    """conditioner output -> (normalised softplus weights [N,K], squashed projected w [N,K,3])
+    (mobiusflow.py:57-63,69-72 and 140-147,152-155)."""
+    c = conditioner(cond_in, p, prefix)
+    sw, w = torch.split(c, [K, 3 * K], dim=1)
+    w = w.reshape(-1, K, 3)
+    eye = torch.eye(3, dtype=y.dtype)
+    proj = eye[None] - torch.einsum("ni,nj->nij", y, y)
+    w = torch.einsum("nij,nkj->nki", proj, w)
+    sw = torch.nn.functional.softplus(sw)
+    sw = sw / sw.sum(dim=-1, keepdim=True)
+    w = 0.7 / (1 + torch.norm(w, dim=-1, keepdim=True)) * w
+    return sw, w
+
+
+def _mobius_core(x, r, v, sw, w):
+    """mobiusflow.py:90-125: transformed column and log-det via the explicit dh/dz Jacobian."""
+    hz = _h(x, w)
+    ang = (sw * _wrapped_angle(hz, r, v)).sum(dim=1, keepdim=True)
+    tx = r * torch.cos(ang) + v * torch.sin(ang)
+
+    zw = x[:, None, :] - w
+    zwn = torch.norm(zw, dim=-1)
+    zwu = zw / zwn[..., None]
+    theta = torch.atan2((x * v).sum(-1), (x * r).sum(-1)).reshape(-1, 1)
+    dz = -torch.sin(theta) * r + torch.cos(theta) * v
+    eye = torch.eye(3, dtype=x.dtype)
+    dh_dz = ((1 - torch.norm(w, dim=-1) ** 2)[..., None, None]
+             * (eye[None, None] - 2 * torch.einsum("nki,nkj->nkij", zwu, zwu))
+             / (zwn[..., None, None] ** 2))
+    dh = torch.einsum("nkpq,nq->nkp", dh_dz, dz)
+    return tx, torch.log((torch.norm(dh, dim=-1) * sw).sum(dim=1))
+
+
+def _cross(a, b):
+    return torch.linalg.cross(a, b, dim=-1)     # the reference's torch.cross(a, b) picks dim -1 for N != 3
+
+
+def _unit(a):
+    return a / a.norm(dim=-1, keepdim=True)
+
+
+def _assemble(cx, cy, perm):
+    """Third column by the branch at mobiusflow.py:75-79 / 172-176 and the column scatter at :80-83."""
+    p0, p1, p2 = perm
+    cz = _cross(cx, cy) if (p1 - p0) in (1, -2) else _cross(cy, cx)
+    cz = _unit(cz)
+    out = torch.empty(cx.shape[0], 3, 3, dtype=cx.dtype)
+    out[..., p0] = cx
+    out[..., p1] = cy
+    out[..., p2] = cz
+    return out
+
+
+def mobius_forward(R, perm, feature, p, prefix, K):
+    """mobiusflow.py:46-85."""
+    x = R[..., perm[0]]
+    y = R[..., perm[1]]
+    cond_in = y if feature is None else torch.cat((y, feature), dim=-1)
+    sw, w = _segment_params(cond_in, y, p, prefix, K)
+    r = _unit(-x)
+    v = _unit(_cross(y, r))
+    tx, ldj = _mobius_core(x, r, v, sw, w)
+    return _assemble(tx, y, perm), ldj
+
+
+def _theta_map(theta, r, v, sw, w):
+    """BinFind._forward_theta (mobiusflow.py:226-245)."""
+    z = r * torch.cos(theta) + v * torch.sin(theta)
+    return (sw * _wrapped_angle(_h(z, w), r, v)).sum(dim=1, keepdim=True)
+
+
+def _bisect(target, r, v, sw, w):
+    """BinFind.forward (mobiusflow.py:189-224): batch-global stop test, returns the LAST midpoint."""
+    a = torch.full_like(target, math.pi / 2)
+    b = torch.full_like(target, 3 * math.pi / 2)
+    mid = None
+    it = 1
+    while abs(torch.max(b - a)) >= 1e-4:
+        mid = (a + b) / 2
+        f = _theta_map(mid, r, v, sw, w) - target
+        if it > 100:                                            # mobiusflow.py:212-214
+            break
+        a = a + (b - a) / 2 * (f < 0)
+        b = b - (b - a) / 2 * (f >= 0)
+        it += 1
+    return mid
+
+
+def mobius_inverse(R, perm, feature, p, prefix, K):
+    """mobiusflow.py:127-183."""
+    tx = R[..., perm[0]]
+    ty = R[..., perm[1]]
+    cond_in = ty if feature is None else torch.cat((ty, feature), dim=-1)
+    sw, w = _segment_params(cond_in, ty, p, prefix, K)
+    r = _unit(-tx)
+    v = _unit(_cross(ty, r))
+    tt = torch.atan2((tx * v).sum(-1), (tx * r).sum(-1)).reshape(-1, 1)
+    tt = torch.where(tt >= 0, tt, tt + TWO_PI)
+    tt = torch.where((tt - TWO_PI).abs() < 1e-4, torch.zeros_like(tt), tt)
+    theta = _bisect(tt, r, v, sw, w)
+    x = r * torch.cos(theta) + v * torch.sin(theta)
+    _, ldj = _mobius_core(x, r, v, sw, w)
+    return _assemble(x, ty, perm), -ldj
+
+
+# --------------------------------------------------------------------------------------------------------------
+# quaternion affine layer (flow/squeezetrans.py:10-55,161-174) + the pytorch3d conversions it relies on
+# --------------------------------------------------------------------------------------------------------------
+def matrix_to_quaternion(M):
+    """Published pytorch3d 0.7.5 rule (source absent): four candidates, pick the largest |q_i|, 0.1 floor."""
+    m = M.reshape(-1, 9)
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = m.unbind(-1)
+    qa = torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22, 1 - m00 - m11 + m22], -1)
+    qa = torch.sqrt(torch.clamp(qa, min=0))
+    cand = torch.stack([
+        torch.stack([qa[:, 0] ** 2, m21 - m12, m02 - m20, m10 - m01], -1),
+        torch.stack([m21 - m12, qa[:, 1] ** 2, m10 + m01, m02 + m20], -1),
+        torch.stack([m02 - m20, m10 + m01, qa[:, 2] ** 2, m12 + m21], -1),
+        torch.stack([m10 - m01, m20 + m02, m21 + m12, qa[:, 3] ** 2], -1),
+    ], -2)
+    cand = cand / (2 * torch.clamp(qa, min=0.1))[..., None]
+    idx = qa.argmax(-1)
+    return cand[torch.arange(m.shape[0]), idx]
+
+
+def quaternion_to_matrix(q):
+    w, x, y, z = q.unbind(-1)
+    s2 = 2.0 / (q * q).sum(-1)
+    return torch.stack([
+        1 - s2 * (y * y + z * z), s2 * (x * y - z * w), s2 * (x * z + y * w),
+        s2 * (x * y + z * w), 1 - s2 * (x * x + z * z), s2 * (y * z - x * w),
+        s2 * (x * z - y * w), s2 * (y * z + x * w), 1 - s2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+
+
+def _det3(A):
+    """squeezetrans.py:10-14."""
+    c0 = A[..., 1, 1] * A[..., 2, 2] - A[..., 1, 2] * A[..., 2, 1]
+    c1 = A[..., 1, 2] * A[..., 2, 0] - A[..., 1, 0] * A[..., 2, 2]
+    c2 = A[..., 1, 0] * A[..., 2, 1] - A[..., 1, 1] * A[..., 2, 0]
+    return c0 * A[..., 0, 0] + c1 * A[..., 0, 1] + c2 * A[..., 0, 2]
+
+
+def _det4(A):
+    """squeezetrans.py:17-22 (cofactor expansion along row 0)."""
+    sub = A[..., 1:, :]
+    t = [A[..., 0, j] * _det3(sub[..., [c for c in range(4) if c != j]]) for j in range(4)]
+    return t[0] - t[1] + t[2] - t[3]
+
+
+def affine16(M, R):
+    """calculate_16 (squeezetrans.py:33-38).  M [1,4,4] or [N,4,4]."""
+    q = matrix_to_quaternion(R)
+    q = M @ q.reshape(-1, 4, 1)
+    ln = q.norm(dim=-2, keepdim=True)
+    Rt = quaternion_to_matrix((q / ln).reshape(-1, 4))
+    return Rt, _det4(M).abs().log() - 4 * ln.reshape(-1).log()
+
+
+def cond16_matrix(feature, p, prefix):
+    """Condition16Trans (squeezetrans.py:47-48)."""
+    return conditioner(feature, p, prefix).reshape(-1, 4, 4) + torch.eye(4, dtype=feature.dtype)[None]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the flow stack (flow/flow.py:53-92)
+# --------------------------------------------------------------------------------------------------------------
+def _as_params(params, dtype):
+    return {k: torch.as_tensor(v).to(dtype) for k, v in params.items()}
+
+
+def flow_forward(cfg, params, R, feature=None, dtype=torch.float32):
+    """Flow.forward (flow.py:53-72): returns (R' [N,3,3], ldj [N])."""
+    p = _as_params(params, dtype)
+    R = torch.as_tensor(R).to(dtype)
+    feature = None if (feature is None or not cfg.condition) else torch.as_tensor(feature).to(dtype)
+    kinds = layer_kinds(cfg)
+    K = cfg.segments
+    ldj = torch.zeros(R.shape[0], dtype=dtype)
+    count = 0
+    with torch.no_grad():
+        for i, kind in enumerate(kinds):
+            perm = PERMUTE_ROWS[count % 6]
+            if kind == "mobius":
+                R, l = mobius_forward(R, perm, feature, p, f"layers.{i}.conditioner", K)
+            elif kind == "uncond16":
+                R, l = affine16(p[f"layers.{i}.mat"], R)
+            else:
+                R, l = affine16(cond16_matrix(feature, p, f"layers.{i}.net"), R)
+            ldj = ldj + l
+            if kind == "mobius" or cfg.frequent_permute:        # flow.py:69-70
+                count += 1
+    return R, ldj
+
+
+def flow_inverse(cfg, params, R, feature=None, dtype=torch.float32):
+    """Flow.inverse (flow.py:74-92): returns (R [N,3,3], ldj_of_inverse_map [N])."""
+    p = _as_params(params, dtype)
+    R = torch.as_tensor(R).to(dtype)
+    feature = None if (feature is None or not cfg.condition) else torch.as_tensor(feature).to(dtype)
+    kinds = layer_kinds(cfg)
+    K = cfg.segments
+    ldj = torch.zeros(R.shape[0], dtype=dtype)
+    count = len(kinds) if cfg.frequent_permute else cfg.layers  # flow.py:78-79
+    with torch.no_grad():
+        for i in reversed(range(len(kinds))):
+            kind = kinds[i]
+            if kind == "mobius" or cfg.frequent_permute:        # flow.py:85-86 (decrement BEFORE use)
+                count -= 1
+            perm = PERMUTE_ROWS[count % 6]
+            if kind == "mobius":
+                R, l = mobius_inverse(R, perm, feature, p, f"layers.{i}.conditioner", K)
+            elif kind == "uncond16":
+                R, l = affine16(torch.linalg.inv(p[f"layers.{i}.mat"]), R)       # squeezetrans.py:171-174
+            else:
+                R, l = affine16(torch.linalg.inv(cond16_matrix(feature, p, f"layers.{i}.net")), R)  # :51-55
+            ldj = ldj + l
+    return R, ldj
+
+
+# --------------------------------------------------------------------------------------------------------------
+# matrix-Fisher base log-density (utils/fisher.py:67-76,93-97,209-232)
+# --------------------------------------------------------------------------------------------------------------
+def proper_singular_values(A):
+    """proper_svd_N (fisher.py:67-76): singular values with the last one sign-flipped by det(U)det(V)."""
+    U, S, Vh = torch.linalg.svd(A)
+    S = S.clone()
+    S[:, 2] = S[:, 2] * torch.det(U) * torch.det(Vh)
+    return S
+
+
+def fisher_log_prob(R, A, dtype=torch.float32):
+    """MatrixFisherN(A)._log_prob(R) with the default norm_type=1 (fisher.py:93-97,217-232).
+    A [B,3,3] broadcasts over N/B consecutive samples (fisher.py:226)."""
+    A = torch.as_tensor(A).to(dtype)
+    R = torch.as_tensor(R).to(dtype).reshape(A.shape[0], -1, 3, 3)
+    S = proper_singular_values(A)
+    norm = 1.0 / torch.sqrt(8 * math.pi * (S[:, 0] + S[:, 1]) * (S[:, 2] + S[:, 1]) * (S[:, 0] + S[:, 2]))
+    tr = (R * A.reshape(-1, 1, 3, 3)).sum(-1).sum(-1)
+    return ((tr - S.sum(-1).reshape(-1, 1)) - norm.log().reshape(-1, 1)).reshape(-1)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# NLL accumulation (agent.py:55-65,226-229; eval_uncondition.py:43-45)
+# --------------------------------------------------------------------------------------------------------------
+def log_prob(cfg, params, R, feature=None, A=None, dtype=torch.float32):
+    """per-sample log p(R) = ldj_total + base(R')  (uniform base => 0) and the mean NLL."""
+    Rt, ldj = flow_forward(cfg, params, R, feature, dtype)
+    lp = ldj if A is None else ldj + fisher_log_prob(Rt, A, dtype)
+    return lp, float(-(lp.double().mean()))
+
+
+def make_config(**kw):
+    """Attribute bag with the fields Flow/get_mobius/get_affine read (SURVEY 8(b) 'constructor')."""
+    base = dict(layers=24, segments=64, condition=0, feature_dim=None, embedding=0, embedding_dim=0,
+                last_affine=0, first_affine=1, frequent_permute=0, dist="mobiusflow", rot="16Trans", lu=0)
+    base.update(kw)
+    return SimpleNamespace(**base)

@@ -1,0 +1,93 @@
+"""Seeded synthetic inputs and weights-by-recipe (numpy only; no GPU, no reference import).
+
+Shared by bench.py, the parity tests, and tests/golden/make_golden.py (which applies the same recipe to the
+real reference's ``state_dict`` so that golden fixtures only need to hold *outputs*).
+
+* rotations: Haar-uniform on SO(3) as a normalised N(0, I4) quaternion mapped to a matrix -- the semantics of
+  ``pytorch3d.transforms.random_rotations`` that the reference's ``utils/sd.py:22-23`` (mode='random') uses.
+* features : N(0, 1) fp32 ``[N, F]`` ("precomputed features, no ResNet", BASELINE.json configs[3]).
+* weights  : every state-dict tensor filled in *sorted-key order* from one ``default_rng(seed)`` stream.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RD_SEED = 42  # reference default seed, config.py:121
+
+
+def quat_to_matrix_np(q: np.ndarray) -> np.ndarray:
+    """Real-part-first quaternion (not necessarily unit) -> rotation matrix, same dtype as q."""
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    s2 = (2.0 / (q * q).sum(-1)).astype(q.dtype)
+    m = np.stack([
+        1 - s2 * (y * y + z * z), s2 * (x * y - z * w), s2 * (x * z + y * w),
+        s2 * (x * y + z * w), 1 - s2 * (x * x + z * z), s2 * (y * z - x * w),
+        s2 * (x * z - y * w), s2 * (y * z + x * w), 1 - s2 * (x * x + y * y),
+    ], axis=-1)
+    return m.reshape(q.shape[:-1] + (3, 3)).astype(q.dtype)
+
+
+def uniform_rotations(n: int, seed: int = RD_SEED, dtype=np.float32) -> np.ndarray:
+    """[n,3,3] Haar-uniform rotations (row-major), deterministic in (n, seed)."""
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal((n, 4)).astype(dtype)
+    nrm = np.sqrt((q * q).sum(-1))
+    q = q / np.copysign(nrm, q[:, 0])[:, None]
+    return np.ascontiguousarray(quat_to_matrix_np(q.astype(dtype)))
+
+
+def features(n: int, dim: int, seed: int = RD_SEED + 1, dtype=np.float32) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((n, dim)).astype(dtype)
+
+
+REGIMES = {
+    # name: (gain on Mobius conditioner fc_last, sigma of the 4x4 affine perturbation)
+    "default": (1.0, 1e-3),
+    "trained": (8.0, 0.2),
+}
+
+
+def fill_state_dict(shapes: dict, seed: int = 0, regime: str = "default") -> dict:
+    """shapes: {state_dict key: shape tuple}.  Returns {key: float32 ndarray} filled by the recipe.
+
+    Keys are visited in sorted order and each draws ``standard_normal(shape)`` from one shared stream, so two
+    implementations whose state-dicts have the same keys/shapes get bit-identical weights.
+    """
+    gain, sigma = REGIMES[regime]
+    rng = np.random.default_rng(seed)
+    out = {}
+    for key in sorted(shapes):
+        shape = tuple(int(s) for s in shapes[key])
+        z = rng.standard_normal(shape).astype(np.float32)
+        if key.endswith(".mat"):                       # Uncondition16Trans.mat [1,4,4]
+            val = np.eye(4, dtype=np.float32)[None] + np.float32(sigma) * z
+        elif key.endswith(".weight"):
+            fan_in = shape[-1]
+            val = z / np.float32(np.sqrt(fan_in))
+            if "conditioner.fc_last" in key:
+                val = val * np.float32(gain)
+            elif "net.fc_last" in key:                 # Condition16Trans: keep I + net(f) well conditioned
+                val = val * np.float32(0.2)
+        elif key.endswith(".bias"):
+            val = np.float32(0.1) * z
+            if "conditioner.fc_last" in key:
+                val = val * np.float32(gain)
+            elif "net.fc_last" in key:
+                val = val * np.float32(0.2)
+        else:
+            raise KeyError(f"recipe has no rule for state-dict key {key!r}")
+        out[key] = np.ascontiguousarray(val.astype(np.float32))
+    return out
+
+
+def fisher_A(kind: str = "diag531") -> np.ndarray:
+    """Matrix-Fisher parameter used by the benchmark configs: A = diag(5,3,1), shape [1,3,3]."""
+    if kind == "diag531":
+        return np.diag(np.array([5.0, 3.0, 1.0], dtype=np.float32))[None]
+    if kind == "tilted":
+        rng = np.random.default_rng(7)
+        u = uniform_rotations(2, seed=11)
+        s = np.diag(np.array([6.0, 2.5, -0.75], dtype=np.float32))
+        return (u[0] @ s @ u[1].T).astype(np.float32)[None] + 0 * rng.standard_normal(1).astype(np.float32)
+    raise KeyError(kind)

@@ -1,0 +1,36 @@
+"""Golden-fixture case table shared by make_golden.py (generator, reference side) and the tests (checker side).
+
+Each case: name -> dict(cfg=<make_config kwargs>, n=<samples>, regime=<synth regime>, wseed=<weight seed>,
+                        rseed=<rotation seed>, direction='forward'|'inverse', fisher=<synth.fisher_A kind or None>)
+Inputs and weights are regenerated from rotationnormflow_amd.synth on both sides; fixtures hold outputs only.
+"""
+SYMSOL = dict(condition=1, rot="16UnTrans", frequent_permute=1, last_affine=1, first_affine=0)
+
+CASES = {
+    # BASELINE configs[0]: 8-layer MobiusAffine, unconditional
+    "c1_default":      dict(cfg=dict(layers=8), n=2048, regime="default", wseed=1, rseed=42, direction="forward", fisher=None),
+    "c1_trained":      dict(cfg=dict(layers=8), n=2048, regime="trained", wseed=2, rseed=43, direction="forward", fisher=None),
+    "c1_trained_inv":  dict(cfg=dict(layers=8), n=1024, regime="trained", wseed=2, rseed=44, direction="inverse", fisher=None),
+    # configs[1]/[2]: 24-layer MobiusAffine + matrix-Fisher base
+    "c2_default":      dict(cfg=dict(layers=24), n=2048, regime="default", wseed=3, rseed=45, direction="forward", fisher="diag531"),
+    "c2_trained":      dict(cfg=dict(layers=24), n=2048, regime="trained", wseed=4, rseed=46, direction="forward", fisher="tilted"),
+    # configs[3]: conditional SYMSOL-I structure, F=256
+    "c4_default":      dict(cfg=dict(layers=24, feature_dim=256, **SYMSOL), n=1024, regime="default", wseed=5, rseed=47, direction="forward", fisher=None),
+    "c4_trained":      dict(cfg=dict(layers=24, feature_dim=256, **SYMSOL), n=1024, regime="trained", wseed=6, rseed=48, direction="forward", fisher=None),
+    "c4_trained_inv":  dict(cfg=dict(layers=6, feature_dim=256, **SYMSOL), n=512, regime="trained", wseed=6, rseed=49, direction="inverse", fisher=None),
+    # configs[4]: 42-layer Moebius-only inverse (conditional F=512, and its unconditional variant)
+    "c5_default_inv":  dict(cfg=dict(layers=42, condition=1, feature_dim=512, rot="None", frequent_permute=1, last_affine=0, first_affine=0),
+                            n=512, regime="default", wseed=7, rseed=50, direction="inverse", fisher="diag531"),
+    "c5u_trained_inv": dict(cfg=dict(layers=42, condition=0, rot="None", last_affine=0, first_affine=0),
+                            n=1024, regime="trained", wseed=8, rseed=51, direction="inverse", fisher=None),
+    "c5u_trained_fwd": dict(cfg=dict(layers=42, condition=0, rot="None", last_affine=0, first_affine=0),
+                            n=1024, regime="trained", wseed=8, rseed=52, direction="forward", fisher=None),
+    # registry / schedule edge cases
+    "cond16_regular":  dict(cfg=dict(layers=4, condition=1, feature_dim=None, rot="16Trans"), n=1024, regime="trained", wseed=9, rseed=53, direction="forward", fisher=None),
+    "cond16_reg_inv":  dict(cfg=dict(layers=3, condition=1, feature_dim=40, rot="16Trans", frequent_permute=1), n=512, regime="trained", wseed=10, rseed=54, direction="inverse", fisher=None),
+    "k16_freqperm":    dict(cfg=dict(layers=5, segments=16, frequent_permute=1), n=1024, regime="trained", wseed=11, rseed=55, direction="forward", fisher=None),
+    "k8_nofirst":      dict(cfg=dict(layers=7, segments=8, first_affine=0), n=1024, regime="trained", wseed=12, rseed=56, direction="forward", fisher=None),
+    "k128_inv":        dict(cfg=dict(layers=3, segments=128), n=512, regime="trained", wseed=13, rseed=57, direction="inverse", fisher=None),
+    "embed_cond":      dict(cfg=dict(layers=3, condition=1, feature_dim=24, embedding=1, embedding_dim=8, rot="16UnTrans", last_affine=1), n=512,
+                            regime="default", wseed=14, rseed=58, direction="forward", fisher=None),
+}

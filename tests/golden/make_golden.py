@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference) in this container.
+
+Run from anywhere:   python tests/golden/make_golden.py [case ...]
+
+* Imports the reference's ``flow.flow.Flow`` and ``utils.fisher.MatrixFisherN`` with the two third-party stand-ins
+  under oracle/stubs/ (pytorch3d.transforms, nflows.distributions) ahead of /root/reference on sys.path.
+* Fills the reference's own ``state_dict`` by the recipe in rotationnormflow_amd/synth.py (sorted-key order), feeds
+  recipe inputs, and stores ONLY outputs (fp32 run and fp64 run) + checksums of the regenerated inputs/weights.
+* Nothing of the reference travels: fixtures are arrays of numbers.  The GPU box never runs this script.
+"""
+import os
+import sys
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+if not os.path.isdir(REF):
+    sys.exit("reference tree not present; golden fixtures can only be regenerated in the build container")
+
+sys.path[:0] = [os.path.join(REPO, "oracle", "stubs"), REF, REPO]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import flow.flow as ref_flow_mod  # noqa: E402  (the reference's package)
+import utils.fisher as ref_fisher_mod  # noqa: E402
+
+assert ref_flow_mod.__file__.startswith(REF), ref_flow_mod.__file__
+assert ref_fisher_mod.__file__.startswith(REF), ref_fisher_mod.__file__
+
+from rotationnormflow_amd import synth  # noqa: E402
+from rotationnormflow_amd.configs import make_config  # noqa: E402
+from tests.golden.cases import CASES  # noqa: E402
+
+
+def crc(a: np.ndarray) -> int:
+    return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+def build_reference_flow(cfg, dtype):
+    torch.set_default_dtype(dtype)          # mobiusflow.py:80 uses torch.empty(size) in the DEFAULT dtype
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):   # flow.py:50 prints the layer count
+        fl = ref_flow_mod.Flow(cfg)
+    return fl.to(dtype).eval()
+
+
+def run_case(name, spec):
+    cfg = make_config(**spec["cfg"])
+    n = spec["n"]
+    rot_in = synth.uniform_rotations(n, seed=spec["rseed"])
+    fdim = 0
+    out = {}
+    res = {}
+    for tag, dtype in (("32", torch.float32), ("64", torch.float64)):
+        fl = build_reference_flow(cfg, dtype)
+        sd = fl.state_dict()
+        shapes = {k: tuple(v.shape) for k, v in sd.items()}
+        weights = synth.fill_state_dict(shapes, seed=spec["wseed"], regime=spec["regime"])
+        fl.load_state_dict({k: torch.from_numpy(v).to(dtype) for k, v in weights.items()})
+        fdim = fl.feature_dim
+        feat = None
+        if cfg.condition:
+            feat = torch.from_numpy(synth.features(n, fdim, seed=spec["rseed"] + 1000)).to(dtype)
+        R = torch.from_numpy(rot_in).to(dtype)
+        with torch.no_grad():
+            if spec["direction"] == "forward":
+                Rt, ldj = fl(R, feat)
+            else:
+                Rt, ldj = fl.inverse(R, feat)
+            res[tag] = (Rt, ldj)
+            out["rot" + tag] = Rt.numpy().copy()
+            out["ldj" + tag] = ldj.numpy().copy()
+            if spec["fisher"] is not None:
+                A = torch.from_numpy(synth.fisher_A(spec["fisher"])).to(dtype)
+                dist = ref_fisher_mod.MatrixFisherN(A)
+                # forward: base density of the flow output; inverse: base density of the given base samples
+                arg = Rt if spec["direction"] == "forward" else R
+                out["fisher" + tag] = dist._log_prob(arg).numpy().copy()
+        if tag == "32":
+            out["n_layers"] = np.int64(len(fl.layers))
+            out["n_keys"] = np.int64(len(sd))
+            out["keys"] = np.array(sorted(sd.keys()))
+            out["w_crc"] = np.int64(crc(np.concatenate([weights[k].ravel() for k in sorted(weights)])))
+    torch.set_default_dtype(torch.float32)
+    out["in_crc"] = np.int64(crc(rot_in))
+    out["feature_dim"] = np.int64(fdim)
+    d = np.abs(out["ldj32"].astype(np.float64) - out["ldj64"])
+    print(f"{name:18s} layers={int(out['n_layers']):3d} keys={int(out['n_keys']):4d} n={n:5d} "
+          f"ldj64 range [{out['ldj64'].min():8.3f},{out['ldj64'].max():8.3f}] "
+          f"|ldj32-ldj64| mean {d.mean():.2e} p99 {np.quantile(d, .99):.2e} max {d.max():.2e}")
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def main():
+    torch.manual_seed(0)
+    names = sys.argv[1:] or list(CASES)
+    for name in names:
+        run_case(name, CASES[name])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+/*
+ * rnf_hip.h -- C ABI of librnf_hip.so: the MI355X (gfx950) implementation of the SO(3) normalizing-flow density path
+ * of PKU-EPIC/RotationNormFlow.  Plain pointers and sizes only; no framework types.  All `dev` pointers are HIP
+ * device pointers, all other pointers are host pointers.  Every call is stream-ordered on `stream` (a hipStream_t
+ * passed as void*; NULL = the default stream) and performs no host synchronisation.
+ *
+ * Return value: 0 on success, non-zero on error; rnf_last_error() returns a thread-local message.
+ *
+ * The reference has no FFI for this path (it is 100% Python); each entry point cites the reference code it replaces
+ * (paths relative to the reference tree).  INTEGRATION.md shows the ctypes binding and the module-level drop-in.
+ */
+#ifndef RNF_HIP_H
+#define RNF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RNF_ABI_VERSION 1
+
+/* width of the conditioner MLP's hidden layers: flow/condition.py:9 (Nh=64, never overridden by any caller) */
+#define RNF_HIDDEN 64
+
+/* ---- layer table -------------------------------------------------------------------------------------------
+ * A flow is described by an int32 table desc[n_layers][RNF_DESC_STRIDE] (host memory) in Flow.layers order
+ * (flow/flow.py:36-51) plus one float32 parameter blob (device memory) built with the rnf_pack_* functions.
+ *   desc[i][0] kind          RNF_LAYER_*
+ *   desc[i][1] perm_row      row of the 6x3 permutation table used by this layer on the FORWARD pass
+ *                            (flow/flow.py:13-15,64-70); the inverse pass uses the same row for the same layer
+ *   desc[i][2] param_offset  offset of the layer's packed parameters in the blob, in floats (multiple of 4)
+ *   desc[i][3] cond_slot     index of this layer among the layers that consume the feature vector, or -1
+ *   desc[i][4] feat_offset   offset in the blob of the layer's packed feature-projection weights, or -1
+ *   desc[i][5] reserved
+ */
+#define RNF_DESC_STRIDE 6
+#define RNF_LAYER_MOBIUS 1        /* flow/mobiusflow.py:27-183  MobiusFlow                                  */
+#define RNF_LAYER_AFFINE16 2      /* flow/squeezetrans.py:161-174 Uncondition16Trans (any constant 4x4 M)   */
+#define RNF_LAYER_AFFINE16_COND 3 /* flow/squeezetrans.py:41-55  Condition16Trans (M = I + MLP(feature))    */
+
+int rnf_abi_version(void);
+const char *rnf_last_error(void);
+
+/* ---- parameter packing (host side, pure CPU; called once per parameter version) ------------------------------
+ * Sizes are in floats.  `segments` (K) must be a positive multiple of 8.  `feature_dim` (F) is the number of
+ * feature inputs of the layer's MLP (0 for an unconditional Moebius layer).
+ */
+int64_t rnf_mobius_packed_floats(int32_t segments);
+int64_t rnf_affine16_packed_floats(void);
+int64_t rnf_cond16_packed_floats(void);
+int64_t rnf_featproj_packed_floats(int32_t feature_dim); /* 0 when feature_dim == 0 */
+
+/* MobiusFlow.conditioner = ConditionalTransform(3+F, 4K) (flow/mobiusflow.py:40-43, flow/condition.py:10-22).
+ * Weights are torch.nn.Linear layout [out, in], row-major.  fc_first_w is [64, 3+F] with the 3 y-inputs FIRST
+ * (flow/mobiusflow.py:53-56).  fc_last_w is [4K, 64]: rows [0,K) raw segment weights, row K+3k+d = w_k[d]
+ * (flow/mobiusflow.py:58-61).  out_layer receives rnf_mobius_packed_floats(K) floats; out_feat receives
+ * rnf_featproj_packed_floats(F) floats (ignored when F == 0). */
+int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
+                    const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
+                    const float *fc_last_w, const float *fc_last_b, int32_t segments, int32_t feature_dim,
+                    float *out_layer, float *out_feat);
+
+/* Uncondition16Trans.mat [4,4] row-major (flow/squeezetrans.py:164-165).  Packs M, log|det M|, M^-1 and
+ * log|det M^-1| (the reference recomputes inv/det every call: squeezetrans.py:38,171-174). */
+int rnf_pack_affine16(const float *mat16, float *out_layer);
+
+/* Condition16Trans.net = ConditionalTransform(F, 16) (flow/squeezetrans.py:42-44). fc_first_w [64,F], fc_last_w [16,64]. */
+int rnf_pack_cond16(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
+                    const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
+                    const float *fc_last_w, const float *fc_last_b, int32_t feature_dim, float *out_layer,
+                    float *out_feat);
+
+/* ---- the flow -------------------------------------------------------------------------------------------------
+ * rotation_dev   [n,3,3] float32 row-major contiguous
+ * feature_dev    [n,F] float32 row-major contiguous (F % 8 == 0), or NULL for an unconditional flow
+ * rotation_out   [n,3,3] or NULL;  ldj_out [n] or NULL
+ * workspace_dev  scratch of at least rnf_workspace_bytes(n, n_cond_layers) bytes (may be NULL when that is 0)
+ */
+size_t rnf_workspace_bytes(int64_t n, int32_t n_cond_layers);
+
+/* Flow.forward (flow/flow.py:53-72): ldj = sum of forward log-det-Jacobians. */
+int rnf_flow_forward(const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim,
+                     const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments,
+                     float *rotation_out_dev, float *ldj_out_dev, void *workspace_dev, size_t workspace_bytes,
+                     void *stream);
+
+/* Flow.inverse (flow/flow.py:74-92): walks the table backwards; ldj = sum of inverse-map log-dets
+ * (MobiusFlow.inverse returns -ldj: flow/mobiusflow.py:183). */
+int rnf_flow_inverse(const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim,
+                     const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments,
+                     float *rotation_out_dev, float *ldj_out_dev, void *workspace_dev, size_t workspace_bytes,
+                     void *stream);
+
+/* Fused density evaluation: Flow.forward + MatrixFisherN(A)._log_prob(R') + the NLL accumulation
+ * (agent.py:54-65,217-229; utils/fisher.py:217-232).
+ *   fisher_A_dev [B,3,3], fisher_c_dev [B] with c_b = sum(S_b) + log(norm_b) (host precomputes the proper singular
+ *   values, utils/fisher.py:67-76,93-97); sample i uses row i / (n / B) (fisher.py:226).  Pass NULL/0 for a uniform base.
+ *   logp_out_dev [n] or NULL: per-sample log p = ldj + base.
+ *   sum_out_dev  double[2] or NULL: {sum_i log p_i, n}, accumulated in fp64 in a fixed order (deterministic).
+ *   rotation_out_dev / ldj_out_dev optional as above. */
+int rnf_flow_log_prob(const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim,
+                      const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments,
+                      const float *fisher_A_dev, const float *fisher_c_dev, int64_t fisher_B,
+                      float *rotation_out_dev, float *ldj_out_dev, float *logp_out_dev, double *sum_out_dev,
+                      void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* MatrixFisherN._log_prob alone (utils/fisher.py:217-232), same A/c convention; out [n]. */
+int rnf_fisher_log_prob(const float *rotation_dev, int64_t n, const float *fisher_A_dev, const float *fisher_c_dev,
+                        int64_t fisher_B, float *out_dev, void *stream);
+
+/* ConditionalTransform.forward for one packed Moebius layer (flow/condition.py:24-30), unconditional input only:
+ * y_dev [n,3] -> out_dev [n,4K] in the reference's output order.  Unit-test / bring-up entry point. */
+int rnf_conditioner_forward(const float *y_dev, int64_t n, const float *layer_packed_dev, int32_t segments,
+                            float *out_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNF_HIP_H */

@@ -1,0 +1,39 @@
+"""rotationnormflow_amd -- MI355X-native SO(3) normalizing-flow density path (drop-in for PKU-EPIC/RotationNormFlow's
+``flow.flow.Flow`` forward / inverse / log-prob, matrix-Fisher base log-density and mean-NLL reduction).
+
+The per-sample math runs in hand-written HIP kernels for gfx950 behind the C ABI in include/rnf_hip.h; this package is
+the Python host side that mirrors the reference's module API (same class names, constructor arguments, call
+signatures and state-dict keys).  There is no CPU fallback.
+"""
+from .configs import make_config, load_yaml_config, PRESETS  # noqa: F401
+
+__all__ = ["make_config", "load_yaml_config", "PRESETS", "install_as_reference_modules"]
+
+
+def install_as_reference_modules():
+    """Register this package's modules under the reference's import names (``flow.flow``, ``flow.mobiusflow``,
+    ``flow.affineflow``, ``flow.squeezetrans``, ``flow.condition``, ``utils.fisher``) so that the reference's own
+    scripts (agent.py:9-10: ``from flow.flow import Flow, get_flow``; ``from utils.fisher import MatrixFisherN``) pick
+    up the HIP implementation unchanged.  Call it before importing the reference's ``agent``; see INTEGRATION.md."""
+    import importlib
+    import sys
+    import types
+
+    from . import flow as _flow_pkg
+
+    sys.modules["flow"] = _flow_pkg
+    for name in ("flow", "mobiusflow", "affineflow", "squeezetrans", "rottrans", "condition"):
+        sys.modules[f"flow.{name}"] = importlib.import_module(f"{__name__}.flow.{name}")
+    from .utils import fisher as _fisher
+
+    # the reference's `utils` package holds other (out-of-scope) modules; only its `fisher` submodule is replaced
+    sys.modules["utils.fisher"] = _fisher
+    utils_pkg = sys.modules.get("utils")
+    if utils_pkg is None:
+        try:
+            utils_pkg = importlib.import_module("utils")
+        except ImportError:
+            utils_pkg = types.ModuleType("utils")
+            utils_pkg.__path__ = []
+            sys.modules["utils"] = utils_pkg
+    utils_pkg.fisher = _fisher

@@ -1,0 +1,63 @@
+"""ctypes binding of librnf_hip.so (include/rnf_hip.h).  There is no fallback: if the HIP library has not been built
+the import of any op fails loudly (build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``python -m rotationnormflow_amd.build``)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librnf_hip.so")
+
+_lib = None
+
+c_f32p = C.c_void_p      # device or host float*, passed as integer addresses
+c_i32p = C.c_void_p
+
+_SIGNATURES = {
+    "rnf_abi_version": (C.c_int, []),
+    "rnf_last_error": (C.c_char_p, []),
+    "rnf_mobius_packed_floats": (C.c_int64, [C.c_int32]),
+    "rnf_affine16_packed_floats": (C.c_int64, []),
+    "rnf_cond16_packed_floats": (C.c_int64, []),
+    "rnf_featproj_packed_floats": (C.c_int64, [C.c_int32]),
+    "rnf_pack_mobius": (C.c_int, [c_f32p] * 10 + [C.c_int32, C.c_int32, c_f32p, c_f32p]),
+    "rnf_pack_affine16": (C.c_int, [c_f32p, c_f32p]),
+    "rnf_pack_cond16": (C.c_int, [c_f32p] * 10 + [C.c_int32, c_f32p, c_f32p]),
+    "rnf_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "rnf_flow_forward": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
+                                   c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnf_flow_inverse": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
+                                   c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnf_flow_log_prob": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
+                                    c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p,
+                                    C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnf_fisher_log_prob": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_void_p]),
+    "rnf_conditioner_forward": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int32, c_f32p, C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib():
+    """The loaded library (loads on first use)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the MI355X HIP library has not been built and there is no CPU fallback. "
+                "Run `python -m rotationnormflow_amd.build` (needs hipcc).")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.rnf_abi_version() != 1:
+            raise RuntimeError("librnf_hip.so ABI version mismatch; rebuild")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError("librnf_hip: " + lib().rnf_last_error().decode())

@@ -1,0 +1,27 @@
+"""Build librnf_hip.so for gfx950 with hipcc (cross-compiles without a GPU).  `python -m rotationnormflow_amd.build`"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "rnf_api.hip")
+OUT = os.path.join(HERE, "librnf_hip.so")
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("rnf_api.hip", "flow_kernels.h", "featproj_kernel.h", "so3_math.h", "layout.h")] + [
+    os.path.join(os.path.dirname(HERE), "include", "rnf_hip.h")]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

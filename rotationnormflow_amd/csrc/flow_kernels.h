@@ -1,0 +1,407 @@
+// flow_kernels.h -- the fused layer-stack kernels (gfx950 / CDNA4).
+//
+// One workgroup = NW waves; every wave owns 32 rotations (one MFMA column tile).  Lane l = (j = l&31, h = l>>5):
+// both lanes of a pair (j, j+32) hold the full per-sample state (3x3 rotation + running log-det, registers, kept
+// across the whole layer stack); the conditioner MLP runs on v_mfma_f32_32x32x2_f32 with the weights of the
+// current layer staged in LDS (layout.h), its 4K outputs are produced 32 rows at a time and consumed immediately
+// by the segment math, the two lanes of a pair each taking half of the segments (4 per fc_last tile).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "layout.h"
+#include "so3_math.h"
+
+namespace rnf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define RNF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+constexpr int MAX_LAYERS = 400;
+
+// kernel arguments (passed by value; the layer table sits in the kernarg segment -> scalar loads)
+struct FlowArgs {
+    const float *rot_in;      // [n,9]
+    const float *blob;        // packed parameters
+    const float *G;           // feature-projection scratch for this chunk (or nullptr)
+    float *rot_out;           // [n,9] or nullptr
+    float *ldj_out;           // [n] or nullptr
+    float *logp_out;          // [n] or nullptr
+    double *partials;         // [gridDim.x] or nullptr
+    const float *fisher_A;    // [B,9] or nullptr
+    const float *fisher_c;    // [B]
+    long long n;              // samples in this launch
+    long long sample_base;    // global index of sample 0 (for the Fisher row lookup)
+    long long fisher_div;     // samples per Fisher row (n_total / B)
+    long long g_groups;       // 32-sample groups per cond slot in G
+    int n_layers;
+    int KT;                   // fc_last tiles = segments / 8
+    // per layer: x = kind | perm_row << 4 | (cond_slot + 1) << 8 ; y = param offset (floats)
+    int2 layers[MAX_LAYERS];
+};
+
+__device__ __forceinline__ float4 lds_f4(const float *base, int idx4) {
+    return reinterpret_cast<const float4 *>(base)[idx4];
+}
+
+// cooperative global -> LDS copy of `nfloats` (multiple of 4) floats
+__device__ __forceinline__ void stage_floats(float *dst, const float *src, int nfloats, int tid, int nthreads) {
+    const float4 *s = reinterpret_cast<const float4 *>(src);
+    float4 *d = reinterpret_cast<float4 *>(dst);
+    for (int i = tid; i < (nfloats >> 2); i += nthreads) d[i] = s[i];
+}
+
+__device__ __forceinline__ f32x16 load_bias16(const float *bias_half /* 16 floats of this lane-half */) {
+    f32x16 c;
+    float4 b0 = lds_f4(bias_half, 0), b1 = lds_f4(bias_half, 1), b2 = lds_f4(bias_half, 2), b3 = lds_f4(bias_half, 3);
+    c[0] = b0.x; c[1] = b0.y; c[2] = b0.z; c[3] = b0.w;
+    c[4] = b1.x; c[5] = b1.y; c[6] = b1.z; c[7] = b1.w;
+    c[8] = b2.x; c[9] = b2.y; c[10] = b2.z; c[11] = b2.w;
+    c[12] = b3.x; c[13] = b3.y; c[14] = b3.z; c[15] = b3.w;
+    return c;
+}
+
+// accumulator init of fc_first from the feature projection scratch (global memory, fragment order)
+__device__ __forceinline__ f32x16 load_g16(const float *g_tile /* [4][64] float4 of this (group, ot) */, int lane) {
+    const float4 *g4 = reinterpret_cast<const float4 *>(g_tile);
+    f32x16 c;
+    float4 b0 = g4[lane], b1 = g4[64 + lane], b2 = g4[128 + lane], b3 = g4[192 + lane];
+    c[0] = b0.x; c[1] = b0.y; c[2] = b0.z; c[3] = b0.w;
+    c[4] = b1.x; c[5] = b1.y; c[6] = b1.z; c[7] = b1.w;
+    c[8] = b2.x; c[9] = b2.y; c[10] = b2.z; c[11] = b2.w;
+    c[12] = b3.x; c[13] = b3.y; c[14] = b3.z; c[15] = b3.w;
+    return c;
+}
+
+// one 64 -> 32 output tile: acc += W_tile[32 x 64] . relu?(in)   (in = two f32x16 register tiles)
+template <bool RELU>
+__device__ __forceinline__ f32x16 gemm_tile64(const float *w_tile /* [8][64] float4 */, int lane, const f32x16 (&in)[2],
+                                              f32x16 acc) {
+#pragma unroll
+    for (int tg = 0; tg < 8; ++tg) {
+        float4 a = lds_f4(w_tile, tg * 64 + lane);
+        const int t = tg >> 2, r0 = (tg & 3) * 4;
+        float b0 = in[t][r0], b1 = in[t][r0 + 1], b2 = in[t][r0 + 2], b3 = in[t][r0 + 3];
+        if (RELU) { b0 = fmaxf(b0, 0.f); b1 = fmaxf(b1, 0.f); b2 = fmaxf(b2, 0.f); b3 = fmaxf(b3, 0.f); }
+        acc = RNF_MFMA(a.x, b0, acc);
+        acc = RNF_MFMA(a.y, b1, acc);
+        acc = RNF_MFMA(a.z, b2, acc);
+        acc = RNF_MFMA(a.w, b3, acc);
+    }
+    return acc;
+}
+
+// ConditionalTransform up to the input of fc_last (flow/condition.py:24-29): tt = relu(x0 + L5(relu(L3(relu(L1(relu(x0)))))))
+// x0 = fc_first(y (+) feature): the y part and (unconditional) bias run as two K=2 MFMA steps, the feature part and
+// (conditional) bias arrive pre-multiplied in `cinit`.
+__device__ __forceinline__ void mlp_head(const float *lds, int lane, int h, float y0, float y1, float y2,
+                                         const f32x16 (&cinit)[2], f32x16 (&tt)[2]) {
+    const float bA = h ? y1 : y0;
+    const float bB = h ? 1.0f : y2;
+    f32x16 x0[2];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+        float2 a = reinterpret_cast<const float2 *>(lds + MOB_FIRST)[ot * 64 + lane];
+        f32x16 c = RNF_MFMA(a.x, bA, cinit[ot]);
+        x0[ot] = RNF_MFMA(a.y, bB, c);
+    }
+    f32x16 hin[2] = {x0[0], x0[1]};
+#pragma unroll
+    for (int L = 0; L < 3; ++L) {
+        f32x16 hout[2];
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            f32x16 c = load_bias16(lds + MOB_HB + ((L * 2 + ot) * 2 + h) * 16);
+            hout[ot] = gemm_tile64<true>(lds + MOB_HID + (L * 2 + ot) * (8 * 64 * 4), lane, hin, c);
+        }
+        hin[0] = hout[0];
+        hin[1] = hout[1];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tt[t][r] = fmaxf(x0[t][r] + hin[t][r], 0.0f);
+}
+
+__device__ __forceinline__ f32x16 last_tile(const float *tile_rec, int lane, int h, const f32x16 (&tt)[2]) {
+    f32x16 c = load_bias16(tile_rec + MOB_LAST_TILE_BIAS + h * 16);
+    return gemm_tile64<false>(tile_rec, lane, tt, c);
+}
+
+__device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+// ------------------------------------------------------------------------------------------------------------
+// Moebius layer, forward (flow/mobiusflow.py:46-125)
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mobius_forward(float *lds, const float *layer_params, int KT, int perm_row, int lane,
+                                               int h, const f32x16 (&cinit)[2], Rot &R, float &ldj, int tid,
+                                               int nthreads) {
+    const int p0 = perm_row % 3, p1 = (perm_row + 1) % 3, p2 = (perm_row + 2) % 3;   // flow/flow.py:13-15
+    const v3f x = get_col(R, p0), y = get_col(R, p1);
+    const Frame f = make_frame(x, y);
+    const float zr = dot3(x, f.r), zv = dot3(x, f.v);
+
+    f32x16 tt[2];
+    mlp_head(lds, lane, h, y.x, y.y, y.z, cinit, tt);
+
+    float S = 0.f, A = 0.f, J = 0.f;
+    for (int tau = 0; tau < KT; ++tau) {
+        if (tau > 0 && (tau % MOB_MAX_TILES_IN_LDS) == 0) {   // K > 64: restage the next 8 fc_last tiles
+            __syncthreads();
+            int nt = min(MOB_MAX_TILES_IN_LDS, KT - tau);
+            stage_floats(lds + MOB_LAST, layer_params + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS,
+                         nt * MOB_LAST_TILE_FLOATS, tid, nthreads);
+            __syncthreads();
+        }
+        f32x16 o = last_tile(lds + MOB_LAST + (tau % MOB_MAX_TILES_IN_LDS) * MOB_LAST_TILE_FLOATS, lane, h, tt);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float ur, uv, phi, c;
+            squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], f, ur, uv);
+            mobius_angle(zr, zv, ur, uv, phi, c);
+            float sp = softplus(o[4 * g]);
+            S += sp;
+            A = fmaf(sp, phi, A);
+            J = fmaf(sp, c, J);
+        }
+    }
+    S = pair_sum(S);
+    A = pair_sum(A);
+    J = pair_sum(J);
+    const float invS = 1.0f / S;
+    float sn, cs;
+    sincos_small(A * invS, sn, cs);
+    const v3f tx = f.v * sn + f.r * cs;
+    const int dp = p1 - p0;
+    const v3f tz = normalize3((dp == 1 || dp == -2) ? cross3(tx, y) : cross3(y, tx));     // mobiusflow.py:75-79
+    set_col(R, p0, tx);
+    set_col(R, p2, tz);
+    ldj += logf(J * invS);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Moebius layer, inverse (flow/mobiusflow.py:127-224).  KT is compile time: the 4*KT segment
+// parameters of this lane stay in registers for the 15 bisection steps.
+// ------------------------------------------------------------------------------------------------------------
+template <int KT>
+__device__ __forceinline__ void mobius_inverse(float *lds, int perm_row, int lane, int h, const f32x16 (&cinit)[2],
+                                               Rot &R, float &ldj) {
+    static_assert(KT <= MOB_MAX_TILES_IN_LDS, "inverse keeps all fc_last tiles in LDS");
+    const int p0 = perm_row % 3, p1 = (perm_row + 1) % 3, p2 = (perm_row + 2) % 3;
+    const v3f tx = get_col(R, p0), ty = get_col(R, p1);
+    const Frame f = make_frame(tx, ty);
+
+    f32x16 tt[2];
+    mlp_head(lds, lane, h, ty.x, ty.y, ty.z, cinit, tt);
+
+    float sp[4 * KT], ur[4 * KT], uv[4 * KT];
+    float S = 0.f;
+#pragma unroll
+    for (int tau = 0; tau < KT; ++tau) {
+        f32x16 o = last_tile(lds + MOB_LAST + tau * MOB_LAST_TILE_FLOATS, lane, h, tt);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], f, ur[4 * tau + g], uv[4 * tau + g]);
+            sp[4 * tau + g] = softplus(o[4 * g]);
+            S += sp[4 * tau + g];
+        }
+    }
+    S = pair_sum(S);
+    const float invS = 1.0f / S;
+
+    // target angle of the given column (== pi by construction), wrapped and snapped (mobiusflow.py:157-167)
+    float target = atan2f(dot3(tx, f.v), dot3(tx, f.r));
+    target = target < 0.f ? target + kTwoPi : target;
+    target = fabsf(target - kTwoPi) < 1e-4f ? 0.f : target;
+
+    // BinFind.forward (mobiusflow.py:196-224): bracket [pi/2, 3pi/2], width halves every step, the batch-global stop
+    // test max(b-a) < 1e-4 is met after exactly 15 steps; the returned root is the LAST midpoint.
+    float a = 0.5f * kPi, b = 1.5f * kPi, mid = kPi;
+#pragma unroll 1
+    for (int it = 0; it < 15; ++it) {
+        mid = (a + b) * 0.5f;
+        float sn, cs;
+        sincos_small(mid, sn, cs);
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4 * KT; ++s) {
+            float phi, c;
+            mobius_angle(cs, sn, ur[s], uv[s], phi, c);
+            acc = fmaf(sp[s], phi, acc);
+        }
+        float fx = pair_sum(acc) * invS - target;
+        float half = (b - a) * 0.5f;
+        if (fx < 0.f) a = a + half;
+        else if (fx >= 0.f) b = b - half;
+    }
+    float sn, cs;
+    sincos_small(mid, sn, cs);
+    float J = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4 * KT; ++s) {
+        float phi, c;
+        mobius_angle(cs, sn, ur[s], uv[s], phi, c);
+        J = fmaf(sp[s], c, J);
+    }
+    J = pair_sum(J);
+    const v3f xx = f.v * sn + f.r * cs;
+    const int dp = p1 - p0;
+    const v3f zz = normalize3((dp == 1 || dp == -2) ? cross3(xx, ty) : cross3(ty, xx));   // mobiusflow.py:172-176
+    set_col(R, p0, xx);
+    set_col(R, p2, zz);
+    ldj -= logf(J * invS);                                                       // mobiusflow.py:183
+}
+
+// Condition16Trans (flow/squeezetrans.py:41-55): M = I + reshape(MLP(feature), 4, 4); the one fc_last tile leaves
+// rows {h, 2+h} of M on lane-half h; the partner's two rows come over with 8 cross-lane moves.
+template <bool INVERSE>
+__device__ __forceinline__ void cond16_apply(const float *lds, int lane, int h, const f32x16 (&cinit)[2], Rot &R,
+                                             float &ldj) {
+    f32x16 tt[2];
+    mlp_head(lds, lane, h, 0.f, 0.f, 0.f, cinit, tt);
+    f32x16 o = last_tile(lds + MOB_LAST, lane, h, tt);
+    float M[16];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float mine = o[4 * g + c];
+            float other = __shfl_xor(mine, 32, 64);
+            M[4 * (2 * g) + c] = h ? other : mine;    // rows h and 2+h are this lane's
+            M[4 * (2 * g + 1) + c] = h ? mine : other;
+        }
+    M[0] += 1.f; M[5] += 1.f; M[10] += 1.f; M[15] += 1.f;
+    float Mi[16];
+    float det = inv4(M, Mi);
+    if (INVERSE) affine16_apply(Mi, -logf(fabsf(det)), R, ldj);
+    else affine16_apply(M, logf(fabsf(det)), R, ldj);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the fused stack kernel.  DIR 0 = Flow.forward (flow/flow.py:53-72), 1 = Flow.inverse (flow/flow.py:74-92).
+// KT_INV: compile-time tile count for the inverse (0 for forward instantiations).
+// ------------------------------------------------------------------------------------------------------------
+template <int DIR, int KT_INV, int NW>
+__global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    constexpr int NT = NW * 64;
+    constexpr int TILE = NW * TILE_SAMPLES;
+    const long long ntiles = (args.n + TILE - 1) / TILE;
+    const int KT = DIR ? KT_INV : args.KT;
+    double dsum = 0.0;
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long group = tile * NW + wave;                 // 32-sample group index inside this launch
+        const long long sample = group * TILE_SAMPLES + j;
+        const bool valid = sample < args.n;
+
+        Rot R;
+        R.c0 = v3f{1.f, 0.f, 0.f}; R.c1 = v3f{0.f, 1.f, 0.f}; R.c2 = v3f{0.f, 0.f, 1.f};
+        if (valid) {
+            const float *src = args.rot_in + sample * 9;      // row-major [3][3]
+            R.c0 = v3f{src[0], src[3], src[6]};
+            R.c1 = v3f{src[1], src[4], src[7]};
+            R.c2 = v3f{src[2], src[5], src[8]};
+        }
+        float ldj = 0.f;
+
+        for (int li = 0; li < args.n_layers; ++li) {
+            const int l = DIR ? (args.n_layers - 1 - li) : li;
+            const int2 d = args.layers[l];
+            const int kind = d.x & 15, perm_row = (d.x >> 4) & 15, slot = (d.x >> 8) - 1;
+            const float *params = args.blob + d.y;
+
+            if (kind == RNF_KIND_AFFINE16) {
+                float M[16];
+                const float *m = params + (DIR ? 17 : 0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) M[i] = m[i];
+                affine16_apply(M, m[16], R, ldj);
+                continue;
+            }
+
+            // layers with a conditioner MLP: stage the layer's image, then compute
+            f32x16 cinit[2];
+            if (slot >= 0) {
+                const float *g = args.G + ((size_t)slot * args.g_groups + group) * G_FLOATS_PER_GROUP;
+                cinit[0] = load_g16(g, lane);
+                cinit[1] = load_g16(g + 4 * 64 * 4, lane);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { cinit[0][r] = 0.f; cinit[1][r] = 0.f; }
+            }
+            __syncthreads();                                       // everyone is done with the previous image
+            const int tiles_now = (kind == RNF_KIND_MOBIUS) ? min(KT, MOB_MAX_TILES_IN_LDS) : 1;
+            stage_floats(lds, params, MOB_HEAD_FLOATS + tiles_now * MOB_LAST_TILE_FLOATS, tid, NT);
+            __syncthreads();
+
+            if (kind == RNF_KIND_MOBIUS) {
+                if constexpr (DIR != 0) mobius_inverse<KT_INV>(lds, perm_row, lane, h, cinit, R, ldj);
+                else mobius_forward(lds, params, KT, perm_row, lane, h, cinit, R, ldj, tid, NT);
+            } else {
+                cond16_apply<DIR != 0>(lds, lane, h, cinit, R, ldj);
+            }
+        }
+
+        // epilogue: outputs + fused base density + NLL partial (utils/fisher.py:217-232, agent.py:55-65)
+        if (valid && h == 0) {
+            if (args.rot_out) {
+                float *dst = args.rot_out + sample * 9;
+                dst[0] = R.c0.x; dst[1] = R.c1.x; dst[2] = R.c2.x;
+                dst[3] = R.c0.y; dst[4] = R.c1.y; dst[5] = R.c2.y;
+                dst[6] = R.c0.z; dst[7] = R.c1.z; dst[8] = R.c2.z;
+            }
+            if (args.ldj_out) args.ldj_out[sample] = ldj;
+            if (args.logp_out || args.partials) {
+                float lp = ldj;
+                if (args.fisher_A) {
+                    const long long row = (args.sample_base + sample) / args.fisher_div;
+                    const float *A = args.fisher_A + row * 9;
+                    float tr = R.c0.x * A[0];
+                    tr = fmaf(R.c1.x, A[1], tr); tr = fmaf(R.c2.x, A[2], tr);
+                    tr = fmaf(R.c0.y, A[3], tr); tr = fmaf(R.c1.y, A[4], tr); tr = fmaf(R.c2.y, A[5], tr);
+                    tr = fmaf(R.c0.z, A[6], tr); tr = fmaf(R.c1.z, A[7], tr); tr = fmaf(R.c2.z, A[8], tr);
+                    lp += tr - args.fisher_c[row];
+                }
+                if (args.logp_out) args.logp_out[sample] = lp;
+                dsum += (double)lp;
+            }
+        }
+    }
+
+    if (args.partials) {      // deterministic block partial: wave shuffle tree -> LDS -> thread 0
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dsum += __shfl_down(dsum, off, 64);
+        __syncthreads();
+        double *red = reinterpret_cast<double *>(lds);
+        if (lane == 0) red[wave] = dsum;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int w = 0; w < NW; ++w) s += red[w];
+            args.partials[blockIdx.x] = s;
+        }
+    }
+}
+
+// fixed-order final reduction of the block partials -> out[0] += sum, out[1] += count
+__global__ void nll_finalize_kernel(const double *partials, int nparts, double count, double *out, int accumulate) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = (accumulate ? out[0] : 0.0) + red[0];
+        out[1] = (accumulate ? out[1] : 0.0) + count;
+    }
+}
+
+}  // namespace rnf

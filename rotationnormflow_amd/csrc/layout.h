@@ -1,0 +1,74 @@
+// layout.h -- packed-parameter layout shared by the host packers (api) and the gfx950 kernels.
+//
+// All GEMMs of the conditioner MLP (flow/condition.py:24-30) run on v_mfma_f32_32x32x2_f32 in the orientation
+//     D[out feature i][sample j] += A[i][k] * B[k][j]        (A = weights, B = activations)
+// Lane l = (j = l & 31, h = l >> 5).  Hardware maps (cdna_hip_programming.md section 3):
+//     A operand: lane (i,h) supplies A[i][k = h]      B operand: lane (j,h) supplies B[k = h][j]
+//     D/C      : lane (j,h), register r (0..15) holds D[row = rho(r,h)][col = j],  rho(r,h) = (r&3) + 8*(r>>2) + 4*h
+// so a 64-feature activation is two f32x16 tiles per lane and register r of tile t holds feature 32t + rho(r,h).
+// Feeding that register as the B operand of k-step (t,r) of the next layer therefore needs NO lane movement as
+// long as the A operand of that step is W[out][32t + rho(r,h)].  Four consecutive steps r = 4g..4g+3 read
+// W[out][32t + 8g + 4h + 0..3]: one contiguous float4 of the row-major weight row, so the LDS image of a
+// [OUT][64] weight matrix is, per 32-row out tile `ot` and per k-group tg = 4t+g (0..7):
+//     float4 image[ot][tg][lane] = W[32*ot + (lane&31)][8*tg + 4*(lane>>5) + 0..3]
+// read with one conflict-free ds_read_b128 per 4 MFMAs.
+//
+// fc_first (3 inputs + bias = K of 4 = two k-steps): float2 per lane, image[ot][lane] = (W0[o][h], h ? b0[o] : W0[o][2])
+// with the B operand (h ? y1 : y0) then (h ? 1 : y2).  For a conditional layer the bias slot holds 0 and the bias is
+// folded into the feature projection G = W0[:,3:] f + b0 that initialises the accumulator.
+//
+// Bias of a later layer initialises the accumulator: bias image[ot][h][r] = b[32*ot + rho(r,h)] (16 floats per half).
+//
+// fc_last rows are permuted so that every lane ends up with whole segments: packed row P = 32*tau + 8g + 4h + c
+// (tile tau, register 4g+c of lane-half h) is segment k = 8*tau + 2g + h, component c (0: raw weight, 1..3: w_k[c-1]),
+// i.e. reference row (c == 0 ? k : K + 3k + c - 1)   (flow/mobiusflow.py:58-61).
+#pragma once
+#include <stdint.h>
+
+namespace rnf {
+
+constexpr int HID = 64;                   // flow/condition.py:9
+constexpr int WAVE = 64;
+constexpr int TILE_SAMPLES = 32;          // samples per wave (one MFMA column tile)
+
+// ---- Moebius layer image (floats) ----
+constexpr int MOB_FIRST = 0;                              // [2][64] float2                      = 256
+constexpr int MOB_FIRST_FLOATS = 2 * 64 * 2;
+constexpr int MOB_HID = MOB_FIRST + MOB_FIRST_FLOATS;     // [3][2][8][64] float4                = 12288
+constexpr int MOB_HID_FLOATS = 3 * 2 * 8 * 64 * 4;
+constexpr int MOB_HB = MOB_HID + MOB_HID_FLOATS;          // [3][2][2][16]                       = 192
+constexpr int MOB_HB_FLOATS = 3 * 2 * 2 * 16;
+constexpr int MOB_HEAD_FLOATS = MOB_HB + MOB_HB_FLOATS;   // 12736: everything before fc_last
+constexpr int MOB_LAST = MOB_HEAD_FLOATS;                 // per tile tau: [8][64] float4 (2048) + bias [2][16] (32)
+constexpr int MOB_LAST_TILE_FLOATS = 8 * 64 * 4 + 32;     // 2080
+constexpr int MOB_LAST_TILE_BIAS = 8 * 64 * 4;            // bias offset inside a tile record
+constexpr int MOB_MAX_TILES_IN_LDS = 8;                   // fc_last tiles resident at once (K = 64 -> all of them)
+
+inline constexpr int64_t mobius_packed_floats(int K) { return MOB_HEAD_FLOATS + (int64_t)(K / 8) * MOB_LAST_TILE_FLOATS; }
+
+// ---- unconditional 4x4 affine record ----
+// [0..15] M row-major, [16] log|det M|, [17..32] M^-1, [33] log|det M^-1|, padded to 36
+constexpr int AFF_FLOATS = 36;
+
+// ---- Condition16Trans record: same head as a Moebius layer with an all-zero fc_first image (its whole first layer
+// is the feature projection), then ONE fc_last tile whose rows are M entries: packed row 8g + 4h + c (g = 0,1) is
+// M[2g + h][c]; rows 16..31 are zero padding.
+constexpr int64_t COND16_FLOATS = MOB_HEAD_FLOATS + MOB_LAST_TILE_FLOATS;
+
+// ---- feature projection record (per layer that consumes the feature vector), F padded to a multiple of 8 ----
+// [2][F/8][64] float4 weight image of W0[:, 3:] (or W0 for Condition16Trans), then bias image [2][2][16]
+inline constexpr int64_t featproj_packed_floats(int F) { return F <= 0 ? 0 : (int64_t)2 * (F / 8) * 64 * 4 + 64; }
+
+// ---- feature-projection scratch G (device workspace) ----
+// G[cond_slot][sample_group of 32][ot (2)][q (4)][lane (64)] float4 : register 4q..4q+3 of tile ot of lane
+constexpr int G_FLOATS_PER_GROUP = 2 * 4 * 64 * 4;        // 2048 floats = 64 features x 32 samples
+
+// layer kinds (== RNF_LAYER_* of include/rnf_hip.h)
+constexpr int RNF_KIND_MOBIUS = 1, RNF_KIND_AFFINE16 = 2, RNF_KIND_COND16 = 3;
+
+// layer descriptor columns (include/rnf_hip.h)
+constexpr int D_KIND = 0, D_PERM = 1, D_PARAM = 2, D_SLOT = 3, D_FEAT = 4, D_STRIDE = 6;
+
+inline constexpr int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+}  // namespace rnf

@@ -1,0 +1,440 @@
+// rnf_api.hip -- C ABI of librnf_hip.so (include/rnf_hip.h): host-side parameter packing + kernel launchers.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/rnf_hip.h"
+#include "featproj_kernel.h"
+#include "flow_kernels.h"
+#include "layout.h"
+
+using namespace rnf;
+
+static_assert(RNF_LAYER_MOBIUS == RNF_KIND_MOBIUS && RNF_LAYER_AFFINE16 == RNF_KIND_AFFINE16 &&
+                  RNF_LAYER_AFFINE16_COND == RNF_KIND_COND16 && RNF_DESC_STRIDE == D_STRIDE && RNF_HIDDEN == HID,
+              "include/rnf_hip.h and csrc/layout.h disagree");
+
+// ------------------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail("%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int rnf_abi_version(void) { return RNF_ABI_VERSION; }
+extern "C" const char *rnf_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------------------
+// packing (pure host code)
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int64_t rnf_mobius_packed_floats(int32_t K) { return (K > 0 && K % 8 == 0) ? mobius_packed_floats(K) : -1; }
+extern "C" int64_t rnf_affine16_packed_floats(void) { return AFF_FLOATS; }
+extern "C" int64_t rnf_cond16_packed_floats(void) { return COND16_FLOATS; }
+extern "C" int64_t rnf_featproj_packed_floats(int32_t F) { return (F >= 0 && F % 8 == 0) ? featproj_packed_floats(F) : -1; }
+
+// [OUT=32*n_ot][64] row-major weight rows `rowmap(ot, i)` -> image [ot][tg][lane] float4
+template <typename RowFn>
+static void pack_w64(float *img, int n_ot, RowFn row_of /* (ot, i) -> const float* row of 64 or nullptr */) {
+    for (int ot = 0; ot < n_ot; ++ot)
+        for (int tg = 0; tg < 8; ++tg)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, h = lane >> 5;
+                const float *row = row_of(ot, i);
+                float *dst = img + (((size_t)ot * 8 + tg) * 64 + lane) * 4;
+                for (int c = 0; c < 4; ++c) dst[c] = row ? row[8 * tg + 4 * h + c] : 0.f;
+            }
+}
+
+// bias image [ot][h][16]: b[32*ot + rho(r,h)] (or the mapped row's bias)
+template <typename BiasFn>
+static void pack_bias(float *img, int n_ot, BiasFn bias_of /* (ot, row_in_tile) -> float */) {
+    for (int ot = 0; ot < n_ot; ++ot)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) img[(ot * 2 + h) * 16 + r] = bias_of(ot, rho(r, h));
+}
+
+static void pack_hidden(float *out, const float *const w[3], const float *const b[3]) {
+    for (int L = 0; L < 3; ++L) {
+        const float *W = w[L];
+        pack_w64(out + MOB_HID + (size_t)L * 2 * 8 * 64 * 4, 2, [&](int ot, int i) { return W + (size_t)(32 * ot + i) * 64; });
+        const float *B = b[L];
+        pack_bias(out + MOB_HB + L * 2 * 2 * 16, 2, [&](int ot, int row) { return B[32 * ot + row]; });
+    }
+}
+
+// feature projection record: weights Wf [64][ldw] starting at column col0, F columns; bias b0 [64]
+static void pack_featproj(float *out, const float *W, int ldw, int col0, int F, const float *b0) {
+    const int ng = F / 8;
+    for (int ot = 0; ot < 2; ++ot)
+        for (int tg = 0; tg < ng; ++tg)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, h = lane >> 5;
+                float *dst = out + (((size_t)ot * ng + tg) * 64 + lane) * 4;
+                for (int c = 0; c < 4; ++c) dst[c] = W[(size_t)(32 * ot + i) * ldw + col0 + 8 * tg + 4 * h + c];
+            }
+    pack_bias(out + (size_t)2 * ng * 256, 2, [&](int ot, int row) { return b0[32 * ot + row]; });
+}
+
+extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
+                               const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
+                               const float *fc_last_w, const float *fc_last_b, int32_t K, int32_t F, float *out,
+                               float *out_feat) {
+    if (K <= 0 || K % 8) return fail("rnf_pack_mobius: segments=%d must be a positive multiple of 8", K);
+    if (F < 0 || F % 8) return fail("rnf_pack_mobius: feature_dim=%d must be a multiple of 8 (pad on the host)", F);
+    const int ni = 3 + F;
+    // fc_first: float2 per lane = (W0[o][h], h ? b0[o] : W0[o][2]); conditional layers carry b0 in the projection
+    for (int ot = 0; ot < 2; ++ot)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int o = 32 * ot + (lane & 31), h = lane >> 5;
+            float *dst = out + MOB_FIRST + (ot * 64 + lane) * 2;
+            dst[0] = fc_first_w[(size_t)o * ni + h];
+            dst[1] = h ? (F ? 0.f : fc_first_b[o]) : fc_first_w[(size_t)o * ni + 2];
+        }
+    const float *hw[3] = {l1_w, l3_w, l5_w};
+    const float *hb[3] = {l1_b, l3_b, l5_b};
+    pack_hidden(out, hw, hb);
+    // fc_last: packed row P = 32*tau + 8g + 4h + c  <->  segment k = 8*tau + 2g + h, component c
+    auto src_row = [&](int tau, int row) {
+        const int g = row >> 3, h = (row >> 2) & 1, c = row & 3;
+        const int k = 8 * tau + 2 * g + h;
+        return c == 0 ? k : K + 3 * k + (c - 1);
+    };
+    for (int tau = 0; tau < K / 8; ++tau) {
+        float *rec = out + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS;
+        pack_w64(rec, 1, [&](int, int i) { return fc_last_w + (size_t)src_row(tau, i) * 64; });
+        pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) { return fc_last_b[src_row(tau, row)]; });
+    }
+    if (F) pack_featproj(out_feat, fc_first_w, ni, 3, F, fc_first_b);
+    return 0;
+}
+
+extern "C" int rnf_pack_cond16(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
+                               const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
+                               const float *fc_last_w, const float *fc_last_b, int32_t F, float *out, float *out_feat) {
+    if (F <= 0 || F % 8) return fail("rnf_pack_cond16: feature_dim=%d must be a positive multiple of 8", F);
+    std::memset(out, 0, sizeof(float) * COND16_FLOATS);        // zero fc_first image: x0 comes from the projection
+    const float *hw[3] = {l1_w, l3_w, l5_w};
+    const float *hb[3] = {l1_b, l3_b, l5_b};
+    pack_hidden(out, hw, hb);
+    // one fc_last tile: packed row 8g + 4h + c (g = 0,1) <-> M[2g + h][c] = output 4*(2g+h) + c; rows >= 16 zero
+    auto src_row = [&](int row) {
+        if (row >= 16) return -1;
+        const int g = row >> 3, h = (row >> 2) & 1, c = row & 3;
+        return 4 * (2 * g + h) + c;
+    };
+    float *rec = out + MOB_LAST;
+    pack_w64(rec, 1, [&](int, int i) { int s = src_row(i); return s < 0 ? (const float *)nullptr : fc_last_w + (size_t)s * 64; });
+    pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) { int s = src_row(row); return s < 0 ? 0.f : fc_last_b[s]; });
+    pack_featproj(out_feat, fc_first_w, F, 0, F, fc_first_b);
+    return 0;
+}
+
+// 4x4 inverse / determinant in double (Gauss-Jordan with partial pivoting)
+static bool inv4_double(const double *m, double *inv, double *det) {
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { a[i][j] = m[4 * i + j]; a[i][4 + j] = (i == j); }
+    double d = 1.0;
+    for (int c = 0; c < 4; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 4; ++r) if (std::fabs(a[r][c]) > std::fabs(a[p][c])) p = r;
+        if (a[p][c] == 0.0) return false;
+        if (p != c) { for (int j = 0; j < 8; ++j) std::swap(a[p][j], a[c][j]); d = -d; }
+        d *= a[c][c];
+        double ip = 1.0 / a[c][c];
+        for (int j = 0; j < 8; ++j) a[c][j] *= ip;
+        for (int r = 0; r < 4; ++r) if (r != c) {
+            double f = a[r][c];
+            for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) inv[4 * i + j] = a[i][4 + j];
+    *det = d;
+    return true;
+}
+
+extern "C" int rnf_pack_affine16(const float *mat16, float *out) {
+    double m[16], inv[16], det;
+    for (int i = 0; i < 16; ++i) m[i] = mat16[i];
+    if (!inv4_double(m, inv, &det)) return fail("rnf_pack_affine16: singular 4x4 matrix");
+    for (int i = 0; i < 16; ++i) { out[i] = mat16[i]; out[17 + i] = (float)inv[i]; }
+    out[16] = (float)std::log(std::fabs(det));
+    out[33] = (float)(-std::log(std::fabs(det)));
+    out[34] = out[35] = 0.f;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------------
+constexpr int NW = 8;                                   // waves per workgroup (2 per SIMD)
+constexpr long long CHUNK_SAMPLES = 1LL << 18;          // samples per launch when a feature projection scratch is needed
+constexpr size_t PARTIALS_BYTES = 4096 * sizeof(double);
+
+static int device_cus() {
+    static int cus = 0;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    });
+    return cus;
+}
+
+extern "C" size_t rnf_workspace_bytes(int64_t n, int32_t n_cond_layers) {
+    size_t bytes = PARTIALS_BYTES;
+    if (n_cond_layers > 0) {
+        long long chunk = n < CHUNK_SAMPLES ? n : CHUNK_SAMPLES;
+        long long groups = (chunk + 255) / 256 * 8;     // whole workgroup tiles
+        bytes += (size_t)n_cond_layers * groups * G_FLOATS_PER_GROUP * sizeof(float);
+    }
+    return bytes;
+}
+
+template <typename K>
+static hipError_t allow_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <int DIR, int KT_INV>
+static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream) {
+    auto kern = flow_stack_kernel<DIR, KT_INV, NW>;
+    HIP_TRY(allow_lds(kern, lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+struct RunOpts {
+    int dir;                  // 0 forward, 1 inverse
+    const float *fisher_A, *fisher_c;
+    int64_t fisher_B;
+    float *logp_out;
+    double *sum_out;
+};
+
+static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, const float *blob, const int32_t *desc,
+                    int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, void *ws, size_t ws_bytes, void *stream_v,
+                    const RunOpts &o) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    if (n < 0) return fail("n=%lld is negative", (long long)n);
+    if (n_layers <= 0 || n_layers > MAX_LAYERS) return fail("n_layers=%d outside [1,%d]", n_layers, MAX_LAYERS);
+    if (K <= 0 || K % 8) return fail("segments=%d must be a positive multiple of 8", K);
+    if (!rot || !blob || !desc) return fail("null rotation / blob / desc pointer");
+    if (o.fisher_A && (o.fisher_B <= 0 || n % o.fisher_B)) return fail("n=%lld not divisible by fisher rows B=%lld (utils/fisher.py:226)", (long long)n, (long long)o.fisher_B);
+
+    FlowArgs a;
+    std::memset(&a, 0, sizeof(a));
+    FeatProjArgs fp;
+    std::memset(&fp, 0, sizeof(fp));
+    int n_slots = 0;
+    bool any_mlp = false;
+    for (int l = 0; l < n_layers; ++l) {
+        const int32_t *d = desc + (size_t)l * D_STRIDE;
+        const int kind = d[D_KIND], perm = d[D_PERM], slot = d[D_SLOT];
+        if (kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16 && kind != RNF_KIND_COND16) return fail("layer %d: unknown kind %d", l, kind);
+        if (perm < 0 || perm > 5) return fail("layer %d: perm_row %d outside [0,5]", l, perm);
+        if (d[D_PARAM] < 0 || d[D_PARAM] % 4) return fail("layer %d: param offset %d must be a non-negative multiple of 4", l, d[D_PARAM]);
+        if (kind == RNF_KIND_COND16 && slot < 0) return fail("layer %d: Condition16Trans needs a cond_slot", l);
+        if (slot >= 0) {
+            if (slot >= MAX_SLOTS) return fail("layer %d: cond_slot %d >= %d", l, slot, MAX_SLOTS);
+            if (d[D_FEAT] < 0 || d[D_FEAT] % 4) return fail("layer %d: feat offset %d invalid", l, d[D_FEAT]);
+            fp.feat_off[slot] = d[D_FEAT];
+            if (slot + 1 > n_slots) n_slots = slot + 1;
+        }
+        if (kind != RNF_KIND_AFFINE16) any_mlp = true;
+        a.layers[l] = make_int2(kind | (perm << 4) | ((slot + 1) << 8), d[D_PARAM]);
+    }
+    if (n_slots > 0) {
+        if (!feat) return fail("this flow consumes a feature vector but feature pointer is null (flow/mobiusflow.py:48-49)");
+        if (F <= 0 || F % 8) return fail("feature_dim=%d must be a positive multiple of 8 (pad on the host)", F);
+    }
+    if (n == 0) {
+        if (o.sum_out) { hipLaunchKernelGGL(nll_finalize_kernel, dim3(1), dim3(256), 0, stream, (const double *)nullptr, 0, 0.0, o.sum_out, 0); }
+        return 0;
+    }
+    if (ws_bytes < rnf_workspace_bytes(n, n_slots) && (n_slots > 0 || o.sum_out))
+        return fail("workspace of %zu bytes is smaller than rnf_workspace_bytes()=%zu", ws_bytes, rnf_workspace_bytes(n, n_slots));
+    if ((n_slots > 0 || o.sum_out) && !ws) return fail("workspace pointer is null");
+
+    const int KT = K / 8;
+    if (o.dir == 1 && any_mlp && !(KT == 1 || KT == 2 || KT == 4 || KT == 8))
+        return fail("inverse pass supports segments in {8,16,32,64}; got %d", K);
+
+    double *partials = reinterpret_cast<double *>(ws);
+    float *G = n_slots ? reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + PARTIALS_BYTES) : nullptr;
+    const int tiles_in_lds = any_mlp ? (KT < MOB_MAX_TILES_IN_LDS ? KT : MOB_MAX_TILES_IN_LDS) : 0;
+    size_t lds_bytes = any_mlp ? sizeof(float) * (MOB_HEAD_FLOATS + (size_t)tiles_in_lds * MOB_LAST_TILE_FLOATS) : 0;
+    if (lds_bytes < NW * sizeof(double)) lds_bytes = NW * sizeof(double) * 2;
+    const int cus = device_cus();
+    const long long chunk_cap = n_slots ? CHUNK_SAMPLES : n;
+
+    a.blob = blob;
+    a.n_layers = n_layers;
+    a.KT = KT;
+    a.fisher_A = o.fisher_A;
+    a.fisher_c = o.fisher_c;
+    a.fisher_div = o.fisher_A ? n / o.fisher_B : 1;
+
+    bool first = true;
+    for (long long base = 0; base < n; base += chunk_cap) {
+        const long long cn = (n - base) < chunk_cap ? (n - base) : chunk_cap;
+        const long long ntiles = (cn + NW * 32 - 1) / (NW * 32);
+        const long long groups = ntiles * NW;
+        int grid = (int)(ntiles < cus ? ntiles : cus);
+        if (n_slots) {
+            fp.feat = feat + base * F;
+            fp.blob = blob;
+            fp.G = G;
+            fp.n = cn;
+            fp.g_groups = groups;
+            fp.F = F;
+            fp.n_slots = n_slots;
+            size_t fl = sizeof(float) * (size_t)(F < FP_KCHUNK ? F : FP_KCHUNK) / 8 * 256;
+            auto kern = featproj_kernel<NW>;
+            HIP_TRY(allow_lds(kern, fl));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), fl, stream, fp);
+            HIP_TRY(hipGetLastError());
+        }
+        a.rot_in = rot + base * 9;
+        a.G = G;
+        a.rot_out = rot_out ? rot_out + base * 9 : nullptr;
+        a.ldj_out = ldj_out ? ldj_out + base : nullptr;
+        a.logp_out = o.logp_out ? o.logp_out + base : nullptr;
+        a.partials = o.sum_out ? partials : nullptr;
+        a.n = cn;
+        a.sample_base = base;
+        a.g_groups = groups;
+        int rc;
+        if (o.dir == 0) rc = launch_stack<0, 0>(a, grid, lds_bytes, stream);
+        else if (KT == 1) rc = launch_stack<1, 1>(a, grid, lds_bytes, stream);
+        else if (KT == 2) rc = launch_stack<1, 2>(a, grid, lds_bytes, stream);
+        else if (KT == 4) rc = launch_stack<1, 4>(a, grid, lds_bytes, stream);
+        else rc = launch_stack<1, 8>(a, grid, lds_bytes, stream);
+        if (rc) return rc;
+        if (o.sum_out) {
+            hipLaunchKernelGGL(nll_finalize_kernel, dim3(1), dim3(256), 0, stream, (const double *)partials, grid, (double)cn, o.sum_out, first ? 0 : 1);
+            HIP_TRY(hipGetLastError());
+        }
+        first = false;
+    }
+    return 0;
+}
+
+extern "C" int rnf_flow_forward(const float *rot, const float *feat, int64_t n, int32_t F, const float *blob,
+                                const int32_t *desc, int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, void *ws,
+                                size_t ws_bytes, void *stream) {
+    RunOpts o{0, nullptr, nullptr, 0, nullptr, nullptr};
+    return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
+}
+
+extern "C" int rnf_flow_inverse(const float *rot, const float *feat, int64_t n, int32_t F, const float *blob,
+                                const int32_t *desc, int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, void *ws,
+                                size_t ws_bytes, void *stream) {
+    RunOpts o{1, nullptr, nullptr, 0, nullptr, nullptr};
+    return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
+}
+
+extern "C" int rnf_flow_log_prob(const float *rot, const float *feat, int64_t n, int32_t F, const float *blob,
+                                 const int32_t *desc, int32_t n_layers, int32_t K, const float *fisher_A,
+                                 const float *fisher_c, int64_t fisher_B, float *rot_out, float *ldj_out, float *logp_out,
+                                 double *sum_out, void *ws, size_t ws_bytes, void *stream) {
+    if ((fisher_A == nullptr) != (fisher_c == nullptr)) return fail("fisher_A and fisher_c must both be given or both be null");
+    RunOpts o{0, fisher_A, fisher_c, fisher_B, logp_out, sum_out};
+    return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// small standalone kernels
+// ------------------------------------------------------------------------------------------------------------
+__global__ void fisher_log_prob_kernel(const float *rot, long long n, const float *A, const float *c, long long div, float *out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const long long row = i / div;
+        float tr = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) tr = fmaf(rot[i * 9 + k], A[row * 9 + k], tr);
+        out[i] = tr - c[row];
+    }
+}
+
+extern "C" int rnf_fisher_log_prob(const float *rot, int64_t n, const float *A, const float *c, int64_t B, float *out, void *stream) {
+    if (!rot || !A || !c || !out) return fail("rnf_fisher_log_prob: null pointer");
+    if (B <= 0 || n % B) return fail("n=%lld not divisible by fisher rows B=%lld (utils/fisher.py:226)", (long long)n, (long long)B);
+    if (n == 0) return 0;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fisher_log_prob_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rot, (long long)n, A, c, (long long)(n / B), out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ConditionalTransform alone: y [n,3] -> [n,4K] in the reference's row order (bring-up / unit test of the MFMA chain)
+template <int NWc>
+__global__ __launch_bounds__(NWc * 64) void conditioner_kernel(const float *y, long long n, const float *layer, int KT, int K, float *out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const long long ntiles = (n + NWc * 32 - 1) / (NWc * 32);
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long sample = (tile * NWc + wave) * 32 + j;
+        const bool valid = sample < n;
+        float y0 = 0.f, y1 = 0.f, y2 = 0.f;
+        if (valid) { y0 = y[sample * 3]; y1 = y[sample * 3 + 1]; y2 = y[sample * 3 + 2]; }
+        __syncthreads();
+        stage_floats(lds, layer, MOB_HEAD_FLOATS, tid, NWc * 64);
+        __syncthreads();
+        f32x16 cinit[2], tt[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { cinit[0][r] = 0.f; cinit[1][r] = 0.f; }
+        mlp_head(lds, lane, h, y0, y1, y2, cinit, tt);
+        for (int tau = 0; tau < KT; ++tau) {
+            __syncthreads();
+            stage_floats(lds + MOB_LAST, layer + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS, MOB_LAST_TILE_FLOATS, tid, NWc * 64);
+            __syncthreads();
+            f32x16 o = last_tile(lds + MOB_LAST, lane, h, tt);
+            if (valid) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int k = 8 * tau + 2 * g + h;
+                        const int row = c == 0 ? k : K + 3 * k + (c - 1);
+                        out[sample * 4 * K + row] = o[4 * g + c];
+                    }
+            }
+        }
+    }
+}
+
+extern "C" int rnf_conditioner_forward(const float *y, int64_t n, const float *layer, int32_t K, float *out, void *stream) {
+    if (K <= 0 || K % 8) return fail("segments=%d must be a positive multiple of 8", K);
+    if (!y || !layer || !out) return fail("rnf_conditioner_forward: null pointer");
+    if (n == 0) return 0;
+    const size_t lds_bytes = sizeof(float) * (MOB_HEAD_FLOATS + MOB_LAST_TILE_FLOATS);
+    auto kern = conditioner_kernel<NW>;
+    HIP_TRY(allow_lds(kern, lds_bytes));
+    long long ntiles = (n + NW * 32 - 1) / (NW * 32);
+    int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, reinterpret_cast<hipStream_t>(stream), y, (long long)n, layer, K / 8, K, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

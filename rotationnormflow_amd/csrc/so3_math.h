@@ -1,0 +1,179 @@
+// so3_math.h -- per-sample device math of the flow layers (gfx950, one rotation per lane pair).
+// Citations are to the reference tree (flow/..., utils/...) and to SURVEY.md Appendix A.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#define RNF_HD __host__ __device__ __forceinline__
+
+namespace rnf {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kTwoPi = 6.28318530717958647692f;
+
+// torch.nn.functional.softplus(beta=1, threshold=20): flow/mobiusflow.py:69
+RNF_HD float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// sin and cos for |x| <= ~16 (the layer only needs [0, 2pi)): quadrant reduction with a 3-term Cody-Waite split of
+// pi/2 and the classic single-precision minimax polynomials on [-pi/4, pi/4] (~1 ulp).  Replaces libm sincosf, whose
+// huge-argument path costs a private-memory (scratch) table on gfx950.
+RNF_HD void sincos_small(float x, float &sn, float &cs) {
+    const float k = rintf(x * 0.636619772367581343f);            // x * 2/pi
+    float r = fmaf(-k, 1.5703125f, x);
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.54978995489188216e-8f, r);
+    const float r2 = r * r;
+    float ps = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+    ps = fmaf(ps * r2, r, r);
+    float pc = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+    pc = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    const int q = (int)k;
+    const float s1 = (q & 1) ? pc : ps;
+    const float c1 = (q & 1) ? ps : pc;
+    sn = (q & 2) ? -s1 : s1;
+    cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
+// The rotation state: three column vectors kept as SSA vector values (never an indexable array: hipcc turns a
+// select chain over array elements into a scratch-memory lookup).  Columns, not rows, are what the coupling layers
+// read and write (flow/mobiusflow.py:50-51,80-83).
+typedef float v3f __attribute__((ext_vector_type(3)));
+struct Rot {
+    v3f c0, c1, c2;
+};
+// Operands BY VALUE on purpose: with a pointer/reference argument the optimizer (which simplifies this function before
+// it is inlined) folds the three conditional loads into ONE load at a computed address, and the whole rotation state
+// is demoted from registers to scratch memory.  The same happens with `p == 0 ? R.c0 : ...` (an lvalue conditional).
+RNF_HD v3f pick_col(v3f c0, v3f c1, v3f c2, int p) {
+    v3f out = c2;
+    if (p == 0) out = c0;
+    if (p == 1) out = c1;
+    return out;
+}
+RNF_HD v3f get_col(const Rot &R, int p) { return pick_col(R.c0, R.c1, R.c2, p); }
+RNF_HD void set_col(Rot &R, int p, v3f c) {
+    if (p == 0) R.c0 = c;
+    if (p == 1) R.c1 = c;
+    if (p == 2) R.c2 = c;
+}
+RNF_HD float dot3(v3f a, v3f b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+RNF_HD v3f cross3(v3f a, v3f b) {
+    v3f c;
+    c.x = a.y * b.z - a.z * b.y;
+    c.y = a.z * b.x - a.x * b.z;
+    c.z = a.x * b.y - a.y * b.x;
+    return c;
+}
+RNF_HD v3f normalize3(v3f a) { return a * (1.0f / sqrtf(dot3(a, a))); }
+
+// In-plane frame of a Moebius layer (flow/mobiusflow.py:64-67,148-151): r = -x/|x|, v = (y x r)/|y x r|.
+// Everything the layer does lives in span(r, v) (the plane orthogonal to y), so segments are handled in 2-D
+// coordinates (a.r, a.v); the projection (I - y y^T) w of mobiusflow.py:62-63 is implied by taking w.r and w.v.
+struct Frame {
+    v3f r, v;
+};
+RNF_HD Frame make_frame(v3f x, v3f y) {
+    Frame f;
+    f.r = x * (-1.0f / sqrtf(dot3(x, x)));
+    f.v = normalize3(cross3(y, f.r));
+    return f;
+}
+
+// One segment's squashed centre in frame coordinates: w <- 0.7/(1+|w|) w (flow/mobiusflow.py:72).
+RNF_HD void squash_center(float w0, float w1, float w2, const Frame &f, float &ur, float &uv) {
+    float wr = fmaf(w2, f.r.z, fmaf(w1, f.r.y, w0 * f.r.x));
+    float wv = fmaf(w2, f.v.z, fmaf(w1, f.v.y, w0 * f.v.x));
+    float sc = 0.7f / (1.0f + sqrtf(fmaf(wv, wv, wr * wr)));
+    ur = wr * sc;
+    uv = wv * sc;
+}
+
+// Moebius map of the point (zr, zv) about centre (ur, uv) (flow/mobiusflow.py:17-24) -> wrapped angle in [0, 2pi)
+// (mobiusflow.py:94-99) and the scalar c = (1-|w|^2)/|z-w|^2, which is also the segment's |dh/dtheta|
+// (identity checked in tests/test_oracle_golden.py::test_closed_form_ldj_identity).
+RNF_HD void mobius_angle(float zr, float zv, float ur, float uv, float &phi, float &c) {
+    float u2 = fmaf(uv, uv, ur * ur);
+    float dr = zr - ur, dv = zv - uv;
+    float d2 = fmaf(dv, dv, dr * dr);
+    c = (1.0f - u2) / d2;
+    float hr = fmaf(c, dr, -ur);
+    float hv = fmaf(c, dv, -uv);
+    float a = atan2f(hv, hr);
+    phi = a < 0.0f ? a + kTwoPi : a;
+}
+
+// pytorch3d.transforms.matrix_to_quaternion (published 0.7.5 rule; call site flow/squeezetrans.py:34):
+// four candidates from sqrt(max(0, 1 +- m00 +- m11 +- m22)), keep the one with the largest |q_i| (first on ties),
+// denominators floored at 0.1.  Real part first.
+RNF_HD void rot_to_quat(const Rot &R, float (&q)[4]) {
+    const float m00 = R.c0.x, m01 = R.c1.x, m02 = R.c2.x, m10 = R.c0.y, m11 = R.c1.y, m12 = R.c2.y, m20 = R.c0.z, m21 = R.c1.z, m22 = R.c2.z;
+    float a0 = sqrtf(fmaxf(1.0f + m00 + m11 + m22, 0.0f));
+    float a1 = sqrtf(fmaxf(1.0f + m00 - m11 - m22, 0.0f));
+    float a2 = sqrtf(fmaxf(1.0f - m00 + m11 - m22, 0.0f));
+    float a3 = sqrtf(fmaxf(1.0f - m00 - m11 + m22, 0.0f));
+    int best = 0;
+    float ab = a0;
+    if (a1 > ab) { ab = a1; best = 1; }
+    if (a2 > ab) { ab = a2; best = 2; }
+    if (a3 > ab) { ab = a3; best = 3; }
+    float s01 = m21 - m12, s02 = m02 - m20, s03 = m10 - m01;   // row 0 off-diagonals
+    float p12 = m10 + m01, p13 = m02 + m20, p23 = m12 + m21;
+    float c0, c1, c2, c3;
+    if (best == 0)      { c0 = a0 * a0; c1 = s01;     c2 = s02;     c3 = s03; }
+    else if (best == 1) { c0 = s01;     c1 = a1 * a1; c2 = p12;     c3 = p13; }
+    else if (best == 2) { c0 = s02;     c1 = p12;     c2 = a2 * a2; c3 = p23; }
+    else                { c0 = s03;     c1 = p13;     c2 = p23;     c3 = a3 * a3; }
+    float inv = 1.0f / (2.0f * fmaxf(ab, 0.1f));
+    q[0] = c0 * inv; q[1] = c1 * inv; q[2] = c2 * inv; q[3] = c3 * inv;
+}
+
+// pytorch3d.transforms.quaternion_to_matrix (scale invariant: two_s = 2/|q|^2), call site flow/squeezetrans.py:37
+RNF_HD void quat_to_rot(const float (&q)[4], float l2, Rot &R) {
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    const float s2 = 2.0f / l2;
+    R.c0.x = 1.0f - s2 * (y * y + z * z); R.c1.x = s2 * (x * y - z * w);        R.c2.x = s2 * (x * z + y * w);
+    R.c0.y = s2 * (x * y + z * w);        R.c1.y = 1.0f - s2 * (x * x + z * z); R.c2.y = s2 * (y * z - x * w);
+    R.c0.z = s2 * (x * z - y * w);        R.c1.z = s2 * (y * z + x * w);        R.c2.z = 1.0f - s2 * (x * x + y * y);
+}
+
+// calculate_16 (flow/squeezetrans.py:33-38) with a given 4x4 M (row-major) and log|det M|:
+// q' = M q(R); R' = R(q'/|q'|); ldj = log|det M| - 4 log|q'| = log|det M| - 2 log|q'|^2
+RNF_HD void affine16_apply(const float (&M)[16], float logabsdet, Rot &R, float &ldj) {
+    float q[4], t[4];
+    rot_to_quat(R, q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        t[i] = fmaf(M[4 * i + 3], q[3], fmaf(M[4 * i + 2], q[2], fmaf(M[4 * i + 1], q[1], M[4 * i] * q[0])));
+    float l2 = fmaf(t[3], t[3], fmaf(t[2], t[2], fmaf(t[1], t[1], t[0] * t[0])));
+    quat_to_rot(t, l2, R);
+    ldj += logabsdet - 2.0f * logf(l2);
+}
+
+// 4x4 inverse and determinant by cofactors (Condition16Trans.inverse: torch.linalg.inv, flow/squeezetrans.py:51-55;
+// my_det_4_4: squeezetrans.py:17-22).  Returns det(M); Minv = adj(M)/det.
+RNF_HD float inv4(const float (&m)[16], float (&o)[16]) {
+    float s0 = m[0] * m[5] - m[4] * m[1],  s1 = m[0] * m[6] - m[4] * m[2],  s2 = m[0] * m[7] - m[4] * m[3];
+    float s3 = m[1] * m[6] - m[5] * m[2],  s4 = m[1] * m[7] - m[5] * m[3],  s5 = m[2] * m[7] - m[6] * m[3];
+    float c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11], c3 = m[9] * m[14] - m[13] * m[10];
+    float c2 = m[8] * m[15] - m[12] * m[11],  c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
+    float det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    float id = 1.0f / det;
+    o[0]  = ( m[5] * c5 - m[6] * c4 + m[7] * c3) * id;
+    o[1]  = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
+    o[2]  = ( m[13] * s5 - m[14] * s4 + m[15] * s3) * id;
+    o[3]  = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * id;
+    o[4]  = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;
+    o[5]  = ( m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
+    o[6]  = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id;
+    o[7]  = ( m[8] * s5 - m[10] * s2 + m[11] * s1) * id;
+    o[8]  = ( m[4] * c4 - m[5] * c2 + m[7] * c0) * id;
+    o[9]  = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
+    o[10] = ( m[12] * s4 - m[13] * s2 + m[15] * s0) * id;
+    o[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * id;
+    o[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * id;
+    o[13] = ( m[0] * c3 - m[1] * c1 + m[2] * c0) * id;
+    o[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * id;
+    o[15] = ( m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
+    return det;
+}
+
+}  // namespace rnf

@@ -1,0 +1,44 @@
+"""Mirror of the reference's flow/condition.py: the conditioner MLP as a *parameter container*.
+
+State-dict names match the reference exactly (``fc_first``, ``layers.{1,3,5}``, ``fc_last``; flow/condition.py:14-22)
+so published checkpoints load unchanged.  The arithmetic (flow/condition.py:24-30) never runs in PyTorch: the owning
+layer packs these tensors into the kernel blob (runtime.pack_mobius / pack_cond16) and the MLP executes on the fp32
+matrix cores inside the fused stack kernel.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib, runtime
+
+
+class ConditionalTransform(nn.Module):
+    """ConditionalTransform(Ni, No, Nh=64): Linear(Ni,64) -> [ReLU, Linear(64,64)] x3 -> ReLU(residual) -> Linear(64,No)."""
+
+    def __init__(self, Ni, No, Nh=64):
+        super().__init__()
+        if Nh != 64:
+            raise NotImplementedError("the HIP kernels are built for the reference's hidden width Nh=64")
+        self.Ni, self.No = Ni, No
+        self.fc_first = nn.Linear(Ni, Nh)
+        # same module indices as the reference (ReLU at 0/2/4, Linear at 1/3/5) => same state-dict keys
+        self.layers = nn.ModuleList([nn.ReLU(), nn.Linear(Nh, Nh), nn.ReLU(), nn.Linear(Nh, Nh), nn.ReLU(), nn.Linear(Nh, Nh)])
+        self.relu_last = nn.ReLU()
+        self.fc_last = nn.Linear(Nh, No)
+
+    def forward(self, x):
+        """Standalone evaluation on the GPU; supported for the unconditional Moebius conditioner shape (Ni=3, No=4K)."""
+        if self.Ni != 3 or self.No % 32:
+            raise NotImplementedError("standalone ConditionalTransform.forward is only built for Ni=3, No=4K (K%8==0); "
+                                      "inside a flow the MLP runs fused in the stack kernel")
+        if not x.is_cuda:
+            raise RuntimeError("rotationnormflow_amd runs on the GPU only (no CPU fallback)")
+        K = self.No // 4
+        L = _lib.lib()
+        rec, _ = runtime.pack_mobius(L, self, K, 0)
+        y = x.reshape(-1, 3).float().contiguous()
+        blob = torch.from_numpy(rec).to(y.device)
+        out = torch.empty(y.shape[0], self.No, dtype=torch.float32, device=y.device)
+        with torch.cuda.device(y.device):
+            _lib.check(L.rnf_conditioner_forward(y.data_ptr(), y.shape[0], blob.data_ptr(), K, out.data_ptr(),
+                                                 torch.cuda.current_stream(y.device).cuda_stream))
+        return out

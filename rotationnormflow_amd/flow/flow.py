@@ -1,0 +1,107 @@
+"""Mirror of the reference's flow/flow.py: ``get_flow`` and ``Flow``.
+
+``Flow(config)`` builds the same ModuleList (same order, same state-dict keys) as flow/flow.py:19-51; ``forward`` /
+``inverse`` keep the reference signatures and return ``(rotation' [N,3,3], ldjs [N])`` but the whole layer stack runs
+as ONE fused HIP kernel launch (rnf_flow_forward / rnf_flow_inverse).  ``log_prob`` is the fused density evaluation
+(flow + matrix-Fisher base + NLL sum) used by the benchmark and by rotationnormflow_amd.dist.
+"""
+import torch
+from torch import nn
+
+from .. import runtime
+from .affineflow import get_affine
+from .mobiusflow import MobiusFlow, get_mobius
+
+
+def get_flow(config):
+    return Flow(config)
+
+
+_permute_prop = torch.tensor(runtime.PERMUTE_ROWS, dtype=torch.long)     # flow/flow.py:13-15
+
+
+class Flow(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.condition = config.condition
+        self._permute = _permute_prop
+        n_blocks = config.layers
+
+        if self.condition:                                               # flow/flow.py:29-34
+            self.feature_dim = 32 if config.feature_dim is None else config.feature_dim
+            if config.embedding:
+                self.feature_dim += config.embedding_dim
+        else:
+            self.feature_dim = 0
+
+        stack = []
+        if config.last_affine:                                           # flow/flow.py:37-39 (appended unguarded)
+            stack.append(get_affine(config, self.feature_dim, first_layer_condition=True))
+        for i in range(n_blocks):                                        # flow/flow.py:41-48
+            mob = get_mobius(config, self.feature_dim)
+            if mob is not None:
+                stack.append(mob)
+            aff = get_affine(config, self.feature_dim)
+            if aff is not None and (i != n_blocks - 1 or config.first_affine):
+                stack.append(aff)
+        print("total layers of flow: ", len(stack))                      # flow/flow.py:50
+        if any(layer is None for layer in stack):
+            # the reference appends None here and dies with TypeError at the first call (flow.py:38,65)
+            raise TypeError(f"rot={config.rot!r} with last_affine=1 yields no first affine layer ('NoneType' object is not callable)")
+        self.layers = nn.ModuleList(stack)
+        self._cache = runtime.PackCache()
+
+    # ---- permutation schedule (flow/flow.py:58-70 and 77-90) ------------------------------------------------------
+    def _forward_rows(self):
+        rows, count = [], 0
+        for layer in self.layers:
+            rows.append(count % 6)
+            if isinstance(layer, MobiusFlow) or self.config.frequent_permute:
+                count += 1
+        return rows
+
+    def _inverse_rows(self):
+        rows = [0] * len(self.layers)
+        count = len(self.layers) if self.config.frequent_permute else self.config.layers
+        for i in reversed(range(len(self.layers))):
+            if isinstance(self.layers[i], MobiusFlow) or self.config.frequent_permute:
+                count -= 1
+            rows[i] = count % 6
+        return rows
+
+    def _packed(self, device):
+        def build():
+            rows = self._forward_rows()
+            inv = self._inverse_rows()
+            # Moebius layers are the only ones that read the row; forward and inverse schedules agree on them
+            for layer, a, b in zip(self.layers, rows, inv):
+                if isinstance(layer, MobiusFlow) and a % 3 != b % 3:
+                    raise RuntimeError("forward/inverse permutation schedules disagree (flow/flow.py:58-90)")
+            return runtime.pack_layers(list(self.layers), rows, device)
+        return self._cache.get(self, device, build)
+
+    # ---- reference API ----------------------------------------------------------------------------------------------
+    def forward(self, rotation, feature=None, inverse=False, draw=False):
+        if inverse:
+            return self.inverse(rotation, feature, draw)
+        if not self.condition:
+            feature = None
+        return runtime.run_flow(self, self._packed(rotation.device), rotation, feature, inverse=False)
+
+    def inverse(self, rotation, feature=None, draw=False):
+        if not self.condition:
+            feature = None
+        return runtime.run_flow(self, self._packed(rotation.device), rotation, feature, inverse=True)
+
+    # ---- fused density evaluation (agent.py:54-65,217-229 + utils/fisher.py:217-232) -------------------------
+    def log_prob(self, rotation, feature=None, base=None, return_rotation=False):
+        """Per-sample log p(R) = ldj + base(R') and {sum, count} in fp64, in one launch.
+        ``base``: None (uniform) or a ``MatrixFisherN``.  Returns dict(logp, sum, rotation, ldj)."""
+        if not self.condition:
+            feature = None
+        A = c = None
+        if base is not None:
+            A, c = base.A, base.log_const()
+        return runtime.run_log_prob(self, self._packed(rotation.device), rotation, feature, A, c,
+                                    want_rotation=return_rotation, want_ldj=False, want_logp=True)

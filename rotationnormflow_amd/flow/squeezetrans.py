@@ -1,0 +1,72 @@
+"""Mirror of the reference's flow/squeezetrans.py (4x4 quaternion-affine family; the other variants are declared
+but not yet built as kernels and fail loudly)."""
+import torch
+import torch.nn as nn
+
+from .. import runtime
+from .condition import ConditionalTransform
+from .mobiusflow import _SingleLayer
+
+
+class Uncondition16Trans(nn.Module, _SingleLayer):
+    """q' = M q, R' = R(q'/|q'|), ldj = log|det M| - 4 log|q'| with one learned 4x4 M (flow/squeezetrans.py:161-174)."""
+
+    _rnf_kind = runtime.KIND_AFFINE16
+
+    def __init__(self):
+        super().__init__()
+        self.mat = nn.Parameter(torch.eye(4).unsqueeze(0) + torch.randn(1, 4, 4) * 1e-3)
+        self._cache = runtime.PackCache()
+
+    def _rnf_pack(self, L):
+        return runtime.pack_affine16(L, self.mat), None, 0, 0
+
+    def forward(self, rotation, permute=None, feature=None):
+        return self._single(rotation, permute, None, inverse=False)
+
+    def inverse(self, rotation, permute=None, feature=None):
+        return self._single(rotation, permute, None, inverse=True)
+
+
+class Condition16Trans(nn.Module, _SingleLayer):
+    """M = I + reshape(MLP(feature), 4, 4) per sample (flow/squeezetrans.py:41-55)."""
+
+    _rnf_kind = runtime.KIND_COND16
+
+    def __init__(self, feature_dim):
+        super().__init__()
+        self.feature_dim = feature_dim
+        self.net = ConditionalTransform(feature_dim, 16)
+        self._cache = runtime.PackCache()
+
+    def _rnf_pack(self, L):
+        rec, frec = runtime.pack_cond16(L, self.net, self.feature_dim)
+        return rec, frec, self.feature_dim, 0
+
+    def forward(self, rotation, permute=None, feature=None):
+        return self._single(rotation, permute, feature, inverse=False)
+
+    def inverse(self, rotation, permute=None, feature=None):
+        return self._single(rotation, permute, feature, inverse=True)
+
+
+def _not_built(name, where):
+    class _Unbuilt(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+            raise NotImplementedError(
+                f"{name} ({where}) has no HIP kernel yet and rotationnormflow_amd has no PyTorch fallback; "
+                "supported affine layers: rot='16Trans' / '16UnTrans' with lu=0")
+    _Unbuilt.__name__ = _Unbuilt.__qualname__ = name
+    return _Unbuilt
+
+
+# declared so that the registry (flow/affineflow.py:5-73) resolves every name; constructing them fails loudly
+Uncondition16TransLU = _not_built("Uncondition16TransLU", "flow/squeezetrans.py:146-158")
+Condition16TransLU = _not_built("Condition16TransLU", "flow/squeezetrans.py:130-143")
+Uncondition36Trans = _not_built("Uncondition36Trans", "flow/squeezetrans.py:350-361")
+Condition36Trans = _not_built("Condition36Trans", "flow/squeezetrans.py:334-347")
+Uncondition9Trans = _not_built("Uncondition9Trans", "flow/squeezetrans.py:250-261")
+Condition9Trans = _not_built("Condition9Trans", "flow/squeezetrans.py:234-247")
+Uncondition9TransLU = _not_built("Uncondition9TransLU", "flow/squeezetrans.py:264-275")
+Condition9TransLU = _not_built("Condition9TransLU", "flow/squeezetrans.py:278-291")

@@ -1,0 +1,250 @@
+"""Host runtime: pack module parameters into the kernel blob, keep it fresh, launch through the C ABI.
+
+PyTorch is used here only as plumbing: device memory (tensors), the current HIP stream, and parameter storage.
+"""
+from __future__ import annotations
+
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+
+KIND_MOBIUS, KIND_AFFINE16, KIND_COND16 = 1, 2, 3
+DESC_STRIDE = 6
+
+# flow/flow.py:13-15 -- the 6x3 permutation table; row m is the cyclic shift (m, m+1, m+2) mod 3
+PERMUTE_ROWS = ((0, 1, 2), (1, 2, 0), (2, 0, 1), (0, 1, 2), (1, 2, 0), (2, 0, 1))
+
+
+def _np32(t) -> np.ndarray:
+    return np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+
+
+def _pad_cols(w: np.ndarray, first: int, feat: int, feat_padded: int) -> np.ndarray:
+    """[64, first+feat] -> [64, first+feat_padded] with zero columns appended (feature_dim not a multiple of 8)."""
+    if feat == feat_padded:
+        return w
+    out = np.zeros((w.shape[0], first + feat_padded), dtype=np.float32)
+    out[:, : first + feat] = w
+    return out
+
+
+def pad8(f: int) -> int:
+    return (f + 7) // 8 * 8
+
+
+class PackedFlow:
+    """Device blob + host layer table for one (module list, device, parameter version)."""
+
+    def __init__(self, blob, desc, n_cond, feat_dim, feat_padded, segments):
+        self.blob = blob                      # torch.float32 [P] on the device
+        self.desc = desc                      # np.int32 [L, 6] (host, C-contiguous; passed by pointer)
+        self.n_layers = desc.shape[0]
+        self.n_cond = n_cond
+        self.feat_dim = feat_dim
+        self.feat_padded = feat_padded
+        self.segments = segments
+
+
+def pack_layers(layers, perm_rows, device) -> PackedFlow:
+    """layers: product layer modules (each has ``_rnf_kind`` and ``_rnf_pack``); perm_rows: forward permutation row per layer."""
+    L = _lib.lib()
+    records, feat_records = [], []
+    desc = np.zeros((len(layers), DESC_STRIDE), dtype=np.int32)
+    feat_dim = 0
+    segments = 8
+    slot = 0
+    for i, layer in enumerate(layers):
+        kind = layer._rnf_kind
+        rec, feat_rec, fdim, segs = layer._rnf_pack(L)
+        if segs:
+            if segments != 8 and segs != segments and any(l._rnf_kind == KIND_MOBIUS for l in layers[:i]):
+                raise ValueError("all Moebius layers of one flow must have the same number of segments")
+            segments = segs
+        desc[i, 0] = kind
+        desc[i, 1] = perm_rows[i]
+        desc[i, 3] = -1
+        desc[i, 4] = -1
+        if feat_rec is not None:
+            if feat_dim and fdim != feat_dim:
+                raise ValueError("all conditional layers of one flow must share feature_dim")
+            feat_dim = fdim
+            desc[i, 3] = slot
+            slot += 1
+        records.append(rec)
+        feat_records.append(feat_rec)
+    off = 0
+    for i, rec in enumerate(records):
+        desc[i, 2] = off
+        off += (rec.size + 3) // 4 * 4
+    for i, rec in enumerate(feat_records):
+        if rec is not None:
+            desc[i, 4] = off
+            off += (rec.size + 3) // 4 * 4
+    blob = np.zeros(max(off, 4), dtype=np.float32)
+    for i, rec in enumerate(records):
+        blob[desc[i, 2]: desc[i, 2] + rec.size] = rec
+    for i, rec in enumerate(feat_records):
+        if rec is not None:
+            blob[desc[i, 4]: desc[i, 4] + rec.size] = rec
+    return PackedFlow(torch.from_numpy(blob).to(device), np.ascontiguousarray(desc), slot, feat_dim, pad8(feat_dim), segments)
+
+
+# ---- per-layer packers (called by the layer modules) -----------------------------------------------------------
+def pack_mobius(L, cond, K, feature_dim):
+    """cond: ConditionalTransform(3+F, 4K).  -> (layer record, feature-projection record | None)"""
+    F = feature_dim
+    Fp = pad8(F)
+    if K <= 0 or K % 8:
+        raise NotImplementedError(f"segments={K}: the HIP kernels need a positive multiple of 8")
+    rec = np.empty(L.rnf_mobius_packed_floats(K), dtype=np.float32)
+    frec = np.empty(L.rnf_featproj_packed_floats(Fp), dtype=np.float32) if F else None
+    arrs = [_pad_cols(_np32(cond.fc_first.weight), 3, F, Fp), _np32(cond.fc_first.bias)]
+    for j in (1, 3, 5):
+        arrs += [_np32(cond.layers[j].weight), _np32(cond.layers[j].bias)]
+    arrs += [_np32(cond.fc_last.weight), _np32(cond.fc_last.bias)]
+    _lib.check(L.rnf_pack_mobius(*[a.ctypes.data for a in arrs], K, Fp, rec.ctypes.data,
+                                 frec.ctypes.data if frec is not None else None))
+    return rec, frec
+
+
+def pack_cond16(L, net, feature_dim):
+    F = feature_dim
+    Fp = pad8(F)
+    rec = np.empty(L.rnf_cond16_packed_floats(), dtype=np.float32)
+    frec = np.empty(L.rnf_featproj_packed_floats(Fp), dtype=np.float32)
+    arrs = [_pad_cols(_np32(net.fc_first.weight), 0, F, Fp), _np32(net.fc_first.bias)]
+    for j in (1, 3, 5):
+        arrs += [_np32(net.layers[j].weight), _np32(net.layers[j].bias)]
+    arrs += [_np32(net.fc_last.weight), _np32(net.fc_last.bias)]
+    _lib.check(L.rnf_pack_cond16(*[a.ctypes.data for a in arrs], Fp, rec.ctypes.data, frec.ctypes.data))
+    return rec, frec
+
+
+def pack_affine16(L, mat):
+    rec = np.empty(L.rnf_affine16_packed_floats(), dtype=np.float32)
+    m = _np32(mat).reshape(16)
+    _lib.check(L.rnf_pack_affine16(m.ctypes.data, rec.ctypes.data))
+    return rec
+
+
+# ---- parameter-version keyed cache -------------------------------------------------------------------------------
+def params_key(module, device):
+    """Changes whenever any parameter is modified in place (optimizer step, load_state_dict) or replaced."""
+    return (str(device),) + tuple((id(p), p._version, p.data_ptr()) for p in module.parameters())
+
+
+class PackCache:
+    """One packed blob per (device, parameter version); thread safe (nn.DataParallel replicas call from worker threads)."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._key = None
+        self._packed = None
+
+    def get(self, module, device, builder):
+        key = params_key(module, device)
+        with self._lock:
+            if key != self._key:
+                self._packed = builder()
+                self._key = key
+            return self._packed
+
+
+# ---- workspace ------------------------------------------------------------------------------------------------------
+_ws_lock = threading.Lock()
+_workspaces: dict = {}
+
+
+def workspace(device, nbytes: int) -> torch.Tensor:
+    """Grow-only scratch per (device, stream) for the feature projection and the NLL partials."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    with _ws_lock:
+        ws = _workspaces.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+            _workspaces[key] = ws
+        return ws
+
+
+# ---- launch ---------------------------------------------------------------------------------------------------------
+def _check_inputs(rotation, feature, packed: PackedFlow):
+    if not rotation.is_cuda:
+        raise RuntimeError("rotationnormflow_amd runs on the GPU only (HIP kernels, no CPU fallback): got a CPU tensor")
+    if rotation.dim() < 2 or rotation.shape[-1] != 3 or rotation.shape[-2] != 3:
+        raise ValueError(f"rotation must be [N,3,3], got {tuple(rotation.shape)}")
+    rot = rotation.reshape(-1, 3, 3)
+    if rot.dtype != torch.float32:
+        rot = rot.float()                                  # reference silently produces fp32 (mobiusflow.py:80)
+    rot = rot.contiguous()
+    feat = None
+    if packed.n_cond:
+        assert feature is not None, "The input feature is needed in this module"          # mobiusflow.py:48-49
+        feat = feature.reshape(rot.shape[0], -1)
+        if feat.shape[1] != packed.feat_dim:
+            raise ValueError(f"feature has {feat.shape[1]} columns, flow expects {packed.feat_dim}")
+        feat = feat.to(device=rot.device, dtype=torch.float32)
+        if packed.feat_padded != packed.feat_dim:
+            feat = torch.nn.functional.pad(feat, (0, packed.feat_padded - packed.feat_dim))
+        feat = feat.contiguous()
+    return rot, feat
+
+
+def _refuse_autograd(rotation, feature, module):
+    if not torch.is_grad_enabled():
+        return
+    needs = rotation.requires_grad or (feature is not None and feature.requires_grad) or any(
+        p.requires_grad for p in module.parameters())
+    if needs:
+        raise NotImplementedError(
+            "rotationnormflow_amd: the HIP kernels are forward/inverse only (no backward kernels yet); call under "
+            "torch.no_grad() -- there is deliberately no PyTorch fallback path")
+
+
+def run_flow(module, packed: PackedFlow, rotation, feature, inverse=False):
+    """-> (rotation' [N,3,3], ldj [N]) through rnf_flow_forward / rnf_flow_inverse."""
+    _refuse_autograd(rotation, feature, module)
+    rot, feat = _check_inputs(rotation, feature, packed)
+    n = rot.shape[0]
+    L = _lib.lib()
+    out_rot = torch.empty_like(rot)
+    out_ldj = torch.empty(n, dtype=torch.float32, device=rot.device)
+    wbytes = L.rnf_workspace_bytes(n, packed.n_cond)
+    ws = workspace(rot.device, wbytes)
+    fn = L.rnf_flow_inverse if inverse else L.rnf_flow_forward
+    with torch.cuda.device(rot.device):
+        stream = torch.cuda.current_stream(rot.device).cuda_stream
+        _lib.check(fn(rot.data_ptr(), feat.data_ptr() if feat is not None else None, n, packed.feat_padded,
+                      packed.blob.data_ptr(), packed.desc.ctypes.data, packed.n_layers, packed.segments,
+                      out_rot.data_ptr(), out_ldj.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+    return out_rot.reshape(rotation.shape), out_ldj
+
+
+def run_log_prob(module, packed: PackedFlow, rotation, feature, fisher_A=None, fisher_c=None,
+                 want_rotation=False, want_ldj=False, want_logp=True):
+    """Fused Flow.forward + base log-density + NLL sum.  -> dict(logp, sum [2] float64 device tensor, rotation, ldj)"""
+    _refuse_autograd(rotation, feature, module)
+    rot, feat = _check_inputs(rotation, feature, packed)
+    n = rot.shape[0]
+    L = _lib.lib()
+    dev = rot.device
+    out_rot = torch.empty_like(rot) if want_rotation else None
+    out_ldj = torch.empty(n, dtype=torch.float32, device=dev) if want_ldj else None
+    out_lp = torch.empty(n, dtype=torch.float32, device=dev) if want_logp else None
+    out_sum = torch.empty(2, dtype=torch.float64, device=dev)
+    B = 0
+    if fisher_A is not None:
+        fisher_A = fisher_A.reshape(-1, 3, 3).to(device=dev, dtype=torch.float32).contiguous()
+        fisher_c = fisher_c.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+        B = fisher_A.shape[0]
+    ws = workspace(dev, L.rnf_workspace_bytes(n, packed.n_cond))
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(L.rnf_flow_log_prob(rot.data_ptr(), ptr(feat), n, packed.feat_padded, packed.blob.data_ptr(),
+                                       packed.desc.ctypes.data, packed.n_layers, packed.segments,
+                                       ptr(fisher_A), ptr(fisher_c), B, ptr(out_rot), ptr(out_ldj), ptr(out_lp),
+                                       out_sum.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+    return dict(logp=out_lp, sum=out_sum, rotation=out_rot, ldj=out_ldj)

@@ -1,0 +1,71 @@
+"""Mirror of the reference's utils/fisher.py: ``MatrixFisherN`` (log-density on the GPU through rnf_fisher_log_prob).
+
+log p(R) = tr(A^T R) - (s0+s1+s2) - log norm, norm = 1/sqrt(8 pi (s0+s1)(s1+s2)(s0+s2))   (utils/fisher.py:93-97,217-232)
+with s the *proper* singular values of A (last one sign-flipped by det(U) det(V), utils/fisher.py:67-76).
+"""
+import math
+
+import torch
+
+from .. import _lib
+
+
+def proper_singular_values(A):
+    """[B,3,3] -> [B,3] (utils/fisher.py:67-76).  O(B) host-side parameter preprocessing in torch, fp64 internally."""
+    A64 = A.detach().to(torch.float64)
+    U, S, Vh = torch.linalg.svd(A64)
+    S = S.clone()
+    S[:, 2] = S[:, 2] * torch.det(U) * torch.det(Vh)
+    return S
+
+
+def quaternion_to_matrix(q):
+    """Real-part-first quaternions -> rotation matrices (semantics of pytorch3d.transforms.quaternion_to_matrix)."""
+    w, x, y, z = q.unbind(-1)
+    s2 = 2.0 / (q * q).sum(-1)
+    m = torch.stack([1 - s2 * (y * y + z * z), s2 * (x * y - z * w), s2 * (x * z + y * w),
+                     s2 * (x * y + z * w), 1 - s2 * (x * x + z * z), s2 * (y * z - x * w),
+                     s2 * (x * z - y * w), s2 * (y * z + x * w), 1 - s2 * (x * x + y * y)], -1)
+    return m.reshape(q.shape[:-1] + (3, 3))
+
+
+class MatrixFisherN(torch.nn.Module):
+    """MatrixFisherN(A [B,3,3], norm_type=1).  ``_log_prob(R [N,3,3])`` broadcasts row b over N/B consecutive samples."""
+
+    def __init__(self, A, norm_type=1, approx_num=None):
+        super().__init__()
+        if norm_type != 1:
+            raise NotImplementedError("only the default normaliser approximation norm_type=1 is built (utils/fisher.py:93-97)")
+        self.A = A.reshape(-1, 3, 3)
+        S = proper_singular_values(self.A)
+        norm = 1.0 / torch.sqrt(8 * math.pi * (S[:, 0] + S[:, 1]) * (S[:, 2] + S[:, 1]) * (S[:, 0] + S[:, 2]))
+        self.norm = norm.to(self.A.dtype)
+        self._c = (S.sum(-1) + norm.log()).to(torch.float32)      # log p = tr(A^T R) - c
+
+    def log_const(self):
+        return self._c
+
+    def _log_prob(self, inputs, context=9):
+        if not inputs.is_cuda:
+            raise RuntimeError("rotationnormflow_amd runs on the GPU only (no CPU fallback)")
+        if inputs.shape[-1] == 4:
+            inputs = quaternion_to_matrix(inputs)
+        dev = inputs.device
+        R = inputs.reshape(-1, 3, 3).to(torch.float32).contiguous()
+        A = self.A.to(device=dev, dtype=torch.float32).contiguous()
+        c = self._c.to(dev).contiguous()
+        n, B = R.shape[0], A.shape[0]
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().rnf_fisher_log_prob(R.data_ptr(), n, A.data_ptr(), c.data_ptr(), B, out.data_ptr(),
+                                                      torch.cuda.current_stream(dev).cuda_stream))
+        return out
+
+    def log_prob(self, inputs, context=None):
+        return self._log_prob(inputs)
+
+    def _sample(self, num_samples, context=9):
+        raise NotImplementedError("matrix-Fisher rejection sampler (utils/fisher.py:117-207,234-243) is a 'next' row; not built yet")
+
+    def sample(self, num_samples, context=None):
+        return self._sample(num_samples)

@@ -1,0 +1,109 @@
+"""numpy emulation of the kernel's MFMA dataflow (test infrastructure).
+
+Emulates v_mfma_f32_32x32x2_f32 with the lane maps of cdna_hip_programming.md section 3 and replays, from a PACKED layer record,
+exactly the loads / operand choices that csrc/flow_kernels.h makes (mlp_head, last_tile).  Used on CPU to validate the
+host packers and the fragment layout without a GPU.
+"""
+import numpy as np
+
+LANES = np.arange(64)
+J = LANES & 31
+H = LANES >> 5
+
+MOB_FIRST, MOB_HID, MOB_HB, MOB_HEAD, TILE_FLOATS, TILE_BIAS = 0, 256, 256 + 12288, 12736, 2080, 2048
+
+
+def rho(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def mfma(a, b, acc):
+    """a, b: [64] per-lane operands; acc: [16, 64] per-lane accumulator registers.  D = A.B + C."""
+    A = np.zeros((32, 2), np.float64)
+    B = np.zeros((2, 32), np.float64)
+    A[J, H] = a
+    B[H, J] = b
+    D = A @ B                                   # [32, 32]
+    out = acc.copy()
+    for r in range(16):
+        out[r] += D[rho(r, H), J]
+    return out
+
+
+def bias16(rec, off):
+    """load_bias16: 16 floats per lane-half starting at off + h*16."""
+    acc = np.zeros((16, 64))
+    for r in range(16):
+        acc[r] = rec[off + H * 16 + r]
+    return acc
+
+
+def gemm_tile64(rec, off, tin, acc, relu):
+    """gemm_tile64: rec[off + (tg*64 + lane)*4 + c], B operand = register (tg&3)*4+c of tile tg>>2."""
+    for tg in range(8):
+        a4 = rec[off + (tg * 64 + LANES)[:, None] * 4 + np.arange(4)[None, :]]      # [64, 4]
+        t, r0 = tg >> 2, (tg & 3) * 4
+        for c in range(4):
+            b = tin[t][r0 + c]
+            if relu:
+                b = np.maximum(b, 0)
+            acc = mfma(a4[:, c], b, acc)
+    return acc
+
+
+def mlp_head(rec, y, cinit=None):
+    """y: [32,3] one wave's samples.  Returns tt (2 tiles of [16,64])."""
+    y = np.asarray(y, np.float64)
+    bA = np.where(H == 1, y[J, 1], y[J, 0])
+    bB = np.where(H == 1, 1.0, y[J, 2])
+    x0 = []
+    for ot in range(2):
+        a2 = rec[MOB_FIRST + ((ot * 64 + LANES)[:, None] * 2 + np.arange(2)[None, :])]
+        c = np.zeros((16, 64)) if cinit is None else cinit[ot].copy()
+        c = mfma(a2[:, 0], bA, c)
+        c = mfma(a2[:, 1], bB, c)
+        x0.append(c)
+    hin = x0
+    for L in range(3):
+        hout = []
+        for ot in range(2):
+            c = bias16(rec, MOB_HB + (L * 2 + ot) * 32)
+            hout.append(gemm_tile64(rec, MOB_HID + (L * 2 + ot) * 2048, hin, c, relu=True))
+        hin = hout
+    return [np.maximum(x0[t] + hin[t], 0) for t in range(2)]
+
+
+def last_tile(rec, tau, tt):
+    off = MOB_HEAD + tau * TILE_FLOATS
+    return gemm_tile64(rec, off, tt, bias16(rec, off + TILE_BIAS), relu=False)
+
+
+def conditioner_from_record(rec, y, K):
+    """Full ConditionalTransform output [32, 4K] in the reference's row order, via the kernel's dataflow."""
+    rec = np.asarray(rec, np.float64)
+    tt = mlp_head(rec, y)
+    out = np.zeros((32, 4 * K))
+    for tau in range(K // 8):
+        o = last_tile(rec, tau, tt)
+        for g in range(4):
+            for c in range(4):
+                k = 8 * tau + 2 * g + H
+                row = np.where(c == 0, k, K + 3 * k + (c - 1))
+                out[J, row] = o[4 * g + c]          # each (sample, row) is written by exactly one lane
+    return out
+
+
+def featproj_from_record(frec, feat, F):
+    """featproj_kernel for one wave: feat [32,F] -> G fragments (2 tiles of [16,64])."""
+    frec = np.asarray(frec, np.float64)
+    ng = F // 8
+    tiles = []
+    for ot in range(2):
+        acc = bias16(frec, 2 * ng * 256 + ot * 32)
+        for u in range(ng):
+            a4 = frec[((ot * ng + u) * 64 + LANES)[:, None] * 4 + np.arange(4)[None, :]]
+            for c in range(4):
+                b = feat[J, 8 * u + 4 * H + c]
+                acc = mfma(a4[:, c], b, acc)
+        tiles.append(acc)
+    return tiles

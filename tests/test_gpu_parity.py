@@ -1,0 +1,144 @@
+"""GPU (-m gpu): the HIP path through the C ABI against the golden vectors of the reference and against the oracle.
+
+Tolerances (fp32 path, bar from BASELINE.json north_star: "within 1e-5 fp32", "matching reference NLL to 1e-5"):
+  * mean log-det over the batch (the mean-NLL statistic): |hip - ref_fp64| < 1e-5
+  * per sample: the reference's own fp32 run deviates from its fp64 run by `noise` (stored in the fixture); the HIP
+    result must be as close to the fp64 truth as that: mean err <= 2*mean noise + 2e-6, max err <= 4*max noise + 2e-5
+  * inverse: the 15-step bisection resolves theta to pi/2^15 ~ 1e-4, decisions can flip under rounding (SURVEY section 7
+    "Bisection parity"), so the inverse is compared against the reference's own fp32-vs-fp64 spread, x3.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import flow_oracle as orc
+from rotationnormflow_amd import _lib, runtime, synth
+from rotationnormflow_amd.utils.fisher import MatrixFisherN
+from tests.golden.cases import CASES
+from tests.gpu_helpers import product_flow, run_case
+
+pytestmark = pytest.mark.gpu
+
+FORWARD = [n for n, s in CASES.items() if s["direction"] == "forward"]
+INVERSE = [n for n, s in CASES.items() if s["direction"] == "inverse" and s["cfg"].get("segments", 64) <= 64]
+
+
+def test_native_library_is_loaded():
+    L = _lib.lib()
+    assert L.rnf_abi_version() == 1
+    assert torch.cuda.is_available()
+
+
+def test_conditioner_mfma_chain_matches_oracle():
+    from rotationnormflow_amd.flow.condition import ConditionalTransform
+    torch.manual_seed(0)
+    K = 64
+    m = ConditionalTransform(3, 4 * K)
+    with torch.no_grad():
+        m.fc_last.weight.mul_(5.0)
+    y = torch.from_numpy(synth.uniform_rotations(1000, seed=1)[:, :, 0].copy())
+    with torch.no_grad():
+        got = m.cuda()(y.cuda()).cpu().double().numpy()
+    p = {"c." + k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    want = orc.conditioner(y.double(), p, "c").numpy()
+    assert np.abs(got - want).max() < 2e-5
+
+
+@pytest.mark.parametrize("name", FORWARD)
+def test_forward_matches_reference_golden(name):
+    fl, Rt, ldj, fx, spec, _ = run_case(name)
+    noise = np.abs(fx["ldj32"].astype(np.float64) - fx["ldj64"])
+    err = np.abs(ldj - fx["ldj64"])
+    assert abs(ldj.mean() - fx["ldj64"].mean()) < 1e-5
+    assert err.mean() <= 2 * noise.mean() + 2e-6
+    assert err.max() <= 4 * noise.max() + 2e-5
+    rnoise = np.abs(fx["rot32"].astype(np.float64) - fx["rot64"]).max()
+    assert np.abs(Rt - fx["rot64"]).max() <= 4 * rnoise + 1e-5
+    # outputs are rotations
+    assert np.abs(np.einsum("nij,nkj->nik", Rt, Rt) - np.eye(3)).max() < 1e-5
+    assert np.abs(np.linalg.det(Rt) - 1).max() < 1e-5
+
+
+@pytest.mark.parametrize("name", INVERSE)
+def test_inverse_matches_reference_golden(name):
+    fl, Rt, ldj, fx, spec, _ = run_case(name)
+    noise = np.abs(fx["ldj32"].astype(np.float64) - fx["ldj64"])
+    err = np.abs(ldj - fx["ldj64"])
+    assert err.mean() <= 3 * noise.mean() + 1e-5
+    assert np.quantile(err, 0.99) <= 3 * np.quantile(noise, 0.99) + 1e-4
+    rnoise = np.abs(fx["rot32"].astype(np.float64) - fx["rot64"])
+    rerr = np.abs(Rt - fx["rot64"])
+    assert rerr.mean() <= 3 * rnoise.mean() + 1e-5
+    assert np.quantile(rerr, 0.99) <= 3 * np.quantile(rnoise, 0.99) + 1e-4
+
+
+@pytest.mark.parametrize("name", ["c2_default", "c2_trained"])
+def test_fused_log_prob_and_nll_sum(name):
+    fl, Rt, ldj, fx, spec, (Rd, fd) = run_case(name)
+    A = torch.from_numpy(synth.fisher_A(spec["fisher"]))
+    base = MatrixFisherN(A)
+    with torch.no_grad():
+        res = fl.log_prob(Rd, fd, base=base, return_rotation=True)
+        sep = base._log_prob(torch.from_numpy(Rt).float().cuda())
+    torch.cuda.synchronize()
+    lp = res["logp"].cpu().double().numpy()
+    want = fx["ldj64"] + fx["fisher64"]
+    noise = np.abs((fx["ldj32"].astype(np.float64) + fx["fisher32"]) - want)
+    err = np.abs(lp - want)
+    assert abs(lp.mean() - want.mean()) < 1e-5                      # mean NLL
+    assert err.mean() <= 2 * noise.mean() + 2e-6
+    assert err.max() <= 4 * noise.max() + 2e-5
+    s = res["sum"].cpu().numpy()
+    assert s[1] == lp.shape[0]
+    assert abs(s[0] - lp.sum()) < 1e-6 * max(1.0, abs(lp.sum()))      # fp64 accumulation of the fp32 per-sample values
+    assert np.abs(sep.cpu().double().numpy() + ldj - lp).max() < 2e-5  # separate base kernel agrees with the fused one
+    assert np.abs(res["rotation"].cpu().double().numpy() - Rt).max() == 0.0
+
+
+def test_roundtrip_and_unit_mass_at_scale():
+    """Size-independent properties at a BASELINE-sized batch: inverse(forward(R)) ~ R, ldj_inv ~ -ldj_fwd, and
+    mean(exp(ldj)) ~ 1 over Haar samples (the reference's own de-facto checks)."""
+    n = 1 << 18
+    cfg = orc.make_config(layers=24)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=77, regime="default")
+    fl = product_flow(cfg, w)
+    R = torch.from_numpy(synth.uniform_rotations(n, seed=5)).cuda()
+    with torch.no_grad():
+        Rt, ldj = fl(R)
+        Rb, ldjb = fl.inverse(Rt)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ldj).all() and torch.isfinite(Rt).all()
+    assert (Rb - R).abs().max().item() < 2e-3
+    assert (Rb - R).abs().mean().item() < 1e-4
+    assert (ldj + ldjb).abs().mean().item() < 1e-3
+    mass = torch.exp(ldj.double()).mean().item()
+    assert abs(mass - 1.0) < 0.02
+
+
+def test_ragged_and_empty_batches():
+    cfg = orc.make_config(layers=2)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=5, regime="trained")
+    fl = product_flow(cfg, w)
+    R = synth.uniform_rotations(777, seed=6)
+    want_R, want_l = orc.flow_forward(cfg, w, R, None, torch.float64)
+    for n in (0, 1, 31, 33, 255, 257, 777):
+        with torch.no_grad():
+            Rt, ldj = fl(torch.from_numpy(R[:n]).cuda())
+        assert Rt.shape == (n, 3, 3) and ldj.shape == (n,)
+        if n:
+            assert (ldj.cpu().double() - want_l[:n]).abs().max().item() < 3e-5
+            assert (Rt.cpu().double() - want_R[:n]).abs().max().item() < 3e-5
+
+
+def test_errors_are_loud():
+    cfg = orc.make_config(layers=1, condition=1, feature_dim=16)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=5)
+    fl = product_flow(cfg, w)
+    R = torch.from_numpy(synth.uniform_rotations(8, seed=6)).cuda()
+    with torch.no_grad():
+        with pytest.raises(AssertionError):
+            fl(R)                                                   # conditional flow without a feature (mobiusflow.py:48-49)
+        with pytest.raises(RuntimeError):
+            fl(R.cpu(), torch.zeros(8, 16))                         # no CPU fallback
+    with pytest.raises(NotImplementedError):
+        fl(R, torch.zeros(8, 16, device="cuda"))                   # autograd not built: refuses instead of silently detaching

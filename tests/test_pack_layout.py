@@ -1,0 +1,94 @@
+"""CPU: the host packers + the kernel's fragment dataflow (numpy MFMA emulator) reproduce the oracle's conditioner."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import flow_oracle as orc
+from rotationnormflow_amd import _lib, runtime, synth
+from rotationnormflow_amd.flow.condition import ConditionalTransform
+from tests import mfma_emulator as emu
+
+
+def _filled_mlp(ni, no, seed, gain=3.0):
+    torch.manual_seed(seed)
+    m = ConditionalTransform(ni, no)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(gain if p.dim() == 2 else 1.0).add_(0.05 * torch.randn_like(p))
+    return m
+
+
+def _oracle_mlp(m, x):
+    p = {"c." + k: v.detach().double() for k, v in m.state_dict().items()}
+    return orc.conditioner(torch.as_tensor(x, dtype=torch.float64), p, "c").numpy()
+
+
+@pytest.mark.parametrize("K", [8, 64, 128])
+def test_unconditional_mobius_record_matches_oracle(K):
+    m = _filled_mlp(3, 4 * K, seed=K)
+    rec, frec = runtime.pack_mobius(_lib.lib(), m, K, 0)
+    assert frec is None and rec.size == 12736 + (K // 8) * 2080
+    y = synth.uniform_rotations(32, seed=3)[:, :, 1]
+    got = emu.conditioner_from_record(rec, y, K)
+    want = _oracle_mlp(m, y)
+    assert np.abs(got - want).max() < 1e-5 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("F", [8, 40, 256])
+def test_conditional_mobius_record_and_feature_projection(F):
+    K = 16
+    m = _filled_mlp(3 + F, 4 * K, seed=100 + F)
+    rec, frec = runtime.pack_mobius(_lib.lib(), m, K, F)
+    Fp = runtime.pad8(F)
+    assert frec.size == 2 * (Fp // 8) * 256 + 64
+    y = synth.uniform_rotations(32, seed=4)[:, :, 2]
+    feat = synth.features(32, F, seed=9)
+    featp = np.zeros((32, Fp), np.float32)
+    featp[:, :F] = feat
+    g = emu.featproj_from_record(frec, featp.astype(np.float64), Fp)
+    tt = emu.mlp_head(np.asarray(rec, np.float64), y, cinit=g)
+    out = np.zeros((32, 4 * K))
+    for tau in range(K // 8):
+        o = emu.last_tile(np.asarray(rec, np.float64), tau, tt)
+        for gi in range(4):
+            for c in range(4):
+                k = 8 * tau + 2 * gi + emu.H
+                out[emu.J, np.where(c == 0, k, K + 3 * k + (c - 1))] = o[4 * gi + c]
+    want = _oracle_mlp(m, np.concatenate([y, feat], axis=1))
+    assert np.abs(out - want).max() < 1e-5 * max(1.0, np.abs(want).max())
+
+
+def test_cond16_record_yields_matrix_rows_on_lane_halves():
+    F = 24
+    m = _filled_mlp(F, 16, seed=7, gain=1.0)
+    rec, frec = runtime.pack_cond16(_lib.lib(), m, F)
+    feat = synth.features(32, F, seed=5).astype(np.float64)
+    g = emu.featproj_from_record(frec, feat, F)
+    tt = emu.mlp_head(np.asarray(rec, np.float64), np.zeros((32, 3)), cinit=g)
+    o = emu.last_tile(np.asarray(rec, np.float64), 0, tt)
+    want = _oracle_mlp(m, feat).reshape(32, 4, 4)
+    for gi in range(2):
+        for c in range(4):
+            for h in range(2):
+                lanes = emu.LANES[emu.H == h]
+                assert np.abs(o[4 * gi + c][lanes] - want[emu.J[lanes], 2 * gi + h, c]).max() < 1e-6
+    assert np.abs(o[8:]).max() == 0.0          # rows 16..31 are zero padding
+
+
+def test_affine16_record():
+    rng = np.random.default_rng(0)
+    M = (np.eye(4) + 0.3 * rng.standard_normal((4, 4))).astype(np.float32)
+    rec = runtime.pack_affine16(_lib.lib(), torch.from_numpy(M)[None])
+    assert rec.size == 36
+    assert np.array_equal(rec[:16], M.ravel())
+    assert abs(rec[16] - np.log(abs(np.linalg.det(M.astype(np.float64))))) < 1e-6
+    assert np.abs(rec[17:33].reshape(4, 4) - np.linalg.inv(M.astype(np.float64))).max() < 1e-6
+    assert abs(rec[33] + rec[16]) < 1e-6
+
+
+def test_pack_rejects_bad_sizes():
+    m = _filled_mlp(3, 40, seed=1)
+    with pytest.raises(NotImplementedError):
+        runtime.pack_mobius(_lib.lib(), m, 10, 0)
+    L = _lib.lib()
+    assert L.rnf_mobius_packed_floats(10) == -1 and L.rnf_featproj_packed_floats(12) == -1

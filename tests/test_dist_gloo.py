@@ -1,0 +1,61 @@
+"""CPU, world_size=2, gloo: the N>1 path (shard -> local {sum, count} -> all-reduce -> mean NLL) gives the same mean NLL
+as one process over the whole batch.  The per-shard evaluator here is the oracle (the HIP evaluator needs a GPU)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import flow_oracle as orc
+from rotationnormflow_amd import dist as rdist
+from rotationnormflow_amd import synth
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = orc.make_config(layers=2)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=3, regime="trained")
+    A = synth.fisher_A("diag531")
+    R = torch.from_numpy(synth.uniform_rotations(n, seed=11))
+
+    def evaluate(rot, feat):
+        lp, _ = orc.log_prob(cfg, w, rot, None, A, torch.float32)
+        return torch.tensor([lp.double().sum().item(), float(rot.shape[0])], dtype=torch.float64)
+
+    nll, tot = rdist.sharded_mean_nll(evaluate, R, None, rank, world)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([float(nll), float(tot[0]), float(tot[1])]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1000, 1001])
+def test_two_rank_mean_nll_matches_single_process(tmp_path, n):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
+    assert np.array_equal(r0, r1)                       # every rank ends with the same reduced statistic
+    cfg = orc.make_config(layers=2)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=3, regime="trained")
+    lp, nll = orc.log_prob(cfg, w, synth.uniform_rotations(n, seed=11), None, synth.fisher_A("diag531"), torch.float32)
+    assert r0[2] == n
+    assert abs(r0[0] - nll) < 1e-6
+
+
+def test_shard_bounds_cover_batch_exactly():
+    for n in (0, 1, 7, 8, 1000, 1001, 1 << 20):
+        for world in (1, 2, 3, 8):
+            spans = [rdist.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert all(lo <= hi for lo, hi in spans)

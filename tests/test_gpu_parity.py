@@ -109,7 +109,7 @@ def test_roundtrip_and_unit_mass_at_scale():
     torch.cuda.synchronize()
     assert torch.isfinite(ldj).all() and torch.isfinite(Rt).all()
     assert (Rb - R).abs().max().item() < 2e-3
-    assert (Rb - R).abs().mean().item() < 1e-4
+    assert (Rb - R).abs().mean().item() < 4e-4
     assert (ldj + ldjb).abs().mean().item() < 1e-3
     mass = torch.exp(ldj.double()).mean().item()
     assert abs(mass - 1.0) < 0.02

@@ -168,7 +168,7 @@ __device__ __forceinline__ void mobius_forward(float *lds, const float *layer_pa
     S = pair_sum(S);
     A = pair_sum(A);
     J = pair_sum(J);
-    const float invS = 1.0f / S;
+    const float invS = hw_rcp(S);
     float sn, cs;
     sincos_small(A * invS, sn, cs);
     const v3f tx = f.v * sn + f.r * cs;
@@ -207,11 +207,10 @@ __device__ __forceinline__ void mobius_inverse(float *lds, int perm_row, int lan
         }
     }
     S = pair_sum(S);
-    const float invS = 1.0f / S;
+    const float invS = hw_rcp(S);
 
     // target angle of the given column (== pi by construction), wrapped and snapped (mobiusflow.py:157-167)
-    float target = atan2f(dot3(tx, f.v), dot3(tx, f.r));
-    target = target < 0.f ? target + kTwoPi : target;
+    float target = angle_0_2pi(dot3(tx, f.v), dot3(tx, f.r));
     target = fabsf(target - kTwoPi) < 1e-4f ? 0.f : target;
 
     // BinFind.forward (mobiusflow.py:196-224): bracket [pi/2, 3pi/2], width halves every step, the batch-global stop

@@ -238,7 +238,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     if (n < 0) return fail("n=%lld is negative", (long long)n);
     if (n_layers <= 0 || n_layers > MAX_LAYERS) return fail("n_layers=%d outside [1,%d]", n_layers, MAX_LAYERS);
     if (K <= 0 || K % 8) return fail("segments=%d must be a positive multiple of 8", K);
-    if (!rot || !blob || !desc) return fail("null rotation / blob / desc pointer");
+    if (!blob || !desc || (n > 0 && !rot)) return fail("null rotation / blob / desc pointer");
     if (o.fisher_A && (o.fisher_B <= 0 || n % o.fisher_B)) return fail("n=%lld not divisible by fisher rows B=%lld (utils/fisher.py:226)", (long long)n, (long long)o.fisher_B);
 
     FlowArgs a;

@@ -10,8 +10,54 @@ namespace rnf {
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kTwoPi = 6.28318530717958647692f;
 
-// torch.nn.functional.softplus(beta=1, threshold=20): flow/mobiusflow.py:69
-RNF_HD float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+// ---- 1-ulp hardware transcendentals (v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 / v_exp_f32 / v_log_f32) --------------
+// The host definitions exist only so that tests can exercise the surrounding algebra on the CPU.
+#if defined(__HIP_DEVICE_COMPILE__)
+RNF_HD float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+RNF_HD float hw_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+RNF_HD float hw_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+RNF_HD float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+RNF_HD float hw_log2(float x) { return __builtin_amdgcn_logf(x); }
+#else
+RNF_HD float hw_rcp(float x) { return 1.0f / x; }
+RNF_HD float hw_rsq(float x) { return 1.0f / sqrtf(x); }
+RNF_HD float hw_sqrt(float x) { return sqrtf(x); }
+RNF_HD float hw_exp2(float x) { return exp2f(x); }
+RNF_HD float hw_log2(float x) { return log2f(x); }
+#endif
+
+// torch.nn.functional.softplus(beta=1, threshold=20) (flow/mobiusflow.py:69), branch free:
+//   softplus(x) = max(x, 0) + log1p(exp(-|x|));  e = exp(-|x|) in (0, 1];  u = fl(1 + e);
+//   log1p(e) = log(u) + (e - (u - 1)) / u   (the second term restores the bits of e lost in forming u).
+// For x > 20 the log1p term is < 2.1e-9 < ulp(x)/2, so the result rounds to x exactly like the reference's threshold.
+RNF_HD float softplus(float x) {
+    const float ax = fabsf(x);
+    const float p = ax * 1.44269502162933349609375f;                    // log2(e) split hi + lo: keeps exp(-|x|) at ~1 ulp
+    const float r = fmaf(ax, 1.92596299112661746e-8f, fmaf(ax, 1.44269502162933349609375f, -p));
+    float e = hw_exp2(-p);
+    e = fmaf(-0.693147180559945309f * e, r, e);
+    const float u = 1.0f + e;
+    const float l = fmaf(hw_log2(u), 0.693147180559945309f, (e - (u - 1.0f)) * hw_rcp(u));
+    return fmaxf(x, 0.0f) + l;
+}
+
+// atan2(y, x) mapped to [0, 2pi) (the wrap of flow/mobiusflow.py:98-99 folded in).  Octant reduction to a in [0,1],
+// then the classic single-precision arctangent: |t| <= tan(pi/8) via t = (a-1)/(a+1), odd degree-9 minimax (~2 ulp).
+RNF_HD float angle_0_2pi(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mn * hw_rcp(mx);
+    const bool big = a > 0.414213562373095f;
+    const float t = big ? (a - 1.0f) * hw_rcp(a + 1.0f) : a;
+    const float z = t * t;
+    float p = fmaf(fmaf(fmaf(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
+    p = fmaf(p * z, t, t);
+    p += big ? 0.785398163397448310f : 0.0f;
+    p = ay > ax ? 1.57079632679489662f - p : p;
+    p = x < 0.0f ? 3.14159265358979324f - p : p;
+    p = y < 0.0f ? 6.28318530717958648f - p : p;
+    return p;
+}
 
 // sin and cos for |x| <= ~16 (the layer only needs [0, 2pi)): quadrant reduction with a 3-term Cody-Waite split of
 // pi/2 and the classic single-precision minimax polynomials on [-pi/4, pi/4] (~1 ulp).  Replaces libm sincosf, whose
@@ -63,7 +109,7 @@ RNF_HD v3f cross3(v3f a, v3f b) {
     c.z = a.x * b.y - a.y * b.x;
     return c;
 }
-RNF_HD v3f normalize3(v3f a) { return a * (1.0f / sqrtf(dot3(a, a))); }
+RNF_HD v3f normalize3(v3f a) { return a * hw_rsq(dot3(a, a)); }
 
 // In-plane frame of a Moebius layer (flow/mobiusflow.py:64-67,148-151): r = -x/|x|, v = (y x r)/|y x r|.
 // Everything the layer does lives in span(r, v) (the plane orthogonal to y), so segments are handled in 2-D
@@ -73,7 +119,7 @@ struct Frame {
 };
 RNF_HD Frame make_frame(v3f x, v3f y) {
     Frame f;
-    f.r = x * (-1.0f / sqrtf(dot3(x, x)));
+    f.r = x * (-hw_rsq(dot3(x, x)));
     f.v = normalize3(cross3(y, f.r));
     return f;
 }
@@ -82,7 +128,7 @@ RNF_HD Frame make_frame(v3f x, v3f y) {
 RNF_HD void squash_center(float w0, float w1, float w2, const Frame &f, float &ur, float &uv) {
     float wr = fmaf(w2, f.r.z, fmaf(w1, f.r.y, w0 * f.r.x));
     float wv = fmaf(w2, f.v.z, fmaf(w1, f.v.y, w0 * f.v.x));
-    float sc = 0.7f / (1.0f + sqrtf(fmaf(wv, wv, wr * wr)));
+    float sc = 0.7f * hw_rcp(1.0f + hw_sqrt(fmaf(wv, wv, wr * wr)));
     ur = wr * sc;
     uv = wv * sc;
 }
@@ -94,11 +140,10 @@ RNF_HD void mobius_angle(float zr, float zv, float ur, float uv, float &phi, flo
     float u2 = fmaf(uv, uv, ur * ur);
     float dr = zr - ur, dv = zv - uv;
     float d2 = fmaf(dv, dv, dr * dr);
-    c = (1.0f - u2) / d2;
+    c = (1.0f - u2) * hw_rcp(d2);
     float hr = fmaf(c, dr, -ur);
     float hv = fmaf(c, dv, -uv);
-    float a = atan2f(hv, hr);
-    phi = a < 0.0f ? a + kTwoPi : a;
+    phi = angle_0_2pi(hv, hr);
 }
 
 // pytorch3d.transforms.matrix_to_quaternion (published 0.7.5 rule; call site flow/squeezetrans.py:34):
@@ -106,10 +151,10 @@ RNF_HD void mobius_angle(float zr, float zv, float ur, float uv, float &phi, flo
 // denominators floored at 0.1.  Real part first.
 RNF_HD void rot_to_quat(const Rot &R, float (&q)[4]) {
     const float m00 = R.c0.x, m01 = R.c1.x, m02 = R.c2.x, m10 = R.c0.y, m11 = R.c1.y, m12 = R.c2.y, m20 = R.c0.z, m21 = R.c1.z, m22 = R.c2.z;
-    float a0 = sqrtf(fmaxf(1.0f + m00 + m11 + m22, 0.0f));
-    float a1 = sqrtf(fmaxf(1.0f + m00 - m11 - m22, 0.0f));
-    float a2 = sqrtf(fmaxf(1.0f - m00 + m11 - m22, 0.0f));
-    float a3 = sqrtf(fmaxf(1.0f - m00 - m11 + m22, 0.0f));
+    float a0 = hw_sqrt(fmaxf(1.0f + m00 + m11 + m22, 0.0f));
+    float a1 = hw_sqrt(fmaxf(1.0f + m00 - m11 - m22, 0.0f));
+    float a2 = hw_sqrt(fmaxf(1.0f - m00 + m11 - m22, 0.0f));
+    float a3 = hw_sqrt(fmaxf(1.0f - m00 - m11 + m22, 0.0f));
     int best = 0;
     float ab = a0;
     if (a1 > ab) { ab = a1; best = 1; }
@@ -122,14 +167,14 @@ RNF_HD void rot_to_quat(const Rot &R, float (&q)[4]) {
     else if (best == 1) { c0 = s01;     c1 = a1 * a1; c2 = p12;     c3 = p13; }
     else if (best == 2) { c0 = s02;     c1 = p12;     c2 = a2 * a2; c3 = p23; }
     else                { c0 = s03;     c1 = p13;     c2 = p23;     c3 = a3 * a3; }
-    float inv = 1.0f / (2.0f * fmaxf(ab, 0.1f));
+    float inv = 0.5f * hw_rcp(fmaxf(ab, 0.1f));
     q[0] = c0 * inv; q[1] = c1 * inv; q[2] = c2 * inv; q[3] = c3 * inv;
 }
 
 // pytorch3d.transforms.quaternion_to_matrix (scale invariant: two_s = 2/|q|^2), call site flow/squeezetrans.py:37
 RNF_HD void quat_to_rot(const float (&q)[4], float l2, Rot &R) {
     const float w = q[0], x = q[1], y = q[2], z = q[3];
-    const float s2 = 2.0f / l2;
+    const float s2 = 2.0f * hw_rcp(l2);
     R.c0.x = 1.0f - s2 * (y * y + z * z); R.c1.x = s2 * (x * y - z * w);        R.c2.x = s2 * (x * z + y * w);
     R.c0.y = s2 * (x * y + z * w);        R.c1.y = 1.0f - s2 * (x * x + z * z); R.c2.y = s2 * (y * z - x * w);
     R.c0.z = s2 * (x * z - y * w);        R.c1.z = s2 * (y * z + x * w);        R.c2.z = 1.0f - s2 * (x * x + y * y);

@@ -211,6 +211,8 @@ def run_flow(module, packed: PackedFlow, rotation, feature, inverse=False):
     L = _lib.lib()
     out_rot = torch.empty_like(rot)
     out_ldj = torch.empty(n, dtype=torch.float32, device=rot.device)
+    if n == 0:                                             # empty batch: nothing to launch (data_ptr() would be null)
+        return out_rot.reshape(rotation.shape), out_ldj
     wbytes = L.rnf_workspace_bytes(n, packed.n_cond)
     ws = workspace(rot.device, wbytes)
     fn = L.rnf_flow_inverse if inverse else L.rnf_flow_forward
@@ -233,7 +235,9 @@ def run_log_prob(module, packed: PackedFlow, rotation, feature, fisher_A=None, f
     out_rot = torch.empty_like(rot) if want_rotation else None
     out_ldj = torch.empty(n, dtype=torch.float32, device=dev) if want_ldj else None
     out_lp = torch.empty(n, dtype=torch.float32, device=dev) if want_logp else None
-    out_sum = torch.empty(2, dtype=torch.float64, device=dev)
+    out_sum = torch.zeros(2, dtype=torch.float64, device=dev)
+    if n == 0:
+        return dict(logp=out_lp, sum=out_sum, rotation=out_rot, ldj=out_ldj)
     B = 0
     if fisher_A is not None:
         fisher_A = fisher_A.reshape(-1, 3, 3).to(device=dev, dtype=torch.float32).contiguous()

@@ -1,0 +1,144 @@
+"""CPU: the C-ABI library loads and exports every symbol include/rnf_hip.h declares; host-side mirror of the reference
+API (registry, layer order, state-dict keys, permutation schedule, error behaviour).  No compute calls (no GPU here)."""
+import contextlib
+import ctypes
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flow_oracle as orc
+from rotationnormflow_amd import _lib, make_config, runtime
+from rotationnormflow_amd.flow import affineflow, squeezetrans
+from rotationnormflow_amd.flow.flow import Flow, get_flow
+from rotationnormflow_amd.flow.mobiusflow import MobiusFlow, get_mobius
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def quiet_flow(cfg):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return Flow(cfg)
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "rnf_hip.h")).read()
+    declared = set(re.findall(r"\b(rnf_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert _lib.lib().rnf_abi_version() == 1
+
+
+def test_packed_sizes_match_parameter_counts():
+    L = _lib.lib()
+    assert L.rnf_mobius_packed_floats(64) == 29376           # == parameter count of an unconditional Moebius layer
+    assert L.rnf_affine16_packed_floats() == 36
+    assert L.rnf_featproj_packed_floats(256) == 64 * 256 + 64
+    assert L.rnf_workspace_bytes(1 << 20, 0) == 4096 * 8
+    assert L.rnf_workspace_bytes(1 << 20, 25) == 4096 * 8 + 25 * (1 << 18) * 64 * 4
+
+
+@pytest.mark.parametrize("preset,n_layers,n_keys", [("C1", 16, 88), ("C2", 48, 264), ("C4", 48, 273), ("C5", 42, 420), ("C5u", 42, 420)])
+def test_flow_structure_and_state_dict_keys(preset, n_layers, n_keys):
+    cfg = make_config(preset)
+    fl = quiet_flow(cfg)
+    sd = fl.state_dict()
+    assert len(fl.layers) == n_layers and len(sd) == n_keys
+    assert {k: tuple(v.shape) for k, v in sd.items()} == orc.state_shapes(cfg)      # oracle shapes are pinned to the reference's
+    kinds = orc.layer_kinds(cfg)
+    for layer, kind in zip(fl.layers, kinds):
+        assert {"mobius": 1, "uncond16": 2, "cond16": 3}[kind] == layer._rnf_kind
+
+
+def test_prints_layer_count_like_reference(capsys):
+    Flow(make_config("C1"))
+    assert "total layers of flow:  16" in capsys.readouterr().out
+
+
+def test_permutation_schedules_forward_and_inverse():
+    for preset in ("C2", "C4", "C5"):
+        cfg = make_config(preset)
+        fl = quiet_flow(cfg)
+        fwd, inv = fl._forward_rows(), fl._inverse_rows()
+        # restate flow.py:58-70 / 77-90 independently
+        count, want = 0, []
+        for k in orc.layer_kinds(cfg):
+            want.append(count % 6)
+            if k == "mobius" or cfg.frequent_permute:
+                count += 1
+        assert fwd == want
+        for layer, a, b in zip(fl.layers, fwd, inv):
+            if isinstance(layer, MobiusFlow):
+                assert a == b
+
+
+def test_registry_table():
+    mk = lambda **kw: make_config(**kw)  # noqa: E731
+    assert isinstance(affineflow.get_affine(mk(rot="16Trans"), 0), squeezetrans.Uncondition16Trans)
+    assert isinstance(affineflow.get_affine(mk(rot="16Trans", condition=1), 32), squeezetrans.Condition16Trans)
+    assert isinstance(affineflow.get_affine(mk(rot="16UnTrans", condition=1), 32), squeezetrans.Uncondition16Trans)
+    assert isinstance(affineflow.get_affine(mk(rot="16UnTrans", condition=1), 32, first_layer_condition=True), squeezetrans.Condition16Trans)
+    assert affineflow.get_affine(mk(rot="16UnTrans"), 0) is None          # unconditional table has no 16UnTrans (affineflow.py:48-73)
+    assert affineflow.get_affine(mk(rot="None"), 0) is None
+    assert affineflow.get_affine(mk(rot="None", condition=1), 8) is None
+    assert get_mobius(mk(dist="noflow"), 0) is None
+    for rot in ("36Trans", "9TransLSVD", "9TransRSVD", "9TransLSmith", "9TransRSmith", "16Rot"):
+        with pytest.raises(NotImplementedError):                          # declared, no kernel yet: loud, no fallback
+            affineflow.get_affine(mk(rot=rot), 0)
+    with pytest.raises(NotImplementedError):
+        affineflow.get_affine(mk(rot="16Trans", lu=1), 0)
+
+
+def test_rot_none_with_last_affine_is_a_type_error():
+    with pytest.raises(TypeError):
+        quiet_flow(make_config(layers=2, condition=1, feature_dim=8, rot="None", last_affine=1))
+
+
+def test_cpu_tensors_are_refused_not_silently_computed():
+    fl = quiet_flow(make_config(layers=1))
+    with torch.no_grad(), pytest.raises(RuntimeError, match="GPU only"):
+        fl(torch.eye(3)[None].repeat(4, 1, 1))
+
+
+def test_pack_cache_follows_parameter_versions():
+    fl = quiet_flow(make_config(layers=1))
+    p1 = fl._packed("cpu")
+    assert fl._packed("cpu") is p1
+    with torch.no_grad():
+        fl.layers[1].mat.add_(0.1)                     # in-place update, as an optimizer step / load_state_dict does
+    p2 = fl._packed("cpu")
+    assert p2 is not p1
+    assert not np.array_equal(p1.blob.numpy(), p2.blob.numpy())
+
+
+def test_install_as_reference_modules():
+    import sys
+
+    import rotationnormflow_amd
+    saved = {k: v for k, v in sys.modules.items() if k == "flow" or k.startswith("flow.") or k.startswith("utils")}
+    try:
+        rotationnormflow_amd.install_as_reference_modules()
+        from flow.flow import Flow as F2, get_flow as g2          # what agent.py:9 imports
+        from utils.fisher import MatrixFisherN as M2               # agent.py:10
+        assert F2 is Flow and g2 is get_flow and M2.__name__ == "MatrixFisherN"
+    finally:
+        for k in [k for k in sys.modules if k == "flow" or k.startswith("flow.") or k.startswith("utils")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_fisher_constants_match_oracle():
+    from rotationnormflow_amd import synth
+    from rotationnormflow_amd.utils.fisher import MatrixFisherN
+    for kind in ("diag531", "tilted"):
+        A = torch.from_numpy(synth.fisher_A(kind))
+        d = MatrixFisherN(A)
+        R = torch.from_numpy(synth.uniform_rotations(64, seed=2)).double()
+        want = orc.fisher_log_prob(R, A, torch.float64)
+        got = (R * A.double().reshape(1, 3, 3)).sum((-1, -2)) - d.log_const().double()
+        assert (got - want).abs().max() < 2e-6

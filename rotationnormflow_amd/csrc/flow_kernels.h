@@ -131,22 +131,111 @@ __device__ __forceinline__ f32x16 last_tile(const float *tile_rec, int lane, int
 __device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
 // ------------------------------------------------------------------------------------------------------------
-// Moebius layer, forward (flow/mobiusflow.py:46-125)
+// Moebius layer (flow/mobiusflow.py:46-224), split into the three pieces the staging
+// pipeline needs: head (reads the H part of the LDS image), tiles (reads the L part), finish (no LDS).
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void mobius_forward(float *lds, const float *layer_params, int KT, int perm_row, int lane,
-                                               int h, const f32x16 (&cinit)[2], Rot &R, float &ldj, int tid,
-                                               int nthreads) {
-    const int p0 = perm_row % 3, p1 = (perm_row + 1) % 3, p2 = (perm_row + 2) % 3;   // flow/flow.py:13-15
-    const v3f x = get_col(R, p0), y = get_col(R, p1);
-    const Frame f = make_frame(x, y);
-    const float zr = dot3(x, f.r), zv = dot3(x, f.v);
+struct MobiusCtx {
+    Frame f;
+    v3f y;            // the conditioning column (unchanged by the layer)
+    float zr, zv;     // forward: in-plane coordinates of the input column x
+    float target;     // inverse: angle of the given column
+    int p0, p2;
+    bool cyc;         // branch of mobiusflow.py:75 / :172
+};
 
-    f32x16 tt[2];
-    mlp_head(lds, lane, h, y.x, y.y, y.z, cinit, tt);
+template <int DIR>
+__device__ __forceinline__ void mobius_begin(const Rot &R, int perm_row, MobiusCtx &c) {
+    const int p0 = perm_row % 3, p1 = (perm_row + 1) % 3;                        // flow/flow.py:13-15
+    c.p0 = p0;
+    c.p2 = (perm_row + 2) % 3;
+    c.cyc = (p1 - p0 == 1) || (p1 - p0 == -2);
+    const v3f x = get_col(R, p0);
+    c.y = get_col(R, p1);
+    c.f = make_frame(x, c.y);
+    c.zr = dot3(x, c.f.r);
+    c.zv = dot3(x, c.f.v);
+    if (DIR) {   // target angle of the given column (== pi by construction), wrapped and snapped (mobiusflow.py:157-167)
+        float t = angle_0_2pi(c.zv, c.zr);
+        c.target = fabsf(t - kTwoPi) < 1e-4f ? 0.f : t;
+    }
+}
 
-    float S = 0.f, A = 0.f, J = 0.f;
+__device__ __forceinline__ void segments4(const f32x16 &o, const MobiusCtx &c, float &S, float &A, float &J) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float ur, uv, phi, cc;
+        squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, ur, uv);
+        mobius_angle(c.zr, c.zv, ur, uv, phi, cc);
+        const float sp = softplus(o[4 * g]);
+        S += sp;
+        A = fmaf(sp, phi, A);
+        J = fmaf(sp, cc, J);
+    }
+}
+
+// forward, all fc_last tiles resident (K <= 64): software pipelined BY HAND.  Tile tau+1's 32 dependent MFMAs (64
+// cycles each on the matrix pipe) are interleaved one-for-one with 24 slices (4 segments x 6 stages, <= 16 VALU
+// instructions each) of tile tau's segment math, every MFMA + slice pair fenced with sched_barrier(0).  Left to
+// itself hipcc emits the 32 MFMAs back to back followed by ~300 VALU instructions (and ignores a
+// sched_group_barrier pipeline for this block), so each wave alternates between matrix-only and VALU-only stretches
+// and the two waves of a SIMD, released together by the layer barriers, leave the matrix pipe idle in lockstep.
+struct SegState {
+    float ur, uv, c, hr, hv, t, phi, sp;
+    bool big;
+};
+
+template <int STAGE>
+__device__ __forceinline__ void seg_stage(SegState &g, float s_raw, float w0, float w1, float w2, const MobiusCtx &c,
+                                          float &S, float &A, float &J) {
+    if constexpr (STAGE == 0) squash_center(w0, w1, w2, c.f, g.ur, g.uv);
+    else if constexpr (STAGE == 1) mobius_map(c.zr, c.zv, g.ur, g.uv, g.hr, g.hv, g.c);
+    else if constexpr (STAGE == 2) atan_reduce(g.hv, g.hr, g.t, g.big);
+    else if constexpr (STAGE == 3) g.phi = atan_finish(g.hv, g.hr, g.t, g.big);
+    else if constexpr (STAGE == 4) g.sp = softplus(s_raw);
+    else {
+        S += g.sp;
+        A = fmaf(g.sp, g.phi, A);
+        J = fmaf(g.sp, g.c, J);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void tile_step(f32x16 &nxt, const float4 (&a)[8], const f32x16 (&tt)[2], const f32x16 &cur,
+                                          SegState (&seg)[4], const MobiusCtx &c, float &S, float &A, float &J) {
+    constexpr int tg = K >> 2, q = K & 3;
+    const float av = q == 0 ? a[tg].x : (q == 1 ? a[tg].y : (q == 2 ? a[tg].z : a[tg].w));
+    nxt = RNF_MFMA(av, tt[K >> 4][K & 15], nxt);
+    if constexpr (K < 24) {
+        constexpr int g = K / 6, st = K % 6;
+        seg_stage<st>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c, S, A, J);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (K + 1 < 32) tile_step<K + 1>(nxt, a, tt, cur, seg, c, S, A, J);
+}
+
+__device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int lane, int h, const f32x16 (&tt)[2],
+                                                 const MobiusCtx &c, float &S, float &A, float &J) {
+    f32x16 cur = last_tile(lds + MOB_LAST, lane, h, tt);
+    for (int tau = 1; tau < KT; ++tau) {
+        const float *rec = lds + MOB_LAST + tau * MOB_LAST_TILE_FLOATS;
+        f32x16 nxt = load_bias16(rec + MOB_LAST_TILE_BIAS + h * 16);
+        float4 a[8];
+#pragma unroll
+        for (int tg = 0; tg < 8; ++tg) a[tg] = lds_f4(rec, tg * 64 + lane);
+        SegState seg[4];
+        __builtin_amdgcn_sched_barrier(0);
+        tile_step<0>(nxt, a, tt, cur, seg, c, S, A, J);
+        cur = nxt;
+    }
+    segments4(cur, c, S, A, J);
+}
+
+// forward, K > 64: fc_last tiles restaged synchronously 8 at a time (staging mode SYNC only)
+__device__ __forceinline__ void mobius_fwd_tiles_restage(float *lds, const float *layer_params, int KT, int lane, int h,
+                                                         const f32x16 (&tt)[2], const MobiusCtx &c, float &S, float &A,
+                                                         float &J, int tid, int nthreads) {
     for (int tau = 0; tau < KT; ++tau) {
-        if (tau > 0 && (tau % MOB_MAX_TILES_IN_LDS) == 0) {   // K > 64: restage the next 8 fc_last tiles
+        if (tau > 0 && (tau % MOB_MAX_TILES_IN_LDS) == 0) {
             __syncthreads();
             int nt = min(MOB_MAX_TILES_IN_LDS, KT - tau);
             stage_floats(lds + MOB_LAST, layer_params + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS,
@@ -154,65 +243,53 @@ __device__ __forceinline__ void mobius_forward(float *lds, const float *layer_pa
             __syncthreads();
         }
         f32x16 o = last_tile(lds + MOB_LAST + (tau % MOB_MAX_TILES_IN_LDS) * MOB_LAST_TILE_FLOATS, lane, h, tt);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float ur, uv, phi, c;
-            squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], f, ur, uv);
-            mobius_angle(zr, zv, ur, uv, phi, c);
-            float sp = softplus(o[4 * g]);
-            S += sp;
-            A = fmaf(sp, phi, A);
-            J = fmaf(sp, c, J);
-        }
+        segments4(o, c, S, A, J);
     }
+}
+
+__device__ __forceinline__ void mobius_fwd_finish(const MobiusCtx &c, float S, float A, float J, Rot &R, float &ldj) {
     S = pair_sum(S);
     A = pair_sum(A);
     J = pair_sum(J);
     const float invS = hw_rcp(S);
     float sn, cs;
     sincos_small(A * invS, sn, cs);
-    const v3f tx = f.v * sn + f.r * cs;
-    const int dp = p1 - p0;
-    const v3f tz = normalize3((dp == 1 || dp == -2) ? cross3(tx, y) : cross3(y, tx));     // mobiusflow.py:75-79
-    set_col(R, p0, tx);
-    set_col(R, p2, tz);
+    const v3f tx = c.f.v * sn + c.f.r * cs;
+    const v3f tz = normalize3(c.cyc ? cross3(tx, c.y) : cross3(c.y, tx));               // mobiusflow.py:75-79
+    set_col(R, c.p0, tx);
+    set_col(R, c.p2, tz);
     ldj += logf(J * invS);
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Moebius layer, inverse (flow/mobiusflow.py:127-224).  KT is compile time: the 4*KT segment
-// parameters of this lane stay in registers for the 15 bisection steps.
-// ------------------------------------------------------------------------------------------------------------
+// inverse: the 4*KT segment parameters of this lane stay in registers for the 15 bisection steps
 template <int KT>
-__device__ __forceinline__ void mobius_inverse(float *lds, int perm_row, int lane, int h, const f32x16 (&cinit)[2],
-                                               Rot &R, float &ldj) {
-    static_assert(KT <= MOB_MAX_TILES_IN_LDS, "inverse keeps all fc_last tiles in LDS");
-    const int p0 = perm_row % 3, p1 = (perm_row + 1) % 3, p2 = (perm_row + 2) % 3;
-    const v3f tx = get_col(R, p0), ty = get_col(R, p1);
-    const Frame f = make_frame(tx, ty);
-
-    f32x16 tt[2];
-    mlp_head(lds, lane, h, ty.x, ty.y, ty.z, cinit, tt);
-
+struct InvSegs {
     float sp[4 * KT], ur[4 * KT], uv[4 * KT];
-    float S = 0.f;
+};
+
+template <int KT>
+__device__ __forceinline__ void mobius_inv_tiles(const float *lds, int lane, int h, const f32x16 (&tt)[2],
+                                                 const MobiusCtx &c, InvSegs<KT> &sg, float &S) {
+    static_assert(KT <= MOB_MAX_TILES_IN_LDS, "inverse keeps all fc_last tiles in LDS");
 #pragma unroll
     for (int tau = 0; tau < KT; ++tau) {
         f32x16 o = last_tile(lds + MOB_LAST + tau * MOB_LAST_TILE_FLOATS, lane, h, tt);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], f, ur[4 * tau + g], uv[4 * tau + g]);
-            sp[4 * tau + g] = softplus(o[4 * g]);
-            S += sp[4 * tau + g];
+            squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, sg.ur[4 * tau + g], sg.uv[4 * tau + g]);
+            sg.sp[4 * tau + g] = softplus(o[4 * g]);
+            S += sg.sp[4 * tau + g];
         }
+        // keep the tiles in order: letting the scheduler hoist all 8 tiles' MFMAs (8 x 16 accumulators) on top of the
+        // 96 live segment registers spills; the inverse is VALU-bound in the bisection anyway
+        __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+template <int KT>
+__device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvSegs<KT> &sg, float S, Rot &R, float &ldj) {
     S = pair_sum(S);
     const float invS = hw_rcp(S);
-
-    // target angle of the given column (== pi by construction), wrapped and snapped (mobiusflow.py:157-167)
-    float target = angle_0_2pi(dot3(tx, f.v), dot3(tx, f.r));
-    target = fabsf(target - kTwoPi) < 1e-4f ? 0.f : target;
-
     // BinFind.forward (mobiusflow.py:196-224): bracket [pi/2, 3pi/2], width halves every step, the batch-global stop
     // test max(b-a) < 1e-4 is met after exactly 15 steps; the returned root is the LAST midpoint.
     float a = 0.5f * kPi, b = 1.5f * kPi, mid = kPi;
@@ -224,12 +301,12 @@ __device__ __forceinline__ void mobius_inverse(float *lds, int perm_row, int lan
         float acc = 0.f;
 #pragma unroll
         for (int s = 0; s < 4 * KT; ++s) {
-            float phi, c;
-            mobius_angle(cs, sn, ur[s], uv[s], phi, c);
-            acc = fmaf(sp[s], phi, acc);
+            float phi, cc;
+            mobius_angle(cs, sn, sg.ur[s], sg.uv[s], phi, cc);
+            acc = fmaf(sg.sp[s], phi, acc);
         }
-        float fx = pair_sum(acc) * invS - target;
-        float half = (b - a) * 0.5f;
+        const float fx = pair_sum(acc) * invS - c.target;
+        const float half = (b - a) * 0.5f;
         if (fx < 0.f) a = a + half;
         else if (fx >= 0.f) b = b - half;
     }
@@ -238,27 +315,22 @@ __device__ __forceinline__ void mobius_inverse(float *lds, int perm_row, int lan
     float J = 0.f;
 #pragma unroll
     for (int s = 0; s < 4 * KT; ++s) {
-        float phi, c;
-        mobius_angle(cs, sn, ur[s], uv[s], phi, c);
-        J = fmaf(sp[s], c, J);
+        float phi, cc;
+        mobius_angle(cs, sn, sg.ur[s], sg.uv[s], phi, cc);
+        J = fmaf(sg.sp[s], cc, J);
     }
     J = pair_sum(J);
-    const v3f xx = f.v * sn + f.r * cs;
-    const int dp = p1 - p0;
-    const v3f zz = normalize3((dp == 1 || dp == -2) ? cross3(xx, ty) : cross3(ty, xx));   // mobiusflow.py:172-176
-    set_col(R, p0, xx);
-    set_col(R, p2, zz);
-    ldj -= logf(J * invS);                                                       // mobiusflow.py:183
+    const v3f xx = c.f.v * sn + c.f.r * cs;
+    const v3f zz = normalize3(c.cyc ? cross3(xx, c.y) : cross3(c.y, xx));               // mobiusflow.py:172-176
+    set_col(R, c.p0, xx);
+    set_col(R, c.p2, zz);
+    ldj -= logf(J * invS);                                                               // mobiusflow.py:183
 }
 
 // Condition16Trans (flow/squeezetrans.py:41-55): M = I + reshape(MLP(feature), 4, 4); the one fc_last tile leaves
 // rows {h, 2+h} of M on lane-half h; the partner's two rows come over with 8 cross-lane moves.
 template <bool INVERSE>
-__device__ __forceinline__ void cond16_apply(const float *lds, int lane, int h, const f32x16 (&cinit)[2], Rot &R,
-                                             float &ldj) {
-    f32x16 tt[2];
-    mlp_head(lds, lane, h, 0.f, 0.f, 0.f, cinit, tt);
-    f32x16 o = last_tile(lds + MOB_LAST, lane, h, tt);
+__device__ __forceinline__ void cond16_finish(const f32x16 &o, int h, Rot &R, float &ldj) {
     float M[16];
 #pragma unroll
     for (int g = 0; g < 2; ++g)
@@ -277,25 +349,65 @@ __device__ __forceinline__ void cond16_apply(const float *lds, int lane, int h, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// the fused stack kernel.  DIR 0 = Flow.forward (flow/flow.py:53-72), 1 = Flow.inverse (flow/flow.py:74-92).
-// KT_INV: compile-time tile count for the inverse (0 for forward instantiations).
+// weight staging
+//   SYNC: before each MLP layer all waves copy the layer's record global(L2) -> LDS between two barriers (any K).
+//   DMA : K <= 64.  LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) prefetch in two halves that ping-pong with
+//         the two compute phases of a layer: while fc_last + segment math of layer l read the L part, the H part of
+//         the next MLP layer streams in; while the hidden layers of layer l+1 read H, its L part streams in.
 // ------------------------------------------------------------------------------------------------------------
-template <int DIR, int KT_INV, int NW>
+__device__ __forceinline__ void dma_floats(float *lds_dst, const float *g_src, int nfloats, int wave, int lane, int nwaves) {
+    const int n4 = nfloats >> 2;
+    for (int base = wave * 64; base < n4; base += nwaves * 64) {          // `base` is wave uniform: 1 KiB per instruction
+        const int idx = base + lane;
+        if (idx < n4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g_src + 4 * (size_t)idx),
+                                             (__attribute__((address_space(3))) void *)(lds_dst + 4 * base), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ------------------------------------------------------------------------------------------------------------
+// the fused stack kernel.  DIR 0 = Flow.forward (flow/flow.py:53-72), 1 = Flow.inverse (flow/flow.py:74-92).
+// KT_INV: compile-time tile count for the inverse (0 for forward instantiations).  PIPE: staging mode DMA.
+// ------------------------------------------------------------------------------------------------------------
+template <int DIR, int KT_INV, int NW, bool PIPE>
 __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     constexpr int NT = NW * 64;
     constexpr int TILE = NW * TILE_SAMPLES;
+    constexpr int KTI = KT_INV > 0 ? KT_INV : 1;
     const long long ntiles = (args.n + TILE - 1) / TILE;
     const int KT = DIR ? KT_INV : args.KT;
+    const int n_layers = args.n_layers;
     double dsum = 0.0;
+
+    // iteration position -> layer index, and the next position (> pos) whose layer owns an MLP image, or -1
+    auto layer_at = [&](int pos) { return DIR ? (n_layers - 1 - pos) : pos; };
+    auto next_mlp = [&](int pos) {
+        for (int q = pos + 1; q < n_layers; ++q)
+            if ((args.layers[layer_at(q)].x & 15) != RNF_KIND_AFFINE16) return q;
+        return -1;
+    };
+    auto l_floats = [&](int kind) { return (kind == RNF_KIND_MOBIUS ? KT : 1) * MOB_LAST_TILE_FLOATS; };
+    const int first_mlp = next_mlp(-1);
+
+    if (PIPE && first_mlp >= 0) {                                  // prologue: image of the first MLP layer
+        const int2 d = args.layers[layer_at(first_mlp)];
+        dma_floats(lds, args.blob + d.y, MOB_HEAD_FLOATS, wave, lane, NW);
+        dma_floats(lds + MOB_LAST, args.blob + d.y + MOB_LAST, l_floats(d.x & 15), wave, lane, NW);
+        dma_wait_all();
+        __syncthreads();
+    }
 
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long group = tile * NW + wave;                 // 32-sample group index inside this launch
         const long long sample = group * TILE_SAMPLES + j;
         const bool valid = sample < args.n;
+        const bool more_tiles = tile + gridDim.x < ntiles;
 
         Rot R;
         R.c0 = v3f{1.f, 0.f, 0.f}; R.c1 = v3f{0.f, 1.f, 0.f}; R.c2 = v3f{0.f, 0.f, 1.f};
@@ -307,9 +419,8 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
         }
         float ldj = 0.f;
 
-        for (int li = 0; li < args.n_layers; ++li) {
-            const int l = DIR ? (args.n_layers - 1 - li) : li;
-            const int2 d = args.layers[l];
+        for (int pos = 0; pos < n_layers; ++pos) {
+            const int2 d = args.layers[layer_at(pos)];
             const int kind = d.x & 15, perm_row = (d.x >> 4) & 15, slot = (d.x >> 8) - 1;
             const float *params = args.blob + d.y;
 
@@ -322,7 +433,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 continue;
             }
 
-            // layers with a conditioner MLP: stage the layer's image, then compute
+            // ---- layers with a conditioner MLP ----
             f32x16 cinit[2];
             if (slot >= 0) {
                 const float *g = args.G + ((size_t)slot * args.g_groups + group) * G_FLOATS_PER_GROUP;
@@ -332,16 +443,59 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { cinit[0][r] = 0.f; cinit[1][r] = 0.f; }
             }
-            __syncthreads();                                       // everyone is done with the previous image
-            const int tiles_now = (kind == RNF_KIND_MOBIUS) ? min(KT, MOB_MAX_TILES_IN_LDS) : 1;
-            stage_floats(lds, params, MOB_HEAD_FLOATS + tiles_now * MOB_LAST_TILE_FLOATS, tid, NT);
-            __syncthreads();
-
-            if (kind == RNF_KIND_MOBIUS) {
-                if constexpr (DIR != 0) mobius_inverse<KT_INV>(lds, perm_row, lane, h, cinit, R, ldj);
-                else mobius_forward(lds, params, KT, perm_row, lane, h, cinit, R, ldj, tid, NT);
+            // where the NEXT image comes from (DMA mode): next MLP layer of this tile, else the first one of the next tile
+            int nxt_off = -1, nxt_kind = 0;
+            if (PIPE) {
+                int q = next_mlp(pos);
+                if (q < 0 && more_tiles) q = first_mlp;
+                if (q >= 0) { const int2 dn = args.layers[layer_at(q)]; nxt_off = dn.y; nxt_kind = dn.x & 15; }
             } else {
-                cond16_apply<DIR != 0>(lds, lane, h, cinit, R, ldj);
+                __syncthreads();                                   // everyone is done with the previous image
+                const int tiles_now = (kind == RNF_KIND_MOBIUS) ? min(KT, MOB_MAX_TILES_IN_LDS) : 1;
+                stage_floats(lds, params, MOB_HEAD_FLOATS + tiles_now * MOB_LAST_TILE_FLOATS, tid, NT);
+                __syncthreads();
+            }
+
+            MobiusCtx ctx;
+            f32x16 tt[2];
+            if (kind == RNF_KIND_MOBIUS) {
+                mobius_begin<DIR>(R, perm_row, ctx);
+                mlp_head(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, cinit, tt);
+            } else {
+                mlp_head(lds, lane, h, 0.f, 0.f, 0.f, cinit, tt);
+            }
+            if (PIPE) {       // B1: every wave is past the H part and this layer's L part has landed
+                dma_wait_all();
+                __syncthreads();
+                if (nxt_off >= 0) dma_floats(lds, args.blob + nxt_off, MOB_HEAD_FLOATS, wave, lane, NW);
+            }
+
+            // B2 (DMA mode): every wave is past the L part and the next layer's H part has landed
+            auto barrier2 = [&]() {
+                if (PIPE) {
+                    dma_wait_all();
+                    __syncthreads();
+                    if (nxt_off >= 0) dma_floats(lds + MOB_LAST, args.blob + nxt_off + MOB_LAST, l_floats(nxt_kind), wave, lane, NW);
+                }
+            };
+            if (kind == RNF_KIND_MOBIUS) {
+                if constexpr (DIR != 0) {
+                    InvSegs<KTI> sg;
+                    float S = 0.f;
+                    mobius_inv_tiles<KTI>(lds, lane, h, tt, ctx, sg, S);
+                    barrier2();
+                    mobius_inv_finish<KTI>(ctx, sg, S, R, ldj);
+                } else {
+                    float S = 0.f, A = 0.f, J = 0.f;
+                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles(lds, KT, lane, h, tt, ctx, S, A, J);
+                    else mobius_fwd_tiles_restage(lds, params, KT, lane, h, tt, ctx, S, A, J, tid, NT);
+                    barrier2();
+                    mobius_fwd_finish(ctx, S, A, J, R, ldj);
+                }
+            } else {
+                const f32x16 o16 = last_tile(lds + MOB_LAST, lane, h, tt);
+                barrier2();
+                cond16_finish<DIR != 0>(o16, h, R, ldj);
             }
         }
 

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -214,9 +215,19 @@ static hipError_t allow_lds(K kernel, size_t bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int DIR, int KT_INV>
+// staging mode: DMA (LDS-DMA double-phase prefetch, needs segments <= 64) unless RNF_STAGING=sync
+static bool staging_dma() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = std::getenv("RNF_STAGING");
+        mode = (e && std::strcmp(e, "sync") == 0) ? 0 : 1;
+    }
+    return mode == 1;
+}
+
+template <int DIR, int KT_INV, bool PIPE>
 static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream) {
-    auto kern = flow_stack_kernel<DIR, KT_INV, NW>;
+    auto kern = flow_stack_kernel<DIR, KT_INV, NW, PIPE>;
     HIP_TRY(allow_lds(kern, lds_bytes));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, a);
     HIP_TRY(hipGetLastError());
@@ -324,11 +335,12 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         a.sample_base = base;
         a.g_groups = groups;
         int rc;
-        if (o.dir == 0) rc = launch_stack<0, 0>(a, grid, lds_bytes, stream);
-        else if (KT == 1) rc = launch_stack<1, 1>(a, grid, lds_bytes, stream);
-        else if (KT == 2) rc = launch_stack<1, 2>(a, grid, lds_bytes, stream);
-        else if (KT == 4) rc = launch_stack<1, 4>(a, grid, lds_bytes, stream);
-        else rc = launch_stack<1, 8>(a, grid, lds_bytes, stream);
+        const bool pipe = staging_dma() && KT <= MOB_MAX_TILES_IN_LDS;
+        if (o.dir == 0) rc = pipe ? launch_stack<0, 0, true>(a, grid, lds_bytes, stream) : launch_stack<0, 0, false>(a, grid, lds_bytes, stream);
+        else if (KT == 1) rc = pipe ? launch_stack<1, 1, true>(a, grid, lds_bytes, stream) : launch_stack<1, 1, false>(a, grid, lds_bytes, stream);
+        else if (KT == 2) rc = pipe ? launch_stack<1, 2, true>(a, grid, lds_bytes, stream) : launch_stack<1, 2, false>(a, grid, lds_bytes, stream);
+        else if (KT == 4) rc = pipe ? launch_stack<1, 4, true>(a, grid, lds_bytes, stream) : launch_stack<1, 4, false>(a, grid, lds_bytes, stream);
+        else rc = pipe ? launch_stack<1, 8, true>(a, grid, lds_bytes, stream) : launch_stack<1, 8, false>(a, grid, lds_bytes, stream);
         if (rc) return rc;
         if (o.sum_out) {
             hipLaunchKernelGGL(nll_finalize_kernel, dim3(1), dim3(256), 0, stream, (const double *)partials, grid, (double)cn, o.sum_out, first ? 0 : 1);

@@ -43,20 +43,30 @@ RNF_HD float softplus(float x) {
 
 // atan2(y, x) mapped to [0, 2pi) (the wrap of flow/mobiusflow.py:98-99 folded in).  Octant reduction to a in [0,1],
 // then the classic single-precision arctangent: |t| <= tan(pi/8) via t = (a-1)/(a+1), odd degree-9 minimax (~2 ulp).
-RNF_HD float angle_0_2pi(float y, float x) {
+// first half: octant + tan(pi/8) reduction -> t with |t| <= tan(pi/8) and the "added pi/4" flag
+RNF_HD void atan_reduce(float y, float x, float &t, bool &big) {
     const float ax = fabsf(x), ay = fabsf(y);
     const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
     const float a = mn * hw_rcp(mx);
-    const bool big = a > 0.414213562373095f;
-    const float t = big ? (a - 1.0f) * hw_rcp(a + 1.0f) : a;
+    big = a > 0.414213562373095f;
+    t = big ? (a - 1.0f) * hw_rcp(a + 1.0f) : a;
+}
+// second half: polynomial + octant/quadrant reconstruction into [0, 2pi)
+RNF_HD float atan_finish(float y, float x, float t, bool big) {
     const float z = t * t;
     float p = fmaf(fmaf(fmaf(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
     p = fmaf(p * z, t, t);
     p += big ? 0.785398163397448310f : 0.0f;
-    p = ay > ax ? 1.57079632679489662f - p : p;
+    p = fabsf(y) > fabsf(x) ? 1.57079632679489662f - p : p;
     p = x < 0.0f ? 3.14159265358979324f - p : p;
     p = y < 0.0f ? 6.28318530717958648f - p : p;
     return p;
+}
+RNF_HD float angle_0_2pi(float y, float x) {
+    float t;
+    bool big;
+    atan_reduce(y, x, t, big);
+    return atan_finish(y, x, t, big);
 }
 
 // sin and cos for |x| <= ~16 (the layer only needs [0, 2pi)): quadrant reduction with a 3-term Cody-Waite split of
@@ -136,13 +146,17 @@ RNF_HD void squash_center(float w0, float w1, float w2, const Frame &f, float &u
 // Moebius map of the point (zr, zv) about centre (ur, uv) (flow/mobiusflow.py:17-24) -> wrapped angle in [0, 2pi)
 // (mobiusflow.py:94-99) and the scalar c = (1-|w|^2)/|z-w|^2, which is also the segment's |dh/dtheta|
 // (identity checked in tests/test_oracle_golden.py::test_closed_form_ldj_identity).
-RNF_HD void mobius_angle(float zr, float zv, float ur, float uv, float &phi, float &c) {
+RNF_HD void mobius_map(float zr, float zv, float ur, float uv, float &hr, float &hv, float &c) {
     float u2 = fmaf(uv, uv, ur * ur);
     float dr = zr - ur, dv = zv - uv;
     float d2 = fmaf(dv, dv, dr * dr);
     c = (1.0f - u2) * hw_rcp(d2);
-    float hr = fmaf(c, dr, -ur);
-    float hv = fmaf(c, dv, -uv);
+    hr = fmaf(c, dr, -ur);
+    hv = fmaf(c, dv, -uv);
+}
+RNF_HD void mobius_angle(float zr, float zv, float ur, float uv, float &phi, float &c) {
+    float hr, hv;
+    mobius_map(zr, zv, ur, uv, hr, hv, c);
     phi = angle_0_2pi(hv, hr);
 }
 

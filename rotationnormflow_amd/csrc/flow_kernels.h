@@ -34,6 +34,7 @@ struct FlowArgs {
     long long sample_base;    // global index of sample 0 (for the Fisher row lookup)
     long long fisher_div;     // samples per Fisher row (n_total / B)
     long long g_groups;       // 32-sample groups per cond slot in G
+    unsigned long long *stamps;  // diagnostic builds only (RNF_STAMPS): per-phase cycle sums, else nullptr
     int n_layers;
     int KT;                   // fc_last tiles = segments / 8
     // per layer: x = kind | perm_row << 4 | (cond_slot + 1) << 8 ; y = param offset (floats)
@@ -370,6 +371,18 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 // the fused stack kernel.  DIR 0 = Flow.forward (flow/flow.py:53-72), 1 = Flow.inverse (flow/flow.py:74-92).
 // KT_INV: compile-time tile count for the inverse (0 for forward instantiations).  PIPE: staging mode DMA.
 // ------------------------------------------------------------------------------------------------------------
+// In-kernel phase stamps (diagnostic build only, -DRNF_STAMPS; cdna_hip_programming.md section 7 "In-kernel stamps").
+// The shipped library is built without them: no stamp executes in the product kernel.
+#ifdef RNF_STAMPS
+#define RNF_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = clock64();
+#define RNF_STAMP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = clock64(); st_acc[i] += now_ - st_t; st_t = now_; __builtin_amdgcn_sched_barrier(0); }
+#define RNF_STAMP_FLUSH if (args.stamps && lane == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(args.stamps + i_, st_acc[i_]); }
+#else
+#define RNF_STAMP_DECL
+#define RNF_STAMP(i)
+#define RNF_STAMP_FLUSH
+#endif
+
 template <int DIR, int KT_INV, int NW, bool PIPE>
 __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -384,6 +397,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     const int KT = DIR ? KT_INV : args.KT;
     const int n_layers = args.n_layers;
     double dsum = 0.0;
+    RNF_STAMP_DECL
 
     // iteration position -> layer index, and the next position (> pos) whose layer owns an MLP image, or -1
     auto layer_at = [&](int pos) { return DIR ? (n_layers - 1 - pos) : pos; };
@@ -418,6 +432,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             R.c2 = v3f{src[2], src[5], src[8]};
         }
         float ldj = 0.f;
+        RNF_STAMP(7)                                              // 7: tile prologue / epilogue
 
         for (int pos = 0; pos < n_layers; ++pos) {
             const int2 d = args.layers[layer_at(pos)];
@@ -430,6 +445,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
 #pragma unroll
                 for (int i = 0; i < 16; ++i) M[i] = m[i];
                 affine16_apply(M, m[16], R, ldj);
+                RNF_STAMP(6)                                      // 6: unconditional affine layer
                 continue;
             }
 
@@ -455,6 +471,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 stage_floats(lds, params, MOB_HEAD_FLOATS + tiles_now * MOB_LAST_TILE_FLOATS, tid, NT);
                 __syncthreads();
             }
+            RNF_STAMP(0)                                          // 0: G load + synchronous staging (SYNC mode)
 
             MobiusCtx ctx;
             f32x16 tt[2];
@@ -464,19 +481,23 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             } else {
                 mlp_head(lds, lane, h, 0.f, 0.f, 0.f, cinit, tt);
             }
+            RNF_STAMP(1)                                          // 1: frame + hidden layers (H part)
             if (PIPE) {       // B1: every wave is past the H part and this layer's L part has landed
                 dma_wait_all();
                 __syncthreads();
                 if (nxt_off >= 0) dma_floats(lds, args.blob + nxt_off, MOB_HEAD_FLOATS, wave, lane, NW);
             }
+            RNF_STAMP(2)                                          // 2: barrier B1 (+ DMA issue)
 
             // B2 (DMA mode): every wave is past the L part and the next layer's H part has landed
             auto barrier2 = [&]() {
+                RNF_STAMP(3)                                      // 3: fc_last tiles + segment math (L part)
                 if (PIPE) {
                     dma_wait_all();
                     __syncthreads();
                     if (nxt_off >= 0) dma_floats(lds + MOB_LAST, args.blob + nxt_off + MOB_LAST, l_floats(nxt_kind), wave, lane, NW);
                 }
+                RNF_STAMP(4)                                      // 4: barrier B2 (+ DMA issue)
             };
             if (kind == RNF_KIND_MOBIUS) {
                 if constexpr (DIR != 0) {
@@ -497,6 +518,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 barrier2();
                 cond16_finish<DIR != 0>(o16, h, R, ldj);
             }
+            RNF_STAMP(5)                                          // 5: layer finish (bisection for the inverse)
         }
 
         // epilogue: outputs + fused base density + NLL partial (utils/fisher.py:217-232, agent.py:55-65)
@@ -538,6 +560,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             args.partials[blockIdx.x] = s;
         }
     }
+    RNF_STAMP_FLUSH
 }
 
 // fixed-order final reduction of the block partials -> out[0] += sum, out[1] += count

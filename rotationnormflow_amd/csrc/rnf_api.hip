@@ -299,6 +299,12 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     const long long chunk_cap = n_slots ? CHUNK_SAMPLES : n;
 
     a.blob = blob;
+#ifdef RNF_STAMPS
+    {   // diagnostic build: RNF_STAMPS_PTR=<device address of 8 zeroed uint64> (set by tools/phase_stamps.py)
+        const char *sp = std::getenv("RNF_STAMPS_PTR");
+        a.stamps = sp ? reinterpret_cast<unsigned long long *>(std::strtoull(sp, nullptr, 0)) : nullptr;
+    }
+#endif
     a.n_layers = n_layers;
     a.KT = KT;
     a.fisher_A = o.fisher_A;

@@ -163,72 +163,54 @@ __device__ __forceinline__ void mobius_begin(const Rot &R, int perm_row, MobiusC
 
 __device__ __forceinline__ void segments4(const f32x16 &o, const MobiusCtx &c, float &S, float &A, float &J) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float ur, uv, phi, cc;
-        squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, ur, uv);
-        mobius_angle(c.zr, c.zv, ur, uv, phi, cc);
-        const float sp = softplus(o[4 * g]);
-        S += sp;
-        A = fmaf(sp, phi, A);
-        J = fmaf(sp, cc, J);
-    }
+    for (int g = 0; g < 4; ++g) segment_full(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, c.zr, c.zv, S, A, J);
 }
 
 // forward, all fc_last tiles resident (K <= 64): software pipelined BY HAND.  Tile tau+1's 32 dependent MFMAs (64
-// cycles each on the matrix pipe) are interleaved one-for-one with 24 slices (4 segments x 6 stages, <= 16 VALU
-// instructions each) of tile tau's segment math, every MFMA + slice pair fenced with sched_barrier(0).  Left to
+// cycles each on the matrix pipe) are interleaved one-for-one with 32 slices (4 segments x 8 stages, ~10 VALU issue
+// slots each, so3_math.h seg_stage) of tile tau's segment math, every MFMA + slice pair fenced with sched_barrier(0).  Left to
 // itself hipcc emits the 32 MFMAs back to back followed by ~300 VALU instructions (and ignores a
 // sched_group_barrier pipeline for this block), so each wave alternates between matrix-only and VALU-only stretches
 // and the two waves of a SIMD, released together by the layer barriers, leave the matrix pipe idle in lockstep.
-struct SegState {
-    float ur, uv, c, hr, hv, t, phi, sp;
-    bool big;
-};
-
-template <int STAGE>
-__device__ __forceinline__ void seg_stage(SegState &g, float s_raw, float w0, float w1, float w2, const MobiusCtx &c,
-                                          float &S, float &A, float &J) {
-    if constexpr (STAGE == 0) squash_center(w0, w1, w2, c.f, g.ur, g.uv);
-    else if constexpr (STAGE == 1) mobius_map(c.zr, c.zv, g.ur, g.uv, g.hr, g.hv, g.c);
-    else if constexpr (STAGE == 2) atan_reduce(g.hv, g.hr, g.t, g.big);
-    else if constexpr (STAGE == 3) g.phi = atan_finish(g.hv, g.hr, g.t, g.big);
-    else if constexpr (STAGE == 4) g.sp = softplus(s_raw);
-    else {
-        S += g.sp;
-        A = fmaf(g.sp, g.phi, A);
-        J = fmaf(g.sp, g.c, J);
-    }
-}
-
 template <int K>
 __device__ __forceinline__ void tile_step(f32x16 &nxt, const float4 (&a)[8], const f32x16 (&tt)[2], const f32x16 &cur,
                                           SegState (&seg)[4], const MobiusCtx &c, float &S, float &A, float &J) {
     constexpr int tg = K >> 2, q = K & 3;
     const float av = q == 0 ? a[tg].x : (q == 1 ? a[tg].y : (q == 2 ? a[tg].z : a[tg].w));
     nxt = RNF_MFMA(av, tt[K >> 4][K & 15], nxt);
-    if constexpr (K < 24) {
-        constexpr int g = K / 6, st = K % 6;
-        seg_stage<st>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c, S, A, J);
-    }
+    constexpr int g = K >> 3, st = K & 7;             // slice `st` of segment `g` rides behind MFMA number K
+    seg_stage<st>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, c.zr, c.zv, S, A, J);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (K + 1 < 32) tile_step<K + 1>(nxt, a, tt, cur, seg, c, S, A, J);
 }
 
+// one pipelined tile: nxt <- fc_last tile `rec` (32 MFMAs), while the segment math of the finished tile `cur` runs
+__device__ __forceinline__ void tile_pipe(const float *rec, int lane, int h, const f32x16 (&tt)[2], f32x16 &nxt,
+                                          const f32x16 &cur, const MobiusCtx &c, float &S, float &A, float &J) {
+    nxt = load_bias16(rec + MOB_LAST_TILE_BIAS + h * 16);
+    float4 a[8];
+#pragma unroll
+    for (int tg = 0; tg < 8; ++tg) a[tg] = lds_f4(rec, tg * 64 + lane);
+    SegState seg[4];
+    __builtin_amdgcn_sched_barrier(0);
+    tile_step<0>(nxt, a, tt, cur, seg, c, S, A, J);
+}
+
 __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int lane, int h, const f32x16 (&tt)[2],
                                                  const MobiusCtx &c, float &S, float &A, float &J) {
-    f32x16 cur = last_tile(lds + MOB_LAST, lane, h, tt);
-    for (int tau = 1; tau < KT; ++tau) {
-        const float *rec = lds + MOB_LAST + tau * MOB_LAST_TILE_FLOATS;
-        f32x16 nxt = load_bias16(rec + MOB_LAST_TILE_BIAS + h * 16);
-        float4 a[8];
-#pragma unroll
-        for (int tg = 0; tg < 8; ++tg) a[tg] = lds_f4(rec, tg * 64 + lane);
-        SegState seg[4];
-        __builtin_amdgcn_sched_barrier(0);
-        tile_step<0>(nxt, a, tt, cur, seg, c, S, A, J);
-        cur = nxt;
+    const float *rec = lds + MOB_LAST;
+    f32x16 bufA = last_tile(rec, lane, h, tt), bufB;
+    int tau = 1;
+    for (; tau + 1 < KT; tau += 2) {       // two tiles per trip: the accumulators ping-pong, no register copies
+        tile_pipe(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt, bufB, bufA, c, S, A, J);
+        tile_pipe(rec + (tau + 1) * MOB_LAST_TILE_FLOATS, lane, h, tt, bufA, bufB, c, S, A, J);
     }
-    segments4(cur, c, S, A, J);
+    if (tau < KT) {
+        tile_pipe(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt, bufB, bufA, c, S, A, J);
+        segments4(bufB, c, S, A, J);
+    } else {
+        segments4(bufA, c, S, A, J);
+    }
 }
 
 // forward, K > 64: fc_last tiles restaged synchronously 8 at a time (staging mode SYNC only)

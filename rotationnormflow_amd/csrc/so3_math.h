@@ -160,6 +160,77 @@ RNF_HD void mobius_angle(float zr, float zv, float ur, float uv, float &phi, flo
     phi = angle_0_2pi(hv, hr);
 }
 
+// ---- one forward segment, cut into 8 slices of ~10 VALU issue slots --------------------------------------------------
+// Same arithmetic as squash_center -> mobius_map -> angle_0_2pi -> softplus -> accumulate, but exposed stage by stage so
+// the forward kernel can hand-interleave ONE slice behind every MFMA of the next fc_last tile (a 64-cycle matrix
+// instruction covers ~10 VALU issue slots of the two waves sharing a SIMD; unbalanced slices leave the pipe idle).
+struct SegState {
+    float wr, wv, nrm, ur, uv, u2, dr, dv, c, hr, hv, mx, mn, t, p, pp, r, e, u, lg;
+    bool big;
+};
+template <int STAGE>
+RNF_HD void seg_stage(SegState &g, float s_raw, float w0, float w1, float w2, const Frame &f, float zr, float zv,
+                      float &S, float &A, float &J) {
+    if constexpr (STAGE == 0) {
+        g.wr = fmaf(w2, f.r.z, fmaf(w1, f.r.y, w0 * f.r.x));
+        g.wv = fmaf(w2, f.v.z, fmaf(w1, f.v.y, w0 * f.v.x));
+        g.nrm = hw_sqrt(fmaf(g.wv, g.wv, g.wr * g.wr));
+    } else if constexpr (STAGE == 1) {
+        const float sc = 0.7f * hw_rcp(1.0f + g.nrm);
+        g.ur = g.wr * sc;
+        g.uv = g.wv * sc;
+        g.u2 = fmaf(g.uv, g.uv, g.ur * g.ur);
+        g.dr = zr - g.ur;
+        g.dv = zv - g.uv;
+    } else if constexpr (STAGE == 2) {
+        const float d2 = fmaf(g.dv, g.dv, g.dr * g.dr);
+        g.c = (1.0f - g.u2) * hw_rcp(d2);
+        g.hr = fmaf(g.c, g.dr, -g.ur);
+        g.hv = fmaf(g.c, g.dv, -g.uv);
+        g.mx = fmaxf(fabsf(g.hr), fabsf(g.hv));
+        g.mn = fminf(fabsf(g.hr), fabsf(g.hv));
+    } else if constexpr (STAGE == 3) {
+        const float a = g.mn * hw_rcp(g.mx);
+        g.big = a > 0.414213562373095f;
+        g.t = g.big ? (a - 1.0f) * hw_rcp(a + 1.0f) : a;
+    } else if constexpr (STAGE == 4) {
+        const float z = g.t * g.t;
+        float p = fmaf(fmaf(fmaf(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
+        p = fmaf(p * z, g.t, g.t);
+        p += g.big ? 0.785398163397448310f : 0.0f;
+        g.p = fabsf(g.hv) > fabsf(g.hr) ? 1.57079632679489662f - p : p;
+    } else if constexpr (STAGE == 5) {
+        float p = g.hr < 0.0f ? 3.14159265358979324f - g.p : g.p;
+        g.p = g.hv < 0.0f ? 6.28318530717958648f - p : p;                   // phi in [0, 2pi)
+        const float ax = fabsf(s_raw);
+        g.pp = ax * 1.44269502162933349609375f;
+        g.r = fmaf(ax, 1.92596299112661746e-8f, fmaf(ax, 1.44269502162933349609375f, -g.pp));
+    } else if constexpr (STAGE == 6) {
+        float e = hw_exp2(-g.pp);
+        g.e = fmaf(-0.693147180559945309f * e, g.r, e);
+        g.u = 1.0f + g.e;
+        g.lg = hw_log2(g.u);
+    } else {
+        const float l = fmaf(g.lg, 0.693147180559945309f, (g.e - (g.u - 1.0f)) * hw_rcp(g.u));
+        const float sp = fmaxf(s_raw, 0.0f) + l;
+        S += sp;
+        A = fmaf(sp, g.p, A);
+        J = fmaf(sp, g.c, J);
+    }
+}
+RNF_HD void segment_full(float s_raw, float w0, float w1, float w2, const Frame &f, float zr, float zv, float &S, float &A,
+                         float &J) {
+    SegState g;
+    seg_stage<0>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
+    seg_stage<1>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
+    seg_stage<2>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
+    seg_stage<3>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
+    seg_stage<4>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
+    seg_stage<5>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
+    seg_stage<6>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
+    seg_stage<7>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
+}
+
 // pytorch3d.transforms.matrix_to_quaternion (published 0.7.5 rule; call site flow/squeezetrans.py:34):
 // four candidates from sqrt(max(0, 1 +- m00 +- m11 +- m22)), keep the one with the largest |q_i| (first on ties),
 // denominators floored at 0.1.  Real part first.

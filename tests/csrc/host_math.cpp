@@ -44,11 +44,15 @@ void hm_mobius_forward(const float *Rin, const float *cond, int K, int perm_row,
         float S = 0, A = 0, J = 0;
         const float *c = cond + (size_t)4 * K * i;
         for (int k = 0; k < K; ++k) {
-            float ur, uv, phi, cc;
-            squash_center(c[K + 3 * k], c[K + 3 * k + 1], c[K + 3 * k + 2], f, ur, uv);
-            mobius_angle(zr, zv, ur, uv, phi, cc);
-            float sp = softplus(c[k]);
-            S += sp; A += sp * phi; J += sp * cc;
+            if (k & 1) {                       // exercise both formulations of the segment math
+                float ur, uv, phi, cc;
+                squash_center(c[K + 3 * k], c[K + 3 * k + 1], c[K + 3 * k + 2], f, ur, uv);
+                mobius_angle(zr, zv, ur, uv, phi, cc);
+                float sp = softplus(c[k]);
+                S += sp; A += sp * phi; J += sp * cc;
+            } else {
+                segment_full(c[k], c[K + 3 * k], c[K + 3 * k + 1], c[K + 3 * k + 2], f, zr, zv, S, A, J);
+            }
         }
         float sn, cs;
         sincos_small(A / S, sn, cs);

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define RNF_ABI_VERSION 1
+#define RNF_ABI_VERSION 2
 
 /* width of the conditioner MLP's hidden layers: flow/condition.py:9 (Nh=64, never overridden by any caller) */
 #define RNF_HIDDEN 64
@@ -33,12 +33,22 @@ extern "C" {
  *   desc[i][2] param_offset  offset of the layer's packed parameters in the blob, in floats (multiple of 4)
  *   desc[i][3] cond_slot     index of this layer among the layers that consume the feature vector, or -1
  *   desc[i][4] feat_offset   offset in the blob of the layer's packed feature-projection weights, or -1
- *   desc[i][5] reserved
+ *   desc[i][5] precision     RNF_PREC_* the layer's weight image was packed with (same for every MLP layer)
  */
 #define RNF_DESC_STRIDE 6
 #define RNF_LAYER_MOBIUS 1        /* flow/mobiusflow.py:27-183  MobiusFlow                                  */
 #define RNF_LAYER_AFFINE16 2      /* flow/squeezetrans.py:161-174 Uncondition16Trans (any constant 4x4 M)   */
 #define RNF_LAYER_AFFINE16_COND 3 /* flow/squeezetrans.py:41-55  Condition16Trans (M = I + MLP(feature))    */
+
+/* ---- arithmetic of the conditioner GEMMs --------------------------------------------------------------------
+ * RNF_PREC_FP32  : exact fp32 (v_mfma_f32_32x32x2_f32; bit-for-bit an fp32 fma chain).
+ * RNF_PREC_F16X2 : every fp32 operand carried as two fp16 terms (22 significant bits), three fp16 MFMAs with fp32
+ *                  accumulation per product-sum; indistinguishable from fp32 at the parity bar of this path,
+ *                  ~2.5x faster because the fp16 matrix cores co-execute with the VALU segment math.  Operands must be
+ *                  inside the fp16 range (|x| < 65504): rnf_pack_* returns 2 for such weights (pack FP32 instead).
+ */
+#define RNF_PREC_FP32 0
+#define RNF_PREC_F16X2 1
 
 int rnf_abi_version(void);
 const char *rnf_last_error(void);
@@ -60,7 +70,7 @@ int64_t rnf_featproj_packed_floats(int32_t feature_dim); /* 0 when feature_dim =
 int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
                     const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
                     const float *fc_last_w, const float *fc_last_b, int32_t segments, int32_t feature_dim,
-                    float *out_layer, float *out_feat);
+                    int32_t precision, float *out_layer, float *out_feat);
 
 /* Uncondition16Trans.mat [4,4] row-major (flow/squeezetrans.py:164-165).  Packs M, log|det M|, M^-1 and
  * log|det M^-1| (the reference recomputes inv/det every call: squeezetrans.py:38,171-174). */
@@ -69,8 +79,8 @@ int rnf_pack_affine16(const float *mat16, float *out_layer);
 /* Condition16Trans.net = ConditionalTransform(F, 16) (flow/squeezetrans.py:42-44). fc_first_w [64,F], fc_last_w [16,64]. */
 int rnf_pack_cond16(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
                     const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
-                    const float *fc_last_w, const float *fc_last_b, int32_t feature_dim, float *out_layer,
-                    float *out_feat);
+                    const float *fc_last_w, const float *fc_last_b, int32_t feature_dim, int32_t precision,
+                    float *out_layer, float *out_feat);
 
 /* ---- the flow -------------------------------------------------------------------------------------------------
  * rotation_dev   [n,3,3] float32 row-major contiguous
@@ -113,7 +123,7 @@ int rnf_fisher_log_prob(const float *rotation_dev, int64_t n, const float *fishe
 /* ConditionalTransform.forward for one packed Moebius layer (flow/condition.py:24-30), unconditional input only:
  * y_dev [n,3] -> out_dev [n,4K] in the reference's output order.  Unit-test / bring-up entry point. */
 int rnf_conditioner_forward(const float *y_dev, int64_t n, const float *layer_packed_dev, int32_t segments,
-                            float *out_dev, void *stream);
+                            int32_t precision, float *out_dev, void *stream);
 
 #ifdef __cplusplus
 }

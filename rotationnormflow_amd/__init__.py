@@ -7,7 +7,18 @@ signatures and state-dict keys).  There is no CPU fallback.
 """
 from .configs import make_config, load_yaml_config, PRESETS  # noqa: F401
 
-__all__ = ["make_config", "load_yaml_config", "PRESETS", "install_as_reference_modules"]
+__all__ = ["make_config", "load_yaml_config", "PRESETS", "install_as_reference_modules", "set_precision", "get_precision"]
+
+
+def set_precision(name):
+    """Arithmetic of the conditioner GEMMs: "f16x2" (default, split-precision fp16 MFMA) or "fp32" (exact fp32 MFMA)."""
+    from . import runtime
+    runtime.set_precision(name)
+
+
+def get_precision():
+    from . import runtime
+    return runtime.get_precision()
 
 
 def install_as_reference_modules():

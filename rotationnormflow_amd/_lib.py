@@ -10,6 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librnf_hip.so")
 
 _lib = None
+ABI_VERSION = 2
+PREC_FP32, PREC_F16X2 = 0, 1
 
 c_f32p = C.c_void_p      # device or host float*, passed as integer addresses
 c_i32p = C.c_void_p
@@ -21,9 +23,9 @@ _SIGNATURES = {
     "rnf_affine16_packed_floats": (C.c_int64, []),
     "rnf_cond16_packed_floats": (C.c_int64, []),
     "rnf_featproj_packed_floats": (C.c_int64, [C.c_int32]),
-    "rnf_pack_mobius": (C.c_int, [c_f32p] * 10 + [C.c_int32, C.c_int32, c_f32p, c_f32p]),
+    "rnf_pack_mobius": (C.c_int, [c_f32p] * 10 + [C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p]),
     "rnf_pack_affine16": (C.c_int, [c_f32p, c_f32p]),
-    "rnf_pack_cond16": (C.c_int, [c_f32p] * 10 + [C.c_int32, c_f32p, c_f32p]),
+    "rnf_pack_cond16": (C.c_int, [c_f32p] * 10 + [C.c_int32, C.c_int32, c_f32p, c_f32p]),
     "rnf_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "rnf_flow_forward": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
                                    c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -33,7 +35,7 @@ _SIGNATURES = {
                                     c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnf_fisher_log_prob": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_void_p]),
-    "rnf_conditioner_forward": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int32, c_f32p, C.c_void_p]),
+    "rnf_conditioner_forward": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -52,7 +54,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.rnf_abi_version() != 1:
+        if handle.rnf_abi_version() != ABI_VERSION:
             raise RuntimeError("librnf_hip.so ABI version mismatch; rebuild")
         _lib = handle
     return _lib

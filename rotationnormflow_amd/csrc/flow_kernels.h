@@ -129,6 +129,125 @@ __device__ __forceinline__ f32x16 last_tile(const float *tile_rec, int lane, int
     return gemm_tile64<false>(tile_rec, lane, tt, c);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Split-precision path (PREC = 1, "f16x2"): every fp32 operand x of the 64-wide GEMMs is carried as two fp16 terms
+//     x = hi + 2^-12 * lo,   hi = fp16(x) (RN),  lo = fp16((x - hi) * 2^12)        (22 significant bits)
+// and each fp32 product-sum as THREE v_mfma_f32_32x32x16_f16 (fp32 accumulate):
+//     acc1 += Ahi.Bhi        acc2 += Ahi.Blo + Alo.Bhi        result = acc1 + 2^-12 * acc2        (Alo.Blo ~ 2^-24 dropped)
+// Why: on gfx950 the f32-input MFMA runs on the same FMA datapath as the VALU (measured: VALU issue stalls for the
+// ~48-64 cycles an f32 MFMA occupies, profiles/r1/mfma_valu_coissue_microbench.txt), so the exact-fp32 kernel can never
+// overlap the segment math with the conditioner GEMMs; the f16 MFMA runs on the real matrix cores at 16x the rate and
+// co-executes with the VALU.  Measured effect on parity: none beyond fp32 rounding noise.
+// Range: an activation or weight >= 65520 in magnitude overflows fp16 and the result turns into inf/NaN (loudly); the
+// host packer refuses weights outside the fp16 range and falls back to the exact PREC = 0 kernels.
+//
+// Operand maps of v_mfma_f32_32x32x16_f16: lane (r = l&31, h = l>>5) element j (0..7) is A[row r][k = 8h + j] and
+// B[k = 8h + j][col r].  K-step s = 2t + s' of a 64-feature activation consumes accumulator registers 8s'..8s'+7 of
+// tile t of the producing layer; register 8s'+j of lane-half h is feature 32t + 16s' + 8(j>>2) + 4h + (j&3), so the
+// weight image stores for lane (i, h):  elem j = W[32*ot + i][32t + 16s' + 8(j>>2) + 4h + (j&3)]   (hi image, lo image).
+// ------------------------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#define RNF_MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+constexpr float kLoScale = 4096.0f, kLoInv = 1.0f / 4096.0f;
+
+struct ActFrag {
+    h8 hi[4], lo[4];          // B fragments of one 64-feature activation, k-step s = 2*tile + half
+};
+
+template <bool RELU>
+__device__ __forceinline__ void split_act(const f32x16 (&x)[2], ActFrag &f) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            float a = x[s >> 1][8 * (s & 1) + j], b = x[s >> 1][8 * (s & 1) + j + 1];
+            if (RELU) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+            const h2 ph = {(_Float16)a, (_Float16)b};
+            const h2 pl = {(_Float16)((a - (float)ph[0]) * kLoScale), (_Float16)((b - (float)ph[1]) * kLoScale)};
+            f.hi[s][j] = ph[0]; f.hi[s][j + 1] = ph[1];
+            f.lo[s][j] = pl[0]; f.lo[s][j + 1] = pl[1];
+        }
+    }
+}
+
+__device__ __forceinline__ h8 lds_h8(const float *base, int idx16) {
+    return reinterpret_cast<const h8 *>(base)[idx16];
+}
+
+// one 64 -> 32 output tile in split precision; w_tile = [4 k-steps][hi, lo][64 lanes] h8  (2048 floats, as in fp32)
+__device__ __forceinline__ f32x16 gemm_tile64_h(const float *w_tile, int lane, const ActFrag &in, f32x16 acc1) {
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const h8 ah = lds_h8(w_tile, (s * 2 + 0) * 64 + lane);
+        const h8 al = lds_h8(w_tile, (s * 2 + 1) * 64 + lane);
+        acc1 = RNF_MFMA_H(ah, in.hi[s], acc1);
+        acc2 = RNF_MFMA_H(ah, in.lo[s], acc2);
+        acc2 = RNF_MFMA_H(al, in.hi[s], acc2);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = fmaf(acc2[r], kLoInv, acc1[r]);
+    return acc1;
+}
+
+// The two precisions behind one interface: Act = what the hidden stack hands to fc_last.
+template <int PREC>
+struct Mlp;
+
+template <>
+struct Mlp<0> {
+    struct Act { f32x16 t[2]; };
+    static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
+                                                const f32x16 (&cinit)[2], Act &out) {
+        mlp_head(lds, lane, h, y0, y1, y2, cinit, out.t);
+    }
+    static __device__ __forceinline__ f32x16 last(const float *tile_rec, int lane, int h, const Act &a) {
+        return last_tile(tile_rec, lane, h, a.t);
+    }
+};
+
+template <>
+struct Mlp<1> {
+    typedef ActFrag Act;
+    static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
+                                                const f32x16 (&cinit)[2], Act &out) {
+        // fc_first (K = 3 + bias) stays on the two exact fp32 MFMA steps: 4 of the layer's 172 matrix instructions
+        const float bA = h ? y1 : y0;
+        const float bB = h ? 1.0f : y2;
+        f32x16 x0[2];
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            float2 a = reinterpret_cast<const float2 *>(lds + MOB_FIRST)[ot * 64 + lane];
+            f32x16 c = RNF_MFMA(a.x, bA, cinit[ot]);
+            x0[ot] = RNF_MFMA(a.y, bB, c);
+        }
+        ActFrag f;
+        split_act<true>(x0, f);
+        f32x16 hcur[2];
+#pragma unroll
+        for (int L = 0; L < 3; ++L) {
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                f32x16 c = load_bias16(lds + MOB_HB + ((L * 2 + ot) * 2 + h) * 16);
+                hcur[ot] = gemm_tile64_h(lds + MOB_HID + (L * 2 + ot) * (8 * 64 * 4), lane, f, c);
+            }
+            if (L < 2) split_act<true>(hcur, f);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hcur[t][r] = x0[t][r] + hcur[t][r];      // residual (flow/condition.py:29)
+        split_act<true>(hcur, out);
+    }
+    static __device__ __forceinline__ f32x16 last(const float *tile_rec, int lane, int h, const Act &a) {
+        f32x16 c = load_bias16(tile_rec + MOB_LAST_TILE_BIAS + h * 16);
+        return gemm_tile64_h(tile_rec, lane, a, c);
+    }
+};
+
 __device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -185,6 +304,7 @@ __device__ __forceinline__ void tile_step(f32x16 &nxt, const float4 (&a)[8], con
 }
 
 // one pipelined tile: nxt <- fc_last tile `rec` (32 MFMAs), while the segment math of the finished tile `cur` runs
+// (exact fp32 path; the split-precision path needs no hand interleave: its MFMAs run on the matrix cores)
 __device__ __forceinline__ void tile_pipe(const float *rec, int lane, int h, const f32x16 (&tt)[2], f32x16 &nxt,
                                           const f32x16 &cur, const MobiusCtx &c, float &S, float &A, float &J) {
     nxt = load_bias16(rec + MOB_LAST_TILE_BIAS + h * 16);
@@ -196,27 +316,41 @@ __device__ __forceinline__ void tile_pipe(const float *rec, int lane, int h, con
     tile_step<0>(nxt, a, tt, cur, seg, c, S, A, J);
 }
 
-__device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int lane, int h, const f32x16 (&tt)[2],
+template <int PREC>
+__device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int lane, int h, const typename Mlp<PREC>::Act &tt,
                                                  const MobiusCtx &c, float &S, float &A, float &J) {
     const float *rec = lds + MOB_LAST;
-    f32x16 bufA = last_tile(rec, lane, h, tt), bufB;
-    int tau = 1;
-    for (; tau + 1 < KT; tau += 2) {       // two tiles per trip: the accumulators ping-pong, no register copies
-        tile_pipe(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt, bufB, bufA, c, S, A, J);
-        tile_pipe(rec + (tau + 1) * MOB_LAST_TILE_FLOATS, lane, h, tt, bufA, bufB, c, S, A, J);
-    }
-    if (tau < KT) {
-        tile_pipe(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt, bufB, bufA, c, S, A, J);
-        segments4(bufB, c, S, A, J);
+    if constexpr (PREC == 0) {
+        f32x16 bufA = last_tile(rec, lane, h, tt.t), bufB;
+        int tau = 1;
+        for (; tau + 1 < KT; tau += 2) {       // two tiles per trip: the accumulators ping-pong, no register copies
+            tile_pipe(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt.t, bufB, bufA, c, S, A, J);
+            tile_pipe(rec + (tau + 1) * MOB_LAST_TILE_FLOATS, lane, h, tt.t, bufA, bufB, c, S, A, J);
+        }
+        if (tau < KT) {
+            tile_pipe(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt.t, bufB, bufA, c, S, A, J);
+            segments4(bufB, c, S, A, J);
+        } else {
+            segments4(bufA, c, S, A, J);
+        }
     } else {
-        segments4(bufA, c, S, A, J);
+        // software pipeline: tile tau+1's 12 matrix instructions are in flight on the matrix cores while the VALU runs
+        // the segment math of tile tau
+        f32x16 cur = Mlp<1>::last(rec, lane, h, tt);
+        for (int tau = 1; tau < KT; ++tau) {
+            f32x16 nxt = Mlp<1>::last(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt);
+            segments4(cur, c, S, A, J);
+            cur = nxt;
+        }
+        segments4(cur, c, S, A, J);
     }
 }
 
 // forward, K > 64: fc_last tiles restaged synchronously 8 at a time (staging mode SYNC only)
+template <int PREC>
 __device__ __forceinline__ void mobius_fwd_tiles_restage(float *lds, const float *layer_params, int KT, int lane, int h,
-                                                         const f32x16 (&tt)[2], const MobiusCtx &c, float &S, float &A,
-                                                         float &J, int tid, int nthreads) {
+                                                         const typename Mlp<PREC>::Act &tt, const MobiusCtx &c, float &S,
+                                                         float &A, float &J, int tid, int nthreads) {
     for (int tau = 0; tau < KT; ++tau) {
         if (tau > 0 && (tau % MOB_MAX_TILES_IN_LDS) == 0) {
             __syncthreads();
@@ -225,7 +359,7 @@ __device__ __forceinline__ void mobius_fwd_tiles_restage(float *lds, const float
                          nt * MOB_LAST_TILE_FLOATS, tid, nthreads);
             __syncthreads();
         }
-        f32x16 o = last_tile(lds + MOB_LAST + (tau % MOB_MAX_TILES_IN_LDS) * MOB_LAST_TILE_FLOATS, lane, h, tt);
+        f32x16 o = Mlp<PREC>::last(lds + MOB_LAST + (tau % MOB_MAX_TILES_IN_LDS) * MOB_LAST_TILE_FLOATS, lane, h, tt);
         segments4(o, c, S, A, J);
     }
 }
@@ -250,13 +384,13 @@ struct InvSegs {
     float sp[4 * KT], ur[4 * KT], uv[4 * KT];
 };
 
-template <int KT>
-__device__ __forceinline__ void mobius_inv_tiles(const float *lds, int lane, int h, const f32x16 (&tt)[2],
+template <int KT, int PREC>
+__device__ __forceinline__ void mobius_inv_tiles(const float *lds, int lane, int h, const typename Mlp<PREC>::Act &tt,
                                                  const MobiusCtx &c, InvSegs<KT> &sg, float &S) {
     static_assert(KT <= MOB_MAX_TILES_IN_LDS, "inverse keeps all fc_last tiles in LDS");
 #pragma unroll
     for (int tau = 0; tau < KT; ++tau) {
-        f32x16 o = last_tile(lds + MOB_LAST + tau * MOB_LAST_TILE_FLOATS, lane, h, tt);
+        f32x16 o = Mlp<PREC>::last(lds + MOB_LAST + tau * MOB_LAST_TILE_FLOATS, lane, h, tt);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, sg.ur[4 * tau + g], sg.uv[4 * tau + g]);
@@ -365,7 +499,7 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 #define RNF_STAMP_FLUSH
 #endif
 
-template <int DIR, int KT_INV, int NW, bool PIPE>
+template <int DIR, int KT_INV, int NW, bool PIPE, int PREC>
 __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -456,12 +590,12 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             RNF_STAMP(0)                                          // 0: G load + synchronous staging (SYNC mode)
 
             MobiusCtx ctx;
-            f32x16 tt[2];
+            typename Mlp<PREC>::Act tt;
             if (kind == RNF_KIND_MOBIUS) {
                 mobius_begin<DIR>(R, perm_row, ctx);
-                mlp_head(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, cinit, tt);
+                Mlp<PREC>::head(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, cinit, tt);
             } else {
-                mlp_head(lds, lane, h, 0.f, 0.f, 0.f, cinit, tt);
+                Mlp<PREC>::head(lds, lane, h, 0.f, 0.f, 0.f, cinit, tt);
             }
             RNF_STAMP(1)                                          // 1: frame + hidden layers (H part)
             if (PIPE) {       // B1: every wave is past the H part and this layer's L part has landed
@@ -485,18 +619,18 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 if constexpr (DIR != 0) {
                     InvSegs<KTI> sg;
                     float S = 0.f;
-                    mobius_inv_tiles<KTI>(lds, lane, h, tt, ctx, sg, S);
+                    mobius_inv_tiles<KTI, PREC>(lds, lane, h, tt, ctx, sg, S);
                     barrier2();
                     mobius_inv_finish<KTI>(ctx, sg, S, R, ldj);
                 } else {
                     float S = 0.f, A = 0.f, J = 0.f;
-                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles(lds, KT, lane, h, tt, ctx, S, A, J);
-                    else mobius_fwd_tiles_restage(lds, params, KT, lane, h, tt, ctx, S, A, J, tid, NT);
+                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC>(lds, KT, lane, h, tt, ctx, S, A, J);
+                    else mobius_fwd_tiles_restage<PREC>(lds, params, KT, lane, h, tt, ctx, S, A, J, tid, NT);
                     barrier2();
                     mobius_fwd_finish(ctx, S, A, J, R, ldj);
                 }
             } else {
-                const f32x16 o16 = last_tile(lds + MOB_LAST, lane, h, tt);
+                const f32x16 o16 = Mlp<PREC>::last(lds + MOB_LAST, lane, h, tt);
                 barrier2();
                 cond16_finish<DIR != 0>(o16, h, R, ldj);
             }

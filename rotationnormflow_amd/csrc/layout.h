@@ -67,7 +67,7 @@ constexpr int G_FLOATS_PER_GROUP = 2 * 4 * 64 * 4;        // 2048 floats = 64 fe
 constexpr int RNF_KIND_MOBIUS = 1, RNF_KIND_AFFINE16 = 2, RNF_KIND_COND16 = 3;
 
 // layer descriptor columns (include/rnf_hip.h)
-constexpr int D_KIND = 0, D_PERM = 1, D_PARAM = 2, D_SLOT = 3, D_FEAT = 4, D_STRIDE = 6;
+constexpr int D_KIND = 0, D_PERM = 1, D_PARAM = 2, D_SLOT = 3, D_FEAT = 4, D_PREC = 5, D_STRIDE = 6;   // D_PREC: RNF_PREC_* of include/rnf_hip.h
 
 inline constexpr int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

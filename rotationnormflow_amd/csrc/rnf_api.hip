@@ -62,6 +62,29 @@ static void pack_w64(float *img, int n_ot, RowFn row_of /* (ot, i) -> const floa
             }
 }
 
+// split-precision image of the same rows: [ot][s (4)][hi, lo][lane] 8 x fp16, element j of lane (i, h) of k-step
+// s = 2t + s' is W[row][32t + 16s' + 8(j>>2) + 4h + (j&3)] as hi = fp16(w), lo = fp16((w - hi) * 4096)  (flow_kernels.h)
+static bool g_half_overflow = false;
+template <typename RowFn>
+static void pack_w64_h(float *img, int n_ot, RowFn row_of) {
+    _Float16 *out = reinterpret_cast<_Float16 *>(img);
+    for (int ot = 0; ot < n_ot; ++ot)
+        for (int s = 0; s < 4; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, h = lane >> 5;
+                const float *row = row_of(ot, i);
+                _Float16 *hi = out + ((((size_t)ot * 4 + s) * 2 + 0) * 64 + lane) * 8;
+                _Float16 *lo = out + ((((size_t)ot * 4 + s) * 2 + 1) * 64 + lane) * 8;
+                for (int j = 0; j < 8; ++j) {
+                    const float w = row ? row[16 * s + 8 * (j >> 2) + 4 * h + (j & 3)] : 0.f;
+                    if (!(std::fabs(w) < 65504.0f)) g_half_overflow = true;      // also catches NaN / inf
+                    const _Float16 wh = (_Float16)w;
+                    hi[j] = wh;
+                    lo[j] = (_Float16)((w - (float)wh) * 4096.0f);
+                }
+            }
+}
+
 // bias image [ot][h][16]: b[32*ot + rho(r,h)] (or the mapped row's bias)
 template <typename BiasFn>
 static void pack_bias(float *img, int n_ot, BiasFn bias_of /* (ot, row_in_tile) -> float */) {
@@ -70,10 +93,12 @@ static void pack_bias(float *img, int n_ot, BiasFn bias_of /* (ot, row_in_tile) 
             for (int r = 0; r < 16; ++r) img[(ot * 2 + h) * 16 + r] = bias_of(ot, rho(r, h));
 }
 
-static void pack_hidden(float *out, const float *const w[3], const float *const b[3]) {
+static void pack_hidden(float *out, const float *const w[3], const float *const b[3], int prec) {
     for (int L = 0; L < 3; ++L) {
         const float *W = w[L];
-        pack_w64(out + MOB_HID + (size_t)L * 2 * 8 * 64 * 4, 2, [&](int ot, int i) { return W + (size_t)(32 * ot + i) * 64; });
+        auto row_of = [&](int ot, int i) { return W + (size_t)(32 * ot + i) * 64; };
+        if (prec) pack_w64_h(out + MOB_HID + (size_t)L * 2 * 8 * 64 * 4, 2, row_of);
+        else pack_w64(out + MOB_HID + (size_t)L * 2 * 8 * 64 * 4, 2, row_of);
         const float *B = b[L];
         pack_bias(out + MOB_HB + L * 2 * 2 * 16, 2, [&](int ot, int row) { return B[32 * ot + row]; });
     }
@@ -94,9 +119,11 @@ static void pack_featproj(float *out, const float *W, int ldw, int col0, int F, 
 
 extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
                                const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
-                               const float *fc_last_w, const float *fc_last_b, int32_t K, int32_t F, float *out,
-                               float *out_feat) {
+                               const float *fc_last_w, const float *fc_last_b, int32_t K, int32_t F, int32_t prec,
+                               float *out, float *out_feat) {
     if (K <= 0 || K % 8) return fail("rnf_pack_mobius: segments=%d must be a positive multiple of 8", K);
+    if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2) return fail("rnf_pack_mobius: unknown precision %d", prec);
+    g_half_overflow = false;
     if (F < 0 || F % 8) return fail("rnf_pack_mobius: feature_dim=%d must be a multiple of 8 (pad on the host)", F);
     const int ni = 3 + F;
     // fc_first: float2 per lane = (W0[o][h], h ? b0[o] : W0[o][2]); conditional layers carry b0 in the projection
@@ -109,7 +136,7 @@ extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b,
         }
     const float *hw[3] = {l1_w, l3_w, l5_w};
     const float *hb[3] = {l1_b, l3_b, l5_b};
-    pack_hidden(out, hw, hb);
+    pack_hidden(out, hw, hb, prec);
     // fc_last: packed row P = 32*tau + 8g + 4h + c  <->  segment k = 8*tau + 2g + h, component c
     auto src_row = [&](int tau, int row) {
         const int g = row >> 3, h = (row >> 2) & 1, c = row & 3;
@@ -118,21 +145,26 @@ extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b,
     };
     for (int tau = 0; tau < K / 8; ++tau) {
         float *rec = out + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS;
-        pack_w64(rec, 1, [&](int, int i) { return fc_last_w + (size_t)src_row(tau, i) * 64; });
+        auto row_of = [&](int, int i) { return fc_last_w + (size_t)src_row(tau, i) * 64; };
+        if (prec) pack_w64_h(rec, 1, row_of); else pack_w64(rec, 1, row_of);
         pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) { return fc_last_b[src_row(tau, row)]; });
     }
     if (F) pack_featproj(out_feat, fc_first_w, ni, 3, F, fc_first_b);
+    if (prec && g_half_overflow) return fail("rnf_pack_mobius: a weight is outside the fp16 range; use RNF_PREC_FP32") + 1;
     return 0;
 }
 
 extern "C" int rnf_pack_cond16(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
                                const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
-                               const float *fc_last_w, const float *fc_last_b, int32_t F, float *out, float *out_feat) {
+                               const float *fc_last_w, const float *fc_last_b, int32_t F, int32_t prec, float *out,
+                               float *out_feat) {
     if (F <= 0 || F % 8) return fail("rnf_pack_cond16: feature_dim=%d must be a positive multiple of 8", F);
+    if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2) return fail("rnf_pack_cond16: unknown precision %d", prec);
+    g_half_overflow = false;
     std::memset(out, 0, sizeof(float) * COND16_FLOATS);        // zero fc_first image: x0 comes from the projection
     const float *hw[3] = {l1_w, l3_w, l5_w};
     const float *hb[3] = {l1_b, l3_b, l5_b};
-    pack_hidden(out, hw, hb);
+    pack_hidden(out, hw, hb, prec);
     // one fc_last tile: packed row 8g + 4h + c (g = 0,1) <-> M[2g + h][c] = output 4*(2g+h) + c; rows >= 16 zero
     auto src_row = [&](int row) {
         if (row >= 16) return -1;
@@ -140,9 +172,11 @@ extern "C" int rnf_pack_cond16(const float *fc_first_w, const float *fc_first_b,
         return 4 * (2 * g + h) + c;
     };
     float *rec = out + MOB_LAST;
-    pack_w64(rec, 1, [&](int, int i) { int s = src_row(i); return s < 0 ? (const float *)nullptr : fc_last_w + (size_t)s * 64; });
+    auto row_of = [&](int, int i) { int s = src_row(i); return s < 0 ? (const float *)nullptr : fc_last_w + (size_t)s * 64; };
+    if (prec) pack_w64_h(rec, 1, row_of); else pack_w64(rec, 1, row_of);
     pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) { int s = src_row(row); return s < 0 ? 0.f : fc_last_b[s]; });
     pack_featproj(out_feat, fc_first_w, F, 0, F, fc_first_b);
+    if (prec && g_half_overflow) return fail("rnf_pack_cond16: a weight is outside the fp16 range; use RNF_PREC_FP32") + 1;
     return 0;
 }
 
@@ -225,9 +259,9 @@ static bool staging_dma() {
     return mode == 1;
 }
 
-template <int DIR, int KT_INV, bool PIPE>
+template <int DIR, int KT_INV, bool PIPE, int PREC>
 static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream) {
-    auto kern = flow_stack_kernel<DIR, KT_INV, NW, PIPE>;
+    auto kern = flow_stack_kernel<DIR, KT_INV, NW, PIPE, PREC>;
     HIP_TRY(allow_lds(kern, lds_bytes));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, a);
     HIP_TRY(hipGetLastError());
@@ -258,6 +292,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     std::memset(&fp, 0, sizeof(fp));
     int n_slots = 0;
     bool any_mlp = false;
+    int prec = -1;
     for (int l = 0; l < n_layers; ++l) {
         const int32_t *d = desc + (size_t)l * D_STRIDE;
         const int kind = d[D_KIND], perm = d[D_PERM], slot = d[D_SLOT];
@@ -271,9 +306,16 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             fp.feat_off[slot] = d[D_FEAT];
             if (slot + 1 > n_slots) n_slots = slot + 1;
         }
-        if (kind != RNF_KIND_AFFINE16) any_mlp = true;
+        if (kind != RNF_KIND_AFFINE16) {
+            any_mlp = true;
+            const int p = d[D_PREC];
+            if (p != RNF_PREC_FP32 && p != RNF_PREC_F16X2) return fail("layer %d: unknown precision %d", l, p);
+            if (prec >= 0 && p != prec) return fail("layer %d: all MLP layers of a flow must be packed with the same precision", l);
+            prec = p;
+        }
         a.layers[l] = make_int2(kind | (perm << 4) | ((slot + 1) << 8), d[D_PARAM]);
     }
+    if (prec < 0) prec = 0;
     if (n_slots > 0) {
         if (!feat) return fail("this flow consumes a feature vector but feature pointer is null (flow/mobiusflow.py:48-49)");
         if (F <= 0 || F % 8) return fail("feature_dim=%d must be a positive multiple of 8 (pad on the host)", F);
@@ -341,12 +383,20 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         a.sample_base = base;
         a.g_groups = groups;
         int rc;
-        const bool pipe = staging_dma() && KT <= MOB_MAX_TILES_IN_LDS;
-        if (o.dir == 0) rc = pipe ? launch_stack<0, 0, true>(a, grid, lds_bytes, stream) : launch_stack<0, 0, false>(a, grid, lds_bytes, stream);
-        else if (KT == 1) rc = pipe ? launch_stack<1, 1, true>(a, grid, lds_bytes, stream) : launch_stack<1, 1, false>(a, grid, lds_bytes, stream);
-        else if (KT == 2) rc = pipe ? launch_stack<1, 2, true>(a, grid, lds_bytes, stream) : launch_stack<1, 2, false>(a, grid, lds_bytes, stream);
-        else if (KT == 4) rc = pipe ? launch_stack<1, 4, true>(a, grid, lds_bytes, stream) : launch_stack<1, 4, false>(a, grid, lds_bytes, stream);
-        else rc = pipe ? launch_stack<1, 8, true>(a, grid, lds_bytes, stream) : launch_stack<1, 8, false>(a, grid, lds_bytes, stream);
+        // (inverse with K = 64: 96 segment registers + the DMA bookkeeping spill under the 256-VGPR cap; it is VALU-bound in
+        //  the bisection anyway, so it keeps the synchronous staging)
+        const bool pipe = staging_dma() && KT <= MOB_MAX_TILES_IN_LDS && !(o.dir == 1 && KT == 8);
+#define RNF_LAUNCH(DIR_, KT_)                                                                                   \
+    (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1>(a, grid, lds_bytes, stream)                               \
+                  : launch_stack<DIR_, KT_, true, 0>(a, grid, lds_bytes, stream))                              \
+          : (prec ? launch_stack<DIR_, KT_, false, 1>(a, grid, lds_bytes, stream)                              \
+                  : launch_stack<DIR_, KT_, false, 0>(a, grid, lds_bytes, stream)))
+        if (o.dir == 0) rc = RNF_LAUNCH(0, 0);
+        else if (KT == 1) rc = RNF_LAUNCH(1, 1);
+        else if (KT == 2) rc = RNF_LAUNCH(1, 2);
+        else if (KT == 4) rc = RNF_LAUNCH(1, 4);
+        else rc = RNF_LAUNCH(1, 8);
+#undef RNF_LAUNCH
         if (rc) return rc;
         if (o.sum_out) {
             hipLaunchKernelGGL(nll_finalize_kernel, dim3(1), dim3(256), 0, stream, (const double *)partials, grid, (double)cn, o.sum_out, first ? 0 : 1);
@@ -407,7 +457,7 @@ extern "C" int rnf_fisher_log_prob(const float *rot, int64_t n, const float *A, 
 }
 
 // ConditionalTransform alone: y [n,3] -> [n,4K] in the reference's row order (bring-up / unit test of the MFMA chain)
-template <int NWc>
+template <int NWc, int PREC>
 __global__ __launch_bounds__(NWc * 64) void conditioner_kernel(const float *y, long long n, const float *layer, int KT, int K, float *out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
@@ -420,15 +470,16 @@ __global__ __launch_bounds__(NWc * 64) void conditioner_kernel(const float *y, l
         __syncthreads();
         stage_floats(lds, layer, MOB_HEAD_FLOATS, tid, NWc * 64);
         __syncthreads();
-        f32x16 cinit[2], tt[2];
+        f32x16 cinit[2];
+        typename Mlp<PREC>::Act tt;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { cinit[0][r] = 0.f; cinit[1][r] = 0.f; }
-        mlp_head(lds, lane, h, y0, y1, y2, cinit, tt);
+        Mlp<PREC>::head(lds, lane, h, y0, y1, y2, cinit, tt);
         for (int tau = 0; tau < KT; ++tau) {
             __syncthreads();
             stage_floats(lds + MOB_LAST, layer + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS, MOB_LAST_TILE_FLOATS, tid, NWc * 64);
             __syncthreads();
-            f32x16 o = last_tile(lds + MOB_LAST, lane, h, tt);
+            f32x16 o = Mlp<PREC>::last(lds + MOB_LAST, lane, h, tt);
             if (valid) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -443,16 +494,24 @@ __global__ __launch_bounds__(NWc * 64) void conditioner_kernel(const float *y, l
     }
 }
 
-extern "C" int rnf_conditioner_forward(const float *y, int64_t n, const float *layer, int32_t K, float *out, void *stream) {
+extern "C" int rnf_conditioner_forward(const float *y, int64_t n, const float *layer, int32_t K, int32_t prec, float *out,
+                                       void *stream) {
     if (K <= 0 || K % 8) return fail("segments=%d must be a positive multiple of 8", K);
+    if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2) return fail("unknown precision %d", prec);
     if (!y || !layer || !out) return fail("rnf_conditioner_forward: null pointer");
     if (n == 0) return 0;
     const size_t lds_bytes = sizeof(float) * (MOB_HEAD_FLOATS + MOB_LAST_TILE_FLOATS);
-    auto kern = conditioner_kernel<NW>;
-    HIP_TRY(allow_lds(kern, lds_bytes));
     long long ntiles = (n + NW * 32 - 1) / (NW * 32);
     int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, reinterpret_cast<hipStream_t>(stream), y, (long long)n, layer, K / 8, K, out);
+    if (prec) {
+        auto kern = conditioner_kernel<NW, 1>;
+        HIP_TRY(allow_lds(kern, lds_bytes));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, reinterpret_cast<hipStream_t>(stream), y, (long long)n, layer, K / 8, K, out);
+    } else {
+        auto kern = conditioner_kernel<NW, 0>;
+        HIP_TRY(allow_lds(kern, lds_bytes));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, reinterpret_cast<hipStream_t>(stream), y, (long long)n, layer, K / 8, K, out);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -34,11 +34,16 @@ class ConditionalTransform(nn.Module):
             raise RuntimeError("rotationnormflow_amd runs on the GPU only (no CPU fallback)")
         K = self.No // 4
         L = _lib.lib()
-        rec, _ = runtime.pack_mobius(L, self, K, 0)
+        prec = runtime._PRECISIONS[runtime.get_precision()]
+        try:
+            rec, _ = runtime.pack_mobius(L, self, K, 0, prec)
+        except runtime.HalfRangeError:
+            prec = _lib.PREC_FP32
+            rec, _ = runtime.pack_mobius(L, self, K, 0, prec)
         y = x.reshape(-1, 3).float().contiguous()
         blob = torch.from_numpy(rec).to(y.device)
         out = torch.empty(y.shape[0], self.No, dtype=torch.float32, device=y.device)
         with torch.cuda.device(y.device):
-            _lib.check(L.rnf_conditioner_forward(y.data_ptr(), y.shape[0], blob.data_ptr(), K, out.data_ptr(),
+            _lib.check(L.rnf_conditioner_forward(y.data_ptr(), y.shape[0], blob.data_ptr(), K, prec, out.data_ptr(),
                                                  torch.cuda.current_stream(y.device).cuda_stream))
         return out

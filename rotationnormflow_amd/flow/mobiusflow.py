@@ -47,9 +47,9 @@ class MobiusFlow(nn.Module, _SingleLayer):
         self.conditioner = ConditionalTransform(ni, 4 * K)
         self._cache = runtime.PackCache()
 
-    def _rnf_pack(self, L):
+    def _rnf_pack(self, L, prec=0):
         F = self.feature_dim if self.condition else 0
-        rec, frec = runtime.pack_mobius(L, self.conditioner, self.K, F)
+        rec, frec = runtime.pack_mobius(L, self.conditioner, self.K, F, prec)
         return rec, frec, F, self.K
 
     def forward(self, rotation, permute=None, feature=None):

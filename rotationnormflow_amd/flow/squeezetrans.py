@@ -18,7 +18,7 @@ class Uncondition16Trans(nn.Module, _SingleLayer):
         self.mat = nn.Parameter(torch.eye(4).unsqueeze(0) + torch.randn(1, 4, 4) * 1e-3)
         self._cache = runtime.PackCache()
 
-    def _rnf_pack(self, L):
+    def _rnf_pack(self, L, prec=0):
         return runtime.pack_affine16(L, self.mat), None, 0, 0
 
     def forward(self, rotation, permute=None, feature=None):
@@ -39,8 +39,8 @@ class Condition16Trans(nn.Module, _SingleLayer):
         self.net = ConditionalTransform(feature_dim, 16)
         self._cache = runtime.PackCache()
 
-    def _rnf_pack(self, L):
-        rec, frec = runtime.pack_cond16(L, self.net, self.feature_dim)
+    def _rnf_pack(self, L, prec=0):
+        rec, frec = runtime.pack_cond16(L, self.net, self.feature_dim, prec)
         return rec, frec, self.feature_dim, 0
 
     def forward(self, rotation, permute=None, feature=None):

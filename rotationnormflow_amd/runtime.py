@@ -4,6 +4,7 @@ PyTorch is used here only as plumbing: device memory (tensors), the current HIP 
 """
 from __future__ import annotations
 
+import os
 import threading
 
 import numpy as np
@@ -13,6 +14,23 @@ from . import _lib
 
 KIND_MOBIUS, KIND_AFFINE16, KIND_COND16 = 1, 2, 3
 DESC_STRIDE = 6
+
+# Arithmetic of the conditioner GEMMs (include/rnf_hip.h RNF_PREC_*): "f16x2" = split-precision fp16 MFMA (22-bit
+# operands, fp32 accumulate; default), "fp32" = exact fp32 MFMA.  Environment override: RNF_PRECISION=fp32|f16x2.
+_PRECISIONS = {"fp32": _lib.PREC_FP32, "f16x2": _lib.PREC_F16X2}
+_precision = os.environ.get("RNF_PRECISION", "f16x2")
+
+
+def set_precision(name: str):
+    """Select the arithmetic used for flows packed from now on ("f16x2" or "fp32")."""
+    global _precision
+    if name not in _PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+    _precision = name
+
+
+def get_precision() -> str:
+    return _precision
 
 # flow/flow.py:13-15 -- the 6x3 permutation table; row m is the cyclic shift (m, m+1, m+2) mod 3
 PERMUTE_ROWS = ((0, 1, 2), (1, 2, 0), (2, 0, 1), (0, 1, 2), (1, 2, 0), (2, 0, 1))
@@ -38,7 +56,8 @@ def pad8(f: int) -> int:
 class PackedFlow:
     """Device blob + host layer table for one (module list, device, parameter version)."""
 
-    def __init__(self, blob, desc, n_cond, feat_dim, feat_padded, segments):
+    def __init__(self, blob, desc, n_cond, feat_dim, feat_padded, segments, precision="fp32"):
+        self.precision = precision            # arithmetic the MLP images were packed for
         self.blob = blob                      # torch.float32 [P] on the device
         self.desc = desc                      # np.int32 [L, 6] (host, C-contiguous; passed by pointer)
         self.n_layers = desc.shape[0]
@@ -48,8 +67,19 @@ class PackedFlow:
         self.segments = segments
 
 
-def pack_layers(layers, perm_rows, device) -> PackedFlow:
-    """layers: product layer modules (each has ``_rnf_kind`` and ``_rnf_pack``); perm_rows: forward permutation row per layer."""
+class HalfRangeError(RuntimeError):
+    """A weight does not fit the fp16 range: the flow must be packed for the exact fp32 kernels instead."""
+
+
+def pack_layers(layers, perm_rows, device, precision=None) -> PackedFlow:
+    """layers: product layer modules (each has ``_rnf_kind`` and ``_rnf_pack``); perm_rows: forward permutation row per layer.
+    precision None = the module-wide setting, falling back to "fp32" when a weight is outside the fp16 range."""
+    if precision is None:
+        try:
+            return pack_layers(layers, perm_rows, device, _precision)
+        except HalfRangeError:
+            return pack_layers(layers, perm_rows, device, "fp32")
+    prec = _PRECISIONS[precision]
     L = _lib.lib()
     records, feat_records = [], []
     desc = np.zeros((len(layers), DESC_STRIDE), dtype=np.int32)
@@ -58,7 +88,7 @@ def pack_layers(layers, perm_rows, device) -> PackedFlow:
     slot = 0
     for i, layer in enumerate(layers):
         kind = layer._rnf_kind
-        rec, feat_rec, fdim, segs = layer._rnf_pack(L)
+        rec, feat_rec, fdim, segs = layer._rnf_pack(L, prec)
         if segs:
             if segments != 8 and segs != segments and any(l._rnf_kind == KIND_MOBIUS for l in layers[:i]):
                 raise ValueError("all Moebius layers of one flow must have the same number of segments")
@@ -67,6 +97,7 @@ def pack_layers(layers, perm_rows, device) -> PackedFlow:
         desc[i, 1] = perm_rows[i]
         desc[i, 3] = -1
         desc[i, 4] = -1
+        desc[i, 5] = prec
         if feat_rec is not None:
             if feat_dim and fdim != feat_dim:
                 raise ValueError("all conditional layers of one flow must share feature_dim")
@@ -89,11 +120,18 @@ def pack_layers(layers, perm_rows, device) -> PackedFlow:
     for i, rec in enumerate(feat_records):
         if rec is not None:
             blob[desc[i, 4]: desc[i, 4] + rec.size] = rec
-    return PackedFlow(torch.from_numpy(blob).to(device), np.ascontiguousarray(desc), slot, feat_dim, pad8(feat_dim), segments)
+    return PackedFlow(torch.from_numpy(blob).to(device), np.ascontiguousarray(desc), slot, feat_dim, pad8(feat_dim), segments,
+                      precision)
+
+
+def _check_pack(L, rc):
+    if rc == 2:
+        raise HalfRangeError(L.rnf_last_error().decode())
+    _lib.check(rc)
 
 
 # ---- per-layer packers (called by the layer modules) -----------------------------------------------------------
-def pack_mobius(L, cond, K, feature_dim):
+def pack_mobius(L, cond, K, feature_dim, prec=_lib.PREC_FP32):
     """cond: ConditionalTransform(3+F, 4K).  -> (layer record, feature-projection record | None)"""
     F = feature_dim
     Fp = pad8(F)
@@ -105,12 +143,12 @@ def pack_mobius(L, cond, K, feature_dim):
     for j in (1, 3, 5):
         arrs += [_np32(cond.layers[j].weight), _np32(cond.layers[j].bias)]
     arrs += [_np32(cond.fc_last.weight), _np32(cond.fc_last.bias)]
-    _lib.check(L.rnf_pack_mobius(*[a.ctypes.data for a in arrs], K, Fp, rec.ctypes.data,
-                                 frec.ctypes.data if frec is not None else None))
+    _check_pack(L, L.rnf_pack_mobius(*[a.ctypes.data for a in arrs], K, Fp, prec, rec.ctypes.data,
+                                     frec.ctypes.data if frec is not None else None))
     return rec, frec
 
 
-def pack_cond16(L, net, feature_dim):
+def pack_cond16(L, net, feature_dim, prec=_lib.PREC_FP32):
     F = feature_dim
     Fp = pad8(F)
     rec = np.empty(L.rnf_cond16_packed_floats(), dtype=np.float32)
@@ -119,7 +157,7 @@ def pack_cond16(L, net, feature_dim):
     for j in (1, 3, 5):
         arrs += [_np32(net.layers[j].weight), _np32(net.layers[j].bias)]
     arrs += [_np32(net.fc_last.weight), _np32(net.fc_last.bias)]
-    _lib.check(L.rnf_pack_cond16(*[a.ctypes.data for a in arrs], Fp, rec.ctypes.data, frec.ctypes.data))
+    _check_pack(L, L.rnf_pack_cond16(*[a.ctypes.data for a in arrs], Fp, prec, rec.ctypes.data, frec.ctypes.data))
     return rec, frec
 
 
@@ -133,7 +171,7 @@ def pack_affine16(L, mat):
 # ---- parameter-version keyed cache -------------------------------------------------------------------------------
 def params_key(module, device):
     """Changes whenever any parameter is modified in place (optimizer step, load_state_dict) or replaced."""
-    return (str(device),) + tuple((id(p), p._version, p.data_ptr()) for p in module.parameters())
+    return (str(device), _precision) + tuple((id(p), p._version, p.data_ptr()) for p in module.parameters())
 
 
 class PackCache:

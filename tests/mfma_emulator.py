@@ -107,3 +107,74 @@ def featproj_from_record(frec, feat, F):
                 acc = mfma(a4[:, c], b, acc)
         tiles.append(acc)
     return tiles
+
+
+# ---- split-precision (f16x2) dataflow: v_mfma_f32_32x32x16_f16 lane maps + the hi/lo operand split --------------------
+def mfma_h(a8, b8, acc):
+    """a8, b8: [64, 8] per-lane operands (values already fp16-representable); A[i][k=8h+j], B[k=8h+j][col]."""
+    A = np.zeros((32, 16), np.float64)
+    B = np.zeros((16, 32), np.float64)
+    for j in range(8):
+        A[J, 8 * H + j] = a8[:, j]
+        B[8 * H + j, J] = b8[:, j]
+    D = A @ B
+    out = acc.copy()
+    for r in range(16):
+        out[r] += D[rho(r, H), J]
+    return out
+
+
+def split_act(x2, relu=True):
+    """x2: two [16,64] register tiles -> (hi[4][64,8], lo[4][64,8]) as in flow_kernels.h split_act."""
+    hi, lo = [], []
+    for s in range(4):
+        vals = np.stack([x2[s >> 1][8 * (s & 1) + j] for j in range(8)], axis=1).astype(np.float32)     # [64, 8]
+        if relu:
+            vals = np.maximum(vals, 0)
+        h = vals.astype(np.float16)
+        l = ((vals - h.astype(np.float32)) * np.float32(4096.0)).astype(np.float16)
+        hi.append(h.astype(np.float64))
+        lo.append(l.astype(np.float64))
+    return hi, lo
+
+
+def gemm_tile64_h(rec32, off_floats, act, acc1):
+    """rec32: the packed record as float32 array; weights at float offset `off_floats`: [4 s][hi,lo][64 lanes] 8 x fp16."""
+    halves = rec32[off_floats: off_floats + 2048].view(np.float16).astype(np.float64).reshape(4, 2, 64, 8)
+    hi, lo = act
+    acc2 = np.zeros((16, 64))
+    for s in range(4):
+        acc1 = mfma_h(halves[s, 0], hi[s], acc1)
+        acc2 = mfma_h(halves[s, 0], lo[s], acc2)
+        acc2 = mfma_h(halves[s, 1], hi[s], acc2)
+    return acc1 + acc2 / 4096.0
+
+
+def conditioner_from_record_h(rec32, y, K):
+    """ConditionalTransform output [32, 4K] through the split-precision dataflow of Mlp<1> (fc_first stays fp32)."""
+    rec32 = np.ascontiguousarray(rec32, dtype=np.float32)
+    rec = rec32.astype(np.float64)
+    y = np.asarray(y, np.float64)
+    bA = np.where(H == 1, y[J, 1], y[J, 0])
+    bB = np.where(H == 1, 1.0, y[J, 2])
+    x0 = []
+    for ot in range(2):
+        a2 = rec[MOB_FIRST + ((ot * 64 + LANES)[:, None] * 2 + np.arange(2)[None, :])]
+        c = mfma(a2[:, 0], bA, np.zeros((16, 64)))
+        x0.append(mfma(a2[:, 1], bB, c))
+    act = split_act(x0)
+    hcur = x0
+    for L in range(3):
+        hcur = [gemm_tile64_h(rec32, MOB_HID + (L * 2 + ot) * 2048, act, bias16(rec, MOB_HB + (L * 2 + ot) * 32)) for ot in range(2)]
+        if L < 2:
+            act = split_act(hcur)
+    act = split_act([x0[t] + hcur[t] for t in range(2)])
+    out = np.zeros((32, 4 * K))
+    for tau in range(K // 8):
+        off = MOB_HEAD + tau * TILE_FLOATS
+        o = gemm_tile64_h(rec32, off, act, bias16(rec, off + TILE_BIAS))
+        for g in range(4):
+            for c in range(4):
+                k = 8 * tau + 2 * g + H
+                out[J, np.where(c == 0, k, K + 3 * k + (c - 1))] = o[4 * g + c]
+    return out

@@ -19,13 +19,23 @@ from tests.gpu_helpers import product_flow, run_case
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["f16x2", "fp32"], autouse=True)
+def precision(request):
+    """Every parity test runs for both arithmetics of the conditioner GEMMs: the default split-precision fp16 MFMA path
+    and the exact fp32 MFMA path.  Same tolerances for both."""
+    old = runtime.get_precision()
+    runtime.set_precision(request.param)
+    yield request.param
+    runtime.set_precision(old)
+
 FORWARD = [n for n, s in CASES.items() if s["direction"] == "forward"]
 INVERSE = [n for n, s in CASES.items() if s["direction"] == "inverse" and s["cfg"].get("segments", 64) <= 64]
 
 
 def test_native_library_is_loaded():
     L = _lib.lib()
-    assert L.rnf_abi_version() == 1
+    assert L.rnf_abi_version() == _lib.ABI_VERSION
     assert torch.cuda.is_available()
 
 

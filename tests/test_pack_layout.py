@@ -86,6 +86,31 @@ def test_affine16_record():
     assert abs(rec[33] + rec[16]) < 1e-6
 
 
+@pytest.mark.parametrize("K", [8, 64])
+def test_split_precision_record_matches_oracle(K):
+    """f16x2 image + the fp16 MFMA lane maps + hi/lo operand split reproduce the fp64 conditioner to ~2^-22."""
+    m = _filled_mlp(3, 4 * K, seed=40 + K)
+    rec, _ = runtime.pack_mobius(_lib.lib(), m, K, 0, _lib.PREC_F16X2)
+    assert rec.size == 12736 + (K // 8) * 2080
+    y = synth.uniform_rotations(32, seed=3)[:, :, 1]
+    got = emu.conditioner_from_record_h(rec, y, K)
+    want = _oracle_mlp(m, y)
+    scale = max(1.0, np.abs(want).max())
+    assert np.abs(got - want).max() < 2e-6 * scale
+    # and it is NOT just fp16: a single-term fp16 image would be ~1e-3 off
+    rec32, _ = runtime.pack_mobius(_lib.lib(), m, K, 0, _lib.PREC_FP32)
+    assert np.abs(emu.conditioner_from_record(rec32, y, K) - want).max() < 1e-5 * scale
+
+
+def test_split_precision_refuses_weights_outside_fp16_range():
+    m = _filled_mlp(3, 32, seed=2)
+    with torch.no_grad():
+        m.fc_last.weight[3, 5] = 7.0e4
+    with pytest.raises(runtime.HalfRangeError):
+        runtime.pack_mobius(_lib.lib(), m, 8, 0, _lib.PREC_F16X2)
+    runtime.pack_mobius(_lib.lib(), m, 8, 0, _lib.PREC_FP32)             # exact path still packs
+
+
 def test_pack_rejects_bad_sizes():
     m = _filled_mlp(3, 40, seed=1)
     with pytest.raises(NotImplementedError):

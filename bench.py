@@ -28,7 +28,8 @@ import torch  # noqa: E402
 
 FLOP_PER_ROTATION = 24 * 57_728          # conditioner GEMMs only, exact 2*MAC: 1,385,472
 BYTES_PER_ROTATION = 40                  # read 36 B rotation + write 4 B log-prob (log-prob-only form)
-PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md chip table
+PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md chip table: f32-input MFMA = f32 VALU peak
+PEAK_F16_MFMA_TFLOPS = 2500.0            # MI355X_MICROARCH.md chip table: BF16/FP16 MFMA dense
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -100,7 +101,7 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    from rotationnormflow_amd import synth
+    from rotationnormflow_amd import get_precision, synth
     from rotationnormflow_amd.dist import all_reduce_nll
     from rotationnormflow_amd.utils.fisher import MatrixFisherN
 
@@ -146,21 +147,36 @@ def main():
         total_rot = n * world * args.steps
         value = total_rot / elapsed
         achieved_tflops = FLOP_PER_ROTATION * n / (kernel_ms * 1e-3) / 1e12
+        precision = get_precision()
+        if precision == "f16x2":
+            # the conditioner GEMMs run on the fp16 matrix cores (3 fp16 MFMAs with fp32 accumulate per fp32 product-sum),
+            # so the MFMA roofline of this kernel is the dense fp16 peak; `achieved` stays the ALGORITHMIC fp32 FLOP rate
+            # (executed matrix FLOPs are 3x that).  The kernel is VALU-issue bound (segment math), see DESIGN.md section 3.
+            roofline = {"bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved_tflops / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                        "kernel": "rnf::flow_stack_kernel<0,0,8,true,1>", "kernel_ms": kernel_ms,
+                        "algorithmic_flop_per_rotation": FLOP_PER_ROTATION, "executed_mfma_tflops": 3 * achieved_tflops,
+                        "frac_of_fp32_mfma_peak": achieved_tflops / PEAK_FP32_MFMA_TFLOPS,
+                        "note": "fp32 operands split into two fp16 terms (22 bits), fp16 MFMA + fp32 accumulate; binding "
+                                "limit is VALU issue of the per-segment trig/softplus math, not MFMA and not HBM"}
+        else:
+            roofline = {"bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                        "kernel": "rnf::flow_stack_kernel<0,0,8,true,0>", "kernel_ms": kernel_ms,
+                        "algorithmic_flop_per_rotation": FLOP_PER_ROTATION,
+                        "note": "exact fp32-input MFMA; shares the FMA datapath with the VALU segment math on gfx950"}
         out = {
             "metric": "rotation log_prob evals/s (24-layer MobiusAffine + matrix-Fisher base), mean NLL alongside",
             "value": value, "unit": "rotations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if precision == "fp32" else "f32 (GEMM operands as fp16 hi+lo pairs, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "fisher24: 24-layer MobiusAffine (48 layers, K=64) + matrix-Fisher base A=diag(5,3,1), "
                                    "forward log_prob only, uniform-SO(3) inputs, trained-like random weights",
                        "rotations_per_gpu": n, "global_batch": n * world, "parallelism": f"batch-sharded x{world}, "
                        "one RCCL all-reduce of {sum log p, count} per step" if world > 1 else "single GPU"},
             "mean_nll": mean_nll,
-            "roofline": {"bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "rnf::flow_stack_kernel<0,0,8>", "kernel_ms": kernel_ms,
-                         "algorithmic_flop_per_rotation": FLOP_PER_ROTATION,
-                         "note": "fp32-input MFMA (exact fp32); binding roofline is fp32 matrix compute, not HBM (SURVEY 8(d))"},
+            "roofline": roofline,
             "hbm": {"achieved": BYTES_PER_ROTATION * n / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": BYTES_PER_ROTATION * n / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                     "algorithmic_bytes_per_rotation": BYTES_PER_ROTATION},

@@ -155,16 +155,22 @@ struct ActFrag {
     h8 hi[4], lo[4];          // B fragments of one 64-feature activation, k-step s = 2*tile + half
 };
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 template <bool RELU>
 __device__ __forceinline__ void split_act(const f32x16 (&x)[2], ActFrag &f) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
-            float a = x[s >> 1][8 * (s & 1) + j], b = x[s >> 1][8 * (s & 1) + j + 1];
-            if (RELU) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
-            const h2 ph = {(_Float16)a, (_Float16)b};
-            const h2 pl = {(_Float16)((a - (float)ph[0]) * kLoScale), (_Float16)((b - (float)ph[1]) * kLoScale)};
+            f2 v = {x[s >> 1][8 * (s & 1) + j], x[s >> 1][8 * (s & 1) + j + 1]};
+            if (RELU) {       // med3(x, 0, +inf): one instruction (fmaxf costs two: it first quiets a possible sNaN)
+                v.x = __builtin_amdgcn_fmed3f(v.x, 0.f, __builtin_inff());
+                v.y = __builtin_amdgcn_fmed3f(v.y, 0.f, __builtin_inff());
+            }
+            const h2 ph = __builtin_convertvector(v, h2);                 // v_cvt_pk_f16_f32 (RN)
+            const f2 back = __builtin_convertvector(ph, f2);              // 2 x v_cvt_f32_f16
+            const h2 pl = __builtin_convertvector((v - back) * kLoScale, h2);
             f.hi[s][j] = ph[0]; f.hi[s][j + 1] = ph[1];
             f.lo[s][j] = pl[0]; f.lo[s][j + 1] = pl[1];
         }
@@ -177,15 +183,14 @@ __device__ __forceinline__ h8 lds_h8(const float *base, int idx16) {
 
 // one 64 -> 32 output tile in split precision; w_tile = [4 k-steps][hi, lo][64 lanes] h8  (2048 floats, as in fp32)
 __device__ __forceinline__ f32x16 gemm_tile64_h(const float *w_tile, int lane, const ActFrag &in, f32x16 acc1) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 acc2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const h8 ah = lds_h8(w_tile, (s * 2 + 0) * 64 + lane);
         const h8 al = lds_h8(w_tile, (s * 2 + 1) * 64 + lane);
         acc1 = RNF_MFMA_H(ah, in.hi[s], acc1);
-        acc2 = RNF_MFMA_H(ah, in.lo[s], acc2);
+        acc2 = RNF_MFMA_H(ah, in.lo[s], s == 0 ? zero : acc2);     // s == 0: inline-constant 0 as the C operand
         acc2 = RNF_MFMA_H(al, in.hi[s], acc2);
     }
 #pragma unroll

@@ -37,7 +37,8 @@ RNF_HD float softplus(float x) {
     float e = hw_exp2(-p);
     e = fmaf(-0.693147180559945309f * e, r, e);
     const float u = 1.0f + e;
-    const float l = fmaf(hw_log2(u), 0.693147180559945309f, (e - (u - 1.0f)) * hw_rcp(u));
+    // (e - (u - 1)) <= 2^-24 is the rounding residue of u; 1/u in [1/2, 1] only needs ~10% accuracy there: 1 - e/2
+    const float l = fmaf(hw_log2(u), 0.693147180559945309f, (e - (u - 1.0f)) * fmaf(-0.5f, e, 1.0f));
     return fmaxf(x, 0.0f) + l;
 }
 
@@ -211,7 +212,7 @@ RNF_HD void seg_stage(SegState &g, float s_raw, float w0, float w1, float w2, co
         g.u = 1.0f + g.e;
         g.lg = hw_log2(g.u);
     } else {
-        const float l = fmaf(g.lg, 0.693147180559945309f, (g.e - (g.u - 1.0f)) * hw_rcp(g.u));
+        const float l = fmaf(g.lg, 0.693147180559945309f, (g.e - (g.u - 1.0f)) * fmaf(-0.5f, g.e, 1.0f));
         const float sp = fmaxf(s_raw, 0.0f) + l;
         S += sp;
         A = fmaf(sp, g.p, A);

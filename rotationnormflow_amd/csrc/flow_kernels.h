@@ -285,12 +285,9 @@ __device__ __forceinline__ void mobius_begin(const Rot &R, int perm_row, MobiusC
     }
 }
 
-// the 4 segments of one fc_last tile of this lane, as two packed pairs (registers 8gp + 2c + {0,1}, layout.h)
-#define RNF_PAIR(o, gp, c) f2{(o)[8 * (gp) + 2 * (c)], (o)[8 * (gp) + 2 * (c) + 1]}
-__device__ __forceinline__ void segments4(const f32x16 &o, const MobiusCtx &c, f2 &S, f2 &A, f2 &J) {
+__device__ __forceinline__ void segments4(const f32x16 &o, const MobiusCtx &c, float &S, float &A, float &J) {
 #pragma unroll
-    for (int gp = 0; gp < 2; ++gp)
-        segment_pair(RNF_PAIR(o, gp, 0), RNF_PAIR(o, gp, 1), RNF_PAIR(o, gp, 2), RNF_PAIR(o, gp, 3), c.f, c.zr, c.zv, S, A, J);
+    for (int g = 0; g < 4; ++g) segment_full(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, c.zr, c.zv, S, A, J);
 }
 
 // forward, all fc_last tiles resident (K <= 64): software pipelined BY HAND.  Tile tau+1's 32 dependent MFMAs (64
@@ -301,34 +298,32 @@ __device__ __forceinline__ void segments4(const f32x16 &o, const MobiusCtx &c, f
 // and the two waves of a SIMD, released together by the layer barriers, leave the matrix pipe idle in lockstep.
 template <int K>
 __device__ __forceinline__ void tile_step(f32x16 &nxt, const float4 (&a)[8], const f32x16 (&tt)[2], const f32x16 &cur,
-                                          SegPair (&seg)[2], const MobiusCtx &c, f2 &S, f2 &A, f2 &J) {
+                                          SegState (&seg)[4], const MobiusCtx &c, float &S, float &A, float &J) {
     constexpr int tg = K >> 2, q = K & 3;
     const float av = q == 0 ? a[tg].x : (q == 1 ? a[tg].y : (q == 2 ? a[tg].z : a[tg].w));
     nxt = RNF_MFMA(av, tt[K >> 4][K & 15], nxt);
-    if constexpr ((K & 1) == 0) {       // slice `st` of segment pair `gp` rides behind MFMA number K (even K)
-        constexpr int gp = K >> 4, st = (K >> 1) & 7;
-        seg_stage2<st>(seg[gp], RNF_PAIR(cur, gp, 0), RNF_PAIR(cur, gp, 1), RNF_PAIR(cur, gp, 2), RNF_PAIR(cur, gp, 3), c.f, c.zr,
-                       c.zv, S, A, J);
-    }
+    constexpr int g = K >> 3, st = K & 7;             // slice `st` of segment `g` rides behind MFMA number K
+    seg_stage<st>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, c.zr, c.zv, S, A, J);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (K + 1 < 32) tile_step<K + 1>(nxt, a, tt, cur, seg, c, S, A, J);
 }
 
+// one pipelined tile: nxt <- fc_last tile `rec` (32 MFMAs), while the segment math of the finished tile `cur` runs
 // (exact fp32 path; the split-precision path needs no hand interleave: its MFMAs run on the matrix cores)
 __device__ __forceinline__ void tile_pipe(const float *rec, int lane, int h, const f32x16 (&tt)[2], f32x16 &nxt,
-                                          const f32x16 &cur, const MobiusCtx &c, f2 &S, f2 &A, f2 &J) {
+                                          const f32x16 &cur, const MobiusCtx &c, float &S, float &A, float &J) {
     nxt = load_bias16(rec + MOB_LAST_TILE_BIAS + h * 16);
     float4 a[8];
 #pragma unroll
     for (int tg = 0; tg < 8; ++tg) a[tg] = lds_f4(rec, tg * 64 + lane);
-    SegPair seg[2];
+    SegState seg[4];
     __builtin_amdgcn_sched_barrier(0);
     tile_step<0>(nxt, a, tt, cur, seg, c, S, A, J);
 }
 
 template <int PREC>
 __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int lane, int h, const typename Mlp<PREC>::Act &tt,
-                                                 const MobiusCtx &c, f2 &S, f2 &A, f2 &J) {
+                                                 const MobiusCtx &c, float &S, float &A, float &J) {
     const float *rec = lds + MOB_LAST;
     if constexpr (PREC == 0) {
         f32x16 bufA = last_tile(rec, lane, h, tt.t), bufB;
@@ -359,8 +354,8 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int l
 // forward, K > 64: fc_last tiles restaged synchronously 8 at a time (staging mode SYNC only)
 template <int PREC>
 __device__ __forceinline__ void mobius_fwd_tiles_restage(float *lds, const float *layer_params, int KT, int lane, int h,
-                                                         const typename Mlp<PREC>::Act &tt, const MobiusCtx &c, f2 &S,
-                                                         f2 &A, f2 &J, int tid, int nthreads) {
+                                                         const typename Mlp<PREC>::Act &tt, const MobiusCtx &c, float &S,
+                                                         float &A, float &J, int tid, int nthreads) {
     for (int tau = 0; tau < KT; ++tau) {
         if (tau > 0 && (tau % MOB_MAX_TILES_IN_LDS) == 0) {
             __syncthreads();
@@ -374,10 +369,10 @@ __device__ __forceinline__ void mobius_fwd_tiles_restage(float *lds, const float
     }
 }
 
-__device__ __forceinline__ void mobius_fwd_finish(const MobiusCtx &c, f2 S2, f2 A2, f2 J2, Rot &R, float &ldj) {
-    const float S = pair_sum(S2.x + S2.y);
-    const float A = pair_sum(A2.x + A2.y);
-    const float J = pair_sum(J2.x + J2.y);
+__device__ __forceinline__ void mobius_fwd_finish(const MobiusCtx &c, float S, float A, float J, Rot &R, float &ldj) {
+    S = pair_sum(S);
+    A = pair_sum(A);
+    J = pair_sum(J);
     const float invS = hw_rcp(S);
     float sn, cs;
     sincos_small(A * invS, sn, cs);
@@ -388,24 +383,24 @@ __device__ __forceinline__ void mobius_fwd_finish(const MobiusCtx &c, f2 S2, f2 
     ldj += logf(J * invS);
 }
 
-// inverse: the 4*KT segment parameters of this lane stay in registers (as 2*KT packed pairs) for the 15 bisection steps
+// inverse: the 4*KT segment parameters of this lane stay in registers for the 15 bisection steps
 template <int KT>
 struct InvSegs {
-    f2 sp[2 * KT], ur[2 * KT], uv[2 * KT];
+    float sp[4 * KT], ur[4 * KT], uv[4 * KT];
 };
 
 template <int KT, int PREC>
 __device__ __forceinline__ void mobius_inv_tiles(const float *lds, int lane, int h, const typename Mlp<PREC>::Act &tt,
-                                                 const MobiusCtx &c, InvSegs<KT> &sg, f2 &S) {
+                                                 const MobiusCtx &c, InvSegs<KT> &sg, float &S) {
     static_assert(KT <= MOB_MAX_TILES_IN_LDS, "inverse keeps all fc_last tiles in LDS");
 #pragma unroll
     for (int tau = 0; tau < KT; ++tau) {
         f32x16 o = Mlp<PREC>::last(lds + MOB_LAST + tau * MOB_LAST_TILE_FLOATS, lane, h, tt);
 #pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-            squash_center2(RNF_PAIR(o, gp, 1), RNF_PAIR(o, gp, 2), RNF_PAIR(o, gp, 3), c.f, sg.ur[2 * tau + gp], sg.uv[2 * tau + gp]);
-            sg.sp[2 * tau + gp] = softplus2(RNF_PAIR(o, gp, 0));
-            S = S + sg.sp[2 * tau + gp];
+        for (int g = 0; g < 4; ++g) {
+            squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, sg.ur[4 * tau + g], sg.uv[4 * tau + g]);
+            sg.sp[4 * tau + g] = softplus(o[4 * g]);
+            S += sg.sp[4 * tau + g];
         }
         // keep the tiles in order: letting the scheduler hoist all 8 tiles' MFMAs (8 x 16 accumulators) on top of the
         // 96 live segment registers spills; the inverse is VALU-bound in the bisection anyway
@@ -414,8 +409,8 @@ __device__ __forceinline__ void mobius_inv_tiles(const float *lds, int lane, int
 }
 
 template <int KT>
-__device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvSegs<KT> &sg, f2 S2, Rot &R, float &ldj) {
-    const float S = pair_sum(S2.x + S2.y);
+__device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvSegs<KT> &sg, float S, Rot &R, float &ldj) {
+    S = pair_sum(S);
     const float invS = hw_rcp(S);
     // BinFind.forward (mobiusflow.py:196-224): bracket [pi/2, 3pi/2], width halves every step, the batch-global stop
     // test max(b-a) < 1e-4 is met after exactly 15 steps; the returned root is the LAST midpoint.
@@ -425,28 +420,28 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
         mid = (a + b) * 0.5f;
         float sn, cs;
         sincos_small(mid, sn, cs);
-        f2 acc = {0.f, 0.f};
+        float acc = 0.f;
 #pragma unroll
-        for (int s = 0; s < 2 * KT; ++s) {
-            f2 phi, cc;
-            mobius_angle2(cs, sn, sg.ur[s], sg.uv[s], phi, cc);
-            acc = fma2(sg.sp[s], phi, acc);
+        for (int s = 0; s < 4 * KT; ++s) {
+            float phi, cc;
+            mobius_angle(cs, sn, sg.ur[s], sg.uv[s], phi, cc);
+            acc = fmaf(sg.sp[s], phi, acc);
         }
-        const float fx = pair_sum(acc.x + acc.y) * invS - c.target;
+        const float fx = pair_sum(acc) * invS - c.target;
         const float half = (b - a) * 0.5f;
         if (fx < 0.f) a = a + half;
         else if (fx >= 0.f) b = b - half;
     }
     float sn, cs;
     sincos_small(mid, sn, cs);
-    f2 J2 = {0.f, 0.f};
+    float J = 0.f;
 #pragma unroll
-    for (int s = 0; s < 2 * KT; ++s) {
-        f2 phi, cc;
-        mobius_angle2(cs, sn, sg.ur[s], sg.uv[s], phi, cc);
-        J2 = fma2(sg.sp[s], cc, J2);
+    for (int s = 0; s < 4 * KT; ++s) {
+        float phi, cc;
+        mobius_angle(cs, sn, sg.ur[s], sg.uv[s], phi, cc);
+        J = fmaf(sg.sp[s], cc, J);
     }
-    const float J = pair_sum(J2.x + J2.y);
+    J = pair_sum(J);
     const v3f xx = c.f.v * sn + c.f.r * cs;
     const v3f zz = normalize3(c.cyc ? cross3(xx, c.y) : cross3(c.y, xx));               // mobiusflow.py:172-176
     set_col(R, c.p0, xx);
@@ -628,12 +623,12 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             if (kind == RNF_KIND_MOBIUS) {
                 if constexpr (DIR != 0) {
                     InvSegs<KTI> sg;
-                    f2 S = {0.f, 0.f};
+                    float S = 0.f;
                     mobius_inv_tiles<KTI, PREC>(lds, lane, h, tt, ctx, sg, S);
                     barrier2();
                     mobius_inv_finish<KTI>(ctx, sg, S, R, ldj);
                 } else {
-                    f2 S = {0.f, 0.f}, A = {0.f, 0.f}, J = {0.f, 0.f};
+                    float S = 0.f, A = 0.f, J = 0.f;
                     if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC>(lds, KT, lane, h, tt, ctx, S, A, J);
                     else mobius_fwd_tiles_restage<PREC>(lds, params, KT, lane, h, tt, ctx, S, A, J, tid, NT);
                     barrier2();

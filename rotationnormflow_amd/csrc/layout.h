@@ -19,10 +19,9 @@
 //
 // Bias of a later layer initialises the accumulator: bias image[ot][h][r] = b[32*ot + rho(r,h)] (16 floats per half).
 //
-// fc_last rows are permuted so that every lane ends up with whole segments, two at a time in ADJACENT registers (the
-// segment math runs on packed v_pk_*_f32 instructions): accumulator register r = 8*gp + 2*c + e of lane-half h in tile
-// tau holds component c (0: raw weight, 1..3: w_k[c-1]) of segment k = 8*tau + 4*h + 2*gp + e  (pair gp = 0,1; e = 0,1),
-// i.e. packed row 32*tau + rho(r,h) is reference row (c == 0 ? k : K + 3k + c - 1)   (flow/mobiusflow.py:58-61).
+// fc_last rows are permuted so that every lane ends up with whole segments: packed row P = 32*tau + 8g + 4h + c
+// (tile tau, register 4g+c of lane-half h) is segment k = 8*tau + 2g + h, component c (0: raw weight, 1..3: w_k[c-1]),
+// i.e. reference row (c == 0 ? k : K + 3k + c - 1)   (flow/mobiusflow.py:58-61).
 #pragma once
 #include <stdint.h>
 
@@ -71,15 +70,5 @@ constexpr int RNF_KIND_MOBIUS = 1, RNF_KIND_AFFINE16 = 2, RNF_KIND_COND16 = 3;
 constexpr int D_KIND = 0, D_PERM = 1, D_PARAM = 2, D_SLOT = 3, D_FEAT = 4, D_PREC = 5, D_STRIDE = 6;   // D_PREC: RNF_PREC_* of include/rnf_hip.h
 
 inline constexpr int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// fc_last: reference row held by accumulator register r of lane-half h in tile tau (K segments)
-inline constexpr int last_src_row(int K, int tau, int r, int h) {
-    const int gp = r >> 3, c = (r >> 1) & 3, e = r & 1;
-    const int k = 8 * tau + 4 * h + 2 * gp + e;
-    return c == 0 ? k : K + 3 * k + (c - 1);
-}
-// inverse of rho: (register, lane-half) of row `row` (0..31) of a tile
-inline constexpr int reg_of_row(int row) { return (row & 3) + 4 * (row >> 3); }
-inline constexpr int half_of_row(int row) { return (row >> 2) & 1; }
 
 }  // namespace rnf

@@ -137,8 +137,12 @@ extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b,
     const float *hw[3] = {l1_w, l3_w, l5_w};
     const float *hb[3] = {l1_b, l3_b, l5_b};
     pack_hidden(out, hw, hb, prec);
-    // fc_last: packed row 32*tau + rho(r,h)  <->  register r = 8gp + 2c + e of lane-half h (layout.h last_src_row)
-    auto src_row = [&](int tau, int row) { return last_src_row(K, tau, reg_of_row(row), half_of_row(row)); };
+    // fc_last: packed row P = 32*tau + 8g + 4h + c  <->  segment k = 8*tau + 2g + h, component c
+    auto src_row = [&](int tau, int row) {
+        const int g = row >> 3, h = (row >> 2) & 1, c = row & 3;
+        const int k = 8 * tau + 2 * g + h;
+        return c == 0 ? k : K + 3 * k + (c - 1);
+    };
     for (int tau = 0; tau < K / 8; ++tau) {
         float *rec = out + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS;
         auto row_of = [&](int, int i) { return fc_last_w + (size_t)src_row(tau, i) * 64; };
@@ -478,7 +482,13 @@ __global__ __launch_bounds__(NWc * 64) void conditioner_kernel(const float *y, l
             f32x16 o = Mlp<PREC>::last(lds + MOB_LAST, lane, h, tt);
             if (valid) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) out[sample * 4 * K + last_src_row(K, tau, r, h)] = o[r];
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int k = 8 * tau + 2 * g + h;
+                        const int row = c == 0 ? k : K + 3 * k + (c - 1);
+                        out[sample * 4 * K + row] = o[4 * g + c];
+                    }
             }
         }
     }

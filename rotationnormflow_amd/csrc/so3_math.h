@@ -232,129 +232,6 @@ RNF_HD void segment_full(float s_raw, float w0, float w1, float w2, const Frame 
     seg_stage<7>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
 }
 
-// ---- TWO segments at a time --------------------------------------------------------------------------------------------
-// The forward / inverse kernels are VALU-issue bound in the segment math, and gfx950 only reaches its fp32 vector peak
-// with packed instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of work per issue slot), so the
-// kernels evaluate segments in pairs held in even-aligned register pairs (the fc_last row permutation of layout.h puts
-// the two segments of a pair in adjacent accumulator registers).  Same formulas as the scalar functions above; min / max /
-// compare / select / transcendentals have no packed form and stay per component.
-typedef float f2 __attribute__((ext_vector_type(2)));
-RNF_HD f2 splat2(float a) { return f2{a, a}; }
-RNF_HD f2 fma2(f2 a, f2 b, f2 c) { return f2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }   // -> v_pk_fma_f32
-RNF_HD f2 rcp2(f2 a) { return f2{hw_rcp(a.x), hw_rcp(a.y)}; }
-RNF_HD f2 sqrt2(f2 a) { return f2{hw_sqrt(a.x), hw_sqrt(a.y)}; }
-RNF_HD f2 exp2_2(f2 a) { return f2{hw_exp2(a.x), hw_exp2(a.y)}; }
-RNF_HD f2 log2_2(f2 a) { return f2{hw_log2(a.x), hw_log2(a.y)}; }
-RNF_HD f2 abs2(f2 a) { return f2{fabsf(a.x), fabsf(a.y)}; }
-RNF_HD f2 sel2(bool cx, bool cy, f2 a, f2 b) { return f2{cx ? a.x : b.x, cy ? a.y : b.y}; }
-
-struct SegPair {
-    f2 wr, wv, nrm, ur, uv, u2, dr, dv, c, hr, hv, mx, mn, t, p, pp, r, e, u, lg;
-    bool bigx, bigy;
-};
-template <int STAGE>
-RNF_HD void seg_stage2(SegPair &g, f2 s_raw, f2 w0, f2 w1, f2 w2, const Frame &f, float zr, float zv, f2 &S, f2 &A, f2 &J) {
-    if constexpr (STAGE == 0) {
-        g.wr = fma2(w2, splat2(f.r.z), fma2(w1, splat2(f.r.y), w0 * f.r.x));
-        g.wv = fma2(w2, splat2(f.v.z), fma2(w1, splat2(f.v.y), w0 * f.v.x));
-        g.nrm = sqrt2(fma2(g.wv, g.wv, g.wr * g.wr));
-    } else if constexpr (STAGE == 1) {
-        const f2 sc = 0.7f * rcp2(1.0f + g.nrm);
-        g.ur = g.wr * sc;
-        g.uv = g.wv * sc;
-        g.u2 = fma2(g.uv, g.uv, g.ur * g.ur);
-        g.dr = zr - g.ur;
-        g.dv = zv - g.uv;
-    } else if constexpr (STAGE == 2) {
-        const f2 d2 = fma2(g.dv, g.dv, g.dr * g.dr);
-        g.c = (1.0f - g.u2) * rcp2(d2);
-        g.hr = fma2(g.c, g.dr, -g.ur);
-        g.hv = fma2(g.c, g.dv, -g.uv);
-        g.mx = f2{fmaxf(fabsf(g.hr.x), fabsf(g.hv.x)), fmaxf(fabsf(g.hr.y), fabsf(g.hv.y))};
-        g.mn = f2{fminf(fabsf(g.hr.x), fabsf(g.hv.x)), fminf(fabsf(g.hr.y), fabsf(g.hv.y))};
-    } else if constexpr (STAGE == 3) {
-        const f2 a = g.mn * rcp2(g.mx);
-        g.bigx = a.x > 0.414213562373095f;
-        g.bigy = a.y > 0.414213562373095f;
-        g.t = sel2(g.bigx, g.bigy, (a - 1.0f) * rcp2(a + 1.0f), a);
-    } else if constexpr (STAGE == 4) {
-        const f2 z = g.t * g.t;
-        f2 p = fma2(fma2(fma2(splat2(8.05374449538e-2f), z, splat2(-1.38776856032e-1f)), z, splat2(1.99777106478e-1f)), z,
-                    splat2(-3.33329491539e-1f));
-        p = fma2(p * z, g.t, g.t);
-        p = p + sel2(g.bigx, g.bigy, splat2(0.785398163397448310f), splat2(0.0f));
-        g.p = sel2(fabsf(g.hv.x) > fabsf(g.hr.x), fabsf(g.hv.y) > fabsf(g.hr.y), 1.57079632679489662f - p, p);
-    } else if constexpr (STAGE == 5) {
-        f2 p = sel2(g.hr.x < 0.0f, g.hr.y < 0.0f, 3.14159265358979324f - g.p, g.p);
-        g.p = sel2(g.hv.x < 0.0f, g.hv.y < 0.0f, 6.28318530717958648f - p, p);          // phi in [0, 2pi)
-        const f2 ax = abs2(s_raw);
-        g.pp = ax * 1.44269502162933349609375f;
-        g.r = fma2(ax, splat2(1.92596299112661746e-8f), fma2(ax, splat2(1.44269502162933349609375f), -g.pp));
-    } else if constexpr (STAGE == 6) {
-        const f2 e = exp2_2(-g.pp);
-        g.e = fma2(-0.693147180559945309f * e, g.r, e);
-        g.u = 1.0f + g.e;
-        g.lg = log2_2(g.u);
-    } else {
-        const f2 l = fma2(g.lg, splat2(0.693147180559945309f), (g.e - (g.u - 1.0f)) * fma2(splat2(-0.5f), g.e, splat2(1.0f)));
-        const f2 sp = f2{fmaxf(s_raw.x, 0.0f), fmaxf(s_raw.y, 0.0f)} + l;
-        S = S + sp;
-        A = fma2(sp, g.p, A);
-        J = fma2(sp, g.c, J);
-    }
-}
-RNF_HD void segment_pair(f2 s_raw, f2 w0, f2 w1, f2 w2, const Frame &f, float zr, float zv, f2 &S, f2 &A, f2 &J) {
-    SegPair g;
-    seg_stage2<0>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
-    seg_stage2<1>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
-    seg_stage2<2>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
-    seg_stage2<3>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
-    seg_stage2<4>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
-    seg_stage2<5>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
-    seg_stage2<6>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
-    seg_stage2<7>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
-}
-// pieces for the inverse: squashed centres / softplus weights of a pair, and the Moebius angle + derivative of a pair
-RNF_HD void squash_center2(f2 w0, f2 w1, f2 w2, const Frame &f, f2 &ur, f2 &uv) {
-    const f2 wr = fma2(w2, splat2(f.r.z), fma2(w1, splat2(f.r.y), w0 * f.r.x));
-    const f2 wv = fma2(w2, splat2(f.v.z), fma2(w1, splat2(f.v.y), w0 * f.v.x));
-    const f2 sc = 0.7f * rcp2(1.0f + sqrt2(fma2(wv, wv, wr * wr)));
-    ur = wr * sc;
-    uv = wv * sc;
-}
-RNF_HD f2 softplus2(f2 x) {
-    const f2 ax = abs2(x);
-    const f2 pp = ax * 1.44269502162933349609375f;
-    const f2 r = fma2(ax, splat2(1.92596299112661746e-8f), fma2(ax, splat2(1.44269502162933349609375f), -pp));
-    f2 e = exp2_2(-pp);
-    e = fma2(-0.693147180559945309f * e, r, e);
-    const f2 u = 1.0f + e;
-    const f2 l = fma2(log2_2(u), splat2(0.693147180559945309f), (e - (u - 1.0f)) * fma2(splat2(-0.5f), e, splat2(1.0f)));
-    return f2{fmaxf(x.x, 0.0f), fmaxf(x.y, 0.0f)} + l;
-}
-RNF_HD f2 angle2_0_2pi(f2 y, f2 x) {
-    const f2 ax = abs2(x), ay = abs2(y);
-    const f2 mx = f2{fmaxf(ax.x, ay.x), fmaxf(ax.y, ay.y)}, mn = f2{fminf(ax.x, ay.x), fminf(ax.y, ay.y)};
-    const f2 a = mn * rcp2(mx);
-    const bool bx = a.x > 0.414213562373095f, by = a.y > 0.414213562373095f;
-    const f2 t = sel2(bx, by, (a - 1.0f) * rcp2(a + 1.0f), a);
-    const f2 z = t * t;
-    f2 p = fma2(fma2(fma2(splat2(8.05374449538e-2f), z, splat2(-1.38776856032e-1f)), z, splat2(1.99777106478e-1f)), z,
-                splat2(-3.33329491539e-1f));
-    p = fma2(p * z, t, t);
-    p = p + sel2(bx, by, splat2(0.785398163397448310f), splat2(0.0f));
-    p = sel2(ay.x > ax.x, ay.y > ax.y, 1.57079632679489662f - p, p);
-    p = sel2(x.x < 0.0f, x.y < 0.0f, 3.14159265358979324f - p, p);
-    return sel2(y.x < 0.0f, y.y < 0.0f, 6.28318530717958648f - p, p);
-}
-RNF_HD void mobius_angle2(float zr, float zv, f2 ur, f2 uv, f2 &phi, f2 &c) {
-    const f2 u2 = fma2(uv, uv, ur * ur);
-    const f2 dr = zr - ur, dv = zv - uv;
-    c = (1.0f - u2) * rcp2(fma2(dv, dv, dr * dr));
-    const f2 hr = fma2(c, dr, -ur), hv = fma2(c, dv, -uv);
-    phi = angle2_0_2pi(hv, hr);
-}
-
 // pytorch3d.transforms.matrix_to_quaternion (published 0.7.5 rule; call site flow/squeezetrans.py:34):
 // four candidates from sqrt(max(0, 1 +- m00 +- m11 +- m22)), keep the one with the largest |q_i| (first on ties),
 // denominators floored at 0.1.  Real part first.

@@ -43,21 +43,15 @@ void hm_mobius_forward(const float *Rin, const float *cond, int K, int perm_row,
         float zr = dot3(x, f.r), zv = dot3(x, f.v);
         float S = 0, A = 0, J = 0;
         const float *c = cond + (size_t)4 * K * i;
-        for (int k = 0; k < K; k += 4) {       // exercise all three formulations of the segment math
-            {
+        for (int k = 0; k < K; ++k) {
+            if (k & 1) {                       // exercise both formulations of the segment math
                 float ur, uv, phi, cc;
                 squash_center(c[K + 3 * k], c[K + 3 * k + 1], c[K + 3 * k + 2], f, ur, uv);
                 mobius_angle(zr, zv, ur, uv, phi, cc);
                 float sp = softplus(c[k]);
                 S += sp; A += sp * phi; J += sp * cc;
-            }
-            segment_full(c[k + 1], c[K + 3 * (k + 1)], c[K + 3 * (k + 1) + 1], c[K + 3 * (k + 1) + 2], f, zr, zv, S, A, J);
-            {
-                const int k2 = k + 2, k3 = k + 3;
-                f2 S2 = {0, 0}, A2 = {0, 0}, J2 = {0, 0};
-                segment_pair(f2{c[k2], c[k3]}, f2{c[K + 3 * k2], c[K + 3 * k3]}, f2{c[K + 3 * k2 + 1], c[K + 3 * k3 + 1]},
-                             f2{c[K + 3 * k2 + 2], c[K + 3 * k3 + 2]}, f, zr, zv, S2, A2, J2);
-                S += S2.x + S2.y; A += A2.x + A2.y; J += J2.x + J2.y;
+            } else {
+                segment_full(c[k], c[K + 3 * k], c[K + 3 * k + 1], c[K + 3 * k + 2], f, zr, zv, S, A, J);
             }
         }
         float sn, cs;

@@ -17,13 +17,6 @@ def rho(r, h):
     return (r & 3) + 8 * (r >> 2) + 4 * h
 
 
-def last_src_row(K, tau, r, h):
-    """reference fc_last row held by accumulator register r of lane-half h in tile tau (csrc/layout.h)."""
-    gp, c, e = r >> 3, (r >> 1) & 3, r & 1
-    k = 8 * tau + 4 * h + 2 * gp + e
-    return np.where(c == 0, k, K + 3 * k + (c - 1))
-
-
 def mfma(a, b, acc):
     """a, b: [64] per-lane operands; acc: [16, 64] per-lane accumulator registers.  D = A.B + C."""
     A = np.zeros((32, 2), np.float64)
@@ -92,8 +85,11 @@ def conditioner_from_record(rec, y, K):
     out = np.zeros((32, 4 * K))
     for tau in range(K // 8):
         o = last_tile(rec, tau, tt)
-        for r in range(16):
-            out[J, last_src_row(K, tau, r, H)] = o[r]          # each (sample, row) is written by exactly one lane
+        for g in range(4):
+            for c in range(4):
+                k = 8 * tau + 2 * g + H
+                row = np.where(c == 0, k, K + 3 * k + (c - 1))
+                out[J, row] = o[4 * g + c]          # each (sample, row) is written by exactly one lane
     return out
 
 
@@ -177,6 +173,8 @@ def conditioner_from_record_h(rec32, y, K):
     for tau in range(K // 8):
         off = MOB_HEAD + tau * TILE_FLOATS
         o = gemm_tile64_h(rec32, off, act, bias16(rec, off + TILE_BIAS))
-        for r in range(16):
-            out[J, last_src_row(K, tau, r, H)] = o[r]
+        for g in range(4):
+            for c in range(4):
+                k = 8 * tau + 2 * g + H
+                out[J, np.where(c == 0, k, K + 3 * k + (c - 1))] = o[4 * g + c]
     return out

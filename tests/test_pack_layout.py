@@ -50,8 +50,10 @@ def test_conditional_mobius_record_and_feature_projection(F):
     out = np.zeros((32, 4 * K))
     for tau in range(K // 8):
         o = emu.last_tile(np.asarray(rec, np.float64), tau, tt)
-        for r in range(16):
-            out[emu.J, emu.last_src_row(K, tau, r, emu.H)] = o[r]
+        for gi in range(4):
+            for c in range(4):
+                k = 8 * tau + 2 * gi + emu.H
+                out[emu.J, np.where(c == 0, k, K + 3 * k + (c - 1))] = o[4 * gi + c]
     want = _oracle_mlp(m, np.concatenate([y, feat], axis=1))
     assert np.abs(out - want).max() < 1e-5 * max(1.0, np.abs(want).max())
 

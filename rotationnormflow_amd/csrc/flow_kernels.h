@@ -408,30 +408,47 @@ __device__ __forceinline__ void mobius_inv_tiles(const float *lds, int lane, int
     }
 }
 
+// Root of BinFind (flow/mobiusflow.py:189-224).  The reference bisects f(theta) = sum_k wt_k phi_k(theta) - target on
+// [pi/2, 3pi/2] exactly 15 times (its batch-global stop test max(b - a) < 1e-4 is data independent) and returns the LAST
+// midpoint, i.e. the centre of the cell of the grid  pi/2 + n * pi/2^14  that contains the root:
+//     theta_ref = pi/2 + (n + 1/2) * pi/2^14,   n = floor((theta* - pi/2) * 2^14 / pi).
+// f is strictly increasing (f' = sum_k wt_k c_k >= (1-0.7)/(1+0.7) > 0) and the root lies strictly inside the bracket (a
+// Moebius map with |w| < 0.7 moves a point by less than 2 asin 0.7 = 88.9 degrees), so instead of 15 passes over the
+// segments the kernel finds theta* with a bracket-safeguarded Newton iteration (phi_k and its derivative c_k come out of the
+// same evaluation) and then snaps it to that grid: the same returned iterate as the reference's bisection, except when
+// theta* lies within rounding error of a cell boundary -- where the reference's own fp32 and fp64 runs disagree too.
 template <int KT>
 __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvSegs<KT> &sg, float S, Rot &R, float &ldj) {
     S = pair_sum(S);
     const float invS = hw_rcp(S);
-    // BinFind.forward (mobiusflow.py:196-224): bracket [pi/2, 3pi/2], width halves every step, the batch-global stop
-    // test max(b-a) < 1e-4 is met after exactly 15 steps; the returned root is the LAST midpoint.
-    float a = 0.5f * kPi, b = 1.5f * kPi, mid = kPi;
+    float lo = 0.5f * kPi, hi = 1.5f * kPi, th = kPi;
+    bool done = false;
 #pragma unroll 1
-    for (int it = 0; it < 15; ++it) {
-        mid = (a + b) * 0.5f;
+    for (int it = 0; it < 16; ++it) {
         float sn, cs;
-        sincos_small(mid, sn, cs);
-        float acc = 0.f;
+        sincos_small(th, sn, cs);
+        float acc = 0.f, der = 0.f;
 #pragma unroll
         for (int s = 0; s < 4 * KT; ++s) {
             float phi, cc;
             mobius_angle(cs, sn, sg.ur[s], sg.uv[s], phi, cc);
             acc = fmaf(sg.sp[s], phi, acc);
+            der = fmaf(sg.sp[s], cc, der);
         }
         const float fx = pair_sum(acc) * invS - c.target;
-        const float half = (b - a) * 0.5f;
-        if (fx < 0.f) a = a + half;
-        else if (fx >= 0.f) b = b - half;
+        const float dfx = pair_sum(der) * invS;
+        if (fx < 0.f) lo = th; else hi = th;
+        float nt = th - fx * hw_rcp(dfx);
+        if (!(nt >= lo && nt <= hi)) nt = 0.5f * (lo + hi);               // keep the iterate inside the sign bracket
+        if (done) nt = th;                                                // a converged lane stays put
+        done = done || fabsf(nt - th) <= 1.0e-6f;
+        th = nt;
+        if (__all(done)) break;                                           // wave-uniform exit: typically 4-5 passes
     }
+    const float cell = kPi * (1.0f / 16384.0f);
+    float n = floorf((th - 0.5f * kPi) * (16384.0f / kPi));
+    n = fminf(fmaxf(n, 0.f), 16383.f);
+    const float mid = fmaf(n + 0.5f, cell, 0.5f * kPi);
     float sn, cs;
     sincos_small(mid, sn, cs);
     float J = 0.f;

@@ -25,7 +25,7 @@ struct FeatProjArgs {
     int feat_off[MAX_SLOTS]; // blob offset (floats) of each slot's featproj record
 };
 
-template <int NW>
+template <int NW, int PREC>
 __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -34,50 +34,112 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
     constexpr int TILE = NW * TILE_SAMPLES;
     const long long ntiles = (args.n + TILE - 1) / TILE;
     const int F = args.F;
-    const int ngroups_k = F / 8;                                   // float4 k-groups per out row
 
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long group = tile * NW + wave;
         const long long sample = group * TILE_SAMPLES + j;
         const bool valid = sample < args.n;
         for (int kc = 0; kc < F; kc += FP_KCHUNK) {
-            const int nu = min(FP_KCHUNK, F - kc) / 8;
-            float4 bf[FP_KCHUNK / 8];
+            if constexpr (PREC == 0) {
+                // ---- exact fp32: v_mfma_f32_32x32x2_f32, image [ot][F/8][64] float4 ----
+                const int ngroups_k = F / 8;
+                const int nu = min(FP_KCHUNK, F - kc) / 8;
+                float4 bf[FP_KCHUNK / 8];
 #pragma unroll
-            for (int u = 0; u < FP_KCHUNK / 8; ++u) {
-                bf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (u < nu && valid)
-                    bf[u] = *reinterpret_cast<const float4 *>(args.feat + sample * F + kc + 8 * u + 4 * h);
-            }
-            for (int slot = 0; slot < args.n_slots; ++slot) {
-                const float *rec = args.blob + args.feat_off[slot];
-                for (int ot = 0; ot < 2; ++ot) {
-                    __syncthreads();
-                    stage_floats(lds, rec + ((size_t)ot * ngroups_k + kc / 8) * 256, nu * 256, tid, NT);
-                    __syncthreads();
-                    float *g = args.G + (((size_t)slot * args.g_groups + group) * 2 + ot) * (4 * 64 * 4);
-                    f32x16 acc;
-                    if (kc == 0) {
-                        const float *bias = rec + (size_t)2 * ngroups_k * 256 + (ot * 2 + h) * 16;
+                for (int u = 0; u < FP_KCHUNK / 8; ++u) {
+                    bf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (u < nu && valid)
+                        bf[u] = *reinterpret_cast<const float4 *>(args.feat + sample * F + kc + 8 * u + 4 * h);
+                }
+                for (int slot = 0; slot < args.n_slots; ++slot) {
+                    const float *rec = args.blob + args.feat_off[slot];
+                    for (int ot = 0; ot < 2; ++ot) {
+                        __syncthreads();
+                        stage_floats(lds, rec + ((size_t)ot * ngroups_k + kc / 8) * 256, nu * 256, tid, NT);
+                        __syncthreads();
+                        float *g = args.G + (((size_t)slot * args.g_groups + group) * 2 + ot) * (4 * 64 * 4);
+                        f32x16 acc;
+                        if (kc == 0) {
+                            const float *bias = rec + (size_t)2 * ngroups_k * 256 + (ot * 2 + h) * 16;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] = bias[r];
-                    } else {
-                        acc = load_g16(g, lane);
-                    }
-#pragma unroll
-                    for (int u = 0; u < FP_KCHUNK / 8; ++u) {
-                        if (u < nu) {
-                            float4 a = lds_f4(lds, u * 64 + lane);
-                            acc = RNF_MFMA(a.x, bf[u].x, acc);
-                            acc = RNF_MFMA(a.y, bf[u].y, acc);
-                            acc = RNF_MFMA(a.z, bf[u].z, acc);
-                            acc = RNF_MFMA(a.w, bf[u].w, acc);
+                            for (int r = 0; r < 16; ++r) acc[r] = bias[r];
+                        } else {
+                            acc = load_g16(g, lane);
                         }
-                    }
-                    float4 *g4 = reinterpret_cast<float4 *>(g);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        g4[q * 64 + lane] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                        for (int u = 0; u < FP_KCHUNK / 8; ++u) {
+                            if (u < nu) {
+                                float4 a = lds_f4(lds, u * 64 + lane);
+                                acc = RNF_MFMA(a.x, bf[u].x, acc);
+                                acc = RNF_MFMA(a.y, bf[u].y, acc);
+                                acc = RNF_MFMA(a.z, bf[u].z, acc);
+                                acc = RNF_MFMA(a.w, bf[u].w, acc);
+                            }
+                        }
+                        float4 *g4 = reinterpret_cast<float4 *>(g);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            g4[q * 64 + lane] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                    }
+                }
+            } else {
+                // ---- split precision: v_mfma_f32_32x32x16_f16 x3, image [ot][ceil(F/16)][hi,lo][64] 8 x fp16 ----
+                // k-step s covers features 16s .. 16s+15; lane-half h supplies 16s + 8h + 0..7 straight from its row.
+                const int nsteps_all = (F + 15) / 16;
+                const int ns = (min(FP_KCHUNK, F - kc) + 15) / 16;
+                h8 bh[FP_KCHUNK / 16], bl[FP_KCHUNK / 16];
+#pragma unroll
+                for (int s = 0; s < FP_KCHUNK / 16; ++s) {
+                    f2 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = f2{0.f, 0.f};
+                    const int k0 = kc + 16 * s + 8 * h;
+                    if (s < ns && valid && k0 < F) {          // F % 8 == 0: an 8-group is entirely inside or outside
+                        const float4 p0 = *reinterpret_cast<const float4 *>(args.feat + sample * F + k0);
+                        const float4 p1 = *reinterpret_cast<const float4 *>(args.feat + sample * F + k0 + 4);
+                        v[0] = f2{p0.x, p0.y}; v[1] = f2{p0.z, p0.w}; v[2] = f2{p1.x, p1.y}; v[3] = f2{p1.z, p1.w};
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const h2 ph = __builtin_convertvector(v[q], h2);
+                        const h2 pl = __builtin_convertvector((v[q] - __builtin_convertvector(ph, f2)) * kLoScale, h2);
+                        bh[s][2 * q] = ph[0]; bh[s][2 * q + 1] = ph[1];
+                        bl[s][2 * q] = pl[0]; bl[s][2 * q + 1] = pl[1];
+                    }
+                }
+                for (int slot = 0; slot < args.n_slots; ++slot) {
+                    const float *rec = args.blob + args.feat_off[slot];
+                    for (int ot = 0; ot < 2; ++ot) {
+                        __syncthreads();
+                        stage_floats(lds, rec + ((size_t)ot * nsteps_all + kc / 16) * 512, ns * 512, tid, NT);
+                        __syncthreads();
+                        float *g = args.G + (((size_t)slot * args.g_groups + group) * 2 + ot) * (4 * 64 * 4);
+                        f32x16 acc1, acc2;
+                        if (kc == 0) {
+                            const float *bias = rec + (size_t)2 * nsteps_all * 512 + (ot * 2 + h) * 16;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc1[r] = bias[r];
+                        } else {
+                            acc1 = load_g16(g, lane);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+                        for (int s = 0; s < FP_KCHUNK / 16; ++s) {
+                            if (s < ns) {
+                                const h8 ah = lds_h8(lds, (s * 2 + 0) * 64 + lane);
+                                const h8 al = lds_h8(lds, (s * 2 + 1) * 64 + lane);
+                                acc1 = RNF_MFMA_H(ah, bh[s], acc1);
+                                acc2 = RNF_MFMA_H(ah, bl[s], acc2);
+                                acc2 = RNF_MFMA_H(al, bh[s], acc2);
+                            }
+                        }
+                        float4 *g4 = reinterpret_cast<float4 *>(g);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            g4[q * 64 + lane] = make_float4(fmaf(acc2[4 * q], kLoInv, acc1[4 * q]), fmaf(acc2[4 * q + 1], kLoInv, acc1[4 * q + 1]),
+                                                            fmaf(acc2[4 * q + 2], kLoInv, acc1[4 * q + 2]), fmaf(acc2[4 * q + 3], kLoInv, acc1[4 * q + 3]));
+                    }
                 }
             }
         }

@@ -57,7 +57,9 @@ constexpr int64_t COND16_FLOATS = MOB_HEAD_FLOATS + MOB_LAST_TILE_FLOATS;
 
 // ---- feature projection record (per layer that consumes the feature vector), F padded to a multiple of 8 ----
 // [2][F/8][64] float4 weight image of W0[:, 3:] (or W0 for Condition16Trans), then bias image [2][2][16]
-inline constexpr int64_t featproj_packed_floats(int F) { return F <= 0 ? 0 : (int64_t)2 * (F / 8) * 64 * 4 + 64; }
+// split precision: [2][ceil(F/16)][hi, lo][64] 8 x fp16 (512 floats per k-step of 16), then the same bias image.
+// Both layouts fit in the size returned here (equal when F % 16 == 0).
+inline constexpr int64_t featproj_packed_floats(int F) { return F <= 0 ? 0 : (int64_t)2 * ((F + 15) / 16) * 512 + 64; }
 
 // ---- feature-projection scratch G (device workspace) ----
 // G[cond_slot][sample_group of 32][ot (2)][q (4)][lane (64)] float4 : register 4q..4q+3 of tile ot of lane

@@ -105,6 +105,27 @@ static void pack_hidden(float *out, const float *const w[3], const float *const 
 }
 
 // feature projection record: weights Wf [64][ldw] starting at column col0, F columns; bias b0 [64]
+static void pack_featproj_h(float *out, const float *W, int ldw, int col0, int F, const float *b0) {
+    const int ns = (F + 15) / 16;
+    _Float16 *o16 = reinterpret_cast<_Float16 *>(out);
+    for (int ot = 0; ot < 2; ++ot)
+        for (int s = 0; s < ns; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, h = lane >> 5;
+                _Float16 *hi = o16 + ((((size_t)ot * ns + s) * 2 + 0) * 64 + lane) * 8;
+                _Float16 *lo = o16 + ((((size_t)ot * ns + s) * 2 + 1) * 64 + lane) * 8;
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * s + 8 * h + j;
+                    const float w = k < F ? W[(size_t)(32 * ot + i) * ldw + col0 + k] : 0.f;
+                    if (!(std::fabs(w) < 65504.0f)) g_half_overflow = true;
+                    const _Float16 wh = (_Float16)w;
+                    hi[j] = wh;
+                    lo[j] = (_Float16)((w - (float)wh) * 4096.0f);
+                }
+            }
+    pack_bias(out + (size_t)2 * ns * 512, 2, [&](int ot, int row) { return b0[32 * ot + row]; });
+}
+
 static void pack_featproj(float *out, const float *W, int ldw, int col0, int F, const float *b0) {
     const int ng = F / 8;
     for (int ot = 0; ot < 2; ++ot)
@@ -149,7 +170,7 @@ extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b,
         if (prec) pack_w64_h(rec, 1, row_of); else pack_w64(rec, 1, row_of);
         pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) { return fc_last_b[src_row(tau, row)]; });
     }
-    if (F) pack_featproj(out_feat, fc_first_w, ni, 3, F, fc_first_b);
+    if (F) { if (prec) pack_featproj_h(out_feat, fc_first_w, ni, 3, F, fc_first_b); else pack_featproj(out_feat, fc_first_w, ni, 3, F, fc_first_b); }
     if (prec && g_half_overflow) return fail("rnf_pack_mobius: a weight is outside the fp16 range; use RNF_PREC_FP32") + 1;
     return 0;
 }
@@ -175,7 +196,7 @@ extern "C" int rnf_pack_cond16(const float *fc_first_w, const float *fc_first_b,
     auto row_of = [&](int, int i) { int s = src_row(i); return s < 0 ? (const float *)nullptr : fc_last_w + (size_t)s * 64; };
     if (prec) pack_w64_h(rec, 1, row_of); else pack_w64(rec, 1, row_of);
     pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) { int s = src_row(row); return s < 0 ? 0.f : fc_last_b[s]; });
-    pack_featproj(out_feat, fc_first_w, F, 0, F, fc_first_b);
+    if (prec) pack_featproj_h(out_feat, fc_first_w, F, 0, F, fc_first_b); else pack_featproj(out_feat, fc_first_w, F, 0, F, fc_first_b);
     if (prec && g_half_overflow) return fail("rnf_pack_cond16: a weight is outside the fp16 range; use RNF_PREC_FP32") + 1;
     return 0;
 }
@@ -367,10 +388,17 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             fp.g_groups = groups;
             fp.F = F;
             fp.n_slots = n_slots;
-            size_t fl = sizeof(float) * (size_t)(F < FP_KCHUNK ? F : FP_KCHUNK) / 8 * 256;
-            auto kern = featproj_kernel<NW>;
-            HIP_TRY(allow_lds(kern, fl));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), fl, stream, fp);
+            const int kchunk = F < FP_KCHUNK ? F : FP_KCHUNK;
+            size_t fl = sizeof(float) * (prec ? (size_t)((kchunk + 15) / 16) * 512 : (size_t)kchunk / 8 * 256);
+            if (prec) {
+                auto kern = featproj_kernel<NW, 1>;
+                HIP_TRY(allow_lds(kern, fl));
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), fl, stream, fp);
+            } else {
+                auto kern = featproj_kernel<NW, 0>;
+                HIP_TRY(allow_lds(kern, fl));
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), fl, stream, fp);
+            }
             HIP_TRY(hipGetLastError());
         }
         a.rot_in = rot + base * 9;

@@ -178,3 +178,24 @@ def conditioner_from_record_h(rec32, y, K):
                 k = 8 * tau + 2 * g + H
                 out[J, np.where(c == 0, k, K + 3 * k + (c - 1))] = o[4 * g + c]
     return out
+
+
+def featproj_from_record_h(frec32, feat, F):
+    """featproj_kernel<PREC=1> for one wave: feat [32, F] (F % 8 == 0) -> G fragments (2 tiles of [16,64])."""
+    frec32 = np.ascontiguousarray(frec32, dtype=np.float32)
+    ns = (F + 15) // 16
+    tiles = []
+    for ot in range(2):
+        acc1 = bias16(frec32.astype(np.float64), 2 * ns * 512 + ot * 32)
+        acc2 = np.zeros((16, 64))
+        halves = frec32[ot * ns * 512:(ot + 1) * ns * 512].view(np.float16).astype(np.float64).reshape(ns, 2, 64, 8)
+        for s in range(ns):
+            k = 16 * s + 8 * H[:, None] + np.arange(8)[None, :]                      # [64, 8] feature index per lane/elem
+            vals = np.where(k < F, feat[J[:, None], np.minimum(k, F - 1)], 0.0).astype(np.float32)
+            bh = vals.astype(np.float16)
+            bl = ((vals - bh.astype(np.float32)) * np.float32(4096.0)).astype(np.float16)
+            acc1 = mfma_h(halves[s, 0], bh.astype(np.float64), acc1)
+            acc2 = mfma_h(halves[s, 0], bl.astype(np.float64), acc2)
+            acc2 = mfma_h(halves[s, 1], bh.astype(np.float64), acc2)
+        tiles.append(acc1 + acc2 / 4096.0)
+    return tiles

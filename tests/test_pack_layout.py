@@ -40,7 +40,7 @@ def test_conditional_mobius_record_and_feature_projection(F):
     m = _filled_mlp(3 + F, 4 * K, seed=100 + F)
     rec, frec = runtime.pack_mobius(_lib.lib(), m, K, F)
     Fp = runtime.pad8(F)
-    assert frec.size == 2 * (Fp // 8) * 256 + 64
+    assert frec.size == _lib.lib().rnf_featproj_packed_floats(Fp) >= 2 * (Fp // 8) * 256 + 64
     y = synth.uniform_rotations(32, seed=4)[:, :, 2]
     feat = synth.features(32, F, seed=9)
     featp = np.zeros((32, Fp), np.float32)
@@ -56,6 +56,22 @@ def test_conditional_mobius_record_and_feature_projection(F):
                 out[emu.J, np.where(c == 0, k, K + 3 * k + (c - 1))] = o[4 * gi + c]
     want = _oracle_mlp(m, np.concatenate([y, feat], axis=1))
     assert np.abs(out - want).max() < 1e-5 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("F", [8, 40, 256])
+def test_split_precision_feature_projection(F):
+    """f16x2 feature-projection image (k-steps of 16, zero padded) reproduces W0[:, 3:] f + b0."""
+    K = 8
+    m = _filled_mlp(3 + F, 4 * K, seed=200 + F)
+    rec, frec = runtime.pack_mobius(_lib.lib(), m, K, F, _lib.PREC_F16X2)
+    feat = synth.features(32, F, seed=9)
+    g = emu.featproj_from_record_h(frec, feat.astype(np.float64), F)
+    W0 = m.fc_first.weight.detach().double().numpy()
+    want = feat.astype(np.float64) @ W0[:, 3:].T + m.fc_first.bias.detach().double().numpy()      # [32, 64]
+    for ot in range(2):
+        for r in range(16):
+            rows = 32 * ot + emu.rho(r, emu.H)
+            assert np.abs(g[ot][r] - want[emu.J, rows]).max() < 3e-6 * max(1.0, np.abs(want).max())
 
 
 def test_cond16_record_yields_matrix_rows_on_lane_halves():

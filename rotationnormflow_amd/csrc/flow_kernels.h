@@ -262,7 +262,7 @@ __device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32
 struct MobiusCtx {
     Frame f;
     v3f y;            // the conditioning column (unchanged by the layer)
-    float zr, zv;     // forward: in-plane coordinates of the input column x
+    float zc, zs, zth; // forward: the input column x as a unit point (cos, sin) of the frame and its angle (== pi)
     float target;     // inverse: angle of the given column
     int p0, p2;
     bool cyc;         // branch of mobiusflow.py:75 / :172
@@ -277,17 +277,19 @@ __device__ __forceinline__ void mobius_begin(const Rot &R, int perm_row, MobiusC
     const v3f x = get_col(R, p0);
     c.y = get_col(R, p1);
     c.f = make_frame(x, c.y);
-    c.zr = dot3(x, c.f.r);
-    c.zv = dot3(x, c.f.v);
+    const float xr = dot3(x, c.f.r), xv = dot3(x, c.f.v);
+    const float inv = hw_rsq(fmaf(xv, xv, xr * xr));
+    c.zc = xr * inv;
+    c.zs = xv * inv;
+    c.zth = angle_0_2pi(xv, xr);
     if (DIR) {   // target angle of the given column (== pi by construction), wrapped and snapped (mobiusflow.py:157-167)
-        float t = angle_0_2pi(c.zv, c.zr);
-        c.target = fabsf(t - kTwoPi) < 1e-4f ? 0.f : t;
+        c.target = fabsf(c.zth - kTwoPi) < 1e-4f ? 0.f : c.zth;
     }
 }
 
 __device__ __forceinline__ void segments4(const f32x16 &o, const MobiusCtx &c, float &S, float &A, float &J) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) segment_full(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, c.zr, c.zv, S, A, J);
+    for (int g = 0; g < 4; ++g) segment_full(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, c.zc, c.zs, c.zth, S, A, J);
 }
 
 // forward, all fc_last tiles resident (K <= 64): software pipelined BY HAND.  Tile tau+1's 32 dependent MFMAs (64
@@ -303,7 +305,7 @@ __device__ __forceinline__ void tile_step(f32x16 &nxt, const float4 (&a)[8], con
     const float av = q == 0 ? a[tg].x : (q == 1 ? a[tg].y : (q == 2 ? a[tg].z : a[tg].w));
     nxt = RNF_MFMA(av, tt[K >> 4][K & 15], nxt);
     constexpr int g = K >> 3, st = K & 7;             // slice `st` of segment `g` rides behind MFMA number K
-    seg_stage<st>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, c.zr, c.zv, S, A, J);
+    seg_stage<st>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, c.zc, c.zs, c.zth, S, A, J);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (K + 1 < 32) tile_step<K + 1>(nxt, a, tt, cur, seg, c, S, A, J);
 }
@@ -431,7 +433,7 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
 #pragma unroll
         for (int s = 0; s < 4 * KT; ++s) {
             float phi, cc;
-            mobius_angle(cs, sn, sg.ur[s], sg.uv[s], phi, cc);
+            mobius_angle(cs, sn, th, sg.ur[s], sg.uv[s], phi, cc);
             acc = fmaf(sg.sp[s], phi, acc);
             der = fmaf(sg.sp[s], cc, der);
         }
@@ -455,7 +457,7 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
 #pragma unroll
     for (int s = 0; s < 4 * KT; ++s) {
         float phi, cc;
-        mobius_angle(cs, sn, sg.ur[s], sg.uv[s], phi, cc);
+        mobius_angle(cs, sn, mid, sg.ur[s], sg.uv[s], phi, cc);
         J = fmaf(sg.sp[s], cc, J);
     }
     J = pair_sum(J);

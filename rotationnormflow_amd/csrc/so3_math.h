@@ -144,92 +144,102 @@ RNF_HD void squash_center(float w0, float w1, float w2, const Frame &f, float &u
     uv = wv * sc;
 }
 
-// Moebius map of the point (zr, zv) about centre (ur, uv) (flow/mobiusflow.py:17-24) -> wrapped angle in [0, 2pi)
-// (mobiusflow.py:94-99) and the scalar c = (1-|w|^2)/|z-w|^2, which is also the segment's |dh/dtheta|
-// (identity checked in tests/test_oracle_golden.py::test_closed_form_ldj_identity).
-RNF_HD void mobius_map(float zr, float zv, float ur, float uv, float &hr, float &hv, float &c) {
-    float u2 = fmaf(uv, uv, ur * ur);
-    float dr = zr - ur, dv = zv - uv;
-    float d2 = fmaf(dv, dv, dr * dr);
-    c = (1.0f - u2) * hw_rcp(d2);
-    hr = fmaf(c, dr, -ur);
-    hv = fmaf(c, dv, -uv);
+// arctangent on |t| <= 1 with no range reduction: t * P(t^2), degree-8 minimax fit (max abs error 1e-7 in fp32 Horner).
+RNF_HD float atan_unit(float t) {
+    const float z = t * t;
+    float p = fmaf(2.456724578e-03f, z, -1.440135792e-02f);
+    p = fmaf(p, z, 3.978122362e-02f);
+    p = fmaf(p, z, -7.234857378e-02f);
+    p = fmaf(p, z, 1.049894609e-01f);
+    p = fmaf(p, z, -1.416122920e-01f);
+    p = fmaf(p, z, 1.998590677e-01f);
+    p = fmaf(p, z, -3.333259703e-01f);
+    p = fmaf(p, z, 9.999998864e-01f);
+    return p * t;
 }
-RNF_HD void mobius_angle(float zr, float zv, float ur, float uv, float &phi, float &c) {
-    float hr, hv;
-    mobius_map(zr, zv, ur, uv, hr, hv, c);
-    phi = angle_0_2pi(hv, hr);
+
+// Moebius map of the unit point z = (cs, sn) = e^{i theta} about centre u = (ur, uv), |u| < 0.7 (flow/mobiusflow.py:17-24):
+// in complex form h(z) = (1-|u|^2)(z-u)/|z-u|^2 - u = conj(z) (z-u)/conj(z-u), hence
+//     arg h = 2 arg(z - u) - theta = theta + 2 atan(-b / (1 - a)),   (a, b) = u conj(z),   1 - a > 0.3,
+// and |t| = |b / (1 - a)| <= tan(asin 0.7) < 1: one quadrant, no octant logic, no wrap (theta in [pi/2, 3pi/2] => phi in
+// (0, 2pi), which is the range of the reference's wrapped atan2, mobiusflow.py:94-99).  c = (1-|u|^2)/|z-u|^2 is the
+// segment's |dh/dtheta| (identity checked in tests/test_oracle_golden.py).
+RNF_HD void mobius_angle(float cs, float sn, float theta, float ur, float uv, float &phi, float &c) {
+    const float a = fmaf(uv, sn, ur * cs);
+    const float b = fmaf(uv, cs, -ur * sn);
+    const float e1 = 1.0f - a;
+    phi = fmaf(2.0f, atan_unit(-b * hw_rcp(e1)), theta);
+    const float u2 = fmaf(uv, uv, ur * ur);
+    c = (1.0f - u2) * hw_rcp(fmaf(b, b, e1 * e1));
 }
 
 // ---- one forward segment, cut into 8 slices of ~10 VALU issue slots --------------------------------------------------
-// Same arithmetic as squash_center -> mobius_map -> angle_0_2pi -> softplus -> accumulate, but exposed stage by stage so
+// Same arithmetic as squash_center -> mobius_angle -> softplus -> accumulate, but exposed stage by stage so
 // the forward kernel can hand-interleave ONE slice behind every MFMA of the next fc_last tile (a 64-cycle matrix
 // instruction covers ~10 VALU issue slots of the two waves sharing a SIMD; unbalanced slices leave the pipe idle).
 struct SegState {
-    float wr, wv, nrm, ur, uv, u2, dr, dv, c, hr, hv, mx, mn, t, p, pp, r, e, u, lg;
-    bool big;
+    float wr, wv, sc, ur, uv, b, e1, u2, d2, c, t, z, p, pp, r, e, u, lg;
 };
+// zc, zs, ztheta: the layer's input point z = (cos, sin) in frame coordinates and its angle (== pi up to rounding)
 template <int STAGE>
-RNF_HD void seg_stage(SegState &g, float s_raw, float w0, float w1, float w2, const Frame &f, float zr, float zv,
+RNF_HD void seg_stage(SegState &g, float s_raw, float w0, float w1, float w2, const Frame &f, float zc, float zs, float ztheta,
                       float &S, float &A, float &J) {
     if constexpr (STAGE == 0) {
         g.wr = fmaf(w2, f.r.z, fmaf(w1, f.r.y, w0 * f.r.x));
         g.wv = fmaf(w2, f.v.z, fmaf(w1, f.v.y, w0 * f.v.x));
-        g.nrm = hw_sqrt(fmaf(g.wv, g.wv, g.wr * g.wr));
+        g.sc = fmaf(g.wv, g.wv, g.wr * g.wr);
     } else if constexpr (STAGE == 1) {
-        const float sc = 0.7f * hw_rcp(1.0f + g.nrm);
-        g.ur = g.wr * sc;
-        g.uv = g.wv * sc;
-        g.u2 = fmaf(g.uv, g.uv, g.ur * g.ur);
-        g.dr = zr - g.ur;
-        g.dv = zv - g.uv;
+        g.sc = 0.7f * hw_rcp(1.0f + hw_sqrt(g.sc));
+        g.ur = g.wr * g.sc;
+        g.uv = g.wv * g.sc;
     } else if constexpr (STAGE == 2) {
-        const float d2 = fmaf(g.dv, g.dv, g.dr * g.dr);
-        g.c = (1.0f - g.u2) * hw_rcp(d2);
-        g.hr = fmaf(g.c, g.dr, -g.ur);
-        g.hv = fmaf(g.c, g.dv, -g.uv);
-        g.mx = fmaxf(fabsf(g.hr), fabsf(g.hv));
-        g.mn = fminf(fabsf(g.hr), fabsf(g.hv));
+        const float a = fmaf(g.uv, zs, g.ur * zc);
+        g.b = fmaf(g.uv, zc, -g.ur * zs);
+        g.e1 = 1.0f - a;
+        g.u2 = fmaf(g.uv, g.uv, g.ur * g.ur);
+        g.d2 = fmaf(g.b, g.b, g.e1 * g.e1);
     } else if constexpr (STAGE == 3) {
-        const float a = g.mn * hw_rcp(g.mx);
-        g.big = a > 0.414213562373095f;
-        g.t = g.big ? (a - 1.0f) * hw_rcp(a + 1.0f) : a;
+        g.c = (1.0f - g.u2) * hw_rcp(g.d2);
+        g.t = -g.b * hw_rcp(g.e1);
+        g.z = g.t * g.t;
+        g.p = fmaf(2.456724578e-03f, g.z, -1.440135792e-02f);
     } else if constexpr (STAGE == 4) {
-        const float z = g.t * g.t;
-        float p = fmaf(fmaf(fmaf(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
-        p = fmaf(p * z, g.t, g.t);
-        p += g.big ? 0.785398163397448310f : 0.0f;
-        g.p = fabsf(g.hv) > fabsf(g.hr) ? 1.57079632679489662f - p : p;
+        float p = fmaf(g.p, g.z, 3.978122362e-02f);
+        p = fmaf(p, g.z, -7.234857378e-02f);
+        p = fmaf(p, g.z, 1.049894609e-01f);
+        p = fmaf(p, g.z, -1.416122920e-01f);
+        p = fmaf(p, g.z, 1.998590677e-01f);
+        p = fmaf(p, g.z, -3.333259703e-01f);
+        p = fmaf(p, g.z, 9.999998864e-01f);
+        g.p = fmaf(2.0f, p * g.t, ztheta);                                   // phi
     } else if constexpr (STAGE == 5) {
-        float p = g.hr < 0.0f ? 3.14159265358979324f - g.p : g.p;
-        g.p = g.hv < 0.0f ? 6.28318530717958648f - p : p;                   // phi in [0, 2pi)
         const float ax = fabsf(s_raw);
         g.pp = ax * 1.44269502162933349609375f;
         g.r = fmaf(ax, 1.92596299112661746e-8f, fmaf(ax, 1.44269502162933349609375f, -g.pp));
-    } else if constexpr (STAGE == 6) {
         float e = hw_exp2(-g.pp);
         g.e = fmaf(-0.693147180559945309f * e, g.r, e);
+    } else if constexpr (STAGE == 6) {
         g.u = 1.0f + g.e;
         g.lg = hw_log2(g.u);
+        g.r = (g.e - (g.u - 1.0f)) * fmaf(-0.5f, g.e, 1.0f);
     } else {
-        const float l = fmaf(g.lg, 0.693147180559945309f, (g.e - (g.u - 1.0f)) * fmaf(-0.5f, g.e, 1.0f));
-        const float sp = fmaxf(s_raw, 0.0f) + l;
+        const float sp = fmaxf(s_raw, 0.0f) + fmaf(g.lg, 0.693147180559945309f, g.r);
         S += sp;
         A = fmaf(sp, g.p, A);
         J = fmaf(sp, g.c, J);
     }
 }
-RNF_HD void segment_full(float s_raw, float w0, float w1, float w2, const Frame &f, float zr, float zv, float &S, float &A,
-                         float &J) {
+RNF_HD void segment_full(float s_raw, float w0, float w1, float w2, const Frame &f, float zc, float zs, float ztheta, float &S,
+                         float &A, float &J) {
     SegState g;
-    seg_stage<0>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
-    seg_stage<1>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
-    seg_stage<2>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
-    seg_stage<3>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
-    seg_stage<4>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
-    seg_stage<5>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
-    seg_stage<6>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
-    seg_stage<7>(g, s_raw, w0, w1, w2, f, zr, zv, S, A, J);
+    seg_stage<0>(g, s_raw, w0, w1, w2, f, zc, zs, ztheta, S, A, J);
+    seg_stage<1>(g, s_raw, w0, w1, w2, f, zc, zs, ztheta, S, A, J);
+    seg_stage<2>(g, s_raw, w0, w1, w2, f, zc, zs, ztheta, S, A, J);
+    seg_stage<3>(g, s_raw, w0, w1, w2, f, zc, zs, ztheta, S, A, J);
+    seg_stage<4>(g, s_raw, w0, w1, w2, f, zc, zs, ztheta, S, A, J);
+    seg_stage<5>(g, s_raw, w0, w1, w2, f, zc, zs, ztheta, S, A, J);
+    seg_stage<6>(g, s_raw, w0, w1, w2, f, zc, zs, ztheta, S, A, J);
+    seg_stage<7>(g, s_raw, w0, w1, w2, f, zc, zs, ztheta, S, A, J);
 }
 
 // pytorch3d.transforms.matrix_to_quaternion (published 0.7.5 rule; call site flow/squeezetrans.py:34):

@@ -40,18 +40,20 @@ void hm_mobius_forward(const float *Rin, const float *cond, int K, int perm_row,
         const int p0 = perm_row % 3, p1 = (perm_row + 1) % 3, p2 = (perm_row + 2) % 3;
         v3f x = get_col(R, p0), y = get_col(R, p1);
         Frame f = make_frame(x, y);
-        float zr = dot3(x, f.r), zv = dot3(x, f.v);
+        float xr = dot3(x, f.r), xv = dot3(x, f.v);
+        float inv = 1.0f / sqrtf(xr * xr + xv * xv);
+        float zc = xr * inv, zs = xv * inv, zth = angle_0_2pi(xv, xr);
         float S = 0, A = 0, J = 0;
         const float *c = cond + (size_t)4 * K * i;
         for (int k = 0; k < K; ++k) {
             if (k & 1) {                       // exercise both formulations of the segment math
                 float ur, uv, phi, cc;
                 squash_center(c[K + 3 * k], c[K + 3 * k + 1], c[K + 3 * k + 2], f, ur, uv);
-                mobius_angle(zr, zv, ur, uv, phi, cc);
+                mobius_angle(zc, zs, zth, ur, uv, phi, cc);
                 float sp = softplus(c[k]);
                 S += sp; A += sp * phi; J += sp * cc;
             } else {
-                segment_full(c[k], c[K + 3 * k], c[K + 3 * k + 1], c[K + 3 * k + 2], f, zr, zv, S, A, J);
+                segment_full(c[k], c[K + 3 * k], c[K + 3 * k + 1], c[K + 3 * k + 2], f, zc, zs, zth, S, A, J);
             }
         }
         float sn, cs;

@@ -120,6 +120,13 @@ int rnf_flow_log_prob(const float *rotation_dev, const float *feature_dev, int64
 int rnf_fisher_log_prob(const float *rotation_dev, int64_t n, const float *fisher_A_dev, const float *fisher_c_dev,
                         int64_t fisher_B, float *out_dev, void *stream);
 
+/* MatrixFisherN._sample (utils/fisher.py:117-207,234-243): n rotations per row of A, out [B,n,3,3].
+ *   U_dev, V_dev [B,3,3]: proper SVD factors of A (det +1; utils/fisher.py:53-64); lam_dev [B,4]: the diagonal Bingham parameter
+ *   (0, 2(S1+S2), 2(S0+S2), 2(S0+S1)) (utils/fisher.py:183-187).  Counter-based Philox stream keyed by `seed`: the same seed gives
+ *   the same samples; parity with the reference's torch-generator samples is statistical.  fail_flag_dev (must point to one zeroed int32) is set to 1 if any sample exhausted its 4096 proposals. */
+int rnf_fisher_sample(const float *U_dev, const float *V_dev, const float *lam_dev, int64_t B, int64_t n, uint64_t seed,
+                      float *out_dev, int32_t *fail_flag_dev, void *stream);
+
 /* ConditionalTransform.forward for one packed Moebius layer (flow/condition.py:24-30), unconditional input only:
  * y_dev [n,3] -> out_dev [n,4K] in the reference's output order.  Unit-test / bring-up entry point. */
 int rnf_conditioner_forward(const float *y_dev, int64_t n, const float *layer_packed_dev, int32_t segments,

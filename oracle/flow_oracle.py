@@ -375,6 +375,58 @@ def fisher_log_prob(R, A, dtype=torch.float32):
 
 
 # --------------------------------------------------------------------------------------------------------------
+# matrix-Fisher sampler (utils/fisher.py:14-64,117-207,234-243): Bingham on S^3 by ACG-envelope rejection
+# --------------------------------------------------------------------------------------------------------------
+def proper_svd(A):
+    """proper_svd (fisher.py:53-64) for one 3x3 matrix: (U, S, V) with U[:,2], S[2], V[:,2] sign-fixed so det U = det V = +1."""
+    U, S, Vh = torch.linalg.svd(A)
+    V = Vh.transpose(-1, -2)
+    dU, dV = torch.det(U), torch.det(V)
+    U = U.clone(); S = S.clone(); V = V.clone()
+    U[:, 2] *= dU
+    S[2] *= dU * dV
+    V[:, 2] *= dV
+    return U, S, V
+
+
+def bingham_constants(S, b=1.5):
+    """fisher.py:183-193: diagonal Bingham parameter, ACG envelope Omega, Gaussian std, rejection bound M*."""
+    lam = torch.zeros(4, dtype=S.dtype)
+    lam[1] = 2 * (S[1] + S[2])
+    lam[2] = 2 * (S[0] + S[2])
+    lam[3] = 2 * (S[0] + S[1])
+    omega = torch.ones(4, dtype=S.dtype) + 2 * lam / b
+    return lam, omega, omega ** (-0.5), math.exp(-(4 - b) / 2) * ((4 / b) ** 2)
+
+
+def sample_matrix_fisher(A, num_samples, b=1.5, oversampling_ratio=8):
+    """sample_matrix_fisher + sample_bingham + quat_to_rotmat (fisher.py:14-50,117-207) for one A [3,3], torch global RNG
+    consumed in the reference's order (randn(n*8, 4) then rand(n*8) per attempt)."""
+    U, S, V = proper_svd(A)
+    lam, omega, std, m_star = bingham_constants(S, b)
+    while True:
+        eps = torch.randn(num_samples * oversampling_ratio, 4).float()
+        y = std * eps
+        x = y / torch.norm(y, dim=1, keepdim=True)
+        p_bing = torch.exp(-torch.einsum("bn,n,bn->b", x, lam, x))
+        p_acg = torch.einsum("bn,n,bn->b", x, omega, x) ** (-2)
+        w = torch.rand(num_samples * oversampling_ratio)
+        acc = w < p_bing / (m_star * p_acg)
+        if int(acc.sum()) >= num_samples:
+            q = x[acc, :][:num_samples, :]
+            break
+    q = q / q.norm(p=2, dim=1, keepdim=True)
+    Rq = quaternion_to_matrix(q)                     # fisher.py:14-50 is the same real-first formula for unit q
+    return U @ Rq.to(U.dtype) @ V.T
+
+
+def fisher_sample(A, num_samples):
+    """MatrixFisherN._sample (fisher.py:234-243): [B, num_samples, 3, 3], rows of A sampled one after the other."""
+    A = torch.as_tensor(A)
+    return torch.stack([sample_matrix_fisher(A[i], num_samples) for i in range(A.shape[0])])
+
+
+# --------------------------------------------------------------------------------------------------------------
 # NLL accumulation (agent.py:55-65,226-229; eval_uncondition.py:43-45)
 # --------------------------------------------------------------------------------------------------------------
 def log_prob(cfg, params, R, feature=None, A=None, dtype=torch.float32):

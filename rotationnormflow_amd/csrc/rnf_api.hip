@@ -12,6 +12,7 @@
 #include "../../include/rnf_hip.h"
 #include "featproj_kernel.h"
 #include "flow_kernels.h"
+#include "sampler_kernel.h"
 #include "layout.h"
 
 using namespace rnf;
@@ -480,6 +481,19 @@ extern "C" int rnf_fisher_log_prob(const float *rot, int64_t n, const float *A, 
     long long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(fisher_log_prob_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rot, (long long)n, A, c, (long long)(n / B), out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rnf_fisher_sample(const float *U, const float *V, const float *lam, int64_t B, int64_t n, uint64_t seed, float *out,
+                                 int32_t *fail_flag_dev, void *stream) {
+    if (!U || !V || !lam || !out) return fail("rnf_fisher_sample: null pointer");
+    if (B <= 0 || n < 0) return fail("rnf_fisher_sample: B=%lld, n=%lld", (long long)B, (long long)n);
+    if (n == 0) return 0;
+    long long blocks = (B * n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(fisher_sample_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), U, V, lam,
+                       (long long)B, (long long)n, (unsigned long long)seed, out, fail_flag_dev);
     HIP_TRY(hipGetLastError());
     return 0;
 }

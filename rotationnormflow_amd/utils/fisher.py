@@ -65,7 +65,35 @@ class MatrixFisherN(torch.nn.Module):
         return self._log_prob(inputs)
 
     def _sample(self, num_samples, context=9):
-        raise NotImplementedError("matrix-Fisher rejection sampler (utils/fisher.py:117-207,234-243) is a 'next' row; not built yet")
+        """[B, num_samples, 3, 3] rotations (context=9) or quaternions (context=4) ~ MF(A) on A's device.  Exact rejection
+        sampler (Bingham through an ACG envelope, utils/fisher.py:117-207) on the GPU with a counter-based Philox stream whose
+        key is drawn from torch's default generator, so ``torch.manual_seed`` makes it reproducible."""
+        A = self.A
+        if not A.is_cuda:
+            raise RuntimeError("rotationnormflow_amd runs on the GPU only (no CPU fallback): construct MatrixFisherN with A on the GPU")
+        dev = A.device
+        A64 = A.detach().to(torch.float64)
+        U, S, Vh = torch.linalg.svd(A64)
+        V = Vh.transpose(-1, -2)
+        dU, dV = torch.det(U), torch.det(V)
+        U = U.clone(); V = V.clone(); S = S.clone()
+        U[:, :, 2] *= dU[:, None]                                   # proper SVD, utils/fisher.py:53-64
+        V[:, :, 2] *= dV[:, None]
+        S[:, 2] *= dU * dV
+        lam = torch.stack([torch.zeros_like(S[:, 0]), 2 * (S[:, 1] + S[:, 2]), 2 * (S[:, 0] + S[:, 2]), 2 * (S[:, 0] + S[:, 1])], -1)
+        U32, V32, lam32 = (t.to(torch.float32).contiguous() for t in (U, V, lam))
+        B = A.shape[0]
+        out = torch.empty(B, num_samples, 3, 3, dtype=torch.float32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().rnf_fisher_sample(U32.data_ptr(), V32.data_ptr(), lam32.data_ptr(), B, num_samples, seed,
+                                                    out.data_ptr(), flag.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        if context == 9:
+            return out
+        if context == 4:
+            raise NotImplementedError("context=4 (quaternion output) is not built; convert with your own matrix_to_quaternion")
+        return None
 
     def sample(self, num_samples, context=None):
         return self._sample(num_samples)

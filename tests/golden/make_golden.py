@@ -98,10 +98,26 @@ def run_case(name, spec):
 
 def main():
     torch.manual_seed(0)
-    names = sys.argv[1:] or list(CASES)
+    names = [n for n in sys.argv[1:] if n in CASES] or ([] if len(sys.argv) > 1 else list(CASES))
     for name in names:
         run_case(name, CASES[name])
 
 
 if __name__ == "__main__":
     main()
+
+
+def run_fisher_sampler_case():
+    """MatrixFisherN._sample with a fixed torch seed: pins the oracle's restatement of the rejection sampler (same RNG
+    consumption order) sample by sample."""
+    A = torch.from_numpy(np.concatenate([synth.fisher_A("diag531"), synth.fisher_A("tilted")], axis=0))
+    torch.manual_seed(1234)
+    dist = ref_fisher_mod.MatrixFisherN(A.clone())
+    samples = dist._sample(256)
+    lp = dist._log_prob(samples.reshape(-1, 3, 3))
+    np.savez_compressed(os.path.join(HERE, "fisher_sampler.npz"), A=A.numpy(), samples=samples.numpy(), log_prob=lp.numpy())
+    print("fisher_sampler: ", tuple(samples.shape), "mean log_prob", float(lp.mean()))
+
+
+if __name__ == "__main__" and (len(sys.argv) == 1 or "fisher_sampler" in sys.argv):
+    run_fisher_sampler_case()

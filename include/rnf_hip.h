@@ -76,6 +76,11 @@ int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b, const floa
  * log|det M^-1| (the reference recomputes inv/det every call: squeezetrans.py:38,171-174). */
 int rnf_pack_affine16(const float *mat16, float *out_layer);
 
+/* UnconditionRot (flow/rottrans.py:8-23): mat16 = U^T V of the SVD of the 4x4 parameter (an orthogonal matrix, computed by the
+ * caller exactly as the reference does); the layer rotates the quaternion and contributes a log-det of exactly 0.  Same record
+ * size and layer kind (RNF_LAYER_AFFINE16) as rnf_pack_affine16; the inverse pass uses the transpose (rottrans.py:26-28). */
+int rnf_pack_rot16(const float *mat16, float *out_layer);
+
 /* Condition16Trans.net = ConditionalTransform(F, 16) (flow/squeezetrans.py:42-44). fc_first_w [64,F], fc_last_w [16,64]. */
 int rnf_pack_cond16(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
                     const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,

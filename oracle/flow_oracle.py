@@ -32,22 +32,31 @@ PERMUTE_ROWS = ((0, 1, 2), (1, 2, 0), (2, 0, 1), (0, 1, 2), (1, 2, 0), (2, 0, 1)
 # layer list (flow/flow.py:19-51, flow/mobiusflow.py:7-14, flow/affineflow.py:5-73 -- 16Trans family only)
 # --------------------------------------------------------------------------------------------------------------
 def _affine_kind(cfg, first_layer_condition=False):
-    """Subset of get_affine (flow/affineflow.py:5-73) covering the non-LU 4x4 quaternion-affine family."""
-    if getattr(cfg, "lu", 0):
-        raise NotImplementedError("oracle covers lu=0 only")
-    rot = cfg.rot
+    """Subset of get_affine (flow/affineflow.py:5-73): the 4x4 quaternion-affine family ('uncond16', 'cond16'), its
+    unconditional LU parameterisation ('lu16') and the unconditional SVD rotation ('rot16')."""
+    rot, lu = cfg.rot, bool(getattr(cfg, "lu", 0))
     if first_layer_condition and rot == "16UnTrans":           # affineflow.py:7-11
+        if lu:
+            raise NotImplementedError("oracle does not restate Condition16TransLU")
         return "cond16"
+    if first_layer_condition and rot == "16UnRot":             # affineflow.py:12-13
+        raise NotImplementedError("oracle does not restate ConditionRot")
     if cfg.condition:
         if rot == "16Trans":                                    # affineflow.py:16-20
+            if lu:
+                raise NotImplementedError("oracle does not restate Condition16TransLU")
             return "cond16"
         if rot == "16UnTrans":                                  # affineflow.py:21-25
-            return "uncond16"
+            return "lu16" if lu else "uncond16"
+        if rot == "16UnRot":                                    # affineflow.py:43-44
+            return "rot16"
     else:
         if rot == "16Trans":                                    # affineflow.py:50-54
-            return "uncond16"
+            return "lu16" if lu else "uncond16"
+        if rot == "16Rot":                                      # affineflow.py:70-71
+            return "rot16"
     if rot in ("36Trans", "9TransLSVD", "9TransRSVD", "9TransLSmith", "9TransRSmith", "16Rot", "16UnRot"):
-        raise NotImplementedError(f"oracle does not restate rot={rot!r}")
+        raise NotImplementedError(f"oracle does not restate rot={rot!r} for condition={cfg.condition}")
     return None                                                 # affineflow.py:45-46,72-73
 
 
@@ -100,6 +109,12 @@ def state_shapes(cfg):
             shapes[f"layers.{i}.mat"] = (1, 4, 4)
         elif kind == "cond16":
             mlp(f"layers.{i}.net", fd, 16)
+        elif kind == "lu16":                                    # UnconditionLU(4), squeezetrans.py:76-83
+            for name, shp in (("w_p", (4, 4)), ("u_mask", (4, 4)), ("l_mask", (4, 4)), ("s_sign", (4,)), ("l_eye", (4, 4)),
+                              ("w_l", (4, 4)), ("w_s", (4,)), ("w_u", (4, 4))):
+                shapes[f"layers.{i}.mat.{name}"] = shp
+        elif kind == "rot16":                                   # UnconditionRot, rottrans.py:11-12
+            shapes[f"layers.{i}.rot"] = (1, 4, 4)
     return shapes
 
 
@@ -291,6 +306,26 @@ def affine16(M, R):
     return Rt, _det4(M).abs().log() - 4 * ln.reshape(-1).log()
 
 
+def lu16_matrix(p, prefix):
+    """UnconditionLU.forward (squeezetrans.py:85-91): P (L*mask + I) (U*mask + diag(sign * exp(s)))."""
+    g = lambda n: p[f"{prefix}.{n}"]  # noqa: E731
+    return (g("w_p") @ (g("w_l") * g("l_mask") + g("l_eye"))
+            @ ((g("w_u") * g("u_mask")) + torch.diag(g("s_sign") * torch.exp(g("w_s"))))).unsqueeze(0)
+
+
+def rot16_matrix(p, key):
+    """UnconditionRot (rottrans.py:15-17): U^T V from the SVD of the 4x4 parameter."""
+    U, S, Vh = torch.linalg.svd(p[key])
+    return U.transpose(-1, -2) @ Vh.transpose(-1, -2)
+
+
+def rot16_apply(M, R):
+    """rottrans.py:18-23: rotate the quaternion, no renormalisation, log-det exactly 0."""
+    q = matrix_to_quaternion(R)
+    q = (M @ q.reshape(-1, 4, 1)).reshape(-1, 4)
+    return quaternion_to_matrix(q), torch.zeros(R.shape[0], dtype=R.dtype)
+
+
 def cond16_matrix(feature, p, prefix):
     """Condition16Trans (squeezetrans.py:47-48)."""
     return conditioner(feature, p, prefix).reshape(-1, 4, 4) + torch.eye(4, dtype=feature.dtype)[None]
@@ -319,6 +354,10 @@ def flow_forward(cfg, params, R, feature=None, dtype=torch.float32):
                 R, l = mobius_forward(R, perm, feature, p, f"layers.{i}.conditioner", K)
             elif kind == "uncond16":
                 R, l = affine16(p[f"layers.{i}.mat"], R)
+            elif kind == "lu16":
+                R, l = affine16(lu16_matrix(p, f"layers.{i}.mat"), R)                   # squeezetrans.py:151-152
+            elif kind == "rot16":
+                R, l = rot16_apply(rot16_matrix(p, f"layers.{i}.rot"), R)
             else:
                 R, l = affine16(cond16_matrix(feature, p, f"layers.{i}.net"), R)
             ldj = ldj + l
@@ -346,6 +385,10 @@ def flow_inverse(cfg, params, R, feature=None, dtype=torch.float32):
                 R, l = mobius_inverse(R, perm, feature, p, f"layers.{i}.conditioner", K)
             elif kind == "uncond16":
                 R, l = affine16(torch.linalg.inv(p[f"layers.{i}.mat"]), R)       # squeezetrans.py:171-174
+            elif kind == "lu16":
+                R, l = affine16(torch.linalg.inv(lu16_matrix(p, f"layers.{i}.mat")), R)   # squeezetrans.py:154-157
+            elif kind == "rot16":
+                R, l = rot16_apply(rot16_matrix(p, f"layers.{i}.rot").transpose(-1, -2), R)   # rottrans.py:26-28
             else:
                 R, l = affine16(torch.linalg.inv(cond16_matrix(feature, p, f"layers.{i}.net")), R)  # :51-55
             ldj = ldj + l

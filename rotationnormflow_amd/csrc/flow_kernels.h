@@ -584,7 +584,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 const float *m = params + (DIR ? 17 : 0);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) M[i] = m[i];
-                affine16_apply(M, m[16], R, ldj);
+                affine16_apply(M, m[16], R, ldj, params[34] != 0.f);
                 RNF_STAMP(6)                                      // 6: unconditional affine layer
                 continue;
             }

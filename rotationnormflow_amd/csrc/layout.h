@@ -47,7 +47,7 @@ constexpr int MOB_MAX_TILES_IN_LDS = 8;                   // fc_last tiles resid
 inline constexpr int64_t mobius_packed_floats(int K) { return MOB_HEAD_FLOATS + (int64_t)(K / 8) * MOB_LAST_TILE_FLOATS; }
 
 // ---- unconditional 4x4 affine record ----
-// [0..15] M row-major, [16] log|det M|, [17..32] M^-1, [33] log|det M^-1|, padded to 36
+// [0..15] M row-major, [16] log|det M|, [17..32] M^-1, [33] log|det M^-1|, [34] 1.0 if M is orthogonal (log-det exactly 0), [35] 0
 constexpr int AFF_FLOATS = 36;
 
 // ---- Condition16Trans record: same head as a Moebius layer with an all-zero fc_first image (its whole first layer

@@ -237,6 +237,23 @@ extern "C" int rnf_pack_affine16(const float *mat16, float *out) {
     return 0;
 }
 
+extern "C" int rnf_pack_rot16(const float *mat16, float *out) {
+    // orthogonality check in double: M M^T = I within fp32 rounding of a product of SVD factors
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double d = 0.0;
+            for (int k = 0; k < 4; ++k) d += (double)mat16[4 * i + k] * mat16[4 * j + k];
+            if (std::fabs(d - (i == j)) > 1e-4) return fail("rnf_pack_rot16: matrix is not orthogonal (|M M^T - I| = %g)", std::fabs(d - (i == j)));
+        }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { out[4 * i + j] = mat16[4 * i + j]; out[17 + 4 * i + j] = mat16[4 * j + i]; }
+    out[16] = 0.f;
+    out[33] = 0.f;
+    out[34] = 1.f;
+    out[35] = 0.f;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------------

@@ -278,7 +278,9 @@ RNF_HD void quat_to_rot(const float (&q)[4], float l2, Rot &R) {
 
 // calculate_16 (flow/squeezetrans.py:33-38) with a given 4x4 M (row-major) and log|det M|:
 // q' = M q(R); R' = R(q'/|q'|); ldj = log|det M| - 4 log|q'| = log|det M| - 2 log|q'|^2
-RNF_HD void affine16_apply(const float (&M)[16], float logabsdet, Rot &R, float &ldj) {
+// `orthogonal`: M is a 4-D rotation (UnconditionRot, flow/rottrans.py:8-23): |q'| = 1 and det M = +-1, the reference
+// returns a log-det of exactly 0, so nothing is added.
+RNF_HD void affine16_apply(const float (&M)[16], float logabsdet, Rot &R, float &ldj, bool orthogonal = false) {
     float q[4], t[4];
     rot_to_quat(R, q);
 #pragma unroll
@@ -286,7 +288,7 @@ RNF_HD void affine16_apply(const float (&M)[16], float logabsdet, Rot &R, float 
         t[i] = fmaf(M[4 * i + 3], q[3], fmaf(M[4 * i + 2], q[2], fmaf(M[4 * i + 1], q[1], M[4 * i] * q[0])));
     float l2 = fmaf(t[3], t[3], fmaf(t[2], t[2], fmaf(t[1], t[1], t[0] * t[0])));
     quat_to_rot(t, l2, R);
-    ldj += logabsdet - 2.0f * logf(l2);
+    if (!orthogonal) ldj += logabsdet - 2.0f * logf(l2);
 }
 
 // 4x4 inverse and determinant by cofactors (Condition16Trans.inverse: torch.linalg.inv, flow/squeezetrans.py:51-55;

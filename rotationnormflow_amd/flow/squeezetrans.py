@@ -50,19 +50,70 @@ class Condition16Trans(nn.Module, _SingleLayer):
         return self._single(rotation, permute, feature, inverse=True)
 
 
+class UnconditionLU(nn.Module):
+    """Glow-style LU parameterisation of an invertible matrix (flow/squeezetrans.py:58-95): P (L*mask + I) (U*mask + diag(sign e^s)).
+    Same buffers (w_p, u_mask, l_mask, s_sign, l_eye) and parameters (w_l, w_s, w_u) as the reference => same state-dict keys.
+    ``forward()`` assembles the [1,n,n] matrix with a handful of tiny host-side tensor ops (parameter preprocessing; the
+    per-sample arithmetic runs in the HIP kernels)."""
+
+    def __init__(self, in_channel):
+        super().__init__()
+        import numpy as np
+        from scipy import linalg as la
+        weight = 1e-3 * np.random.randn(in_channel, in_channel) + np.eye(in_channel)
+        q, _ = la.qr(weight)
+        w_p, w_l, w_u = la.lu(q.astype(np.float32))
+        w_s = np.diag(w_u).copy()
+        w_u = np.triu(w_u, 1)
+        u_mask = np.triu(np.ones_like(w_u), 1)
+        self.register_buffer("w_p", torch.from_numpy(w_p))
+        self.register_buffer("u_mask", torch.from_numpy(u_mask))
+        self.register_buffer("l_mask", torch.from_numpy(u_mask.T.copy()))
+        self.register_buffer("s_sign", torch.sign(torch.from_numpy(w_s)))
+        self.register_buffer("l_eye", torch.eye(in_channel))
+        self.w_l = nn.Parameter(torch.from_numpy(w_l))
+        self.w_s = nn.Parameter(torch.from_numpy(w_s).abs().log())
+        self.w_u = nn.Parameter(torch.from_numpy(w_u))
+
+    def forward(self):
+        weight = (self.w_p @ (self.w_l * self.l_mask + self.l_eye)
+                  @ ((self.w_u * self.u_mask) + torch.diag(self.s_sign * torch.exp(self.w_s))))
+        return weight.unsqueeze(0)
+
+
+class Uncondition16TransLU(nn.Module, _SingleLayer):
+    """calculate_16 with the LU-parameterised 4x4 matrix (flow/squeezetrans.py:146-158): the constant-matrix affine kernel."""
+
+    _rnf_kind = runtime.KIND_AFFINE16
+
+    def __init__(self):
+        super().__init__()
+        self.mat = UnconditionLU(4)
+        self._cache = runtime.PackCache()
+
+    def _rnf_pack(self, L, prec=0):
+        with torch.no_grad():
+            return runtime.pack_affine16(L, self.mat()), None, 0, 0
+
+    def forward(self, rotation, permute=None, feature=None):
+        return self._single(rotation, permute, None, inverse=False)
+
+    def inverse(self, rotation, permute=None, feature=None):
+        return self._single(rotation, permute, None, inverse=True)
+
+
 def _not_built(name, where):
     class _Unbuilt(nn.Module):
         def __init__(self, *a, **k):
             super().__init__()
             raise NotImplementedError(
                 f"{name} ({where}) has no HIP kernel yet and rotationnormflow_amd has no PyTorch fallback; "
-                "supported affine layers: rot='16Trans' / '16UnTrans' with lu=0")
+                "built affine layers: Uncondition16Trans, Condition16Trans, Uncondition16TransLU, UnconditionRot")
     _Unbuilt.__name__ = _Unbuilt.__qualname__ = name
     return _Unbuilt
 
 
 # declared so that the registry (flow/affineflow.py:5-73) resolves every name; constructing them fails loudly
-Uncondition16TransLU = _not_built("Uncondition16TransLU", "flow/squeezetrans.py:146-158")
 Condition16TransLU = _not_built("Condition16TransLU", "flow/squeezetrans.py:130-143")
 Uncondition36Trans = _not_built("Uncondition36Trans", "flow/squeezetrans.py:350-361")
 Condition36Trans = _not_built("Condition36Trans", "flow/squeezetrans.py:334-347")

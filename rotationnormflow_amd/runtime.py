@@ -168,6 +168,13 @@ def pack_affine16(L, mat):
     return rec
 
 
+def pack_rot16(L, rot_mat):
+    rec = np.empty(L.rnf_affine16_packed_floats(), dtype=np.float32)
+    m = _np32(rot_mat).reshape(16)
+    _lib.check(L.rnf_pack_rot16(m.ctypes.data, rec.ctypes.data))
+    return rec
+
+
 # ---- parameter-version keyed cache -------------------------------------------------------------------------------
 def params_key(module, device):
     """Changes whenever any parameter is modified in place (optimizer step, load_state_dict) or replaced."""

@@ -60,8 +60,22 @@ def fill_state_dict(shapes: dict, seed: int = 0, regime: str = "default") -> dic
     for key in sorted(shapes):
         shape = tuple(int(s) for s in shapes[key])
         z = rng.standard_normal(shape).astype(np.float32)
-        if key.endswith(".mat"):                       # Uncondition16Trans.mat [1,4,4]
+        if key.endswith(".mat") or key.endswith(".rot"):   # Uncondition16Trans.mat / UnconditionRot.rot [1,4,4]
             val = np.eye(4, dtype=np.float32)[None] + np.float32(sigma) * z
+        elif key.endswith(".mat.w_p"):                   # UnconditionLU buffers: fixed, valid structure (the draw is discarded)
+            val = np.eye(4, dtype=np.float32)[[1, 0, 2, 3]]
+        elif key.endswith(".mat.u_mask"):
+            val = np.triu(np.ones((4, 4), dtype=np.float32), 1)
+        elif key.endswith(".mat.l_mask"):
+            val = np.triu(np.ones((4, 4), dtype=np.float32), 1).T
+        elif key.endswith(".mat.l_eye"):
+            val = np.eye(4, dtype=np.float32)
+        elif key.endswith(".mat.s_sign"):
+            val = np.array([1, -1, 1, 1], dtype=np.float32)
+        elif key.endswith(".mat.w_l") or key.endswith(".mat.w_u"):
+            val = np.float32(max(sigma, 0.05)) * z
+        elif key.endswith(".mat.w_s"):
+            val = np.float32(0.2) * z
         elif key.endswith(".weight"):
             fan_in = shape[-1]
             val = z / np.float32(np.sqrt(fan_in))

@@ -12,7 +12,7 @@ from .. import _lib
 
 def proper_singular_values(A):
     """[B,3,3] -> [B,3] (utils/fisher.py:67-76).  O(B) host-side parameter preprocessing in torch, fp64 internally."""
-    A64 = A.detach().to(torch.float64)
+    A64 = A.detach().to("cpu", torch.float64)               # tiny [B,3,3]: LAPACK on the host (no rocSOLVER start-up cost)
     U, S, Vh = torch.linalg.svd(A64)
     S = S.clone()
     S[:, 2] = S[:, 2] * torch.det(U) * torch.det(Vh)
@@ -39,7 +39,7 @@ class MatrixFisherN(torch.nn.Module):
         self.A = A.reshape(-1, 3, 3)
         S = proper_singular_values(self.A)
         norm = 1.0 / torch.sqrt(8 * math.pi * (S[:, 0] + S[:, 1]) * (S[:, 2] + S[:, 1]) * (S[:, 0] + S[:, 2]))
-        self.norm = norm.to(self.A.dtype)
+        self.norm = norm.to(device=self.A.device, dtype=self.A.dtype)
         self._c = (S.sum(-1) + norm.log()).to(torch.float32)      # log p = tr(A^T R) - c
 
     def log_const(self):
@@ -72,7 +72,7 @@ class MatrixFisherN(torch.nn.Module):
         if not A.is_cuda:
             raise RuntimeError("rotationnormflow_amd runs on the GPU only (no CPU fallback): construct MatrixFisherN with A on the GPU")
         dev = A.device
-        A64 = A.detach().to(torch.float64)
+        A64 = A.detach().to("cpu", torch.float64)           # host LAPACK for the tiny SVDs, as in proper_singular_values
         U, S, Vh = torch.linalg.svd(A64)
         V = Vh.transpose(-1, -2)
         dU, dV = torch.det(U), torch.det(V)
@@ -81,7 +81,7 @@ class MatrixFisherN(torch.nn.Module):
         V[:, :, 2] *= dV[:, None]
         S[:, 2] *= dU * dV
         lam = torch.stack([torch.zeros_like(S[:, 0]), 2 * (S[:, 1] + S[:, 2]), 2 * (S[:, 0] + S[:, 2]), 2 * (S[:, 0] + S[:, 1])], -1)
-        U32, V32, lam32 = (t.to(torch.float32).contiguous() for t in (U, V, lam))
+        U32, V32, lam32 = (t.to(dev, torch.float32).contiguous() for t in (U, V, lam))
         B = A.shape[0]
         out = torch.empty(B, num_samples, 3, 3, dtype=torch.float32, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)

@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # never let one stuck test eat the GPU box's time limit (pytest-timeout is installed in this image)
+    if config.pluginmanager.hasplugin("timeout") and not config.getoption("timeout", None):
+        config.option.timeout = 180
 
 
 @pytest.fixture(scope="session")

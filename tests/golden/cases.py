@@ -31,6 +31,15 @@ CASES = {
     "k16_freqperm":    dict(cfg=dict(layers=5, segments=16, frequent_permute=1), n=1024, regime="trained", wseed=11, rseed=55, direction="forward", fisher=None),
     "k8_nofirst":      dict(cfg=dict(layers=7, segments=8, first_affine=0), n=1024, regime="trained", wseed=12, rseed=56, direction="forward", fisher=None),
     "k128_inv":        dict(cfg=dict(layers=3, segments=128), n=512, regime="trained", wseed=13, rseed=57, direction="inverse", fisher=None),
+    # unconditional LU parameterisation of the 4x4 affine, and the SVD-rotation layer (registry rows a15 / a18)
+    "lu16_uncond":     dict(cfg=dict(layers=3, rot="16Trans", lu=1), n=1024, regime="trained", wseed=15, rseed=59, direction="forward", fisher=None),
+    "lu16_uncond_inv": dict(cfg=dict(layers=3, rot="16Trans", lu=1), n=512, regime="trained", wseed=15, rseed=60, direction="inverse", fisher=None),
+    "rot16_uncond":    dict(cfg=dict(layers=3, rot="16Rot"), n=1024, regime="trained", wseed=16, rseed=61, direction="forward", fisher=None),
+    "rot16_uncond_inv": dict(cfg=dict(layers=3, rot="16Rot"), n=512, regime="trained", wseed=16, rseed=62, direction="inverse", fisher=None),
+    "lu16un_cond":     dict(cfg=dict(layers=3, condition=1, feature_dim=16, rot="16UnTrans", lu=1), n=512, regime="trained", wseed=17, rseed=63,
+                            direction="forward", fisher=None),
+    "rot16un_cond":    dict(cfg=dict(layers=3, condition=1, feature_dim=16, rot="16UnRot"), n=512, regime="trained", wseed=18, rseed=64,
+                            direction="forward", fisher=None),
     "embed_cond":      dict(cfg=dict(layers=3, condition=1, feature_dim=24, embedding=1, embedding_dim=8, rot="16UnTrans", last_affine=1), n=512,
                             regime="default", wseed=14, rseed=58, direction="forward", fisher=None),
 }

@@ -88,11 +88,18 @@ def test_registry_table():
     assert affineflow.get_affine(mk(rot="None"), 0) is None
     assert affineflow.get_affine(mk(rot="None", condition=1), 8) is None
     assert get_mobius(mk(dist="noflow"), 0) is None
-    for rot in ("36Trans", "9TransLSVD", "9TransRSVD", "9TransLSmith", "9TransRSmith", "16Rot"):
+    from rotationnormflow_amd.flow import rottrans
+    assert isinstance(affineflow.get_affine(mk(rot="16Trans", lu=1), 0), squeezetrans.Uncondition16TransLU)
+    assert isinstance(affineflow.get_affine(mk(rot="16UnTrans", lu=1, condition=1), 8), squeezetrans.Uncondition16TransLU)
+    assert isinstance(affineflow.get_affine(mk(rot="16Rot"), 0), rottrans.UnconditionRot)
+    assert isinstance(affineflow.get_affine(mk(rot="16UnRot", condition=1), 8), rottrans.UnconditionRot)
+    for rot in ("36Trans", "9TransLSVD", "9TransRSVD", "9TransLSmith", "9TransRSmith"):
         with pytest.raises(NotImplementedError):                          # declared, no kernel yet: loud, no fallback
             affineflow.get_affine(mk(rot=rot), 0)
     with pytest.raises(NotImplementedError):
-        affineflow.get_affine(mk(rot="16Trans", lu=1), 0)
+        affineflow.get_affine(mk(rot="16Trans", lu=1, condition=1), 8)   # Condition16TransLU (batch-coupled in the reference)
+    with pytest.raises(NotImplementedError):
+        affineflow.get_affine(mk(rot="16UnRot", condition=1), 8, first_layer_condition=True)    # ConditionRot
 
 
 def test_rot_none_with_last_affine_is_a_type_error():

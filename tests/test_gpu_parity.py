@@ -58,6 +58,12 @@ def test_conditioner_mfma_chain_matches_oracle():
 def test_forward_matches_reference_golden(name):
     fl, Rt, ldj, fx, spec, _ = run_case(name)
     noise = np.abs(fx["ldj32"].astype(np.float64) - fx["ldj64"])
+    if noise.mean() > 1e-3:
+        # UnconditionRot: U^T V depends on the SVD's arbitrary column signs, the reference's own fp32 and fp64 runs give
+        # different rotations (tests/test_oracle_golden.py); the product performs the fp32 SVD like the fp32 reference.
+        assert np.abs(ldj - fx["ldj32"]).max() < 5e-5 and abs(ldj.mean() - fx["ldj32"].astype(np.float64).mean()) < 1e-5
+        assert np.abs(Rt - fx["rot32"]).max() < 5e-5
+        return
     err = np.abs(ldj - fx["ldj64"])
     assert abs(ldj.mean() - fx["ldj64"].mean()) < 1e-5
     assert err.mean() <= 2 * noise.mean() + 2e-6
@@ -73,9 +79,13 @@ def test_forward_matches_reference_golden(name):
 def test_inverse_matches_reference_golden(name):
     fl, Rt, ldj, fx, spec, _ = run_case(name)
     noise = np.abs(fx["ldj32"].astype(np.float64) - fx["ldj64"])
-    err = np.abs(ldj - fx["ldj64"])
-    rnoise = np.abs(fx["rot32"].astype(np.float64) - fx["rot64"]).reshape(len(err), -1).max(1)
-    rerr = np.abs(Rt - fx["rot64"]).reshape(len(err), -1).max(1)
+    ref_l, ref_R = fx["ldj64"], fx["rot64"]
+    if noise.mean() > 1e-3:                       # UnconditionRot: dtype-unstable in the reference itself, see the forward test
+        ref_l, ref_R = fx["ldj32"].astype(np.float64), fx["rot32"].astype(np.float64)
+        noise = np.full_like(noise, 2e-6)
+    err = np.abs(ldj - ref_l)
+    rnoise = np.abs(fx["rot32"].astype(np.float64) - ref_R).reshape(len(err), -1).max(1) + (0 if ref_R is fx["rot64"] else 2e-6)
+    rerr = np.abs(Rt - ref_R).reshape(len(err), -1).max(1)
     # bulk: as close to the fp64 truth as the reference's own fp32 run
     assert err.mean() <= 3 * noise.mean() + 1e-5
     assert rerr.mean() <= 3 * rnoise.mean() + 1e-5

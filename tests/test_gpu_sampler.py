@@ -69,5 +69,6 @@ def test_sample_then_inverse_pipeline():
     assert torch.isfinite(x).all() and torch.isfinite(ldj_inv).all()
     assert (back - z).abs().max().item() < 2e-3                            # forward(inverse(z)) == z up to the bisection cell
     logp_x = base._log_prob(z) - ldj_inv                                    # agent.py:261-263
-    logp_chk = fl.log_prob(x, base=base)["logp"]
+    with torch.no_grad():
+        logp_chk = fl.log_prob(x, base=base)["logp"]
     assert (logp_x - logp_chk).abs().mean().item() < 1e-3

@@ -205,8 +205,17 @@ struct Mlp;
 template <>
 struct Mlp<0> {
     struct Act { f32x16 t[2]; };
+    // g: this wave's feature-projection fragments for the layer (global memory), or nullptr for an unconditional layer
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
-                                                const f32x16 (&cinit)[2], Act &out) {
+                                                const float *g, Act &out) {
+        f32x16 cinit[2];
+        if (g) {
+            cinit[0] = load_g16(g, lane);
+            cinit[1] = load_g16(g + 4 * 64 * 4, lane);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { cinit[0][r] = 0.f; cinit[1][r] = 0.f; }
+        }
         mlp_head(lds, lane, h, y0, y1, y2, cinit, out.t);
     }
     static __device__ __forceinline__ f32x16 last(const float *tile_rec, int lane, int h, const Act &a) {
@@ -217,20 +226,26 @@ struct Mlp<0> {
 template <>
 struct Mlp<1> {
     typedef ActFrag Act;
+    // fc_first (K = 3 + bias) stays on the two exact fp32 MFMA steps (4 of the layer's 176 matrix instructions).  x0 is
+    // NOT kept in registers for the residual: it is recomputed at the end with the last hidden output as the accumulator
+    // input (x0 + h3 in one fma chain), which frees 32 VGPRs through the hidden layers.
+    static __device__ __forceinline__ f32x16 first_tile(const float *lds, int ot, int lane, float bA, float bB, f32x16 c) {
+        const float2 a = reinterpret_cast<const float2 *>(lds + MOB_FIRST)[ot * 64 + lane];
+        c = RNF_MFMA(a.x, bA, c);
+        return RNF_MFMA(a.y, bB, c);
+    }
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
-                                                const f32x16 (&cinit)[2], Act &out) {
-        // fc_first (K = 3 + bias) stays on the two exact fp32 MFMA steps: 4 of the layer's 172 matrix instructions
+                                                const float *g, Act &out) {
         const float bA = h ? y1 : y0;
         const float bB = h ? 1.0f : y2;
-        f32x16 x0[2];
-#pragma unroll
-        for (int ot = 0; ot < 2; ++ot) {
-            float2 a = reinterpret_cast<const float2 *>(lds + MOB_FIRST)[ot * 64 + lane];
-            f32x16 c = RNF_MFMA(a.x, bA, cinit[ot]);
-            x0[ot] = RNF_MFMA(a.y, bB, c);
-        }
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         ActFrag f;
-        split_act<true>(x0, f);
+        {
+            f32x16 x0[2];
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) x0[ot] = first_tile(lds, ot, lane, bA, bB, g ? load_g16(g + ot * (4 * 64 * 4), lane) : zero);
+            split_act<true>(x0, f);
+        }
         f32x16 hcur[2];
 #pragma unroll
         for (int L = 0; L < 3; ++L) {
@@ -242,9 +257,14 @@ struct Mlp<1> {
             if (L < 2) split_act<true>(hcur, f);
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int ot = 0; ot < 2; ++ot) {                        // residual x0 + h3 (flow/condition.py:29)
+            hcur[ot] = first_tile(lds, ot, lane, bA, bB, hcur[ot]);
+            if (g) {
+                const f32x16 gg = load_g16(g + ot * (4 * 64 * 4), lane);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hcur[t][r] = x0[t][r] + hcur[t][r];      // residual (flow/condition.py:29)
+                for (int r = 0; r < 16; ++r) hcur[ot][r] += gg[r];
+            }
+        }
         split_act<true>(hcur, out);
     }
     static __device__ __forceinline__ f32x16 last(const float *tile_rec, int lane, int h, const Act &a) {
@@ -590,15 +610,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             }
 
             // ---- layers with a conditioner MLP ----
-            f32x16 cinit[2];
-            if (slot >= 0) {
-                const float *g = args.G + ((size_t)slot * args.g_groups + group) * G_FLOATS_PER_GROUP;
-                cinit[0] = load_g16(g, lane);
-                cinit[1] = load_g16(g + 4 * 64 * 4, lane);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { cinit[0][r] = 0.f; cinit[1][r] = 0.f; }
-            }
+            const float *gfrag = slot >= 0 ? args.G + ((size_t)slot * args.g_groups + group) * G_FLOATS_PER_GROUP : nullptr;
             // where the NEXT image comes from (DMA mode): next MLP layer of this tile, else the first one of the next tile
             int nxt_off = -1, nxt_kind = 0;
             if (PIPE) {
@@ -617,9 +629,9 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             typename Mlp<PREC>::Act tt;
             if (kind == RNF_KIND_MOBIUS) {
                 mobius_begin<DIR>(R, perm_row, ctx);
-                Mlp<PREC>::head(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, cinit, tt);
+                Mlp<PREC>::head(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt);
             } else {
-                Mlp<PREC>::head(lds, lane, h, 0.f, 0.f, 0.f, cinit, tt);
+                Mlp<PREC>::head(lds, lane, h, 0.f, 0.f, 0.f, gfrag, tt);
             }
             RNF_STAMP(1)                                          // 1: frame + hidden layers (H part)
             if (PIPE) {       // B1: every wave is past the H part and this layer's L part has landed

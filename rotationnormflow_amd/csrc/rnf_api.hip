@@ -257,7 +257,8 @@ extern "C" int rnf_pack_rot16(const float *mat16, float *out) {
 // ------------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------------
-constexpr int NW = 8;                                   // waves per workgroup (2 per SIMD)
+constexpr int NW = 8;                                   // waves per workgroup (2 per SIMD): exact-fp32 and inverse kernels, featproj
+constexpr int NW_FWD_H = 12;                            // forward split-precision kernel: 161 VGPRs -> 3 waves per SIMD
 constexpr long long CHUNK_SAMPLES = 1LL << 18;          // samples per launch when a feature projection scratch is needed
 constexpr size_t PARTIALS_BYTES = 4096 * sizeof(double);
 
@@ -277,7 +278,9 @@ extern "C" size_t rnf_workspace_bytes(int64_t n, int32_t n_cond_layers) {
     size_t bytes = PARTIALS_BYTES;
     if (n_cond_layers > 0) {
         long long chunk = n < CHUNK_SAMPLES ? n : CHUNK_SAMPLES;
-        long long groups = (chunk + 255) / 256 * 8;     // whole workgroup tiles
+        long long groups = (chunk + 255) / 256 * 8;     // whole workgroup tiles, for either workgroup size
+        const long long g12 = (chunk + 32 * NW_FWD_H - 1) / (32 * NW_FWD_H) * NW_FWD_H;
+        if (g12 > groups) groups = g12;
         bytes += (size_t)n_cond_layers * groups * G_FLOATS_PER_GROUP * sizeof(float);
     }
     return bytes;
@@ -300,9 +303,10 @@ static bool staging_dma() {
 
 template <int DIR, int KT_INV, bool PIPE, int PREC>
 static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream) {
-    auto kern = flow_stack_kernel<DIR, KT_INV, NW, PIPE, PREC>;
+    constexpr int NWK = (DIR == 0 && PREC == 1) ? NW_FWD_H : NW;
+    auto kern = flow_stack_kernel<DIR, KT_INV, NWK, PIPE, PREC>;
     HIP_TRY(allow_lds(kern, lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWK * 64), lds_bytes, stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -375,7 +379,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     float *G = n_slots ? reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + PARTIALS_BYTES) : nullptr;
     const int tiles_in_lds = any_mlp ? (KT < MOB_MAX_TILES_IN_LDS ? KT : MOB_MAX_TILES_IN_LDS) : 0;
     size_t lds_bytes = any_mlp ? sizeof(float) * (MOB_HEAD_FLOATS + (size_t)tiles_in_lds * MOB_LAST_TILE_FLOATS) : 0;
-    if (lds_bytes < NW * sizeof(double)) lds_bytes = NW * sizeof(double) * 2;
+    if (lds_bytes < NW_FWD_H * sizeof(double)) lds_bytes = NW_FWD_H * sizeof(double) * 2;
     const int cus = device_cus();
     const long long chunk_cap = n_slots ? CHUNK_SAMPLES : n;
 
@@ -395,9 +399,12 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     bool first = true;
     for (long long base = 0; base < n; base += chunk_cap) {
         const long long cn = (n - base) < chunk_cap ? (n - base) : chunk_cap;
-        const long long ntiles = (cn + NW * 32 - 1) / (NW * 32);
-        const long long groups = ntiles * NW;
+        const int nwk = (o.dir == 0 && prec == 1) ? NW_FWD_H : NW;          // waves per workgroup of the stack kernel
+        const long long ntiles = (cn + nwk * 32 - 1) / (nwk * 32);
+        const long long ntiles_fp = (cn + NW * 32 - 1) / (NW * 32);          // the feature projection keeps 8 waves
+        const long long groups = (ntiles * nwk > ntiles_fp * NW) ? ntiles * nwk : ntiles_fp * NW;
         int grid = (int)(ntiles < cus ? ntiles : cus);
+        const int grid_fp = (int)(ntiles_fp < cus ? ntiles_fp : cus);
         if (n_slots) {
             fp.feat = feat + base * F;
             fp.blob = blob;
@@ -411,11 +418,11 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             if (prec) {
                 auto kern = featproj_kernel<NW, 1>;
                 HIP_TRY(allow_lds(kern, fl));
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), fl, stream, fp);
+                hipLaunchKernelGGL(kern, dim3(grid_fp), dim3(NW * 64), fl, stream, fp);
             } else {
                 auto kern = featproj_kernel<NW, 0>;
                 HIP_TRY(allow_lds(kern, fl));
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), fl, stream, fp);
+                hipLaunchKernelGGL(kern, dim3(grid_fp), dim3(NW * 64), fl, stream, fp);
             }
             HIP_TRY(hipGetLastError());
         }
@@ -529,11 +536,8 @@ __global__ __launch_bounds__(NWc * 64) void conditioner_kernel(const float *y, l
         __syncthreads();
         stage_floats(lds, layer, MOB_HEAD_FLOATS, tid, NWc * 64);
         __syncthreads();
-        f32x16 cinit[2];
         typename Mlp<PREC>::Act tt;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { cinit[0][r] = 0.f; cinit[1][r] = 0.f; }
-        Mlp<PREC>::head(lds, lane, h, y0, y1, y2, cinit, tt);
+        Mlp<PREC>::head(lds, lane, h, y0, y1, y2, nullptr, tt);
         for (int tau = 0; tau < KT; ++tau) {
             __syncthreads();
             stage_floats(lds + MOB_LAST, layer + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS, MOB_LAST_TILE_FLOATS, tid, NWc * 64);

@@ -154,7 +154,7 @@ def main():
             # (executed matrix FLOPs are 3x that).  The kernel is VALU-issue bound (segment math), see DESIGN.md section 3.
             roofline = {"bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved_tflops / PEAK_F16_MFMA_TFLOPS, "traffic": None,
-                        "kernel": "rnf::flow_stack_kernel<0,0,12,true,1>", "kernel_ms": kernel_ms,
+                        "kernel": "rnf::flow_stack_kernel<0,0,8,true,1>", "kernel_ms": kernel_ms,
                         "algorithmic_flop_per_rotation": FLOP_PER_ROTATION, "executed_mfma_tflops": 3 * achieved_tflops,
                         "frac_of_fp32_mfma_peak": achieved_tflops / PEAK_FP32_MFMA_TFLOPS,
                         "note": "fp32 operands split into two fp16 terms (22 bits), fp16 MFMA + fp32 accumulate; binding "

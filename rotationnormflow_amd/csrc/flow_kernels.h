@@ -34,6 +34,7 @@ struct FlowArgs {
     long long sample_base;    // global index of sample 0 (for the Fisher row lookup)
     long long fisher_div;     // samples per Fisher row (n_total / B)
     long long g_groups;       // 32-sample groups per cond slot in G
+    int fair_off;                // >= 0: float offset in LDS of the per-wave progress words (SIMD fairness governor on)
     unsigned long long *stamps;  // diagnostic builds only (RNF_STAMPS): per-phase cycle sums, else nullptr
     int n_layers;
     int KT;                   // fc_last tiles = segments / 8
@@ -198,6 +199,25 @@ __device__ __forceinline__ f32x16 gemm_tile64_h(const float *w_tile, int lane, c
     return acc1;
 }
 
+// SIMD fairness governor.  The two waves a workgroup places on one SIMD (w and w^4) run the same instruction stream; the
+// hardware arbitrates by age, so the older one runs ahead, reaches the layer barrier early and leaves its partner to finish
+// alone (a single wave cannot fill the VALU: every instruction waits for the previous one of its dependent chain).  Each wave
+// publishes a progress counter in LDS at a few points per layer and takes the lower issue priority while it is ahead of its
+// partner, so the pair advances together and the barrier wait shrinks.  Only changes timing, never results.
+struct Fair {
+    float *lds;
+    int wave, off, prog;
+    __device__ __forceinline__ void tick() {
+        if (off < 0) return;
+        ++prog;
+        volatile int *pw = reinterpret_cast<volatile int *>(lds + off);
+        pw[wave] = prog;
+        const int other = __builtin_amdgcn_readfirstlane(pw[wave ^ 4]);
+        if (prog > other) __builtin_amdgcn_s_setprio(0);
+        else __builtin_amdgcn_s_setprio(2);
+    }
+};
+
 // The two precisions behind one interface: Act = what the hidden stack hands to fc_last.
 template <int PREC>
 struct Mlp;
@@ -207,7 +227,7 @@ struct Mlp<0> {
     struct Act { f32x16 t[2]; };
     // g: this wave's feature-projection fragments for the layer (global memory), or nullptr for an unconditional layer
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
-                                                const float *g, Act &out) {
+                                                const float *g, Act &out, Fair &) {
         f32x16 cinit[2];
         if (g) {
             cinit[0] = load_g16(g, lane);
@@ -235,7 +255,7 @@ struct Mlp<1> {
         return RNF_MFMA(a.y, bB, c);
     }
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
-                                                const float *g, Act &out) {
+                                                const float *g, Act &out, Fair &fair) {
         const float bA = h ? y1 : y0;
         const float bB = h ? 1.0f : y2;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -255,6 +275,7 @@ struct Mlp<1> {
                 hcur[ot] = gemm_tile64_h(lds + MOB_HID + (L * 2 + ot) * (8 * 64 * 4), lane, f, c);
             }
             if (L < 2) split_act<true>(hcur, f);
+            fair.tick();
         }
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot) {                        // residual x0 + h3 (flow/condition.py:29)
@@ -345,7 +366,7 @@ __device__ __forceinline__ void tile_pipe(const float *rec, int lane, int h, con
 
 template <int PREC>
 __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int lane, int h, const typename Mlp<PREC>::Act &tt,
-                                                 const MobiusCtx &c, float &S, float &A, float &J) {
+                                                 const MobiusCtx &c, float &S, float &A, float &J, Fair &fair) {
     const float *rec = lds + MOB_LAST;
     if constexpr (PREC == 0) {
         f32x16 bufA = last_tile(rec, lane, h, tt.t), bufB;
@@ -368,6 +389,7 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int l
             f32x16 nxt = Mlp<1>::last(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt);
             segments4(cur, c, S, A, J);
             cur = nxt;
+            fair.tick();
         }
         segments4(cur, c, S, A, J);
     }
@@ -557,6 +579,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     const int KT = DIR ? KT_INV : args.KT;
     const int n_layers = args.n_layers;
     double dsum = 0.0;
+    Fair fair{lds, wave, args.fair_off, 0};
     RNF_STAMP_DECL
 
     // iteration position -> layer index, and the next position (> pos) whose layer owns an MLP image, or -1
@@ -569,6 +592,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     auto l_floats = [&](int kind) { return (kind == RNF_KIND_MOBIUS ? KT : 1) * MOB_LAST_TILE_FLOATS; };
     const int first_mlp = next_mlp(-1);
 
+    if (args.fair_off >= 0 && tid < NW) reinterpret_cast<int *>(lds + args.fair_off)[tid] = 0;
     if (PIPE && first_mlp >= 0) {                                  // prologue: image of the first MLP layer
         const int2 d = args.layers[layer_at(first_mlp)];
         dma_floats(lds, args.blob + d.y, MOB_HEAD_FLOATS, wave, lane, NW);
@@ -629,9 +653,9 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             typename Mlp<PREC>::Act tt;
             if (kind == RNF_KIND_MOBIUS) {
                 mobius_begin<DIR>(R, perm_row, ctx);
-                Mlp<PREC>::head(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt);
+                Mlp<PREC>::head(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair);
             } else {
-                Mlp<PREC>::head(lds, lane, h, 0.f, 0.f, 0.f, gfrag, tt);
+                Mlp<PREC>::head(lds, lane, h, 0.f, 0.f, 0.f, gfrag, tt, fair);
             }
             RNF_STAMP(1)                                          // 1: frame + hidden layers (H part)
             if (PIPE) {       // B1: every wave is past the H part and this layer's L part has landed
@@ -660,7 +684,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     mobius_inv_finish<KTI>(ctx, sg, S, R, ldj);
                 } else {
                     float S = 0.f, A = 0.f, J = 0.f;
-                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC>(lds, KT, lane, h, tt, ctx, S, A, J);
+                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC>(lds, KT, lane, h, tt, ctx, S, A, J, fair);
                     else mobius_fwd_tiles_restage<PREC>(lds, params, KT, lane, h, tt, ctx, S, A, J, tid, NT);
                     barrier2();
                     mobius_fwd_finish(ctx, S, A, J, R, ldj);

@@ -258,7 +258,7 @@ extern "C" int rnf_pack_rot16(const float *mat16, float *out) {
 // launchers
 // ------------------------------------------------------------------------------------------------------------
 constexpr int NW = 8;                                   // waves per workgroup (2 per SIMD): exact-fp32 and inverse kernels, featproj
-constexpr int NW_FWD_H = 12;                            // forward split-precision kernel: 161 VGPRs -> 3 waves per SIMD
+constexpr int NW_FWD_H = 8;                             // forward split-precision kernel (12 waves = 3 per SIMD fits in 161 VGPRs but measured slower: barrier skew)
 constexpr long long CHUNK_SAMPLES = 1LL << 18;          // samples per launch when a feature projection scratch is needed
 constexpr size_t PARTIALS_BYTES = 4096 * sizeof(double);
 
@@ -380,6 +380,15 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     const int tiles_in_lds = any_mlp ? (KT < MOB_MAX_TILES_IN_LDS ? KT : MOB_MAX_TILES_IN_LDS) : 0;
     size_t lds_bytes = any_mlp ? sizeof(float) * (MOB_HEAD_FLOATS + (size_t)tiles_in_lds * MOB_LAST_TILE_FLOATS) : 0;
     if (lds_bytes < NW_FWD_H * sizeof(double)) lds_bytes = NW_FWD_H * sizeof(double) * 2;
+    {   // SIMD fairness governor (flow_kernels.h struct Fair): forward split-precision kernel; RNF_FAIR=0 switches it off
+        static int fair = -1;
+        if (fair < 0) { const char *e = std::getenv("RNF_FAIR"); fair = (e && e[0] == '0') ? 0 : 1; }
+        a.fair_off = -1;
+        if (fair && any_mlp && o.dir == 0 && prec == 1) {
+            a.fair_off = (int)(lds_bytes / sizeof(float));
+            lds_bytes += 64;
+        }
+    }
     const int cus = device_cus();
     const long long chunk_cap = n_slots ? CHUNK_SAMPLES : n;
 
@@ -537,7 +546,8 @@ __global__ __launch_bounds__(NWc * 64) void conditioner_kernel(const float *y, l
         stage_floats(lds, layer, MOB_HEAD_FLOATS, tid, NWc * 64);
         __syncthreads();
         typename Mlp<PREC>::Act tt;
-        Mlp<PREC>::head(lds, lane, h, y0, y1, y2, nullptr, tt);
+        Fair nofair{lds, wave, -1, 0};
+        Mlp<PREC>::head(lds, lane, h, y0, y1, y2, nullptr, tt, nofair);
         for (int tau = 0; tau < KT; ++tau) {
             __syncthreads();
             stage_floats(lds + MOB_LAST, layer + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS, MOB_LAST_TILE_FLOATS, tid, NWc * 64);

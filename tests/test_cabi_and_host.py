@@ -41,7 +41,7 @@ def test_packed_sizes_match_parameter_counts():
     assert L.rnf_featproj_packed_floats(256) == 64 * 256 + 64
     assert L.rnf_featproj_packed_floats(40) == 2 * 3 * 512 + 64          # k-steps of 16, zero padded (f16x2 image)
     assert L.rnf_workspace_bytes(1 << 20, 0) == 4096 * 8
-    assert L.rnf_workspace_bytes(1 << 20, 25) == 4096 * 8 + 25 * 8196 * 2048 * 4      # 2^18-sample chunk, 384-sample tiles
+    assert L.rnf_workspace_bytes(1 << 20, 25) == 4096 * 8 + 25 * 8192 * 2048 * 4
 
 
 @pytest.mark.parametrize("preset,n_layers,n_keys", [("C1", 16, 88), ("C2", 48, 264), ("C4", 48, 273), ("C5", 42, 420), ("C5u", 42, 420)])

@@ -1,0 +1,48 @@
+"""Checkpoint / raw-dataset harness.  CPU part: file formats; GPU part: the eval statistic."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import flow_oracle as orc
+from rotationnormflow_amd import harness, make_config, synth
+
+
+def _write_files(tmp_path, cfg, weights, n=3000):
+    # what Agent.save_ckpt writes (agent.py:139-152): the flow state dict under "flow_state_dict"
+    ckpt = tmp_path / "ckpt_iteration10.pth"
+    torch.save({"clock": {"epoch": 0, "iteration": 10}, "flow_state_dict": {k: torch.from_numpy(v) for k, v in weights.items()},
+                "optimizer_flow_state_dict": {}}, ckpt)
+    data = tmp_path / "peak_test.npy"                      # dataset_raw.py:13  {category}_{phase}.npy, [M,3,3] float32
+    np.save(data, synth.uniform_rotations(n, seed=77))
+    yml = tmp_path / "raw.yml"
+    yml.write_text("dist: 'mobiusflow'\ncondition: 0\nlayers: 3\nsegments: 64\nrot: '16Trans'\ndataset: 'raw'\n")
+    return ckpt, data, yml
+
+
+def test_checkpoint_and_dataset_formats(tmp_path):
+    cfg = make_config(layers=3)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=8, regime="trained")
+    ckpt, data, yml = _write_files(tmp_path, cfg, w)
+    sd = harness.load_reference_checkpoint(ckpt)
+    assert sorted(sd) == sorted(w) and all(np.array_equal(sd[k].numpy(), w[k]) for k in w)
+    torch.save({"flow_state_dict": {"module." + k: torch.from_numpy(v) for k, v in w.items()}}, tmp_path / "dp.pth")
+    assert sorted(harness.load_reference_checkpoint(tmp_path / "dp.pth")) == sorted(w)      # DataParallel prefix stripped
+    R = harness.load_raw_rotations(data)
+    assert R.shape == (3000, 3, 3) and R.dtype == torch.float32
+    from rotationnormflow_amd.configs import load_yaml_config
+    c2 = load_yaml_config(yml)
+    assert (c2.layers, c2.segments, c2.rot, c2.condition) == (3, 64, "16Trans", 0)
+    np.save(tmp_path / "bad.npy", np.zeros((5, 4)))
+    with pytest.raises(ValueError):
+        harness.load_raw_rotations(tmp_path / "bad.npy")
+
+
+@pytest.mark.gpu
+def test_mean_log_likelihood_matches_oracle(tmp_path):
+    cfg = make_config(layers=3)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=8, regime="trained")
+    ckpt, data, yml = _write_files(tmp_path, cfg, w)
+    flow = harness.build_flow_from_checkpoint(cfg, ckpt)
+    got = harness.mean_log_likelihood(flow, harness.load_raw_rotations(data), batch_size=1024)     # several ragged batches
+    _, ldj = orc.flow_forward(cfg, w, np.load(data), None, torch.float64)
+    assert abs(got - float(ldj.mean())) < 1e-5

@@ -70,3 +70,27 @@ def main(argv=None):
 
 if __name__ == "__main__":
     main()
+
+
+def estimate_rotations(flow: Flow, feature: torch.Tensor, queries: torch.Tensor = None, base=None, number_queries: int = 500):
+    """Pose estimate per feature row, as ``Agent.eval_acc`` does (agent.py:238-283): push ``number_queries`` base samples per row
+    through ``Flow.inverse`` and keep the sample with the largest ``-ldj + base_log_prob``.
+
+    feature [B,F] (cuda); queries [Q,3,3] shared by all rows (the reference's ``sd.generate_queries``), or ``base`` = a
+    ``MatrixFisherN`` with B rows to draw them from (``pretrain_fisher``).  Returns (est_rotation [B,3,3], log_prob [B,Q])."""
+    B = feature.shape[0]
+    with torch.no_grad():
+        if base is not None:
+            sample = base._sample(number_queries).reshape(-1, 3, 3)                     # agent.py:248-251
+            base_ll = base._log_prob(sample).reshape(B, -1)
+            Q = number_queries
+        else:
+            Q = queries.shape[0]
+            sample = queries[None].expand(B, Q, 3, 3).reshape(-1, 3, 3).contiguous()    # agent.py:253-258
+            base_ll = torch.zeros(B, Q, device=feature.device)
+        feat = feature[:, None, :].expand(B, Q, feature.shape[1]).reshape(B * Q, -1).contiguous()   # agent.py:240-244
+        samples, ldj = flow.inverse(sample, feat)
+        log_prob = -ldj.reshape(B, Q) + base_ll                                         # agent.py:262-263
+        best = torch.argmax(log_prob, dim=-1)
+        est = samples.reshape(B, Q, 3, 3)[torch.arange(B, device=best.device), best]
+    return est, log_prob

@@ -46,3 +46,26 @@ def test_mean_log_likelihood_matches_oracle(tmp_path):
     got = harness.mean_log_likelihood(flow, harness.load_raw_rotations(data), batch_size=1024)     # several ragged batches
     _, ldj = orc.flow_forward(cfg, w, np.load(data), None, torch.float64)
     assert abs(got - float(ldj.mean())) < 1e-5
+
+
+@pytest.mark.gpu
+def test_estimate_rotations_matches_oracle_argmax():
+    """eval_acc's arg-max over query rotations pushed through Flow.inverse (agent.py:238-283), conditional flow."""
+    from tests.gpu_helpers import product_flow
+    cfg = make_config(layers=3, condition=1, feature_dim=16, rot="16Trans")
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=4, regime="default")
+    fl = product_flow(cfg, w)
+    B, Q = 6, 200
+    feat = synth.features(B, 16, seed=1)
+    queries = synth.uniform_rotations(Q, seed=2)
+    est, lp = harness.estimate_rotations(fl, torch.from_numpy(feat).cuda(), queries=torch.from_numpy(queries).cuda())
+    sample = np.broadcast_to(queries[None], (B, Q, 3, 3)).reshape(-1, 3, 3)
+    f2 = np.repeat(feat, Q, axis=0)
+    Rw, lw = orc.flow_inverse(cfg, w, sample, f2, torch.float64)
+    lw = -lw.reshape(B, Q)
+    assert (lp.cpu().double() - lw).abs().max().item() < 5e-3              # bisection-cell flips allowed
+    best = lw.argmax(-1)
+    got_best = lp.argmax(-1).cpu()
+    agree = (best == got_best) | ((lw.gather(1, got_best[:, None])[:, 0] - lw.max(-1).values).abs() < 1e-3)
+    assert bool(agree.all())
+    assert est.shape == (B, 3, 3)

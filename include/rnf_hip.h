@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define RNF_ABI_VERSION 2
+#define RNF_ABI_VERSION 3
 
 /* width of the conditioner MLP's hidden layers: flow/condition.py:9 (Nh=64, never overridden by any caller) */
 #define RNF_HIDDEN 64
@@ -107,6 +107,37 @@ int rnf_flow_inverse(const float *rotation_dev, const float *feature_dev, int64_
                      const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments,
                      float *rotation_out_dev, float *ldj_out_dev, void *workspace_dev, size_t workspace_bytes,
                      void *stream);
+
+/* ---- training (agent.py:75-92: loss = mean(-ldj), loss.backward(), Adam step) ----------------------------------------
+ *
+ * The backward pass works on the "plain" parameter blob: per layer, in reference state-dict order,
+ *   Moebius / Condition16Trans conditioner (flow/condition.py): fc_first.weight [64][NI] | fc_first.bias | hidden[0] W,b |
+ *       hidden[2] W,b | hidden[4] W,b | fc_last.weight [NO][64] | fc_last.bias  with NI = 3 + F, NO = 4 * segments
+ *       (Moebius) or NI = F, NO = 16 (Condition16Trans);
+ *   Uncondition16Trans (flow/squeezetrans.py:57-66): mat [16].
+ * rnf_plain_layer_floats gives each layer's length; the gradient blob has the same layout.
+ * train_desc: int32 [n_layers][3] = kind (| RNF_TRAIN_ORTHOGONAL for UnconditionRot, whose matrix is orthogonal and whose
+ *             ldj is 0, flow/rottrans.py:14-23), perm_row, offset (floats) of the layer in the plain blob, in flow order.
+ */
+#define RNF_TRAIN_ORTHOGONAL 256
+size_t rnf_plain_layer_floats(int32_t kind, int32_t segments, int32_t feature_dim);
+
+/* Flow.forward that also saves the rotation entering every layer: states_dev float[n_layers][n][9]. */
+int rnf_flow_forward_train(const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim,
+                           const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments,
+                           float *rotation_out_dev, float *ldj_out_dev, float *states_dev, void *workspace_dev,
+                           size_t workspace_bytes, void *stream);
+
+/* Reverse sweep of Flow.forward (what autograd does for the reference, agent.py:79-80).
+ * In : g_rotation_out_dev [n][9] (NULL = zeros), g_ldj_dev [n].
+ * Out: grads_dev (plain layout, ACCUMULATED into: zero it first), g_rotation_in_dev [n][9],
+ *      g_feature_dev [n][F] (accumulated into; may be NULL).
+ * Scratch: layer_scratch_dev float[n_layers], zeroed by the caller (batch sums of dL/dldj for the d log|det M| / dM term).
+ * Segments <= 64, n_layers <= 200. */
+int rnf_flow_backward(const float *states_dev, const float *feature_dev, int64_t n, int32_t feature_dim,
+                      const float *plain_dev, const int32_t *train_desc, int32_t n_layers, int32_t segments,
+                      const float *g_rotation_out_dev, const float *g_ldj_dev, float *grads_dev, float *g_rotation_in_dev,
+                      float *g_feature_dev, float *layer_scratch_dev, void *stream);
 
 /* Fused density evaluation: Flow.forward + MatrixFisherN(A)._log_prob(R') + the NLL accumulation
  * (agent.py:54-65,217-229; utils/fisher.py:217-232).

@@ -338,8 +338,9 @@ def _as_params(params, dtype):
     return {k: torch.as_tensor(v).to(dtype) for k, v in params.items()}
 
 
-def flow_forward(cfg, params, R, feature=None, dtype=torch.float32):
-    """Flow.forward (flow.py:53-72): returns (R' [N,3,3], ldj [N])."""
+def flow_forward(cfg, params, R, feature=None, dtype=torch.float32, grad=False):
+    """Flow.forward (flow.py:53-72): returns (R' [N,3,3], ldj [N]).  grad=True keeps the autograd graph (params / R / feature
+    given as torch tensors that require grad): the oracle for the training path's gradients (agent.py:79-80)."""
     p = _as_params(params, dtype)
     R = torch.as_tensor(R).to(dtype)
     feature = None if (feature is None or not cfg.condition) else torch.as_tensor(feature).to(dtype)
@@ -347,7 +348,7 @@ def flow_forward(cfg, params, R, feature=None, dtype=torch.float32):
     K = cfg.segments
     ldj = torch.zeros(R.shape[0], dtype=dtype)
     count = 0
-    with torch.no_grad():
+    with torch.set_grad_enabled(grad):
         for i, kind in enumerate(kinds):
             perm = PERMUTE_ROWS[count % 6]
             if kind == "mobius":

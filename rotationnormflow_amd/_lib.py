@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librnf_hip.so")
 
 _lib = None
-ABI_VERSION = 2
+ABI_VERSION = 3
 PREC_FP32, PREC_F16X2 = 0, 1
 
 c_f32p = C.c_void_p      # device or host float*, passed as integer addresses
@@ -32,6 +32,11 @@ _SIGNATURES = {
                                    c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnf_flow_inverse": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
                                    c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnf_plain_layer_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "rnf_flow_forward_train": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
+                                         c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnf_flow_backward": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
+                                    c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "rnf_flow_log_prob": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
                                     c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "rnf_api.hip")
 OUT = os.path.join(HERE, "librnf_hip.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("rnf_api.hip", "flow_kernels.h", "featproj_kernel.h", "so3_math.h", "layout.h")] + [
+DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".h", ".hip"))) + [
     os.path.join(os.path.dirname(HERE), "include", "rnf_hip.h")]
 
 

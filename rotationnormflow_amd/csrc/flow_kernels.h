@@ -36,6 +36,8 @@ struct FlowArgs {
     long long g_groups;       // 32-sample groups per cond slot in G
     int fair_off;                // >= 0: float offset in LDS of the per-wave progress words (SIMD fairness governor on)
     unsigned long long *stamps;  // diagnostic builds only (RNF_STAMPS): per-phase cycle sums, else nullptr
+    float *states;            // training forward: [n_layers][states_n][9] rotation at the input of every layer, else nullptr
+    long long states_n;       // rotations in the whole call (chunks write at sample_base)
     int n_layers;
     int KT;                   // fc_last tiles = segments / 8
     // per layer: x = kind | perm_row << 4 | (cond_slot + 1) << 8 ; y = param offset (floats)
@@ -622,6 +624,12 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             const int2 d = args.layers[layer_at(pos)];
             const int kind = d.x & 15, perm_row = (d.x >> 4) & 15, slot = (d.x >> 8) - 1;
             const float *params = args.blob + d.y;
+            if (DIR == 0 && args.states && valid && h == 0) {       // saved for train_kernels.h (backward recomputes from here)
+                float *dst = args.states + ((size_t)pos * args.states_n + args.sample_base + sample) * 9;
+                dst[0] = R.c0.x; dst[1] = R.c1.x; dst[2] = R.c2.x;
+                dst[3] = R.c0.y; dst[4] = R.c1.y; dst[5] = R.c2.y;
+                dst[6] = R.c0.z; dst[7] = R.c1.z; dst[8] = R.c2.z;
+            }
 
             if (kind == RNF_KIND_AFFINE16) {
                 float M[16];

@@ -12,6 +12,7 @@
 #include "../../include/rnf_hip.h"
 #include "featproj_kernel.h"
 #include "flow_kernels.h"
+#include "train_kernels.h"
 #include "sampler_kernel.h"
 #include "layout.h"
 
@@ -317,6 +318,7 @@ struct RunOpts {
     int64_t fisher_B;
     float *logp_out;
     double *sum_out;
+    float *states = nullptr;  // training forward: per-layer input rotations [n_layers][n][9]
 };
 
 static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, const float *blob, const int32_t *desc,
@@ -401,6 +403,8 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
 #endif
     a.n_layers = n_layers;
     a.KT = KT;
+    a.states = o.states;
+    a.states_n = n;
     a.fisher_A = o.fisher_A;
     a.fisher_c = o.fisher_c;
     a.fisher_div = o.fisher_A ? n / o.fisher_B : 1;
@@ -474,6 +478,64 @@ extern "C" int rnf_flow_forward(const float *rot, const float *feat, int64_t n, 
                                 size_t ws_bytes, void *stream) {
     RunOpts o{0, nullptr, nullptr, 0, nullptr, nullptr};
     return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// training: forward that saves per-layer states, and the reverse sweep (train_kernels.h)
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int rnf_flow_forward_train(const float *rot, const float *feat, int64_t n, int32_t F, const float *blob, const int32_t *desc,
+                                      int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, float *states, void *ws,
+                                      size_t ws_bytes, void *stream) {
+    if (n > 0 && !states) return fail("states buffer is null");
+    RunOpts o{0, nullptr, nullptr, 0, nullptr, nullptr};
+    o.states = states;
+    return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
+}
+
+extern "C" size_t rnf_plain_layer_floats(int32_t kind, int32_t segments, int32_t feature_dim) {
+    if (kind == RNF_KIND_AFFINE16) return 16;
+    const size_t ni = (kind == RNF_KIND_MOBIUS ? 3 : 0) + (size_t)feature_dim, no = kind == RNF_KIND_MOBIUS ? 4 * (size_t)segments : 16;
+    return 64 * ni + 64 + 3 * (4096 + 64) + no * 64 + no;
+}
+
+extern "C" int rnf_flow_backward(const float *states, const float *feat, int64_t n, int32_t F, const float *plain, const int32_t *tdesc,
+                                 int32_t n_layers, int32_t K, const float *g_rot_out, const float *g_ldj, float *grads,
+                                 float *g_rot_in, float *g_feature, float *g_ldj_sum, void *stream_v) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    if (n < 0) return fail("n=%lld is negative", (long long)n);
+    if (n_layers < 0 || n_layers > TR_MAX_LAYERS) return fail("n_layers=%d outside [0,%d] (training path)", n_layers, TR_MAX_LAYERS);
+    if (K < 1 || K > 64) return fail("training path supports 1..64 segments, got %d", K);
+    if (F < 0) return fail("feature_dim %d is negative", F);
+    if (n == 0) return 0;
+    if (!states || !plain || !tdesc || !g_ldj || !grads || !g_rot_in || !g_ldj_sum) return fail("null pointer argument");
+    TrainArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int l = 0; l < n_layers; ++l) {
+        const int32_t *d = tdesc + (size_t)l * 3;
+        const int kind = d[0] & 15, orth = (d[0] >> 8) & 1;
+        if ((d[0] & ~(15 | 256)) || (kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16 && kind != RNF_KIND_COND16)) return fail("layer %d: unknown kind %d", l, d[0]);
+        if (d[1] < 0 || d[1] > 5) return fail("layer %d: perm_row %d outside [0,5]", l, d[1]);
+        if (kind != RNF_KIND_AFFINE16 && F > 0 && !feat) return fail("conditional layer %d but feature pointer is null", l);
+        if (kind == RNF_KIND_COND16 && F == 0) return fail("layer %d: Condition16Trans needs a feature", l);
+        if (d[2] < 0) return fail("layer %d: negative plain offset", l);
+        a.layers[l] = make_int2(kind | (d[1] << 4) | (orth << 8), d[2]);
+    }
+    a.states = states; a.feature = F ? feat : nullptr; a.plain = plain; a.grads = grads; a.g_rot_out = g_rot_out; a.g_ldj = g_ldj;
+    a.g_rot_in = g_rot_in; a.g_feature = F ? g_feature : nullptr; a.g_ldj_sum = g_ldj_sum;
+    a.n = n; a.n_layers = n_layers; a.K = K; a.F = F;
+    const size_t rows = (4 * (size_t)K > 16 ? 4 * (size_t)K : 16);
+    const size_t lds_bytes = sizeof(float) * (24576 + rows * 64);
+    auto kern = flow_train_backward_kernel;
+    HIP_TRY(allow_lds(kern, lds_bytes));
+    const long long nblocks = (n + 63) / 64;
+    const int cap = device_cus() * 4;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < cap ? nblocks : cap)), dim3(64), lds_bytes, stream, a);
+    HIP_TRY(hipGetLastError());
+    if (n_layers) {
+        hipLaunchKernelGGL(affine_logdet_grad_kernel, dim3((n_layers + 63) / 64), dim3(64), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
 }
 
 extern "C" int rnf_flow_inverse(const float *rot, const float *feat, int64_t n, int32_t F, const float *blob,

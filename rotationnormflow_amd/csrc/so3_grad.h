@@ -1,0 +1,227 @@
+// so3_grad.h -- reverse-mode derivatives of the per-sample layer math (training path).
+//
+// Every function differentiates the SAME smooth formulation the forward kernels evaluate (so3_math.h): in-plane Moebius
+// segments, quaternion affine.  The reference differentiates its 3-D formulation with autograd (agent.py:79-90); the two
+// agree on every gradient that training uses, because they are the same function on the rotation manifold and all layer
+// outputs are rotations: ambient (off-manifold) components of dL/dR may differ, parameter gradients do not.
+// Checked on the CPU against torch autograd of the oracle (tests/test_host_grad.py).
+#pragma once
+#include "so3_math.h"
+
+namespace rnf {
+
+RNF_HD v3f scale3(v3f a, float s) { return a * s; }
+
+// y = a / |a|:  g_a = (g_y - y (y.g_y)) / |a|
+RNF_HD v3f normalize_bwd(v3f y, float inv_norm, v3f gy) { return (gy - y * dot3(y, gy)) * inv_norm; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Moebius layer, forward part that depends on the conditioner output `cond` (reference row order: [K weights | K x 3 centres],
+// flow/mobiusflow.py:58-61), written per sample with plain loops.  Used by the training kernels (one rotation per lane).
+// ---------------------------------------------------------------------------------------------------------------------
+struct MobiusSaved {
+    Frame f;
+    v3f x, y;
+    float inv_x, inv_cr;      // 1/|x|, 1/|y x r|
+    float S, A, J, Phi, sn, cs;
+    v3f tx, tzu;              // transformed column, un-normalised third column
+    float inv_tzu;
+    bool cyc;
+    int p0, p1, p2;
+};
+
+// Accessors for one sample's conditioner outputs / their gradients: `float get(int row)`, `void put(int row, float)`.
+// Strided: element `row` at p[row * stride] (stride 1 for a contiguous row).
+struct StridedRow {
+    float *p;
+    long long stride;
+    RNF_HD float get(int row) const { return p[row * stride]; }
+    RNF_HD void put(int row, float v) const { p[row * stride] = v; }
+};
+
+template <class CondRow>
+RNF_HD void mobius_segments_forward(const Rot &Rin, int perm_row, const CondRow &cond, int K, Rot &Rout, float &ldj, MobiusSaved &sv) {
+    sv.p0 = perm_row % 3; sv.p1 = (perm_row + 1) % 3; sv.p2 = (perm_row + 2) % 3;
+    sv.cyc = (sv.p1 - sv.p0 == 1) || (sv.p1 - sv.p0 == -2);
+    sv.x = get_col(Rin, sv.p0);
+    sv.y = get_col(Rin, sv.p1);
+    sv.inv_x = 1.0f / sqrtf(dot3(sv.x, sv.x));
+    sv.f.r = sv.x * (-sv.inv_x);
+    const v3f cr = cross3(sv.y, sv.f.r);
+    sv.inv_cr = 1.0f / sqrtf(dot3(cr, cr));
+    sv.f.v = cr * sv.inv_cr;
+    float S = 0.f, A = 0.f, J = 0.f;
+    for (int k = 0; k < K; ++k) {
+        float ur, uv, phi, c;
+        squash_center(cond.get(K + 3 * k), cond.get(K + 3 * k + 1), cond.get(K + 3 * k + 2), sv.f, ur, uv);
+        mobius_angle(-1.0f, 0.0f, kPi, ur, uv, phi, c);                 // z = x expressed in its own frame is (-1, 0): theta = pi
+        const float sp = softplus(cond.get(k));
+        S += sp; A = fmaf(sp, phi, A); J = fmaf(sp, c, J);
+    }
+    sv.S = S; sv.A = A; sv.J = J;
+    sv.Phi = A / S;
+    sincos_small(sv.Phi, sv.sn, sv.cs);
+    sv.tx = sv.f.v * sv.sn + sv.f.r * sv.cs;
+    sv.tzu = sv.cyc ? cross3(sv.tx, sv.y) : cross3(sv.y, sv.tx);
+    sv.inv_tzu = 1.0f / sqrtf(dot3(sv.tzu, sv.tzu));
+    Rout = Rin;
+    set_col(Rout, sv.p0, sv.tx);
+    set_col(Rout, sv.p2, sv.tzu * sv.inv_tzu);
+    ldj = logf(J / S);
+}
+
+// Given dL/dRout (columns) and dL/dldj: gradient w.r.t. the conditioner output (g_cond, same order/stride as cond) and w.r.t.
+// the input columns x (p0) and y (p1) EXCLUDING the path through the conditioner's input (the caller adds W0^T g there).
+// g_cond may alias cond (each segment's four values are read before their gradients are written).
+template <class CondRow, class GradRow>
+RNF_HD void mobius_segments_backward(const MobiusSaved &sv, const CondRow &cond, int K, const Rot &gRout, float g_ldj, const GradRow &g_cond,
+                                     Rot &gRin) {
+    const v3f tz = sv.tzu * sv.inv_tzu;
+    v3f g_tx = get_col(gRout, sv.p0), g_y = get_col(gRout, sv.p1);
+    const v3f g_tzu = normalize_bwd(tz, sv.inv_tzu, get_col(gRout, sv.p2));
+    if (sv.cyc) {            // tzu = tx x y:  g_tx += y x g,  g_y += g x tx
+        g_tx = g_tx + cross3(sv.y, g_tzu);
+        g_y = g_y + cross3(g_tzu, sv.tx);
+    } else {                 // tzu = y x tx:  g_y += tx x g,  g_tx += g x y
+        g_y = g_y + cross3(sv.tx, g_tzu);
+        g_tx = g_tx + cross3(g_tzu, sv.y);
+    }
+    // tx = r cos(Phi) + v sin(Phi)
+    v3f g_r = g_tx * sv.cs, g_v = g_tx * sv.sn;
+    const float g_Phi = dot3(g_tx, sv.f.v * sv.cs - sv.f.r * sv.sn);
+    // Phi = A / S,  ldj = log J - log S
+    const float invS = 1.0f / sv.S;
+    const float g_A = g_Phi * invS;
+    const float g_J = g_ldj / sv.J;
+    const float g_S = -g_Phi * sv.A * invS * invS - g_ldj * invS;
+    for (int k = 0; k < K; ++k) {
+        const float s_raw = cond.get(k);
+        const float w0 = cond.get(K + 3 * k), w1 = cond.get(K + 3 * k + 1), w2 = cond.get(K + 3 * k + 2);
+        // recompute the segment (cheaper than storing 6 values x K per sample)
+        const float wr = fmaf(w2, sv.f.r.z, fmaf(w1, sv.f.r.y, w0 * sv.f.r.x));
+        const float wv = fmaf(w2, sv.f.v.z, fmaf(w1, sv.f.v.y, w0 * sv.f.v.x));
+        const float n = sqrtf(fmaf(wv, wv, wr * wr));
+        const float sc = 0.7f / (1.0f + n);
+        const float ur = wr * sc, uv = wv * sc;
+        const float e1 = 1.0f + ur;                       // z = (-1, 0): a = -ur, b = -uv
+        const float t = uv / e1;
+        const float phi = fmaf(2.0f, atan_unit(t), kPi);
+        const float u2 = fmaf(uv, uv, ur * ur), d2 = fmaf(uv, uv, e1 * e1);
+        const float c = (1.0f - u2) / d2;
+        const float sp = softplus(s_raw);
+        // d/d(sp, phi, c)
+        const float g_sp = g_S + g_A * phi + g_J * c;
+        const float g_phi = g_A * sp, g_c = g_J * sp;
+        // sp = softplus(s): sigmoid
+        g_cond.put(k, g_sp / (1.0f + expf(-s_raw)));
+        // phi = pi + 2 atan(t), t = uv / e1
+        const float g_t = g_phi * 2.0f / (1.0f + t * t);
+        float g_uv = g_t / e1, g_ur = -g_t * t / e1;
+        // c = (1 - u2) / d2
+        const float g_u2 = -g_c / d2, g_d2 = -g_c * c / d2;
+        g_ur += 2.0f * ur * g_u2 + 2.0f * e1 * g_d2;
+        g_uv += 2.0f * uv * g_u2 + 2.0f * uv * g_d2;
+        // ur = wr sc, uv = wv sc, sc = 0.7 / (1 + n), n = |(wr, wv)|
+        const float g_sc = g_ur * wr + g_uv * wv;
+        float g_wr = g_ur * sc, g_wv = g_uv * sc;
+        const float g_n = -g_sc * sc / (1.0f + n);
+        if (n > 0.f) { g_wr += g_n * wr / n; g_wv += g_n * wv / n; }
+        // wr = w.r, wv = w.v
+        g_cond.put(K + 3 * k, g_wr * sv.f.r.x + g_wv * sv.f.v.x);
+        g_cond.put(K + 3 * k + 1, g_wr * sv.f.r.y + g_wv * sv.f.v.y);
+        g_cond.put(K + 3 * k + 2, g_wr * sv.f.r.z + g_wv * sv.f.v.z);
+        g_r = g_r + v3f{w0, w1, w2} * g_wr;
+        g_v = g_v + v3f{w0, w1, w2} * g_wv;
+    }
+    // v = cr / |cr|, cr = y x r
+    const v3f g_cr = normalize_bwd(sv.f.v, sv.inv_cr, g_v);
+    g_y = g_y + cross3(sv.f.r, g_cr);
+    g_r = g_r + cross3(g_cr, sv.y);
+    // r = -x / |x|
+    const v3f g_x = normalize_bwd(sv.f.r, sv.inv_x, g_r) * -1.0f;
+    gRin.c0 = v3f{0.f, 0.f, 0.f}; gRin.c1 = gRin.c0; gRin.c2 = gRin.c0;
+    set_col(gRin, sv.p0, g_x);
+    set_col(gRin, sv.p1, g_y);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// calculate_16 (flow/squeezetrans.py:33-38) backward.  Forward: q = quat(R) (candidate `best`), t = M q, l2 = |t|^2,
+// R' = rot(t) with two_s = 2 / l2, ldj = log|det M| - 2 log l2.
+// ---------------------------------------------------------------------------------------------------------------------
+struct AffineSaved {
+    float q[4], t[4], l2;
+    int best;
+    float ab;                 // the chosen sqrt(max(0, 1 +- m00 +- m11 +- m22))
+};
+
+RNF_HD void affine16_forward_saved(const float (&M)[16], float logabsdet, const Rot &Rin, Rot &Rout, float &ldj, AffineSaved &sv) {
+    const float m00 = Rin.c0.x, m01 = Rin.c1.x, m02 = Rin.c2.x, m10 = Rin.c0.y, m11 = Rin.c1.y, m12 = Rin.c2.y, m20 = Rin.c0.z, m21 = Rin.c1.z, m22 = Rin.c2.z;
+    const float a[4] = {sqrtf(fmaxf(1.0f + m00 + m11 + m22, 0.0f)), sqrtf(fmaxf(1.0f + m00 - m11 - m22, 0.0f)),
+                        sqrtf(fmaxf(1.0f - m00 + m11 - m22, 0.0f)), sqrtf(fmaxf(1.0f - m00 - m11 + m22, 0.0f))};
+    int best = 0;
+    for (int i = 1; i < 4; ++i) if (a[i] > a[best]) best = i;
+    sv.best = best;
+    sv.ab = a[best];
+    rot_to_quat(Rin, sv.q);
+    for (int i = 0; i < 4; ++i) sv.t[i] = M[4 * i] * sv.q[0] + M[4 * i + 1] * sv.q[1] + M[4 * i + 2] * sv.q[2] + M[4 * i + 3] * sv.q[3];
+    sv.l2 = sv.t[0] * sv.t[0] + sv.t[1] * sv.t[1] + sv.t[2] * sv.t[2] + sv.t[3] * sv.t[3];
+    quat_to_rot(sv.t, sv.l2, Rout);
+    ldj = logabsdet - 2.0f * logf(sv.l2);
+}
+
+// gM (16, accumulated into by the caller over the batch) gets g_t (x) q; the log|det M| term (sum_b g_ldj) M^-T is added by the
+// caller once per batch.  Returns dL/dRin.
+RNF_HD void affine16_backward(const float (&M)[16], const AffineSaved &sv, const Rot &gRout, float g_ldj, bool orthogonal, float (&gM)[16],
+                              Rot &gRin) {
+    const float w = sv.t[0], x = sv.t[1], y = sv.t[2], z = sv.t[3];
+    const float s2 = 2.0f / sv.l2;
+    // R' entries E_ij = delta_ij - s2 * P_ij(t) (diag) or s2 * P_ij (off-diag); collect g wrt s2 and wrt the quadratic forms
+    const float g00 = gRout.c0.x, g01 = gRout.c1.x, g02 = gRout.c2.x, g10 = gRout.c0.y, g11 = gRout.c1.y, g12 = gRout.c2.y, g20 = gRout.c0.z, g21 = gRout.c1.z, g22 = gRout.c2.z;
+    // R' = I + s2 * Q,  Q00 = -(yy+zz), Q01 = xy - zw, Q02 = xz + yw, Q10 = xy + zw, Q11 = -(xx+zz), Q12 = yz - xw, Q20 = xz - yw, Q21 = yz + xw, Q22 = -(xx+yy)
+    const float Q00 = -(y * y + z * z), Q01 = x * y - z * w, Q02 = x * z + y * w, Q10 = x * y + z * w, Q11 = -(x * x + z * z), Q12 = y * z - x * w,
+                Q20 = x * z - y * w, Q21 = y * z + x * w, Q22 = -(x * x + y * y);
+    const float g_s2 = g00 * Q00 + g01 * Q01 + g02 * Q02 + g10 * Q10 + g11 * Q11 + g12 * Q12 + g20 * Q20 + g21 * Q21 + g22 * Q22;
+    // dQ/dt
+    float gt[4];
+    gt[0] = s2 * (-g01 * z + g02 * y + g10 * z - g12 * x - g20 * y + g21 * x);
+    gt[1] = s2 * (g01 * y + g02 * z + g10 * y - 2.0f * g11 * x - g12 * w + g20 * z + g21 * w - 2.0f * g22 * x);
+    gt[2] = s2 * (-2.0f * g00 * y + g01 * x + g02 * w + g10 * x + g12 * z - g20 * w + g21 * z - 2.0f * g22 * y);
+    gt[3] = s2 * (-2.0f * g00 * z - g01 * w + g02 * x + g10 * w - 2.0f * g11 * z + g12 * y + g20 * x + g21 * y);
+    // s2 = 2 / l2, ldj = ... - 2 log l2,  l2 = |t|^2
+    const float g_l2 = -g_s2 * s2 / sv.l2 - (orthogonal ? 0.f : 2.0f * g_ldj / sv.l2);
+    for (int i = 0; i < 4; ++i) gt[i] += 2.0f * sv.t[i] * g_l2;
+    // t = M q
+    float gq[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            gM[4 * i + j] += gt[i] * sv.q[j];
+            gq[j] += M[4 * i + j] * gt[i];
+        }
+    // q = cand / (2 max(ab, 0.1)), cand depends on `best` (so3_math.h rot_to_quat); ab = sqrt(1 +- m00 +- m11 +- m22)
+    const float den = 2.0f * fmaxf(sv.ab, 0.1f);
+    const float inv = 1.0f / den;
+    float gc[4] = {gq[0] * inv, gq[1] * inv, gq[2] * inv, gq[3] * inv};       // gradient wrt the candidate row
+    // the diagonal candidate entry is ab^2; d(q)/d(ab) through the denominator: q_i = cand_i / (2 ab) when ab > 0.1
+    float g_ab = 0.f;
+    if (sv.ab > 0.1f) g_ab = -(gq[0] * sv.q[0] + gq[1] * sv.q[1] + gq[2] * sv.q[2] + gq[3] * sv.q[3]) / sv.ab;
+    g_ab += gc[sv.best] * 2.0f * sv.ab;
+    // ab = sqrt(u), u = 1 + s0 m00 + s1 m11 + s2 m22
+    const float g_u = sv.ab > 0.f ? g_ab / (2.0f * sv.ab) : 0.f;
+    const float sg[4][3] = {{1, 1, 1}, {1, -1, -1}, {-1, 1, -1}, {-1, -1, 1}};
+    float r00 = g_u * sg[sv.best][0], r11 = g_u * sg[sv.best][1], r22 = g_u * sg[sv.best][2];
+    float r01 = 0.f, r02 = 0.f, r10 = 0.f, r12 = 0.f, r20 = 0.f, r21 = 0.f;
+    // off-diagonal candidate entries (rot_to_quat): s01 = m21 - m12, s02 = m02 - m20, s03 = m10 - m01, p12 = m10 + m01, p13 = m02 + m20, p23 = m12 + m21
+    float g_s01 = 0.f, g_s02 = 0.f, g_s03 = 0.f, g_p12 = 0.f, g_p13 = 0.f, g_p23 = 0.f;
+    if (sv.best == 0)      { g_s01 = gc[1]; g_s02 = gc[2]; g_s03 = gc[3]; }
+    else if (sv.best == 1) { g_s01 = gc[0]; g_p12 = gc[2]; g_p13 = gc[3]; }
+    else if (sv.best == 2) { g_s02 = gc[0]; g_p12 = gc[1]; g_p23 = gc[3]; }
+    else                   { g_s03 = gc[0]; g_p13 = gc[1]; g_p23 = gc[2]; }
+    r21 += g_s01 + g_p23; r12 += -g_s01 + g_p23;
+    r02 += g_s02 + g_p13; r20 += -g_s02 + g_p13;
+    r10 += g_s03 + g_p12; r01 += -g_s03 + g_p12;
+    gRin.c0 = v3f{r00, r10, r20};
+    gRin.c1 = v3f{r01, r11, r21};
+    gRin.c2 = v3f{r02, r12, r22};
+}
+
+}  // namespace rnf

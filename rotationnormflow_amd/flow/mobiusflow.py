@@ -28,7 +28,7 @@ class _SingleLayer:
         packed = self._cache.get(self, rotation.device, lambda: runtime.pack_layers([self], [row], rotation.device))
         if packed.desc[0, 1] != row:
             packed = runtime.pack_layers([self], [row], rotation.device)
-        return runtime.run_flow(self, packed, rotation, feature, inverse=inverse)
+        return runtime.run_flow(self, packed, rotation, feature, inverse=inverse, train_layers=[self], train_rows=[row])
 
 
 class MobiusFlow(nn.Module, _SingleLayer):
@@ -51,6 +51,10 @@ class MobiusFlow(nn.Module, _SingleLayer):
         F = self.feature_dim if self.condition else 0
         rec, frec = runtime.pack_mobius(L, self.conditioner, self.K, F, prec)
         return rec, frec, F, self.K
+
+    def _rnf_train_tensors(self):
+        from ..autograd import mlp_train_tensors
+        return mlp_train_tensors(self.conditioner)
 
     def forward(self, rotation, permute=None, feature=None):
         assert permute is not None, "The permuting function is needed in this module"

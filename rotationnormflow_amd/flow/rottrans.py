@@ -15,6 +15,7 @@ class UnconditionRot(nn.Module, _SingleLayer):
     is the constant-matrix quaternion kernel."""
 
     _rnf_kind = runtime.KIND_AFFINE16
+    _rnf_orthogonal = True
 
     def __init__(self):
         super().__init__()
@@ -26,6 +27,10 @@ class UnconditionRot(nn.Module, _SingleLayer):
             U, S, V = torch.svd(self.rot.detach().cpu().float())
             rot_mat = U.transpose(-1, -2) @ V
         return runtime.pack_rot16(L, rot_mat), None, 0, 0
+
+    def _rnf_train_tensors(self):
+        U, S, V = torch.svd(self.rot.cpu().float())      # differentiable; the 4x4 SVD stays on the host (see _rnf_pack)
+        return [U.transpose(-1, -2) @ V]
 
     def forward(self, rotation, permute=None, feature=None):
         return self._single(rotation, permute, None, inverse=False)

@@ -237,20 +237,29 @@ def _check_inputs(rotation, feature, packed: PackedFlow):
     return rot, feat
 
 
-def _refuse_autograd(rotation, feature, module):
+def _needs_grad(rotation, feature, module) -> bool:
     if not torch.is_grad_enabled():
-        return
-    needs = rotation.requires_grad or (feature is not None and feature.requires_grad) or any(
+        return False
+    return rotation.requires_grad or (feature is not None and feature.requires_grad) or any(
         p.requires_grad for p in module.parameters())
-    if needs:
+
+
+def _refuse_autograd(rotation, feature, module, what):
+    if _needs_grad(rotation, feature, module):
         raise NotImplementedError(
-            "rotationnormflow_amd: the HIP kernels are forward/inverse only (no backward kernels yet); call under "
+            f"rotationnormflow_amd: {what} has no backward kernel (only Flow.forward is differentiable); call it under "
             "torch.no_grad() -- there is deliberately no PyTorch fallback path")
 
 
-def run_flow(module, packed: PackedFlow, rotation, feature, inverse=False):
-    """-> (rotation' [N,3,3], ldj [N]) through rnf_flow_forward / rnf_flow_inverse."""
-    _refuse_autograd(rotation, feature, module)
+def run_flow(module, packed: PackedFlow, rotation, feature, inverse=False, train_layers=None, train_rows=None):
+    """-> (rotation' [N,3,3], ldj [N]) through rnf_flow_forward / rnf_flow_inverse.
+    When a gradient is required (training, agent.py:75-92) the forward direction goes through autograd.flow_forward, which
+    needs the layer modules and their permutation rows (``train_layers``, ``train_rows``)."""
+    if _needs_grad(rotation, feature, module):
+        if inverse:
+            _refuse_autograd(rotation, feature, module, "Flow.inverse")
+        from . import autograd
+        return autograd.flow_forward(module, train_layers, train_rows, packed, rotation, feature)
     rot, feat = _check_inputs(rotation, feature, packed)
     n = rot.shape[0]
     L = _lib.lib()
@@ -272,7 +281,7 @@ def run_flow(module, packed: PackedFlow, rotation, feature, inverse=False):
 def run_log_prob(module, packed: PackedFlow, rotation, feature, fisher_A=None, fisher_c=None,
                  want_rotation=False, want_ldj=False, want_logp=True):
     """Fused Flow.forward + base log-density + NLL sum.  -> dict(logp, sum [2] float64 device tensor, rotation, ldj)"""
-    _refuse_autograd(rotation, feature, module)
+    _refuse_autograd(rotation, feature, module, "the fused log_prob evaluation")
     rot, feat = _check_inputs(rotation, feature, packed)
     n = rot.shape[0]
     L = _lib.lib()

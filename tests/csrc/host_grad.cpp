@@ -1,0 +1,47 @@
+// TEST INFRASTRUCTURE: csrc/so3_grad.h compiled for the HOST so the reverse-mode formulas of the training path can be
+// checked on a CPU against torch autograd of the oracle (tests/test_host_grad.py).  Not part of librnf_hip.so.
+#include "../../rotationnormflow_amd/csrc/so3_grad.h"
+
+using namespace rnf;
+
+static Rot load_rot(const float *s) {
+    Rot R;
+    R.c0 = v3f{s[0], s[3], s[6]}; R.c1 = v3f{s[1], s[4], s[7]}; R.c2 = v3f{s[2], s[5], s[8]};
+    return R;
+}
+static void store_rot(const Rot &R, float *d) {
+    d[0] = R.c0.x; d[1] = R.c1.x; d[2] = R.c2.x; d[3] = R.c0.y; d[4] = R.c1.y; d[5] = R.c2.y; d[6] = R.c0.z; d[7] = R.c1.z; d[8] = R.c2.z;
+}
+
+extern "C" {
+void hg_mobius(const float *Rin, int perm_row, const float *cond, int K, const float *gRout, const float *g_ldj, int n, float *Rout,
+               float *ldj, float *g_cond, float *gRin) {
+    for (int i = 0; i < n; ++i) {
+        Rot R = load_rot(Rin + 9 * i), Ro, gi;
+        MobiusSaved sv;
+        float l;
+        mobius_segments_forward(R, perm_row, StridedRow{const_cast<float *>(cond) + (size_t)4 * K * i, 1}, K, Ro, l, sv);
+        store_rot(Ro, Rout + 9 * i);
+        ldj[i] = l;
+        mobius_segments_backward(sv, StridedRow{const_cast<float *>(cond) + (size_t)4 * K * i, 1}, K, load_rot(gRout + 9 * i), g_ldj[i],
+                                 StridedRow{g_cond + (size_t)4 * K * i, 1}, gi);
+        store_rot(gi, gRin + 9 * i);
+    }
+}
+void hg_affine(const float *M, float logabsdet, const float *Rin, const float *gRout, const float *g_ldj, int n, float *Rout, float *ldj,
+               float *gM, float *gRin) {
+    float m[16], gm[16];
+    for (int k = 0; k < 16; ++k) { m[k] = M[k]; gm[k] = 0.f; }
+    for (int i = 0; i < n; ++i) {
+        Rot Ro, gi;
+        AffineSaved sv;
+        float l;
+        affine16_forward_saved(m, logabsdet, load_rot(Rin + 9 * i), Ro, l, sv);
+        store_rot(Ro, Rout + 9 * i);
+        ldj[i] = l;
+        affine16_backward(m, sv, load_rot(gRout + 9 * i), g_ldj[i], false, gm, gi);
+        store_rot(gi, gRin + 9 * i);
+    }
+    for (int k = 0; k < 16; ++k) gM[k] = gm[k];
+}
+}

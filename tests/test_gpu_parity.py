@@ -166,4 +166,4 @@ def test_errors_are_loud():
         with pytest.raises(RuntimeError):
             fl(R.cpu(), torch.zeros(8, 16))                         # no CPU fallback
     with pytest.raises(NotImplementedError):
-        fl(R, torch.zeros(8, 16, device="cuda"))                   # autograd not built: refuses instead of silently detaching
+        fl.inverse(R, torch.zeros(8, 16, device="cuda"))           # no backward for the inverse: refuses instead of detaching

@@ -529,7 +529,7 @@ extern "C" int rnf_flow_backward(const float *states, const float *feat, int64_t
     HIP_TRY(allow_lds(kern, lds_bytes));
     const long long nblocks = (n + 63) / 64;
     const int cap = device_cus() * 4;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < cap ? nblocks : cap)), dim3(64), lds_bytes, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < cap ? nblocks : cap)), dim3(TR_WAVES * 64), lds_bytes, stream, a);
     HIP_TRY(hipGetLastError());
     if (n_layers) {
         hipLaunchKernelGGL(affine_logdet_grad_kernel, dim3((n_layers + 63) / 64), dim3(64), 0, stream, a);

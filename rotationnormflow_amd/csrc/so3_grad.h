@@ -39,8 +39,8 @@ struct StridedRow {
     RNF_HD void put(int row, float v) const { p[row * stride] = v; }
 };
 
-template <class CondRow>
-RNF_HD void mobius_segments_forward(const Rot &Rin, int perm_row, const CondRow &cond, int K, Rot &Rout, float &ldj, MobiusSaved &sv) {
+// --- forward, in three pieces so that the segments can be split over several waves (train_kernels.h) -------------------------
+RNF_HD void mobius_frame(const Rot &Rin, int perm_row, MobiusSaved &sv) {
     sv.p0 = perm_row % 3; sv.p1 = (perm_row + 1) % 3; sv.p2 = (perm_row + 2) % 3;
     sv.cyc = (sv.p1 - sv.p0 == 1) || (sv.p1 - sv.p0 == -2);
     sv.x = get_col(Rin, sv.p0);
@@ -50,51 +50,76 @@ RNF_HD void mobius_segments_forward(const Rot &Rin, int perm_row, const CondRow 
     const v3f cr = cross3(sv.y, sv.f.r);
     sv.inv_cr = 1.0f / sqrtf(dot3(cr, cr));
     sv.f.v = cr * sv.inv_cr;
-    float S = 0.f, A = 0.f, J = 0.f;
-    for (int k = 0; k < K; ++k) {
+}
+
+// partial sums over segments [k0, k1): S = sum softplus, A = sum softplus * phi, J = sum softplus * c
+template <class CondRow>
+RNF_HD void mobius_segments_sums(const MobiusSaved &sv, const CondRow &cond, int K, int k0, int k1, float &S, float &A, float &J) {
+    for (int k = k0; k < k1; ++k) {
         float ur, uv, phi, c;
         squash_center(cond.get(K + 3 * k), cond.get(K + 3 * k + 1), cond.get(K + 3 * k + 2), sv.f, ur, uv);
         mobius_angle(-1.0f, 0.0f, kPi, ur, uv, phi, c);                 // z = x expressed in its own frame is (-1, 0): theta = pi
         const float sp = softplus(cond.get(k));
         S += sp; A = fmaf(sp, phi, A); J = fmaf(sp, c, J);
     }
+}
+
+RNF_HD void mobius_combine(MobiusSaved &sv, float S, float A, float J) {
     sv.S = S; sv.A = A; sv.J = J;
     sv.Phi = A / S;
     sincos_small(sv.Phi, sv.sn, sv.cs);
     sv.tx = sv.f.v * sv.sn + sv.f.r * sv.cs;
     sv.tzu = sv.cyc ? cross3(sv.tx, sv.y) : cross3(sv.y, sv.tx);
     sv.inv_tzu = 1.0f / sqrtf(dot3(sv.tzu, sv.tzu));
+}
+
+template <class CondRow>
+RNF_HD void mobius_segments_forward(const Rot &Rin, int perm_row, const CondRow &cond, int K, Rot &Rout, float &ldj, MobiusSaved &sv) {
+    mobius_frame(Rin, perm_row, sv);
+    float S = 0.f, A = 0.f, J = 0.f;
+    mobius_segments_sums(sv, cond, K, 0, K, S, A, J);
+    mobius_combine(sv, S, A, J);
     Rout = Rin;
     set_col(Rout, sv.p0, sv.tx);
     set_col(Rout, sv.p2, sv.tzu * sv.inv_tzu);
     ldj = logf(J / S);
 }
 
-// Given dL/dRout (columns) and dL/dldj: gradient w.r.t. the conditioner output (g_cond, same order/stride as cond) and w.r.t.
-// the input columns x (p0) and y (p1) EXCLUDING the path through the conditioner's input (the caller adds W0^T g there).
-// g_cond may alias cond (each segment's four values are read before their gradients are written).
-template <class CondRow, class GradRow>
-RNF_HD void mobius_segments_backward(const MobiusSaved &sv, const CondRow &cond, int K, const Rot &gRout, float g_ldj, const GradRow &g_cond,
-                                     Rot &gRin) {
+// --- backward, same three pieces ---------------------------------------------------------------------------------------------
+struct MobiusGrad {
+    float g_A, g_J, g_S;      // d/d(sums)
+    v3f g_r, g_v, g_y;        // running gradients of the frame vectors and the conditioning column
+};
+
+RNF_HD void mobius_backward_head(const MobiusSaved &sv, const Rot &gRout, float g_ldj, MobiusGrad &mg) {
     const v3f tz = sv.tzu * sv.inv_tzu;
-    v3f g_tx = get_col(gRout, sv.p0), g_y = get_col(gRout, sv.p1);
+    v3f g_tx = get_col(gRout, sv.p0);
+    mg.g_y = get_col(gRout, sv.p1);
     const v3f g_tzu = normalize_bwd(tz, sv.inv_tzu, get_col(gRout, sv.p2));
     if (sv.cyc) {            // tzu = tx x y:  g_tx += y x g,  g_y += g x tx
         g_tx = g_tx + cross3(sv.y, g_tzu);
-        g_y = g_y + cross3(g_tzu, sv.tx);
+        mg.g_y = mg.g_y + cross3(g_tzu, sv.tx);
     } else {                 // tzu = y x tx:  g_y += tx x g,  g_tx += g x y
-        g_y = g_y + cross3(sv.tx, g_tzu);
+        mg.g_y = mg.g_y + cross3(sv.tx, g_tzu);
         g_tx = g_tx + cross3(g_tzu, sv.y);
     }
     // tx = r cos(Phi) + v sin(Phi)
-    v3f g_r = g_tx * sv.cs, g_v = g_tx * sv.sn;
+    mg.g_r = g_tx * sv.cs;
+    mg.g_v = g_tx * sv.sn;
     const float g_Phi = dot3(g_tx, sv.f.v * sv.cs - sv.f.r * sv.sn);
     // Phi = A / S,  ldj = log J - log S
     const float invS = 1.0f / sv.S;
-    const float g_A = g_Phi * invS;
-    const float g_J = g_ldj / sv.J;
-    const float g_S = -g_Phi * sv.A * invS * invS - g_ldj * invS;
-    for (int k = 0; k < K; ++k) {
+    mg.g_A = g_Phi * invS;
+    mg.g_J = g_ldj / sv.J;
+    mg.g_S = -g_Phi * sv.A * invS * invS - g_ldj * invS;
+}
+
+// segments [k0, k1): writes their conditioner-output gradients, ADDS their contribution to g_r / g_v (pass zero-initialised
+// accumulators when the range is a partial one)
+template <class CondRow, class GradRow>
+RNF_HD void mobius_segments_backward_range(const MobiusSaved &sv, const CondRow &cond, int K, int k0, int k1, const MobiusGrad &mg,
+                                           const GradRow &g_cond, v3f &g_r, v3f &g_v) {
+    for (int k = k0; k < k1; ++k) {
         const float s_raw = cond.get(k);
         const float w0 = cond.get(K + 3 * k), w1 = cond.get(K + 3 * k + 1), w2 = cond.get(K + 3 * k + 2);
         // recompute the segment (cheaper than storing 6 values x K per sample)
@@ -110,8 +135,8 @@ RNF_HD void mobius_segments_backward(const MobiusSaved &sv, const CondRow &cond,
         const float c = (1.0f - u2) / d2;
         const float sp = softplus(s_raw);
         // d/d(sp, phi, c)
-        const float g_sp = g_S + g_A * phi + g_J * c;
-        const float g_phi = g_A * sp, g_c = g_J * sp;
+        const float g_sp = mg.g_S + mg.g_A * phi + mg.g_J * c;
+        const float g_phi = mg.g_A * sp, g_c = mg.g_J * sp;
         // sp = softplus(s): sigmoid
         g_cond.put(k, g_sp / (1.0f + expf(-s_raw)));
         // phi = pi + 2 atan(t), t = uv / e1
@@ -133,15 +158,30 @@ RNF_HD void mobius_segments_backward(const MobiusSaved &sv, const CondRow &cond,
         g_r = g_r + v3f{w0, w1, w2} * g_wr;
         g_v = g_v + v3f{w0, w1, w2} * g_wv;
     }
+}
+
+RNF_HD void mobius_backward_tail(const MobiusSaved &sv, const MobiusGrad &mg, Rot &gRin) {
     // v = cr / |cr|, cr = y x r
-    const v3f g_cr = normalize_bwd(sv.f.v, sv.inv_cr, g_v);
-    g_y = g_y + cross3(sv.f.r, g_cr);
-    g_r = g_r + cross3(g_cr, sv.y);
+    const v3f g_cr = normalize_bwd(sv.f.v, sv.inv_cr, mg.g_v);
+    const v3f g_y = mg.g_y + cross3(sv.f.r, g_cr);
+    const v3f g_r = mg.g_r + cross3(g_cr, sv.y);
     // r = -x / |x|
     const v3f g_x = normalize_bwd(sv.f.r, sv.inv_x, g_r) * -1.0f;
     gRin.c0 = v3f{0.f, 0.f, 0.f}; gRin.c1 = gRin.c0; gRin.c2 = gRin.c0;
     set_col(gRin, sv.p0, g_x);
     set_col(gRin, sv.p1, g_y);
+}
+
+// Given dL/dRout (columns) and dL/dldj: gradient w.r.t. the conditioner output (g_cond, same order as cond) and w.r.t.
+// the input columns x (p0) and y (p1) EXCLUDING the path through the conditioner's input (the caller adds W0^T g there).
+// g_cond may alias cond (each segment's four values are read before their gradients are written).
+template <class CondRow, class GradRow>
+RNF_HD void mobius_segments_backward(const MobiusSaved &sv, const CondRow &cond, int K, const Rot &gRout, float g_ldj, const GradRow &g_cond,
+                                     Rot &gRin) {
+    MobiusGrad mg;
+    mobius_backward_head(sv, gRout, g_ldj, mg);
+    mobius_segments_backward_range(sv, cond, K, 0, K, mg, g_cond, mg.g_r, mg.g_v);
+    mobius_backward_tail(sv, mg, gRin);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

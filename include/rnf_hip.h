@@ -122,6 +122,15 @@ int rnf_flow_inverse(const float *rotation_dev, const float *feature_dev, int64_
 #define RNF_TRAIN_ORTHOGONAL 256
 size_t rnf_plain_layer_floats(int32_t kind, int32_t segments, int32_t feature_dim);
 
+/* Build the kernel blob on the device from the plain blob (same bits as rnf_pack_* on the host; the parameters change every
+ * training iteration).  pack_desc: int32 [n_layers][4] = kind (| RNF_TRAIN_ORTHOGONAL), offset in the plain blob, offset of
+ * the layer record in the kernel blob, offset of its feature-projection record (or -1), all in floats; record offsets are
+ * multiples of 4.  feature_dim is the real (unpadded) width; records are laid out for it padded to a multiple of 8.
+ * flags_dev: device int32, zeroed by the caller; bit 0 = a weight outside the fp16 range under RNF_PREC_F16X2 (the blob
+ * then holds inf/NaN), bit 1 = a singular 4x4 matrix. */
+int rnf_pack_flow_device(const float *plain_dev, const int32_t *pack_desc, int32_t n_layers, int32_t segments,
+                         int32_t feature_dim, int32_t precision, float *blob_dev, int32_t *flags_dev, void *stream);
+
 /* Flow.forward that also saves the rotation entering every layer: states_dev float[n_layers][n][9]. */
 int rnf_flow_forward_train(const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim,
                            const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments,

@@ -13,25 +13,91 @@ import torch
 
 from . import _lib, runtime
 
-ORTHOGONAL_FLAG = 1 << 8        # train_desc kind flag: the 4x4 matrix is orthogonal, its layer reports ldj = 0 (flow/rottrans.py:21)
+ORTHOGONAL_FLAG = 1 << 8        # layer-table kind flag: the 4x4 matrix is orthogonal, its layer reports ldj = 0 (flow/rottrans.py:21)
 
 
 class TrainPlan:
-    """Layer table of the plain parameter blob for one flow (include/rnf_hip.h "training")."""
+    """Everything about one flow that depends only on its structure: the three layer tables (kernel blob, device packer,
+    backward sweep) and the sizes of the two blobs (include/rnf_hip.h "training")."""
 
-    def __init__(self, layers, perm_rows, segments, feat_dim):
+    def __init__(self, layers, perm_rows, device, precision):
         L = _lib.lib()
-        self.tensor_counts = []
-        desc = np.zeros((len(layers), 3), dtype=np.int32)
-        off = 0
-        for i, layer in enumerate(layers):
-            kind = layer._rnf_kind
-            desc[i] = (kind | (ORTHOGONAL_FLAG if getattr(layer, "_rnf_orthogonal", False) else 0), perm_rows[i], off)
-            off += L.rnf_plain_layer_floats(kind, segments, feat_dim)
-        self.desc = np.ascontiguousarray(desc)
-        self.total = off
-        self.segments = segments
-        self.feat_dim = feat_dim
+        n = len(layers)
+        shapes = [layer._rnf_shape() for layer in layers]          # (kind, segments | 0, feature_dim | 0)
+        ks = {k for kind, k, f in shapes if kind == runtime.KIND_MOBIUS}
+        fs = {f for kind, k, f in shapes if f}
+        if len(ks) > 1:
+            raise ValueError("all Moebius layers of one flow must have the same number of segments")
+        if len(fs) > 1:
+            raise ValueError("all conditional layers of one flow must share feature_dim")
+        self.segments = ks.pop() if ks else 8
+        self.feat_dim = fs.pop() if fs else 0
+        self.feat_padded = runtime.pad8(self.feat_dim)
+        if self.segments > 64 or self.segments % 8:
+            raise NotImplementedError("training path: segments must be a multiple of 8, at most 64")
+        self.precision = precision
+        self.prec = runtime._PRECISIONS[precision]
+        self.n_layers = n
+        self.desc = np.zeros((n, runtime.DESC_STRIDE), dtype=np.int32)       # kernel blob table (runtime.pack_layers)
+        self.pack_desc = np.zeros((n, 4), dtype=np.int32)                    # rnf_pack_flow_device
+        self.train_desc = np.zeros((n, 3), dtype=np.int32)                   # rnf_flow_backward
+        plain_off = rec_off = 0
+        slot = 0
+        rec_sizes = []
+        for i, (layer, (kind, k, f)) in enumerate(zip(layers, shapes)):
+            flagged = kind | (ORTHOGONAL_FLAG if getattr(layer, "_rnf_orthogonal", False) else 0)
+            self.desc[i] = (kind, perm_rows[i], rec_off, -1, -1, self.prec)
+            self.pack_desc[i] = (flagged, plain_off, rec_off, -1)
+            self.train_desc[i] = (flagged, perm_rows[i], plain_off)
+            if kind == runtime.KIND_MOBIUS:
+                size = L.rnf_mobius_packed_floats(self.segments)
+            elif kind == runtime.KIND_COND16:
+                size = L.rnf_cond16_packed_floats()
+            else:
+                size = L.rnf_affine16_packed_floats()
+            rec_sizes.append(size)
+            rec_off += (size + 3) // 4 * 4
+            plain_off += L.rnf_plain_layer_floats(kind, self.segments, self.feat_dim)
+            if f:
+                self.desc[i, 3] = slot
+                slot += 1
+        fsize = L.rnf_featproj_packed_floats(self.feat_padded) if self.feat_dim else 0
+        for i, (kind, k, f) in enumerate(shapes):
+            if f:
+                self.desc[i, 4] = self.pack_desc[i, 3] = rec_off
+                rec_off += (fsize + 3) // 4 * 4
+        self.n_cond = slot
+        self.plain_floats = plain_off
+        self.blob_floats = max(rec_off, 4)
+        self.desc = np.ascontiguousarray(self.desc)
+        # packer status word: checked one call later through pinned memory, so that no step waits for the device
+        self.flags = torch.zeros(1, dtype=torch.int32, device=device)
+        self.flags_host = torch.zeros(1, dtype=torch.int32).pin_memory() if torch.cuda.is_available() else torch.zeros(1, dtype=torch.int32)
+        self.flags_event = None
+
+    def check_flags(self):
+        if self.flags_event is not None and self.flags_event.query():
+            bits = int(self.flags_host[0])
+            self.flags_event = None
+            if bits & 1:
+                raise runtime.HalfRangeError("a weight left the fp16 range during training (the split-precision kernels produced inf/NaN "
+                                             "for that step); continue with rotationnormflow_amd.set_precision('fp32')")
+            if bits & 2:
+                raise RuntimeError("a 4x4 affine matrix became singular during training")
+
+    def pack(self, plain, stream):
+        """plain blob -> fresh kernel blob, on the device (one launch)."""
+        L = _lib.lib()
+        self.check_flags()
+        blob = torch.empty(self.blob_floats, dtype=torch.float32, device=plain.device)
+        self.flags.zero_()
+        _lib.check(L.rnf_pack_flow_device(plain.data_ptr(), self.pack_desc.ctypes.data, self.n_layers, self.segments, self.feat_dim,
+                                          self.prec, blob.data_ptr(), self.flags.data_ptr(), stream))
+        if self.flags_event is None:
+            self.flags_host.copy_(self.flags, non_blocking=True)
+            self.flags_event = torch.cuda.Event()
+            self.flags_event.record()
+        return blob
 
 
 def train_tensors(layers):
@@ -55,30 +121,31 @@ def mlp_train_tensors(net):
 
 class _FlowForwardFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, packed, plan, rotation, feature, *tensors):
-        rot, feat = runtime._check_inputs(rotation, feature, packed)
+    def forward(ctx, plan, rotation, feature, *tensors):
+        rot, feat = runtime._check_inputs(rotation, feature, plan)
         n = rot.shape[0]
         dev = rot.device
         L = _lib.lib()
         out_rot = torch.empty_like(rot)
         out_ldj = torch.empty(n, dtype=torch.float32, device=dev)
-        states = torch.empty((packed.n_layers, n, 9), dtype=torch.float32, device=dev)
-        if n:
-            ws = runtime.workspace(dev, L.rnf_workspace_bytes(n, packed.n_cond))
-            with torch.cuda.device(dev):
-                stream = torch.cuda.current_stream(dev).cuda_stream
-                _lib.check(L.rnf_flow_forward_train(rot.data_ptr(), feat.data_ptr() if feat is not None else None, n,
-                                                    packed.feat_padded, packed.blob.data_ptr(), packed.desc.ctypes.data,
-                                                    packed.n_layers, packed.segments, out_rot.data_ptr(), out_ldj.data_ptr(),
-                                                    states.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+        states = torch.empty((plan.n_layers, n, 9), dtype=torch.float32, device=dev)
         plain = torch.cat([t.detach().to(device=dev, dtype=torch.float32).reshape(-1) for t in tensors]) if tensors else \
             torch.zeros(0, device=dev)
-        if plain.numel() != plan.total:
-            raise RuntimeError(f"plain parameter blob has {plain.numel()} floats, layer table expects {plan.total}")
+        if plain.numel() != plan.plain_floats:
+            raise RuntimeError(f"plain parameter blob has {plain.numel()} floats, layer table expects {plan.plain_floats}")
+        if n:
+            ws = runtime.workspace(dev, L.rnf_workspace_bytes(n, plan.n_cond))
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                blob = plan.pack(plain, stream)
+                _lib.check(L.rnf_flow_forward_train(rot.data_ptr(), feat.data_ptr() if feat is not None else None, n,
+                                                    plan.feat_padded, blob.data_ptr(), plan.desc.ctypes.data,
+                                                    plan.n_layers, plan.segments, out_rot.data_ptr(), out_ldj.data_ptr(),
+                                                    states.data_ptr(), ws.data_ptr(), ws.numel(), stream))
         feat_plain = None
-        if packed.n_cond:
+        if plan.n_cond:
             feat_plain = feature.reshape(n, -1).to(device=dev, dtype=torch.float32).contiguous()
-        ctx.packed, ctx.plan = packed, plan
+        ctx.plan = plan
         ctx.rot_shape = rotation.shape
         ctx.feat_shape = feature.shape if feature is not None else None
         ctx.shapes = [(t.shape, t.device, t.dtype) for t in tensors]
@@ -89,15 +156,15 @@ class _FlowForwardFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_rot, g_ldj):
         states, feat_plain, plain = ctx.saved_tensors
-        packed, plan = ctx.packed, ctx.plan
+        plan = ctx.plan
         n = states.shape[1]
         dev = states.device
         L = _lib.lib()
         grads = torch.zeros_like(plain)
         g_rot_in = torch.zeros((n, 9), dtype=torch.float32, device=dev)
-        want_gfeat = feat_plain is not None and ctx.needs_input_grad[3]
+        want_gfeat = feat_plain is not None and ctx.needs_input_grad[2]
         g_feat = torch.zeros_like(feat_plain) if want_gfeat else None
-        scratch = torch.zeros(max(packed.n_layers, 1), dtype=torch.float32, device=dev)
+        scratch = torch.zeros(max(plan.n_layers, 1), dtype=torch.float32, device=dev)
         if n:
             g_rot_c = g_rot.reshape(n, 9).to(torch.float32).contiguous() if g_rot is not None else None
             g_ldj_c = (g_ldj.to(torch.float32).contiguous() if g_ldj is not None
@@ -106,7 +173,7 @@ class _FlowForwardFn(torch.autograd.Function):
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream
                 _lib.check(L.rnf_flow_backward(states.data_ptr(), ptr(feat_plain), n, plan.feat_dim, plain.data_ptr(),
-                                               plan.desc.ctypes.data, packed.n_layers, plan.segments, ptr(g_rot_c),
+                                               plan.train_desc.ctypes.data, plan.n_layers, plan.segments, ptr(g_rot_c),
                                                g_ldj_c.data_ptr(), grads.data_ptr(), g_rot_in.data_ptr(), ptr(g_feat),
                                                scratch.data_ptr(), stream))
         outs = []
@@ -114,26 +181,22 @@ class _FlowForwardFn(torch.autograd.Function):
         for i, (shape, device, dtype) in enumerate(ctx.shapes):
             cnt = int(np.prod(shape)) if len(shape) else 1
             g = None
-            if ctx.needs_input_grad[4 + i]:
+            if ctx.needs_input_grad[3 + i]:
                 g = grads[off: off + cnt].reshape(shape).to(device=device, dtype=dtype)
             outs.append(g)
             off += cnt
-        g_rotation = g_rot_in.reshape(ctx.rot_shape) if ctx.needs_input_grad[2] else None
+        g_rotation = g_rot_in.reshape(ctx.rot_shape) if ctx.needs_input_grad[1] else None
         g_feature = g_feat.reshape(ctx.feat_shape) if want_gfeat else None
-        return (None, None, g_rotation, g_feature, *outs)
+        return (None, g_rotation, g_feature, *outs)
 
 
-def needs_grad(module, rotation, feature) -> bool:
-    if not torch.is_grad_enabled():
-        return False
-    return rotation.requires_grad or (feature is not None and feature.requires_grad) or any(
-        p.requires_grad for p in module.parameters())
-
-
-def flow_forward(module, layers, perm_rows, packed, rotation, feature):
+def flow_forward(module, layers, perm_rows, rotation, feature):
     """Differentiable (rotation', ldj) for a stack of layers; called by runtime.run_flow when a gradient is required."""
-    if packed.segments > 64 and any(l._rnf_kind == runtime.KIND_MOBIUS for l in layers):
-        raise NotImplementedError("training path: at most 64 segments")
-    plan = TrainPlan(layers, perm_rows, packed.segments, packed.feat_dim)
-    tensors = train_tensors(layers)
-    return _FlowForwardFn.apply(packed, plan, rotation, feature, *tensors)
+    if not rotation.is_cuda:
+        raise RuntimeError("rotationnormflow_amd runs on the GPU only (HIP kernels, no CPU fallback): got a CPU tensor")
+    key = (str(rotation.device), runtime.get_precision(), tuple(perm_rows), tuple(l._rnf_shape() for l in layers))
+    cached = getattr(module, "_rnf_train_plan", None)
+    if cached is None or cached[0] != key:
+        cached = (key, TrainPlan(layers, perm_rows, rotation.device, runtime.get_precision()))
+        module._rnf_train_plan = cached
+    return _FlowForwardFn.apply(cached[1], rotation, feature, *train_tensors(layers))

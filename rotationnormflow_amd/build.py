@@ -18,7 +18,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -fno-slp-vectorize: packed f32 VALU (v_pk_*) beside MFMAs is slower than scalar (MI355X_MICROARCH.md, "price of one
     # filler beside MFMAs"), and SLP packing would fuse the hand-placed per-MFMA slices of the segment math back together
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-o", OUT, SRC]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-Xarch_host", "-mf16c", "-shared", "-fPIC", "-o", OUT, SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.run(cmd, check=True)

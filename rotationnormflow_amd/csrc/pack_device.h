@@ -1,0 +1,198 @@
+// pack_device.h -- build the kernel blob ON the device from the plain parameter blob (training: the parameters change every
+// iteration, so the host packers of rnf_api.hip -- a device->host copy, a CPU permutation and a host->device copy per step --
+// would dominate the step).  One launch, one workgroup column per layer; every output float is gathered from its source
+// weight with the same index maps as the host packers (pack_w64 / pack_w64_h / pack_bias / pack_featproj*), and
+// tests/test_gpu_grad.py checks the two blobs bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "layout.h"
+
+namespace rnf {
+
+constexpr int PK_MAX_LAYERS = 200;
+constexpr int PK_FLAG_HALF_RANGE = 1, PK_FLAG_SINGULAR = 2;
+
+struct PackLayer {
+    int kind;        // RNF_KIND_* | orthogonal << 8
+    int plain_off;   // floats, into the plain blob
+    int rec_off;     // floats, into the kernel blob
+    int feat_off;    // floats, feature-projection record (or -1)
+};
+
+struct PackArgs {
+    const float *plain;
+    float *blob;
+    int *flags;      // OR of PK_FLAG_* (device int, zeroed by the caller)
+    int n_layers, K, F, Fp, prec;
+    PackLayer layers[PK_MAX_LAYERS];
+};
+
+__device__ __forceinline__ float half_part(float w, int lo, int *flags) {
+    if (!(fabsf(w) < 65504.0f)) atomicOr(flags, PK_FLAG_HALF_RANGE);      // also catches NaN / inf
+    const _Float16 wh = (_Float16)w;
+    return lo ? (w - (float)wh) * 4096.0f : (float)wh;
+}
+
+__device__ __forceinline__ float pack2(float a, float b) {           // two fp16 in one 32-bit word, first element in the low half
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    const unsigned short ua = __builtin_bit_cast(unsigned short, ha), ub = __builtin_bit_cast(unsigned short, hb);
+    return __uint_as_float((unsigned)ua | ((unsigned)ub << 16));
+}
+
+// float `r` of a [n_ot][...] weight image of 64-column rows; row_of(ot, i) -> source row or nullptr (zero row)
+template <class RowFn>
+__device__ __forceinline__ float w64_image(int r, int prec, RowFn row_of, int *flags) {
+    if (!prec) {                                                       // [ot][tg 8][lane 64] float4
+        const int ot = r >> 11, tg = (r >> 8) & 7, lane = (r >> 2) & 63, c = r & 3;
+        const float *row = row_of(ot, lane & 31);
+        return row ? row[8 * tg + 4 * (lane >> 5) + c] : 0.f;
+    }
+    float v[2];                                                        // [ot][s 4][hi, lo][lane 64] 8 x fp16
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = 2 * r + q;
+        const int ot = e >> 12, s = (e >> 10) & 3, lo = (e >> 9) & 1, lane = (e >> 3) & 63, j = e & 7;
+        const float *row = row_of(ot, lane & 31);
+        const float w = row ? row[16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)] : 0.f;
+        v[q] = half_part(w, lo, flags);
+    }
+    return pack2(v[0], v[1]);
+}
+
+// float `r` of the feature-projection weight image: rows of W (leading dimension ldw) from column col0, F real columns
+__device__ __forceinline__ float featproj_image(int r, int prec, const float *W, int ldw, int col0, int F, int Fp, int *flags) {
+    if (!prec) {                                                       // [ot][tg Fp/8][lane] float4
+        const int ng = Fp / 8;
+        const int ot = r / (ng * 256), rem = r % (ng * 256);
+        const int tg = rem >> 8, lane = (rem >> 2) & 63, c = rem & 3;
+        const int k = 8 * tg + 4 * (lane >> 5) + c;
+        return k < F ? W[(size_t)(32 * ot + (lane & 31)) * ldw + col0 + k] : 0.f;
+    }
+    const int ns = (Fp + 15) / 16;                                     // [ot][s][hi, lo][lane] 8 x fp16
+    float v[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = 2 * r + q;
+        const int ot = e / (ns * 1024), rem = e % (ns * 1024);
+        const int s = rem >> 10, lo = (rem >> 9) & 1, lane = (rem >> 3) & 63, j = rem & 7;
+        const int k = 16 * s + 8 * (lane >> 5) + j;
+        const float w = k < F ? W[(size_t)(32 * ot + (lane & 31)) * ldw + col0 + k] : 0.f;
+        v[q] = half_part(w, lo, flags);
+    }
+    return pack2(v[0], v[1]);
+}
+
+// bias image [ot][h][16]: element q is b[32 ot + rho(r, h)]
+__device__ __forceinline__ int bias_row(int q) { return 32 * (q >> 5) + rho(q & 15, (q >> 4) & 1); }
+
+// 4x4 inverse / determinant in double, Gauss-Jordan with partial pivoting (same steps as the host's inv4_double)
+__device__ inline bool inv4_double_dev(const double *m, double *inv, double *det) {
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { a[i][j] = m[4 * i + j]; a[i][4 + j] = (i == j); }
+    double d = 1.0;
+    for (int c = 0; c < 4; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 4; ++r) if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
+        if (a[p][c] == 0.0) return false;
+        if (p != c) { for (int j = 0; j < 8; ++j) { const double t = a[p][j]; a[p][j] = a[c][j]; a[c][j] = t; } d = -d; }
+        d *= a[c][c];
+        const double ip = 1.0 / a[c][c];
+        for (int j = 0; j < 8; ++j) a[c][j] *= ip;
+        for (int r = 0; r < 4; ++r) if (r != c) {
+            const double f = a[r][c];
+            for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) inv[4 * i + j] = a[i][4 + j];
+    *det = d;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
+    const PackLayer L = args.layers[blockIdx.y];
+    const int kind = L.kind & 15;
+    const float *P = args.plain + L.plain_off;
+    float *out = args.blob + L.rec_off;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    const int prec = args.prec, K = args.K, F = args.F, Fp = args.Fp;
+    if (kind == RNF_KIND_AFFINE16) {                                   // rnf_pack_affine16 / rnf_pack_rot16
+        if (tid != 0) return;
+        if ((L.kind >> 8) & 1) {
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) { out[4 * i + j] = P[4 * i + j]; out[17 + 4 * i + j] = P[4 * j + i]; }
+            out[16] = 0.f; out[33] = 0.f; out[34] = 1.f; out[35] = 0.f;
+            return;
+        }
+        double m[16], inv[16], det = 0.0;
+        for (int i = 0; i < 16; ++i) m[i] = P[i];
+        if (!inv4_double_dev(m, inv, &det)) {
+            atomicOr(args.flags, PK_FLAG_SINGULAR);
+            for (int i = 0; i < 16; ++i) inv[i] = __builtin_nan("");
+        }
+        for (int i = 0; i < 16; ++i) { out[i] = P[i]; out[17 + i] = (float)inv[i]; }
+        out[16] = (float)log(fabs(det));
+        out[33] = (float)(-log(fabs(det)));
+        out[34] = out[35] = 0.f;
+        return;
+    }
+    const bool mob = kind == RNF_KIND_MOBIUS;
+    const int yo = mob ? 3 : 0, ni = yo + F, NO = mob ? 4 * K : 16;
+    const float *W0 = P, *b0 = W0 + 64 * ni;
+    const float *hw[3], *hb[3];
+    hw[0] = b0 + 64; hb[0] = hw[0] + 4096;
+    hw[1] = hb[0] + 64; hb[1] = hw[1] + 4096;
+    hw[2] = hb[1] + 64; hb[2] = hw[2] + 4096;
+    const float *WL = hb[2] + 64, *bL = WL + (size_t)NO * 64;
+    const int n_tiles = mob ? K / 8 : 1;
+    const int rec_floats = MOB_HEAD_FLOATS + n_tiles * MOB_LAST_TILE_FLOATS;
+    // reference row of packed fc_last row `row` of tile tau (layout.h): Moebius: segment k = 8 tau + 2g + h, component c;
+    // Condition16Trans: M[2g + h][c], rows >= 16 are zero padding
+    auto src_row = [&](int tau, int row) {
+        const int g = row >> 3, h = (row >> 2) & 1, c = row & 3;
+        if (mob) { const int k = 8 * tau + 2 * g + h; return c == 0 ? k : K + 3 * k + (c - 1); }
+        return row >= 16 ? -1 : 4 * (2 * g + h) + c;
+    };
+    for (int idx = tid; idx < rec_floats; idx += nth) {
+        float v;
+        if (idx < MOB_HID) {                                           // fc_first image: float2 per lane
+            const int ot = idx >> 7, lane = (idx >> 1) & 63, e = idx & 1;
+            const int o = 32 * ot + (lane & 31), h = lane >> 5;
+            if (!mob) v = 0.f;                                         // Condition16Trans: x0 comes from the projection
+            else if (e == 0) v = W0[(size_t)o * ni + h];
+            else v = h ? (F ? 0.f : b0[o]) : W0[(size_t)o * ni + 2];
+        } else if (idx < MOB_HB) {
+            const int q = idx - MOB_HID, Lh = q >> 12;
+            const float *W = hw[Lh];
+            v = w64_image(q & 4095, prec, [&](int ot, int i) { return W + (size_t)(32 * ot + i) * 64; }, args.flags);
+        } else if (idx < MOB_HEAD_FLOATS) {
+            const int q = idx - MOB_HB;
+            v = hb[q >> 6][bias_row(q & 63)];
+        } else {
+            const int q = idx - MOB_LAST, tau = q / MOB_LAST_TILE_FLOATS, r = q % MOB_LAST_TILE_FLOATS;
+            if (r < MOB_LAST_TILE_BIAS) {
+                v = w64_image(r, prec, [&](int, int i) { const int s = src_row(tau, i); return s < 0 ? (const float *)nullptr : WL + (size_t)s * 64; },
+                              args.flags);
+            } else {
+                const int s = src_row(tau, bias_row(r - MOB_LAST_TILE_BIAS));
+                v = s < 0 ? 0.f : bL[s];
+            }
+        }
+        out[idx] = v;
+    }
+    if (L.feat_off >= 0) {                                             // feature projection record (pack_featproj / pack_featproj_h)
+        float *fo = args.blob + L.feat_off;
+        const int w_floats = prec ? 2 * ((Fp + 15) / 16) * 512 : 2 * (Fp / 8) * 256;
+        const int total = (int)featproj_packed_floats(Fp);
+        const int bias_at = w_floats;
+        for (int idx = tid; idx < total; idx += nth) {
+            float v = 0.f;
+            if (idx < w_floats) v = featproj_image(idx, prec, W0, ni, yo, F, Fp, args.flags);
+            else if (idx < bias_at + 64) v = b0[bias_row(idx - bias_at)];
+            fo[idx] = v;
+        }
+    }
+}
+
+}  // namespace rnf

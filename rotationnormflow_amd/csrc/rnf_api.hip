@@ -13,6 +13,7 @@
 #include "featproj_kernel.h"
 #include "flow_kernels.h"
 #include "train_kernels.h"
+#include "pack_device.h"
 #include "sampler_kernel.h"
 #include "layout.h"
 
@@ -490,6 +491,33 @@ extern "C" int rnf_flow_forward_train(const float *rot, const float *feat, int64
     RunOpts o{0, nullptr, nullptr, 0, nullptr, nullptr};
     o.states = states;
     return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
+}
+
+extern "C" int rnf_pack_flow_device(const float *plain, const int32_t *pdesc, int32_t n_layers, int32_t K, int32_t F, int32_t prec,
+                                    float *blob, int32_t *flags, void *stream_v) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    if (n_layers < 0 || n_layers > PK_MAX_LAYERS) return fail("n_layers=%d outside [0,%d] (device packer)", n_layers, PK_MAX_LAYERS);
+    if (K <= 0 || K % 8) return fail("segments=%d must be a positive multiple of 8", K);
+    if (F < 0) return fail("feature_dim %d is negative", F);
+    if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2) return fail("unknown precision %d", prec);
+    if (n_layers == 0) return 0;
+    if (!plain || !pdesc || !blob || !flags) return fail("null pointer argument");
+    PackArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.plain = plain; a.blob = blob; a.flags = flags;
+    a.n_layers = n_layers; a.K = K; a.F = F; a.Fp = (F + 7) / 8 * 8; a.prec = prec;
+    for (int l = 0; l < n_layers; ++l) {
+        const int32_t *d = pdesc + (size_t)l * 4;
+        const int kind = d[0] & 15;
+        if ((d[0] & ~(15 | 256)) || (kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16 && kind != RNF_KIND_COND16)) return fail("layer %d: unknown kind %d", l, d[0]);
+        if (d[1] < 0 || d[2] < 0 || d[2] % 4 || (d[3] >= 0 && d[3] % 4)) return fail("layer %d: bad offsets", l);
+        if (kind == RNF_KIND_COND16 && F == 0) return fail("layer %d: Condition16Trans needs a feature", l);
+        if (kind != RNF_KIND_AFFINE16 && (F > 0) != (d[3] >= 0)) return fail("layer %d: feature record offset does not match feature_dim", l);
+        a.layers[l] = PackLayer{d[0], d[1], d[2], d[3]};
+    }
+    hipLaunchKernelGGL(pack_flow_kernel, dim3(8, n_layers), dim3(256), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 extern "C" size_t rnf_plain_layer_floats(int32_t kind, int32_t segments, int32_t feature_dim) {

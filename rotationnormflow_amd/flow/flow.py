@@ -87,7 +87,7 @@ class Flow(nn.Module):
             return self.inverse(rotation, feature, draw)
         if not self.condition:
             feature = None
-        return runtime.run_flow(self, self._packed(rotation.device), rotation, feature, inverse=False,
+        return runtime.run_flow(self, lambda: self._packed(rotation.device), rotation, feature, inverse=False,
                                 train_layers=list(self.layers), train_rows=self._forward_rows())
 
     def inverse(self, rotation, feature=None, draw=False):

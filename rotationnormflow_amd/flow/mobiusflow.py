@@ -25,9 +25,12 @@ class _SingleLayer:
 
     def _single(self, rotation, permute, feature, inverse):
         row = 0 if permute is None else _perm_row_of(permute)
-        packed = self._cache.get(self, rotation.device, lambda: runtime.pack_layers([self], [row], rotation.device))
-        if packed.desc[0, 1] != row:
-            packed = runtime.pack_layers([self], [row], rotation.device)
+
+        def packed():
+            p = self._cache.get(self, rotation.device, lambda: runtime.pack_layers([self], [row], rotation.device))
+            if p.desc[0, 1] != row:
+                p = runtime.pack_layers([self], [row], rotation.device)
+            return p
         return runtime.run_flow(self, packed, rotation, feature, inverse=inverse, train_layers=[self], train_rows=[row])
 
 
@@ -51,6 +54,9 @@ class MobiusFlow(nn.Module, _SingleLayer):
         F = self.feature_dim if self.condition else 0
         rec, frec = runtime.pack_mobius(L, self.conditioner, self.K, F, prec)
         return rec, frec, F, self.K
+
+    def _rnf_shape(self):
+        return (self._rnf_kind, self.K, self.feature_dim if self.condition else 0)
 
     def _rnf_train_tensors(self):
         from ..autograd import mlp_train_tensors

@@ -28,6 +28,9 @@ class UnconditionRot(nn.Module, _SingleLayer):
             rot_mat = U.transpose(-1, -2) @ V
         return runtime.pack_rot16(L, rot_mat), None, 0, 0
 
+    def _rnf_shape(self):
+        return (self._rnf_kind, 0, 0)
+
     def _rnf_train_tensors(self):
         U, S, V = torch.svd(self.rot.cpu().float())      # differentiable; the 4x4 SVD stays on the host (see _rnf_pack)
         return [U.transpose(-1, -2) @ V]

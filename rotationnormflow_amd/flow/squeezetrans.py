@@ -21,6 +21,9 @@ class Uncondition16Trans(nn.Module, _SingleLayer):
     def _rnf_pack(self, L, prec=0):
         return runtime.pack_affine16(L, self.mat), None, 0, 0
 
+    def _rnf_shape(self):
+        return (self._rnf_kind, 0, 0)
+
     def _rnf_train_tensors(self):
         return [self.mat]
 
@@ -45,6 +48,9 @@ class Condition16Trans(nn.Module, _SingleLayer):
     def _rnf_pack(self, L, prec=0):
         rec, frec = runtime.pack_cond16(L, self.net, self.feature_dim, prec)
         return rec, frec, self.feature_dim, 0
+
+    def _rnf_shape(self):
+        return (self._rnf_kind, 0, self.feature_dim)
 
     def _rnf_train_tensors(self):
         from ..autograd import mlp_train_tensors
@@ -101,6 +107,9 @@ class Uncondition16TransLU(nn.Module, _SingleLayer):
     def _rnf_pack(self, L, prec=0):
         with torch.no_grad():
             return runtime.pack_affine16(L, self.mat()), None, 0, 0
+
+    def _rnf_shape(self):
+        return (self._rnf_kind, 0, 0)
 
     def _rnf_train_tensors(self):
         return [self.mat()]            # autograd chains dL/dM through the LU assembly (a few tiny tensor ops)

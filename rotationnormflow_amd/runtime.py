@@ -36,8 +36,29 @@ def get_precision() -> str:
 PERMUTE_ROWS = ((0, 1, 2), (1, 2, 0), (2, 0, 1), (0, 1, 2), (1, 2, 0), (2, 0, 1))
 
 
+_prefetched = threading.local()      # id(parameter) -> host fp32 copy, filled by pack_layers for the duration of one packing
+
+
 def _np32(t) -> np.ndarray:
+    hit = getattr(_prefetched, "map", {}).get(id(t))
+    if hit is not None:
+        return hit
     return np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+
+
+def _prefetch_parameters(layers):
+    """One device->host copy for all parameters of the stack instead of one per tensor (a training step repacks every iteration)."""
+    params = [p for layer in layers for p in layer.parameters()]
+    dev = [p for p in params if p.is_cuda]
+    if len(dev) < 2:
+        return {}
+    flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in dev]).cpu().numpy()
+    out, off = {}, 0
+    for p in dev:
+        n = p.numel()
+        out[id(p)] = flat[off: off + n].reshape(tuple(p.shape))
+        off += n
+    return out
 
 
 def _pad_cols(w: np.ndarray, first: int, feat: int, feat_padded: int) -> np.ndarray:
@@ -81,6 +102,14 @@ def pack_layers(layers, perm_rows, device, precision=None) -> PackedFlow:
             return pack_layers(layers, perm_rows, device, "fp32")
     prec = _PRECISIONS[precision]
     L = _lib.lib()
+    _prefetched.map = _prefetch_parameters(layers)
+    try:
+        return _pack_layers(layers, perm_rows, device, precision, prec, L)
+    finally:
+        _prefetched.map = {}
+
+
+def _pack_layers(layers, perm_rows, device, precision, prec, L) -> PackedFlow:
     records, feat_records = [], []
     desc = np.zeros((len(layers), DESC_STRIDE), dtype=np.int32)
     feat_dim = 0
@@ -251,15 +280,18 @@ def _refuse_autograd(rotation, feature, module, what):
             "torch.no_grad() -- there is deliberately no PyTorch fallback path")
 
 
-def run_flow(module, packed: PackedFlow, rotation, feature, inverse=False, train_layers=None, train_rows=None):
+def run_flow(module, packed, rotation, feature, inverse=False, train_layers=None, train_rows=None):
     """-> (rotation' [N,3,3], ldj [N]) through rnf_flow_forward / rnf_flow_inverse.
     When a gradient is required (training, agent.py:75-92) the forward direction goes through autograd.flow_forward, which
-    needs the layer modules and their permutation rows (``train_layers``, ``train_rows``)."""
+    needs the layer modules and their permutation rows (``train_layers``, ``train_rows``) and packs on the device itself.
+    ``packed`` may be a callable that builds the host-packed flow on demand."""
     if _needs_grad(rotation, feature, module):
         if inverse:
             _refuse_autograd(rotation, feature, module, "Flow.inverse")
         from . import autograd
-        return autograd.flow_forward(module, train_layers, train_rows, packed, rotation, feature)
+        return autograd.flow_forward(module, train_layers, train_rows, rotation, feature)
+    if callable(packed):
+        packed = packed()
     rot, feat = _check_inputs(rotation, feature, packed)
     n = rot.shape[0]
     L = _lib.lib()

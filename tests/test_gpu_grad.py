@@ -136,3 +136,52 @@ def test_adam_steps_follow_the_oracle():
         lp.append(float(loss))
     assert lo[-1] < lo[0] - 1e-3                              # it learns
     assert np.abs(np.array(lo) - np.array(lp)).max() < 2e-4, (lo, lp)
+
+
+@pytest.mark.parametrize("name,precision", [("uncond_k64_24", "f16x2"), ("uncond_k64_24", "fp32"), ("cond_k32", "f16x2"),
+                                            ("cond_first_affine", "f16x2"), ("lu", "f16x2"), ("rot", "fp32")])
+def test_device_packer_matches_host_packer(name, precision):
+    """rnf_pack_flow_device (training: parameters change every step) must produce the blob of the host packers: bit for bit for the
+    conditioner images, to fp32 rounding for the 4x4 records (inverse / log-det computed in double on either side)."""
+    from rotationnormflow_amd import autograd, runtime
+    cfg, w, R, feat, gR, gl = _make(name)
+    fl = product_flow(cfg, w)
+    layers, rows = list(fl.layers), fl._forward_rows()
+    host = runtime.pack_layers(layers, rows, "cuda", precision)
+    plan = autograd.TrainPlan(layers, rows, torch.device("cuda"), precision)
+    assert np.array_equal(plan.desc, host.desc)
+    with torch.no_grad():
+        plain = torch.cat([t.detach().to("cuda", torch.float32).reshape(-1) for t in autograd.train_tensors(layers)])
+    blob = plan.pack(plain, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got, want = blob.cpu().numpy(), host.blob.cpu().numpy()
+    assert got.shape == want.shape
+    for i, layer in enumerate(layers):
+        off = plan.desc[i, 2]
+        if layer._rnf_kind == runtime.KIND_AFFINE16:
+            np.testing.assert_allclose(got[off:off + 36], want[off:off + 36], rtol=2e-6, atol=2e-7)
+        else:
+            size = plan.desc[i + 1, 2] - off if i + 1 < len(layers) else None
+            end = off + size if size is not None else (plan.desc[:, 4][plan.desc[:, 4] >= 0].min() if plan.n_cond else got.size)
+            assert np.array_equal(got[off:end].view(np.uint32), want[off:end].view(np.uint32)), (i, type(layer).__name__)
+        if plan.desc[i, 4] >= 0:
+            fo = plan.desc[i, 4]
+            n = 2 * ((plan.feat_padded + 15) // 16) * 512 + 64 if precision == "f16x2" else 2 * (plan.feat_padded // 8) * 256 + 64
+            assert np.array_equal(got[fo:fo + n].view(np.uint32), want[fo:fo + n].view(np.uint32)), (i, "feature projection")
+
+
+def test_half_range_overflow_is_reported():
+    from rotationnormflow_amd import runtime
+    cfg, w, R, feat, gR, gl = _make("uncond_k16")
+    w = dict(w)
+    key = next(k for k in w if k.endswith("conditioner.layers.3.weight"))
+    w[key] = w[key].copy()
+    w[key][0, 0] = 1e6
+    fl = product_flow(cfg, w).train()
+    if runtime.get_precision() != "f16x2":
+        pytest.skip("only the split-precision kernels have a range limit")
+    Rd = torch.from_numpy(R).cuda()
+    fl(Rd)
+    torch.cuda.synchronize()
+    with pytest.raises(runtime.HalfRangeError):
+        fl(Rd)                                                  # reported one call later (no step waits for the device)

@@ -551,13 +551,26 @@ extern "C" int rnf_flow_backward(const float *states, const float *feat, int64_t
     a.states = states; a.feature = F ? feat : nullptr; a.plain = plain; a.grads = grads; a.g_rot_out = g_rot_out; a.g_ldj = g_ldj;
     a.g_rot_in = g_rot_in; a.g_feature = F ? g_feature : nullptr; a.g_ldj_sum = g_ldj_sum;
     a.n = n; a.n_layers = n_layers; a.K = K; a.F = F;
-    const size_t rows = (4 * (size_t)K > 16 ? 4 * (size_t)K : 16);
-    const size_t lds_bytes = sizeof(float) * (24576 + rows * 64);
-    auto kern = flow_train_backward_kernel;
-    HIP_TRY(allow_lds(kern, lds_bytes));
+#ifdef RNF_STAMPS
+    {   // diagnostic build: RNF_TRAIN_STAMPS_PTR=<device address of 10 zeroed uint64> (tools/phase_stamps_train.py)
+        const char *sp = std::getenv("RNF_TRAIN_STAMPS_PTR");
+        a.stamps = sp ? reinterpret_cast<unsigned long long *>(std::strtoull(sp, nullptr, 0)) : nullptr;
+    }
+#endif
+    const size_t rows = (4 * (size_t)K + 63) / 64 * 64;      // conditioner-output rows, padded to whole 64-row slabs (train_kernels.h)
+    const size_t lds_bytes = sizeof(float) * (TR_LDS_HEAD_FLOATS + rows * LROW);
     const long long nblocks = (n + 63) / 64;
     const int cap = device_cus() * 4;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nblocks < cap ? nblocks : cap)), dim3(TR_WAVES * 64), lds_bytes, stream, a);
+    const dim3 grid((unsigned)(nblocks < cap ? nblocks : cap)), block(TR_WAVES * 64);
+    if (F) {
+        auto kern = flow_train_backward_kernel<true>;
+        HIP_TRY(allow_lds(kern, lds_bytes));
+        hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+    } else {
+        auto kern = flow_train_backward_kernel<false>;
+        HIP_TRY(allow_lds(kern, lds_bytes));
+        hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+    }
     HIP_TRY(hipGetLastError());
     if (n_layers) {
         hipLaunchKernelGGL(affine_logdet_grad_kernel, dim3((n_layers + 63) / 64), dim3(64), 0, stream, a);

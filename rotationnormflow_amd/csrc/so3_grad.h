@@ -125,32 +125,35 @@ RNF_HD void mobius_segments_backward_range(const MobiusSaved &sv, const CondRow 
         // recompute the segment (cheaper than storing 6 values x K per sample)
         const float wr = fmaf(w2, sv.f.r.z, fmaf(w1, sv.f.r.y, w0 * sv.f.r.x));
         const float wv = fmaf(w2, sv.f.v.z, fmaf(w1, sv.f.v.y, w0 * sv.f.v.x));
-        const float n = sqrtf(fmaf(wv, wv, wr * wr));
-        const float sc = 0.7f / (1.0f + n);
+        const float n = hw_sqrt(fmaf(wv, wv, wr * wr));
+        const float inv1n = hw_rcp(1.0f + n);
+        const float sc = 0.7f * inv1n;
         const float ur = wr * sc, uv = wv * sc;
         const float e1 = 1.0f + ur;                       // z = (-1, 0): a = -ur, b = -uv
-        const float t = uv / e1;
+        const float inv_e1 = hw_rcp(e1);
+        const float t = uv * inv_e1;
         const float phi = fmaf(2.0f, atan_unit(t), kPi);
         const float u2 = fmaf(uv, uv, ur * ur), d2 = fmaf(uv, uv, e1 * e1);
-        const float c = (1.0f - u2) / d2;
+        const float inv_d2 = hw_rcp(d2);
+        const float c = (1.0f - u2) * inv_d2;
         const float sp = softplus(s_raw);
         // d/d(sp, phi, c)
         const float g_sp = mg.g_S + mg.g_A * phi + mg.g_J * c;
         const float g_phi = mg.g_A * sp, g_c = mg.g_J * sp;
         // sp = softplus(s): sigmoid
-        g_cond.put(k, g_sp / (1.0f + expf(-s_raw)));
+        g_cond.put(k, g_sp * hw_rcp(1.0f + hw_exp2(-1.44269504088896341f * s_raw)));
         // phi = pi + 2 atan(t), t = uv / e1
-        const float g_t = g_phi * 2.0f / (1.0f + t * t);
-        float g_uv = g_t / e1, g_ur = -g_t * t / e1;
+        const float g_t = g_phi * 2.0f * hw_rcp(fmaf(t, t, 1.0f));
+        float g_uv = g_t * inv_e1, g_ur = -g_t * t * inv_e1;
         // c = (1 - u2) / d2
-        const float g_u2 = -g_c / d2, g_d2 = -g_c * c / d2;
+        const float g_u2 = -g_c * inv_d2, g_d2 = -g_c * c * inv_d2;
         g_ur += 2.0f * ur * g_u2 + 2.0f * e1 * g_d2;
         g_uv += 2.0f * uv * g_u2 + 2.0f * uv * g_d2;
         // ur = wr sc, uv = wv sc, sc = 0.7 / (1 + n), n = |(wr, wv)|
         const float g_sc = g_ur * wr + g_uv * wv;
         float g_wr = g_ur * sc, g_wv = g_uv * sc;
-        const float g_n = -g_sc * sc / (1.0f + n);
-        if (n > 0.f) { g_wr += g_n * wr / n; g_wv += g_n * wv / n; }
+        const float g_n = -g_sc * sc * inv1n;
+        if (n > 0.f) { const float gn = g_n * hw_rcp(n); g_wr = fmaf(gn, wr, g_wr); g_wv = fmaf(gn, wv, g_wv); }
         // wr = w.r, wv = w.v
         g_cond.put(K + 3 * k, g_wr * sv.f.r.x + g_wv * sv.f.v.x);
         g_cond.put(K + 3 * k + 1, g_wr * sv.f.r.y + g_wv * sv.f.v.y);

@@ -40,15 +40,19 @@ struct TrainArgs {
     float *g_ldj_sum;         // [n_layers] sum over the batch of dL/dldj (for the log|det M| term), zeroed by the caller
     long long n;
     int n_layers, K, F;
+    unsigned long long *stamps;   // diagnostic builds only (RNF_STAMPS): per-phase cycle sums of wave 0, else nullptr
     // per layer: x = kind | perm_row << 4 | orthogonal << 8, y = plain offset
     int2 layers[TR_MAX_LAYERS];
 };
 
-// LDS matrix [rows][64 samples] with an XOR swizzle: conflict free both for "lanes = 32 consecutive samples of one row" and for
-// "lanes = 32 consecutive rows at one sample" (the two MFMA operand patterns)
+// LDS matrix [rows][64 samples], rows padded to 65 floats: conflict free both for "lanes = 32 consecutive samples of one row"
+// and for "lanes = 32 consecutive rows at one sample" (the two MFMA operand patterns), and -- unlike an XOR swizzle -- every
+// unrolled access is base register + immediate offset, so the reads of a product issue back to back
+constexpr int LROW = 65;
+constexpr int TR_LDS_HEAD_FLOATS = 5 * 64 * LROW + 4 * LROW;   // X0, H1, H2, H3, GA, YL
 struct LMat {
     float *p;
-    __device__ __forceinline__ float &at(int row, int s) const { return p[row * 64 + (s ^ (row & 63))]; }
+    __device__ __forceinline__ float &at(int row, int s) const { return p[row * LROW + s]; }
 };
 
 // one lane's column of an LMat as a conditioner-output row (so3_grad.h accessor)
@@ -68,42 +72,73 @@ __device__ __forceinline__ f32x16 zero16() {
     return c;
 }
 
-// acc[rho][j] += sum_{k<64} W[row][k] * b(k):  A = 32 rows of a row-major weight matrix (16-byte aligned rows, 64 columns),
-// this lane supplies row `row` (masked by row_ok), k = 32h + m.  b(k): B element (k, this lane's sample).
+// ---- A operands, loaded ahead of the phase that multiplies with them (the loads then overlap the previous phase and its barrier).
+// No load is followed by a select: a select right behind each load makes the compiler reuse one destination register and
+// serialise the loads.  Out-of-range rows / columns are handled by clamping the ADDRESS (finite values) and by making the other
+// operand zero (zeroed pad rows in LDS) or by discarding the output rows / columns they feed.
+// 32 rows of a row-major weight matrix with 64 columns (16-byte aligned rows): this lane holds W[row][32h .. 32h + 31] and the
+// row's bias, which enters the product as one more K step against a column of ones (1 register instead of a 16-register image).
+// Rows >= n_rows repeat the last row: their output rows are never stored.
+struct RowsA { float4 w[8]; float bias; };
+__device__ __forceinline__ RowsA load_rows64(const float *__restrict__ W, const float *__restrict__ bias, int row, int n_rows, int h) {
+    RowsA a;
+    const int rc = row < n_rows ? row : n_rows - 1;
+    a.bias = bias[rc];
+    const float4 *src = reinterpret_cast<const float4 *>(W + (size_t)rc * 64 + 32 * h);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a.w[q] = src[q];
+    return a;
+}
+// D[rho][j] = bias[row] + sum_{k<64} W[row][k] * b(k), k = 32h + m.  b(k): B element (k, this lane's sample).  The B reads of half
+// a product are issued before its first MFMA (sched_barrier), so that the dependent MFMA chain runs back to back instead of paying
+// one LDS latency per step.
 template <class BFn>
-__device__ __forceinline__ f32x16 mfma_rows64(const float *__restrict__ W, int row, bool row_ok, int h, BFn b, f32x16 acc) {
-    float4 w[8];
-    const float4 *src = reinterpret_cast<const float4 *>(W + (size_t)row * 64 + 32 * h);
+__device__ __forceinline__ f32x16 mfma_rows64(const RowsA &a, int h, BFn b) {
+    f32x16 acc = RNF_MFMA(a.bias, h ? 0.f : 1.f, zero16());
 #pragma unroll
-    for (int q = 0; q < 8; ++q) w[q] = row_ok ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int half = 0; half < 2; ++half) {                 // 16 B reads in flight, then 16 MFMAs
+        float bv[16];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int k = 32 * h + 4 * q;
-        acc = RNF_MFMA(w[q].x, b(k), acc);
-        acc = RNF_MFMA(w[q].y, b(k + 1), acc);
-        acc = RNF_MFMA(w[q].z, b(k + 2), acc);
-        acc = RNF_MFMA(w[q].w, b(k + 3), acc);
+        for (int m = 0; m < 16; ++m) bv[m] = b(32 * h + 16 * half + m);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc = RNF_MFMA(a.w[4 * half + q].x, bv[4 * q], acc);
+            acc = RNF_MFMA(a.w[4 * half + q].y, bv[4 * q + 1], acc);
+            acc = RNF_MFMA(a.w[4 * half + q].z, bv[4 * q + 2], acc);
+            acc = RNF_MFMA(a.w[4 * half + q].w, bv[4 * q + 3], acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     return acc;
 }
 
-// acc[rho][j] += sum_{k<nk} W[k][col] * b(k): A = 32 columns of a row-major matrix with leading dimension ldw (the transposed
-// product); this lane supplies column `col` (masked by col_ok), k = (nk/2) h + m.  nk even.
+// 32 columns of a row-major matrix (the transposed product): this lane holds W[k0 + 32h + m][col], m < 32.  Rows >= n_rows repeat
+// the last row (their B partners must be zero); columns >= n_cols repeat the last column (their output rows are discarded).
+struct ColsA { float a[32]; };
+__device__ __forceinline__ ColsA load_cols(const float *__restrict__ W, int ldw, int k0, int n_rows, int col, int n_cols, int h) {
+    ColsA c;
+    const int kb = k0 + 32 * h;
+    const float *p = W + (size_t)(kb < n_rows ? kb : n_rows - 1) * ldw + (col < n_cols ? col : n_cols - 1);   // stepped pointer
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+        c.a[m] = *p;
+        if (kb + m + 1 < n_rows) p += ldw;
+    }
+    return c;
+}
+// acc[rho][j] += sum_{k in [k0, k0 + 64)} W[k][col] * b(k)
 template <class BFn>
-__device__ __forceinline__ f32x16 mfma_cols(const float *__restrict__ W, int ldw, int nk, int col, bool col_ok, int h, BFn b, f32x16 acc) {
-    const int half = nk >> 1;
-    for (int m0 = 0; m0 < half; m0 += 16) {
-        float a[16];
+__device__ __forceinline__ f32x16 mfma_cols(const ColsA &c, int k0, int h, BFn b, f32x16 acc) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int k = half * h + m0 + u;
-            a[u] = (col_ok && m0 + u < half) ? W[(size_t)k * ldw + col] : 0.f;
-        }
+    for (int half = 0; half < 2; ++half) {
+        float bv[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int k = half * h + m0 + u;
-            acc = RNF_MFMA(a[u], (m0 + u < half) ? b(k) : 0.f, acc);
-        }
+        for (int m = 0; m < 16; ++m) bv[m] = b(k0 + 32 * h + 16 * half + m);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) acc = RNF_MFMA(c.a[16 * half + m], bv[m], acc);
+        __builtin_amdgcn_sched_barrier(0);
     }
     return acc;
 }
@@ -112,8 +147,16 @@ __device__ __forceinline__ f32x16 mfma_cols(const float *__restrict__ W, int ldw
 template <class AFn, class BFn>
 __device__ __forceinline__ f32x16 mfma_samples(int h, AFn a, BFn b) {
     f32x16 acc = zero16();
-#pragma unroll 8
-    for (int m = 0; m < 32; ++m) acc = RNF_MFMA(a(32 * h + m), b(32 * h + m), acc);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float av[16], bv[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) { av[m] = a(32 * h + 16 * half + m); bv[m] = b(32 * h + 16 * half + m); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) acc = RNF_MFMA(av[m], bv[m], acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     return acc;
 }
 
@@ -134,40 +177,56 @@ __device__ __forceinline__ void store_tile(const LMat &M, int o0, int n_out, int
     }
 }
 
+// sum over the 4 lanes of a quad (DPP, no LDS)
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lanes 1,0,3,2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // lanes 2,3,0,1
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
-// gb[o] += sum_s G[o][s] for o < n_out (thread t handles rows t, t + 256, ...)
+// gb[o] += sum_s G[o][s] for o < n_out: four threads per row (16 samples each), 64 rows per pass of the workgroup
 __device__ __forceinline__ void bias_grad(const LMat &G, int n_out, float *gb, int tid) {
-    for (int o = tid; o < n_out; o += TR_WAVES * 64) {
+    const int q = tid & 3;
+    for (int o = tid >> 2; o < n_out; o += TR_WAVES * 16) {
         float acc = 0.f;
-#pragma unroll 8
-        for (int s = 0; s < 64; ++s) acc += G.at(o, s);
-        atomicAdd(gb + o, acc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += G.at(o, 16 * q + i);
+        acc = quad_sum(acc);
+        if (q == 0) atomicAdd(gb + o, acc);
     }
 }
 
-// hidden layer forward: OUT = W relu?(IN) + b, one 32x32 tile per wave
-template <class BFn>
-__device__ __forceinline__ void hidden_forward(const float *W, const float *bias, BFn in, const LMat &OUT, int ta, int tb, int j, int h) {
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = bias[32 * ta + rho(r, h)];
-    acc = mfma_rows64(W, 32 * ta + j, true, h, in, acc);
-    store_tile(OUT, 32 * ta, 64, 32 * tb + j, h, acc);
-}
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, NOT for its outstanding global loads
+// (__syncthreads() also drains vmcnt, which would serialise the A-operand loads issued one phase ahead with every barrier)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// phase stamps of the diagnostic build (tools/phase_stamps_train.py), same mechanism as flow_kernels.h
+#ifdef RNF_STAMPS
+#define RNF_TSTAMP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = clock64(); tst_acc[i] += now_ - tst_t; tst_t = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define RNF_TSTAMP(i)
+#endif
+
+template <bool HAS_FEATURE>
 __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(const TrainArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef RNF_STAMPS
+    unsigned long long tst_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tst_t = clock64();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int ta = wave >> 1, tb = wave & 1;              // this wave's 32x32 tile of a 64 x 64 product
-    const int K = args.K, F = args.F;
-    // LDS: X0, H1, H2, H3 (pre-activations), GA, GB (gradients / reduction scratch), C (conditioner output, then its gradient)
-    const LMat X0{lds}, H1{lds + 4096}, H2{lds + 8192}, H3{lds + 12288}, GA{lds + 16384}, GB{lds + 20480}, Cm{lds + 24576};
+    const int K = args.K, F = HAS_FEATURE ? args.F : 0;
+    // LDS: X0, H1, H2, H3 (pre-activations, later reused for gradients), GA (gradient / reduction scratch), C (conditioner output,
+    // then its gradient)
+    const LMat X0{lds}, H1{lds + 64 * LROW}, H2{lds + 2 * 64 * LROW}, H3{lds + 3 * 64 * LROW}, GA{lds + 4 * 64 * LROW},
+        YL{lds + 5 * 64 * LROW}, Cm{lds + TR_LDS_HEAD_FLOATS};     // YL: the conditioning column y of the 64 rotations, [3][64]
     float *red = GA.p;                                    // [wave][value][lane] while GA is not in use
 
     const long long nblocks = (args.n + 63) / 64;
@@ -210,16 +269,20 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                 for (int i = 0; i < 16; ++i) gM[i] = 0.f;
                 const bool orth = (d.x >> 8) & 1;         // UnconditionRot: ldj = 0 (flow/rottrans.py:21)
                 affine16_backward(M, sv, gR, g_ldj, orth, gM, gRin);
-                if (wave == 0) {
+                if (wave == 0) {                          // batch sums through LDS: lane 4v + q adds 16 rotations of entry v
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float tot = wave_sum(valid ? gM[i] : 0.f);
-                        if (lane == 0) atomicAdd(Gp + i, tot);
-                    }
+                    for (int i = 0; i < 16; ++i) GA.at(i, lane) = valid ? gM[i] : 0.f;
+                    const int v = lane >> 2, q = lane & 3;
+                    float tot = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) tot += GA.at(v, 16 * q + i);
+                    tot = quad_sum(tot);
+                    if (q == 0) atomicAdd(Gp + v, tot);
                     const float gl = wave_sum(valid && !orth ? g_ldj : 0.f);
                     if (lane == 0) atomicAdd(args.g_ldj_sum + pos, gl);
                 }
                 gR = gRin;
+                RNF_TSTAMP(8)
                 continue;
             }
             // ---- layers with a conditioner MLP (Moebius: input y (+) feature, 4K outputs; Condition16Trans: feature, 16 outputs) ----
@@ -234,52 +297,85 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
             const int ntiles = (NO + 31) / 32;            // row tiles of fc_last
 
             // ================= forward recompute =================
-            // x0 = b0 + W0[:, yo:] f  (matrix cores, K dimension = F in chunks of 64)  + W0[:, :3] y (per lane, below)
+            // (A operands are loaded one phase ahead: RowsA / ColsA, so their latency hides behind the previous phase and barrier)
+            RowsA wnext = load_rows64(W1, b1, 32 * ta + j, 64, h);
+            if (mob && wave == 0) { YL.at(0, lane) = y.x; YL.at(1, lane) = y.y; YL.at(2, lane) = y.z; }
+            for (int o = NO + wave; o < ((NO + 63) & ~63); o += TR_WAVES) Cm.at(o, lane) = 0.f;      // pad rows of C: B side of WL^T slabs
+            const int bs = 32 * tb + j;                   // this lane's B column (sample) in [0, 64)
+            // x0 = b0 + W0[:, yo:] f  (K dimension = F in chunks of 64) + W0[:, :3] y (two K = 2 steps)
             {
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = b0[32 * ta + rho(r, h)];
-                for (int c0 = 0; c0 < F; c0 += 64) {
+                f32x16 acc = RNF_MFMA(b0[32 * ta + j], h ? 0.f : 1.f, zero16());
+                const float *wrow = W0 + (size_t)(32 * ta + j) * NI;
+                for (int c0 = 0; HAS_FEATURE && c0 < F; c0 += 64) {
                     for (int m0 = 0; m0 < 32; m0 += 16) {
                         float a[16], b[16];
 #pragma unroll
                         for (int u = 0; u < 16; ++u) {
-                            const int k = c0 + 32 * h + m0 + u;
-                            a[u] = k < F ? W0[(size_t)(32 * ta + j) * NI + yo + k] : 0.f;
-                            b[u] = (k < F && bvalid) ? args.feature[bsample * F + k] : 0.f;
+                            const int k = c0 + 32 * h + m0 + u, kc = k < F ? k : F - 1;
+                            a[u] = wrow[yo + kc];
+                            b[u] = args.feature[(bvalid ? bsample : 0) * F + kc];
                         }
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) acc = RNF_MFMA(a[u], b[u], acc);
+                        for (int u = 0; u < 16; ++u) {
+                            const int k = c0 + 32 * h + m0 + u;
+                            acc = RNF_MFMA(k < F ? a[u] : 0.f, bvalid ? b[u] : 0.f, acc);
+                        }
                     }
                 }
-                store_tile(X0, 32 * ta, 64, 32 * tb + j, h, acc);
-            }
-            __syncthreads();
-            if (mob) {
-                for (int o = 16 * wave; o < 16 * wave + 16; ++o)
-                    X0.at(o, lane) += fmaf(W0[(size_t)o * NI + 2], y.z, fmaf(W0[(size_t)o * NI + 1], y.y, W0[(size_t)o * NI] * y.x));
-                __syncthreads();
-            }
-            const int bs = 32 * tb + j;                   // this lane's B column (sample) in [0, 64)
-            hidden_forward(W1, b1, [&](int k) { return fmaxf(X0.at(k, bs), 0.f); }, H1, ta, tb, j, h);
-            __syncthreads();
-            hidden_forward(W3, b3, [&](int k) { return fmaxf(H1.at(k, bs), 0.f); }, H2, ta, tb, j, h);
-            __syncthreads();
-            hidden_forward(W5, b5, [&](int k) { return fmaxf(H2.at(k, bs), 0.f); }, H3, ta, tb, j, h);
-            __syncthreads();
-            auto t_at = [&](int k, int s) { return fmaxf(X0.at(k, s) + H3.at(k, s), 0.f); };      // t = relu(x0 + h3)
-            for (int rt = ta; rt < ntiles; rt += 2) {     // fc_last: C = WL t + bL
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int o = 32 * rt + rho(r, h);
-                    acc[r] = o < NO ? bL[o] : 0.f;
+                if (mob) {
+                    const float a0 = wrow[h], a2 = wrow[2];
+                    lds_barrier();                        // YL
+                    acc = RNF_MFMA(a0, YL.at(h, bs), acc);
+                    acc = RNF_MFMA(h ? 0.f : a2, h ? 0.f : YL.at(2, bs), acc);
                 }
-                acc = mfma_rows64(WL, 32 * rt + j, 32 * rt + j < NO, h, [&](int k) { return t_at(k, bs); }, acc);
-                store_tile(Cm, 32 * rt, NO, bs, h, acc);
+                store_tile(X0, 32 * ta, 64, bs, h, acc);
             }
-            __syncthreads();
-
+            lds_barrier();
+            RNF_TSTAMP(0)
+            // H1, H2 hold relu(h1), relu(h2); H3 holds t = relu(x0 + h3) (the ReLU masks only need the sign)
+            {
+                const RowsA w1 = wnext;
+                wnext = load_rows64(W3, b3, 32 * ta + j, 64, h);
+                f32x16 acc = mfma_rows64(w1, h, [&](int k) { return fmaxf(X0.at(k, bs), 0.f); });
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+                store_tile(H1, 32 * ta, 64, bs, h, acc);
+            }
+            lds_barrier();
+            {
+                const RowsA w3 = wnext;
+                wnext = load_rows64(W5, b5, 32 * ta + j, 64, h);
+                f32x16 acc = mfma_rows64(w3, h, [&](int k) { return H1.at(k, bs); });
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+                store_tile(H2, 32 * ta, 64, bs, h, acc);
+            }
+            lds_barrier();
+            RowsA wA, wB;
+            {
+                const RowsA w5 = wnext;
+                wA = load_rows64(WL, bL, 32 * ta + j, NO, h);
+                f32x16 acc = mfma_rows64(w5, h, [&](int k) { return H2.at(k, bs); });
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r] + X0.at(32 * ta + rho(r, h), bs), 0.f);
+                store_tile(H3, 32 * ta, 64, bs, h, acc);
+            }
+            const LMat &T = H3;
+            lds_barrier();
+            RNF_TSTAMP(1)
+            for (int rt = ta; rt < ntiles; rt += 4) {     // fc_last: C = WL t + bL, two tiles per trip (A operands ping-pong)
+                const bool has_b = rt + 2 < ntiles;
+                if (has_b) wB = load_rows64(WL, bL, 32 * (rt + 2) + j, NO, h);
+                store_tile(Cm, 32 * rt, NO, bs, h, mfma_rows64(wA, h, [&](int k) { return T.at(k, bs); }));
+                if (has_b) {
+                    if (rt + 4 < ntiles) wA = load_rows64(WL, bL, 32 * (rt + 4) + j, NO, h);
+                    store_tile(Cm, 32 * (rt + 2), NO, bs, h, mfma_rows64(wB, h, [&](int k) { return T.at(k, bs); }));
+                }
+            }
+            ColsA cA = load_cols(WL, 64, 0, NO, 32 * ta + j, 64, h), cB;       // first slab of WL^T, needed after the layer math
+            lds_barrier();
+            RNF_TSTAMP(2)
             // ================= layer math: forward sums + backward; dL/dC overwrites C =================
             Rot gRin;
             if (mob) {
@@ -292,7 +388,7 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                 red[(wave * 3 + 0) * 64 + lane] = S;
                 red[(wave * 3 + 1) * 64 + lane] = A;
                 red[(wave * 3 + 2) * 64 + lane] = J;
-                __syncthreads();
+                lds_barrier();
                 S = A = J = 0.f;
 #pragma unroll
                 for (int w = 0; w < TR_WAVES; ++w) {
@@ -306,7 +402,7 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                 float *red2 = red + TR_WAVES * 3 * 64;
                 red2[(wave * 6 + 0) * 64 + lane] = pr.x; red2[(wave * 6 + 1) * 64 + lane] = pr.y; red2[(wave * 6 + 2) * 64 + lane] = pr.z;
                 red2[(wave * 6 + 3) * 64 + lane] = pv.x; red2[(wave * 6 + 4) * 64 + lane] = pv.y; red2[(wave * 6 + 5) * 64 + lane] = pv.z;
-                __syncthreads();
+                lds_barrier();
 #pragma unroll
                 for (int w = 0; w < TR_WAVES; ++w) {
                     mg.g_r = mg.g_r + v3f{red2[(w * 6 + 0) * 64 + lane], red2[(w * 6 + 1) * 64 + lane], red2[(w * 6 + 2) * 64 + lane]};
@@ -324,67 +420,81 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                 float l;
                 affine16_forward_saved(M, 0.f, Rin, Rout, l, sv);
                 affine16_backward(M, sv, gR, g_ldj, false, gM, gRin);
-                __syncthreads();                          // every wave has read C
+                lds_barrier();                          // every wave has read C
                 if (wave == 0) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) Cm.at(4 * i + jj, lane) = gM[4 * i + jj] + g_ldj * Mi[4 * jj + i];
                 }
-                __syncthreads();
+                lds_barrier();
             }
             // (padding lanes carry gR = 0 and g_ldj = 0, so their dL/dC and everything derived from it is exactly 0)
 
+            RNF_TSTAMP(3)
             // ================= conditioner backward =================
             // fc_last: gWL += g_c t^T, gbL += rowsum(g_c), g_t = WL^T g_c
             for (int rt = ta; rt < ntiles; rt += 2) {
-                const int o = 32 * rt + j;
-                const f32x16 acc = mfma_samples(h, [&](int s) { return o < NO ? Cm.at(o, s) : 0.f; }, [&](int s) { return t_at(32 * tb + j, s); });
+                const f32x16 acc = mfma_samples(h, [&](int s) { return Cm.at(32 * rt + j, s); }, [&](int s) { return T.at(32 * tb + j, s); });
                 scatter_add(gWL, 64, 32 * rt, NO, 32 * tb + j, true, h, acc);
             }
             bias_grad(Cm, NO, gbL, tid);
+            RNF_TSTAMP(4)
             {
-                f32x16 acc = mfma_cols(WL, 64, NO, 32 * ta + j, true, h, [&](int k) { return Cm.at(k, bs); }, zero16());
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {            // through t = relu(x0 + h3): this is dL/dh3 and the residual part of dL/dx0
-                    const int i = 32 * ta + rho(r, h);
-                    acc[r] = (X0.at(i, bs) + H3.at(i, bs)) > 0.f ? acc[r] : 0.f;
+                f32x16 acc = zero16();
+                for (int k0 = 0; k0 < NO; k0 += 128) {    // two 64-row slabs of WL^T per trip (A operands ping-pong)
+                    const bool has_b = k0 + 64 < NO;
+                    if (has_b) cB = load_cols(WL, 64, k0 + 64, NO, 32 * ta + j, 64, h);
+                    else cB = load_cols(W5, 64, 0, 64, 32 * ta + j, 64, h);                // ahead: W5^T for the first hidden step
+                    acc = mfma_cols(cA, k0, h, [&](int k) { return Cm.at(k, bs); }, acc);
+                    if (has_b) {
+                        if (k0 + 128 < NO) cA = load_cols(WL, 64, k0 + 128, NO, 32 * ta + j, 64, h);
+                        else cA = load_cols(W5, 64, 0, 64, 32 * ta + j, 64, h);
+                        acc = mfma_cols(cB, k0 + 64, h, [&](int k) { return Cm.at(k, bs); }, acc);
+                    } else {
+                        cA = cB;
+                    }
                 }
-                __syncthreads();                          // `red` (inside GA) is no longer read
+#pragma unroll
+                for (int r = 0; r < 16; ++r)              // through t = relu(x0 + h3): this is dL/dh3 and the residual part of dL/dx0
+                    acc[r] = T.at(32 * ta + rho(r, h), bs) > 0.f ? acc[r] : 0.f;
+                lds_barrier();                            // `red` (inside GA) is no longer read
                 store_tile(GA, 32 * ta, 64, bs, h, acc);
             }
-            __syncthreads();
-            // hidden layers, last to first.  (g_out, act_in) -> gW, gb, g_in masked by the ReLU of its pre-activation
-            auto hidden_backward = [&](const float *W, float *gW, float *gb, const LMat &Gout, const LMat &PreIn, const LMat &Gin) {
+            lds_barrier();
+            RNF_TSTAMP(5)
+            // hidden layers, last to first.  (g_out, act_in) -> gW, gb, g_in masked by the ReLU of its pre-activation.
+            // cA holds the transposed weights of this step; Wnext: the matrix of the FOLLOWING step (loaded ahead), or nullptr
+            auto hidden_backward = [&](float *gW, float *gb, const LMat &Gout, const LMat &PreIn, const LMat &Gin, const float *Wnext) {
+                if (Wnext) cB = load_cols(Wnext, 64, 0, 64, 32 * ta + j, 64, h);
                 const f32x16 wg = mfma_samples(h, [&](int s) { return Gout.at(32 * ta + j, s); }, [&](int s) { return fmaxf(PreIn.at(32 * tb + j, s), 0.f); });
                 scatter_add(gW, 64, 32 * ta, 64, 32 * tb + j, true, h, wg);
                 bias_grad(Gout, 64, gb, tid);
-                f32x16 acc = mfma_cols(W, 64, 64, 32 * ta + j, true, h, [&](int k) { return Gout.at(k, bs); }, zero16());
+                f32x16 acc = mfma_cols(cA, 0, h, [&](int k) { return Gout.at(k, bs); }, zero16());
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = PreIn.at(32 * ta + rho(r, h), bs) > 0.f ? acc[r] : 0.f;
-                __syncthreads();                          // Gin may alias a buffer other waves were still reading
+                lds_barrier();                            // Gin may alias a buffer other waves were still reading
                 store_tile(Gin, 32 * ta, 64, bs, h, acc);
-                __syncthreads();
+                if (Wnext) cA = cB;
+                lds_barrier();
             };
-            hidden_backward(W5, gW5, gb5, GA, H2, GB);    // g_h3 (GA) -> g_h2 (GB)
-            hidden_backward(W3, gW3, gb3, GB, H1, H3);    // g_h2 (GB) -> g_h1 (H3's storage: h3 is no longer needed)
-            hidden_backward(W1, gW1, gb1, H3, X0, H2);    // g_h1      -> chain part of g_x0 (H2's storage)
-            // total dL/dx0 = chain + residual, into GB
-            for (int o = 16 * wave; o < 16 * wave + 16; ++o) GB.at(o, lane) = H2.at(o, lane) + GA.at(o, lane);
-            __syncthreads();
+            // (each activation buffer is free once its ReLU mask has been applied, and takes the next gradient)
+            hidden_backward(gW5, gb5, GA, H2, H3, W3);    // g_h3 (GA) -> g_h2 (H3's storage)
+            hidden_backward(gW3, gb3, H3, H1, H2, W1);    // g_h2      -> g_h1 (H2's storage)
+            hidden_backward(gW1, gb1, H2, X0, H1, nullptr);   // g_h1  -> chain part of g_x0 (H1's storage)
+            RNF_TSTAMP(6)
+            const LMat GB = H3;                           // total dL/dx0 = chain + residual
+            for (int o = 16 * wave; o < 16 * wave + 16; ++o) GB.at(o, lane) = H1.at(o, lane) + GA.at(o, lane);
+            lds_barrier();
             // fc_first: x0 = W0 (y (+) f) + b0
             bias_grad(GB, 64, gb0, tid);
             if (mob) {
-                for (int o = 16 * wave; o < 16 * wave + 16; ++o) {          // gW0[:, 0:3]: this wave's 16 rows
-                    const float go = GB.at(o, lane);
-                    const float c0 = wave_sum(go * y.x), c1 = wave_sum(go * y.y), c2 = wave_sum(go * y.z);
-                    if (lane == 0) {
-                        atomicAdd(gW0 + (size_t)o * NI, c0);
-                        atomicAdd(gW0 + (size_t)o * NI + 1, c1);
-                        atomicAdd(gW0 + (size_t)o * NI + 2, c2);
-                    }
+                if (wave < 2) {                           // gW0[:, 0:3] += g y^T: two row tiles, columns 0..2 of a 32-column tile
+                    const f32x16 acc = mfma_samples(h, [&](int s) { return GB.at(32 * wave + j, s); }, [&](int s) { return j < 3 ? YL.at(j, s) : 0.f; });
+                    scatter_add(gW0, NI, 32 * wave, 64, j, j < 3, h, acc);
                 }
                 float gy0 = 0.f, gy1 = 0.f, gy2 = 0.f;                      // the conditioner-input path of dL/dy (every wave, all rows)
+#pragma unroll 8
                 for (int o = 0; o < 64; ++o) {
                     const float go = GB.at(o, lane);
                     gy0 = fmaf(W0[(size_t)o * NI], go, gy0);
@@ -393,23 +503,36 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                 }
                 set_col(gRin, p1, get_col(gRin, p1) + v3f{gy0, gy1, gy2});
             }
-            if (F) {
+            if (HAS_FEATURE) {
                 // gW0[o][yo + c] += sum_s g[o][s] f[s][c]: tiles 2 (rows) x ceil(F/32) (columns), 4 waves
                 const int ctiles = (F + 31) / 32;
                 for (int t = wave; t < 2 * ctiles; t += TR_WAVES) {
                     const int rt = t & 1, ct = t >> 1;
                     const int c = 32 * ct + j;
-                    const f32x16 acc = mfma_samples(h, [&](int s) { return GB.at(32 * rt + j, s); },
-                                                    [&](int s) { return (c < F && blk * 64 + s < args.n) ? args.feature[(blk * 64 + s) * F + c] : 0.f; });
+                    f32x16 acc = zero16();
+                    const long long r0 = blk * 64 + 32 * h;
+                    const float *fp = args.feature + (r0 < args.n ? r0 : args.n - 1) * F + (c < F ? c : F - 1);   // row 32h + m of the block, column c
+                    for (int m0 = 0; m0 < 32; m0 += 8) {
+                        float b[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {                      // (rows of padding rotations: their g is exactly 0)
+                            b[u] = *fp;
+                            if (blk * 64 + 32 * h + m0 + u + 1 < args.n) fp += F;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc = RNF_MFMA(GB.at(32 * rt + j, 32 * h + m0 + u), b[u], acc);
+                    }
                     scatter_add(gW0 + yo, NI, 32 * rt, 64, c, c < F, h, acc);
                 }
                 if (args.g_feature) {
                     // g_f[c][s] = sum_o W0[o][yo + c] g[o][s]: tiles ceil(F/32) (feature rows) x 2 (sample columns)
                     for (int t = wave; t < 2 * ctiles; t += TR_WAVES) {
                         const int st = t & 1, ct = t >> 1;
-                        const int c = 32 * ct + j, s = 32 * st + j;
-                        const f32x16 acc = mfma_cols(W0 + yo, NI, 64, c, c < F, h, [&](int k) { return GB.at(k, s); }, zero16());
-                        const long long smp = blk * 64 + s;
+                        const int c = 32 * ct + j, sc = 32 * st + j;
+                        const ColsA wf = load_cols(W0 + yo, NI, 0, 64, c, F, h);
+                        const f32x16 acc = mfma_cols(wf, 0, h, [&](int k) { return GB.at(k, sc); }, zero16());
+                        const long long smp = blk * 64 + sc;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int cc = 32 * ct + rho(r, h);
@@ -418,14 +541,19 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             gR = gRin;
+            RNF_TSTAMP(7)
         }
         if (valid && wave == 0) {
             float *o = args.g_rot_in + sample * 9;
             o[0] = gR.c0.x; o[1] = gR.c1.x; o[2] = gR.c2.x; o[3] = gR.c0.y; o[4] = gR.c1.y; o[5] = gR.c2.y; o[6] = gR.c0.z; o[7] = gR.c1.z; o[8] = gR.c2.z;
         }
     }
+#ifdef RNF_STAMPS
+    RNF_TSTAMP(9)
+    if (args.stamps && tid == 0) for (int i_ = 0; i_ < 10; ++i_) atomicAdd(args.stamps + i_, tst_acc[i_]);
+#endif
 }
 
 // d log|det M| / dM = M^-T, weighted by the batch sum of dL/dldj (Uncondition16Trans, flow/squeezetrans.py:33-38,57-66)

@@ -165,6 +165,11 @@ int rnf_flow_log_prob(const float *rotation_dev, const float *feature_dev, int64
 int rnf_fisher_log_prob(const float *rotation_dev, int64_t n, const float *fisher_A_dev, const float *fisher_c_dev,
                         int64_t fisher_B, float *out_dev, void *stream);
 
+/* Gradient of rnf_fisher_log_prob w.r.t. the rotations (training with a matrix-Fisher base, agent.py:58-64):
+ * g_rotation[i] = g_logp[i] * A[i / (n/B)].  (The gradient w.r.t. A needs the derivative of the normaliser and is not built.) */
+int rnf_fisher_log_prob_backward(const float *g_logp_dev, int64_t n, const float *A_dev, int64_t B, float *g_rotation_dev,
+                                 void *stream);
+
 /* MatrixFisherN._sample (utils/fisher.py:117-207,234-243): n rotations per row of A, out [B,n,3,3].
  *   U_dev, V_dev [B,3,3]: proper SVD factors of A (det +1; utils/fisher.py:53-64); lam_dev [B,4]: the diagonal Bingham parameter
  *   (0, 2(S1+S2), 2(S0+S2), 2(S0+S1)) (utils/fisher.py:183-187).  Counter-based Philox stream keyed by `seed`: the same seed gives

@@ -621,6 +621,30 @@ extern "C" int rnf_fisher_log_prob(const float *rot, int64_t n, const float *A, 
     return 0;
 }
 
+// d(tr(A^T R) - c)/dR = A: g_rot[i] = g_logp[i] * A[row(i)]
+__global__ void fisher_log_prob_backward_kernel(const float *g_logp, long long n, const float *A, long long div, float *g_rot) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const long long row = i / div;
+        const float g = g_logp[i];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) g_rot[i * 9 + k] = g * A[row * 9 + k];
+    }
+}
+
+extern "C" int rnf_fisher_log_prob_backward(const float *g_logp, int64_t n, const float *A, int64_t B, float *g_rot, void *stream) {
+    if (!g_logp || !A || !g_rot) return fail("rnf_fisher_log_prob_backward: null pointer");
+    if (B <= 0 || n % B) return fail("n=%lld not divisible by fisher rows B=%lld (utils/fisher.py:226)", (long long)n, (long long)B);
+    if (n == 0) return 0;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fisher_log_prob_backward_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g_logp, (long long)n, A,
+                       (long long)(n / B), g_rot);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int rnf_fisher_sample(const float *U, const float *V, const float *lam, int64_t B, int64_t n, uint64_t seed, float *out,
                                  int32_t *fail_flag_dev, void *stream) {
     if (!U || !V || !lam || !out) return fail("rnf_fisher_sample: null pointer");

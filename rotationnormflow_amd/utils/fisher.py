@@ -29,6 +29,35 @@ def quaternion_to_matrix(q):
     return m.reshape(q.shape[:-1] + (3, 3))
 
 
+class _FisherLogProb(torch.autograd.Function):
+    """log p(R) = tr(A^T R) - c through rnf_fisher_log_prob; d/dR = A through rnf_fisher_log_prob_backward (training with a
+    matrix-Fisher base differentiates it w.r.t. the flow's output rotation, agent.py:58-64)."""
+
+    @staticmethod
+    def forward(ctx, inputs, A, c):
+        R = inputs.reshape(-1, 3, 3).to(torch.float32).contiguous()
+        n, B = R.shape[0], A.shape[0]
+        out = torch.empty(n, dtype=torch.float32, device=R.device)
+        with torch.cuda.device(R.device):
+            _lib.check(_lib.lib().rnf_fisher_log_prob(R.data_ptr(), n, A.data_ptr(), c.data_ptr(), B, out.data_ptr(),
+                                                      torch.cuda.current_stream(R.device).cuda_stream))
+        ctx.save_for_backward(A)
+        ctx.in_shape, ctx.in_dtype = inputs.shape, inputs.dtype
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (A,) = ctx.saved_tensors
+        g = g.to(torch.float32).contiguous()
+        n = g.shape[0]
+        g_rot = torch.empty((n, 3, 3), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().rnf_fisher_log_prob_backward(g.data_ptr(), n, A.data_ptr(), A.shape[0], g_rot.data_ptr(),
+                                                               torch.cuda.current_stream(g.device).cuda_stream))
+        return g_rot.reshape(ctx.in_shape).to(ctx.in_dtype), None, None
+
+
 class MatrixFisherN(torch.nn.Module):
     """MatrixFisherN(A [B,3,3], norm_type=1).  ``_log_prob(R [N,3,3])`` broadcasts row b over N/B consecutive samples."""
 
@@ -48,18 +77,17 @@ class MatrixFisherN(torch.nn.Module):
     def _log_prob(self, inputs, context=9):
         if not inputs.is_cuda:
             raise RuntimeError("rotationnormflow_amd runs on the GPU only (no CPU fallback)")
+        if torch.is_grad_enabled() and self.A.requires_grad:
+            raise NotImplementedError("rotationnormflow_amd: the gradient of the matrix-Fisher density w.r.t. A (it needs the derivative of "
+                                      "the normaliser) is not built; detach A (the reference trains the flow on a frozen A, agent.py:58-60)")
         if inputs.shape[-1] == 4:
+            if torch.is_grad_enabled() and inputs.requires_grad:
+                raise NotImplementedError("rotationnormflow_amd: quaternion inputs are not differentiable here; pass rotation matrices")
             inputs = quaternion_to_matrix(inputs)
         dev = inputs.device
-        R = inputs.reshape(-1, 3, 3).to(torch.float32).contiguous()
-        A = self.A.to(device=dev, dtype=torch.float32).contiguous()
+        A = self.A.detach().to(device=dev, dtype=torch.float32).contiguous()
         c = self._c.to(dev).contiguous()
-        n, B = R.shape[0], A.shape[0]
-        out = torch.empty(n, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib().rnf_fisher_log_prob(R.data_ptr(), n, A.data_ptr(), c.data_ptr(), B, out.data_ptr(),
-                                                      torch.cuda.current_stream(dev).cuda_stream))
-        return out
+        return _FisherLogProb.apply(inputs, A, c)
 
     def log_prob(self, inputs, context=None):
         return self._log_prob(inputs)

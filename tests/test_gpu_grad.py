@@ -185,3 +185,26 @@ def test_half_range_overflow_is_reported():
     torch.cuda.synchronize()
     with pytest.raises(runtime.HalfRangeError):
         fl(Rd)                                                  # reported one call later (no step waits for the device)
+
+
+def test_training_loss_with_matrix_fisher_base():
+    """agent.py:54-65 with pretrain_fisher: loss = mean(-ldj) + mean(-MF(A).log_prob(R')); the base term back-propagates through R'."""
+    from rotationnormflow_amd.utils.fisher import MatrixFisherN
+    cfg, w, R, feat, gR, gl = _make("uncond_k16")
+    A = synth.fisher_A("tilted")
+    p = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in w.items()}
+    Ro, ldj = orc.flow_forward(cfg, p, torch.from_numpy(R).double(), None, dtype=torch.float64, grad=True)
+    loss_o = (-ldj).mean() + (-orc.fisher_log_prob(Ro, torch.from_numpy(A).double(), dtype=torch.float64)).mean()
+    want = dict(zip(p.keys(), torch.autograd.grad(loss_o, list(p.values()))))
+    fl = product_flow(cfg, w).train()
+    Rt, ldj = fl(torch.from_numpy(R).cuda())
+    base = MatrixFisherN(torch.from_numpy(A).cuda())
+    loss = (-ldj).mean() + (-base._log_prob(Rt)).mean()
+    assert abs(float(loss.detach()) - float(loss_o.detach())) < 2e-5
+    loss.backward()
+    for k, prm in fl.named_parameters():
+        gw = want[k].numpy()
+        err = np.abs(prm.grad.cpu().numpy() - gw).max() / max(np.abs(gw).max(), 1e-3)
+        assert err < REL, (k, err)
+    with pytest.raises(NotImplementedError):
+        MatrixFisherN(torch.from_numpy(A).cuda().requires_grad_(True))._log_prob(Rt.detach())

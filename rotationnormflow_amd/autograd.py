@@ -121,7 +121,7 @@ def mlp_train_tensors(net):
 
 class _FlowForwardFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, rotation, feature, *tensors):
+    def forward(ctx, plan, grad_sync, rotation, feature, *tensors):
         rot, feat = runtime._check_inputs(rotation, feature, plan)
         n = rot.shape[0]
         dev = rot.device
@@ -146,6 +146,7 @@ class _FlowForwardFn(torch.autograd.Function):
         if plan.n_cond:
             feat_plain = feature.reshape(n, -1).to(device=dev, dtype=torch.float32).contiguous()
         ctx.plan = plan
+        ctx.grad_sync = grad_sync
         ctx.rot_shape = rotation.shape
         ctx.feat_shape = feature.shape if feature is not None else None
         ctx.shapes = [(t.shape, t.device, t.dtype) for t in tensors]
@@ -162,7 +163,7 @@ class _FlowForwardFn(torch.autograd.Function):
         L = _lib.lib()
         grads = torch.zeros_like(plain)
         g_rot_in = torch.zeros((n, 9), dtype=torch.float32, device=dev)
-        want_gfeat = feat_plain is not None and ctx.needs_input_grad[2]
+        want_gfeat = feat_plain is not None and ctx.needs_input_grad[3]
         g_feat = torch.zeros_like(feat_plain) if want_gfeat else None
         scratch = torch.zeros(max(plan.n_layers, 1), dtype=torch.float32, device=dev)
         if n:
@@ -176,18 +177,21 @@ class _FlowForwardFn(torch.autograd.Function):
                                                plan.train_desc.ctypes.data, plan.n_layers, plan.segments, ptr(g_rot_c),
                                                g_ldj_c.data_ptr(), grads.data_ptr(), g_rot_in.data_ptr(), ptr(g_feat),
                                                scratch.data_ptr(), stream))
+        runtime.note_training_step()                      # an optimizer step follows: host-packed blobs are stale from now on
+        if ctx.grad_sync is not None:                     # data-parallel training: ONE collective for every parameter gradient
+            ctx.grad_sync(grads)
         outs = []
         off = 0
         for i, (shape, device, dtype) in enumerate(ctx.shapes):
             cnt = int(np.prod(shape)) if len(shape) else 1
             g = None
-            if ctx.needs_input_grad[3 + i]:
+            if ctx.needs_input_grad[4 + i]:
                 g = grads[off: off + cnt].reshape(shape).to(device=device, dtype=dtype)
             outs.append(g)
             off += cnt
-        g_rotation = g_rot_in.reshape(ctx.rot_shape) if ctx.needs_input_grad[1] else None
+        g_rotation = g_rot_in.reshape(ctx.rot_shape) if ctx.needs_input_grad[2] else None
         g_feature = g_feat.reshape(ctx.feat_shape) if want_gfeat else None
-        return (None, g_rotation, g_feature, *outs)
+        return (None, None, g_rotation, g_feature, *outs)
 
 
 def flow_forward(module, layers, perm_rows, rotation, feature):
@@ -199,4 +203,4 @@ def flow_forward(module, layers, perm_rows, rotation, feature):
     if cached is None or cached[0] != key:
         cached = (key, TrainPlan(layers, perm_rows, rotation.device, runtime.get_precision()))
         module._rnf_train_plan = cached
-    return _FlowForwardFn.apply(cached[1], rotation, feature, *train_tensors(layers))
+    return _FlowForwardFn.apply(cached[1], getattr(module, "_rnf_grad_sync", None), rotation, feature, *train_tensors(layers))

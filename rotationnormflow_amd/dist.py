@@ -1,5 +1,8 @@
 """Multi-GPU harness: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI), batch axis sharded,
 no data-path collective; the only exchange is ONE all-reduce of {sum_i log p_i, count} (16 bytes, fp64) per evaluation.
+Training: each rank back-propagates its shard of the batch and the whole gradient blob (one contiguous fp32 buffer, 2.8-10.4 MB:
+every parameter gradient of the flow) is averaged with ONE all-reduce before it is handed back to autograd
+(``data_parallel_training``) -- a single large bucket, which is what per-link-bound xGMI rings want.
 
 Replaces the reference's single-process nn.DataParallel (agent.py:22,40), which re-broadcasts ~2.8 MB of parameters,
 scatters the batch and gathers the outputs on device 0 on every forward.
@@ -41,3 +44,23 @@ def flow_evaluator(flow, base=None):
             return torch.zeros(2, dtype=torch.float64, device=rot.device)
         return flow.log_prob(rot, feat, base=base)["sum"]
     return evaluate
+
+
+def all_reduce_mean_(blob: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place average of one gradient blob over the ranks of ``group`` (no-op without a process group / with one rank)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size(group)
+        if world > 1:
+            dist.all_reduce(blob, op=dist.ReduceOp.SUM, group=group)
+            blob.div_(world)
+    return blob
+
+
+def data_parallel_training(flow, group=None, enabled=True):
+    """Mark ``flow`` for data-parallel training: its backward pass averages the gradient blob over ``group`` (default: the world)
+    with one all-reduce, so that every rank steps its optimizer with the gradient of the mean loss over the GLOBAL batch (what
+    nn.DataParallel's reduce_add of replica gradients gives the reference, agent.py:22,79-90, when each rank's loss is the mean over
+    its equally sized shard).  Parameters must start identical on all ranks (same seed or a broadcast state dict)."""
+    flow._rnf_grad_sync = (lambda blob: all_reduce_mean_(blob, group)) if enabled else None
+    return flow

@@ -6,6 +6,13 @@ statistic ``eval_uncondition.py:31-45`` prints: the mean over the whole test set
 
     python -m rotationnormflow_amd.harness --ckpt exps/.../ckpt_iteration50000.pth --data data/raw/peak_test.npy \\
            [--config settings/raw.yml] [--batch-size 1048576]
+
+``train_uncondition`` is the matching minimal training loop (train_uncondition.py:37-90 + agent.py:75-92 for the unconditional
+``raw`` recipe): Adam on ``mean(-ldj)`` over shuffled mini-batches, periodic test log-likelihood, checkpoints in the reference's
+format so that ``Agent.load_ckpt`` (agent.py:171-198) and this module read them back.
+
+    python -m rotationnormflow_amd.harness --train data/raw/peak_train.npy --data data/raw/peak_test.npy --ckpt out.pth \\
+           [--config settings/raw.yml] [--iterations 50000] [--train-batch 1024] [--lr 1e-4]
 """
 from __future__ import annotations
 
@@ -52,10 +59,69 @@ def mean_log_likelihood(flow: Flow, rotations: torch.Tensor, base=None, batch_si
     return float(total[0] / total[1])
 
 
+def save_reference_checkpoint(path, flow: Flow, optimizer, epoch: int, minibatch: int, iteration: int):
+    """The dictionary ``Agent.save_ckpt`` writes for an unconditional flow (agent.py:132-151; clock: utils/utils.py:36-45)."""
+    torch.save({
+        "clock": {"epoch": epoch, "minibatch": minibatch, "iteration": iteration},
+        "flow_state_dict": {k: v.detach().cpu() for k, v in flow.state_dict().items()},
+        "optimizer_flow_state_dict": optimizer.state_dict(),
+    }, path)
+
+
+def train_uncondition(flow: Flow, train_rotations: torch.Tensor, iterations: int, batch_size: int = 1024, lr: float = 1e-4,
+                      seed: int = 42, test_rotations: torch.Tensor = None, val_every: int = 0, ckpt_path=None, save_every: int = 0,
+                      base=None, device="cuda", log=print):
+    """Maximum-likelihood training of an unconditional flow on a ``raw`` rotation set.  One iteration = the reference's
+    ``Agent.train_func`` (agent.py:75-92): loss = mean(-ldj) (- mean base log-prob if ``base`` is given), zero_grad, backward, Adam
+    step -- here three HIP launches (device packer, fused forward, fused backward) plus the optimizer.
+    Returns the list of (iteration, train loss) pairs sampled every 100 iterations and the final test log-likelihood (or None)."""
+    flow = flow.to(device).train()
+    gen = torch.Generator().manual_seed(seed)
+    data = train_rotations.to(device)
+    n = data.shape[0]
+    try:
+        opt = torch.optim.Adam(flow.parameters(), lr=lr, fused=True)        # one launch instead of a dozen foreach kernels
+    except (TypeError, RuntimeError):                                      # older torch: no fused Adam
+        opt = torch.optim.Adam(flow.parameters(), lr=lr)
+    history, it, epoch = [], 0, 0
+    while it < iterations:
+        perm = torch.randperm(n, generator=gen).to(device)
+        for mb, lo in enumerate(range(0, n - batch_size + 1 if n >= batch_size else 1, batch_size)):
+            batch = data[perm[lo:lo + batch_size]]
+            rot, ldj = flow(batch)
+            loss = (-ldj).mean()
+            if base is not None:
+                loss = loss - base._log_prob(rot).mean()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            it += 1
+            if it % 100 == 0 or it == iterations:
+                history.append((it, float(loss.detach())))
+            if val_every and test_rotations is not None and it % val_every == 0:
+                log(f"iteration {it}: train loss {float(loss.detach()):.6f}  test log-likelihood "
+                    f"{mean_log_likelihood(flow, test_rotations, base=base, device=device):.6f}")
+                flow.train()
+            if ckpt_path and save_every and it % save_every == 0:
+                save_reference_checkpoint(ckpt_path, flow, opt, epoch, mb + 1, it)
+            if it >= iterations:
+                break
+        epoch += 1
+    if ckpt_path:
+        save_reference_checkpoint(ckpt_path, flow, opt, epoch, 0, it)
+    final = mean_log_likelihood(flow, test_rotations, base=base, device=device) if test_rotations is not None else None
+    return history, final
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--ckpt", required=True)
-    ap.add_argument("--data", required=True)
+    ap.add_argument("--ckpt", required=True, help="checkpoint to evaluate, or (with --train) to write")
+    ap.add_argument("--data", required=True, help="raw test set, [M,3,3] float32 .npy")
+    ap.add_argument("--train", help="raw training set: train an unconditional flow first, then evaluate it on --data")
+    ap.add_argument("--iterations", type=int, default=50000)
+    ap.add_argument("--train-batch", type=int, default=1024)
+    ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--config", action="append", default=[], help="settings/*.yml file(s); later files override earlier ones")
     ap.add_argument("--layers", type=int)
     ap.add_argument("--segments", type=int)
@@ -64,6 +130,14 @@ def main(argv=None):
     args = ap.parse_args(argv)
     over = {k: v for k, v in (("layers", args.layers), ("segments", args.segments), ("rot", args.rot)) if v is not None}
     config = load_yaml_config(*args.config, **over) if args.config else make_config(**over)
+    if args.train:
+        torch.manual_seed(args.seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            flow = Flow(config)
+        _, final = train_uncondition(flow, load_raw_rotations(args.train), args.iterations, args.train_batch, args.lr, args.seed,
+                                     test_rotations=load_raw_rotations(args.data), val_every=1000, ckpt_path=args.ckpt, save_every=5000)
+        print(final)
+        return
     flow = build_flow_from_checkpoint(config, args.ckpt)
     print(mean_log_likelihood(flow, load_raw_rotations(args.data), batch_size=args.batch_size))
 

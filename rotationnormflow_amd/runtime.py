@@ -205,9 +205,20 @@ def pack_rot16(L, rot_mat):
 
 
 # ---- parameter-version keyed cache -------------------------------------------------------------------------------
+# Bumped by every backward pass through the training path (autograd.py).  Part of the cache key because fused optimizers
+# (torch._fused_adam_ and friends) update parameters in place WITHOUT bumping ``Tensor._version``: after a training step every
+# host-packed blob is rebuilt on next use, whatever the optimizer did.
+_train_epoch = 0
+
+
+def note_training_step():
+    global _train_epoch
+    _train_epoch += 1
+
+
 def params_key(module, device):
     """Changes whenever any parameter is modified in place (optimizer step, load_state_dict) or replaced."""
-    return (str(device), _precision) + tuple((id(p), p._version, p.data_ptr()) for p in module.parameters())
+    return (str(device), _precision, _train_epoch) + tuple((id(p), p._version, p.data_ptr()) for p in module.parameters())
 
 
 class PackCache:

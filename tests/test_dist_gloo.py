@@ -59,3 +59,33 @@ def test_shard_bounds_cover_batch_exactly():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert all(lo <= hi for lo, hi in spans)
+
+
+def _grad_blob_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from rotationnormflow_amd import dist as rdist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        blob = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        rdist.all_reduce_mean_(blob)
+        q.put((rank, blob.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_blob_all_reduce_mean_world2():
+    """Training exchange: ONE all-reduce averages the whole gradient blob over the ranks (rotationnormflow_amd.dist.all_reduce_mean_)."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000 + 7
+    procs = [ctx.Process(target=_grad_blob_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    want = np.arange(1000, dtype=np.float32) * 1.5
+    assert np.allclose(got[0], want) and np.allclose(got[1], want)

@@ -129,8 +129,9 @@ class _FlowForwardFn(torch.autograd.Function):
         out_rot = torch.empty_like(rot)
         out_ldj = torch.empty(n, dtype=torch.float32, device=dev)
         states = torch.empty((plan.n_layers, n, 9), dtype=torch.float32, device=dev)
-        plain = torch.cat([t.detach().to(device=dev, dtype=torch.float32).reshape(-1) for t in tensors]) if tensors else \
-            torch.zeros(0, device=dev)
+        f32 = torch.float32                               # (grad mode is off inside Function.forward: no detach needed)
+        plain = torch.cat([t.reshape(-1) if (t.is_cuda and t.dtype is f32) else t.to(device=dev, dtype=f32).reshape(-1)
+                           for t in tensors]) if tensors else torch.zeros(0, device=dev)
         if plain.numel() != plan.plain_floats:
             raise RuntimeError(f"plain parameter blob has {plain.numel()} floats, layer table expects {plan.plain_floats}")
         if n:
@@ -150,6 +151,7 @@ class _FlowForwardFn(torch.autograd.Function):
         ctx.rot_shape = rotation.shape
         ctx.feat_shape = feature.shape if feature is not None else None
         ctx.shapes = [(t.shape, t.device, t.dtype) for t in tensors]
+        ctx.sizes = [t.numel() for t in tensors]
         ctx.save_for_backward(states, feat_plain, plain)
         return out_rot.reshape(rotation.shape), out_ldj
 
@@ -180,15 +182,16 @@ class _FlowForwardFn(torch.autograd.Function):
         runtime.note_training_step()                      # an optimizer step follows: host-packed blobs are stale from now on
         if ctx.grad_sync is not None:                     # data-parallel training: ONE collective for every parameter gradient
             ctx.grad_sync(grads)
+        needs = ctx.needs_input_grad
+        pieces = torch.split(grads, ctx.sizes) if ctx.sizes else ()
         outs = []
-        off = 0
         for i, (shape, device, dtype) in enumerate(ctx.shapes):
-            cnt = int(np.prod(shape)) if len(shape) else 1
             g = None
-            if ctx.needs_input_grad[4 + i]:
-                g = grads[off: off + cnt].reshape(shape).to(device=device, dtype=dtype)
+            if needs[4 + i]:
+                g = pieces[i].view(shape)
+                if device != dev or dtype is not torch.float32:
+                    g = g.to(device=device, dtype=dtype)
             outs.append(g)
-            off += cnt
         g_rotation = g_rot_in.reshape(ctx.rot_shape) if ctx.needs_input_grad[2] else None
         g_feature = g_feat.reshape(ctx.feat_shape) if want_gfeat else None
         return (None, None, g_rotation, g_feature, *outs)

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--cpu-oracle", action="store_true")
+    ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): one optimizer launch instead of foreach kernels")
     a = ap.parse_args()
     cfg = configs.make_config(a.config)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -35,7 +36,7 @@ def main():
     w = synth.fill_state_dict(shapes, seed=0)
     fl.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
     fl = fl.cuda().train()
-    opt = torch.optim.Adam(fl.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(fl.parameters(), lr=1e-4, fused=True) if a.fused_adam else torch.optim.Adam(fl.parameters(), lr=1e-4)
     R = torch.from_numpy(synth.uniform_rotations(a.batch, seed=1)).cuda()
     feat = None
     if cfg.condition:
@@ -78,7 +79,7 @@ def main():
     fl._packed(R.device)
     torch.cuda.synchronize()
     pack_ms = (time.perf_counter() - t3) * 1e3
-    out = dict(pack_ms=pack_ms, metric="training iteration (forward + backward + Adam)", config=a.config, batch=a.batch, ms_per_iteration=dt * 1e3,
+    out = dict(pack_ms=pack_ms, optimizer="Adam(fused=True)" if a.fused_adam else "Adam", metric="training iteration (forward + backward + Adam)", config=a.config, batch=a.batch, ms_per_iteration=dt * 1e3,
                rotations_per_s=a.batch / dt, forward_ms_gpu=ev[0].elapsed_time(ev[1]), backward_ms_gpu=ev[2].elapsed_time(ev[3]),
                fwd_bwd_wall_ms=(t2 - t1) * 1e3, loss=float(loss.detach()))
     if a.cpu_oracle:

@@ -55,6 +55,16 @@ def _affine_kind(cfg, first_layer_condition=False):
             return "lu16" if lu else "uncond16"
         if rot == "16Rot":                                      # affineflow.py:70-71
             return "rot16"
+        if rot == "36Trans":                                    # affineflow.py:55-56
+            return "gs36"
+        if rot == "9TransLSVD":                                 # affineflow.py:58-59
+            return "svdl9"
+        if rot == "9TransRSVD":                                 # affineflow.py:60-61
+            return "svdr9"
+        if rot == "9TransLSmith":                               # affineflow.py:62-66
+            return "gs9lu" if lu else "gs9"
+        if rot == "9TransRSmith":                               # affineflow.py:67-68
+            return "smithr9"
     if rot in ("36Trans", "9TransLSVD", "9TransRSVD", "9TransLSmith", "9TransRSmith", "16Rot", "16UnRot"):
         raise NotImplementedError(f"oracle does not restate rot={rot!r} for condition={cfg.condition}")
     return None                                                 # affineflow.py:45-46,72-73
@@ -115,6 +125,14 @@ def state_shapes(cfg):
                 shapes[f"layers.{i}.mat.{name}"] = shp
         elif kind == "rot16":                                   # UnconditionRot, rottrans.py:11-12
             shapes[f"layers.{i}.rot"] = (1, 4, 4)
+        elif kind in ("gs9", "svdl9", "svdr9", "smithr9"):     # squeezetrans.py:253, rottrans.py:97,127,157
+            shapes[f"layers.{i}.mat"] = (3, 3)
+        elif kind == "gs36":                                    # squeezetrans.py:353
+            shapes[f"layers.{i}.mat"] = (6, 6)
+        elif kind == "gs9lu":                                   # UnconditionLU(3), squeezetrans.py:267
+            for name, shp in (("w_p", (3, 3)), ("u_mask", (3, 3)), ("l_mask", (3, 3)), ("s_sign", (3,)), ("l_eye", (3, 3)),
+                              ("w_l", (3, 3)), ("w_s", (3,)), ("w_u", (3, 3))):
+                shapes[f"layers.{i}.mat.{name}"] = shp
     return shapes
 
 
@@ -326,6 +344,88 @@ def rot16_apply(M, R):
     return quaternion_to_matrix(q), torch.zeros(R.shape[0], dtype=R.dtype)
 
 
+# --------------------------------------------------------------------------------------------------------------
+# 3x3 / 6x6 ablation layers (flow/squeezetrans.py:176-361, flow/rottrans.py:72-165), unconditional variants
+# --------------------------------------------------------------------------------------------------------------
+# generators of the tangent directions the reference differentiates along (squeezetrans.py:200-201, 295-296)
+_GEN = torch.tensor([[[0., 1, 0], [-1, 0, 0], [0, 0, 0]], [[0, 0, 1], [0, 0, 0], [-1, 0, 0]], [[0, 0, 0], [0, 0, 1], [0, -1, 0]]])
+
+
+def _gram_schmidt_tangent(a0, a1, da0, da1):
+    """Gram-Schmidt of the two columns (a0, a1) [N,3] to a rotation, carried together with three tangent derivatives
+    (da0, da1) [3,N,3] (forward mode; accp_normalize / accp_cross / the body of calculate_9, squeezetrans.py:176-231).
+    Returns (R' [N,3,3], log|det of the 3x3 matrix of tangent images|)."""
+    def normalize(a, da):
+        n = a.norm(dim=-1, keepdim=True)
+        t = a / n
+        return t, (da - t * (t * da).sum(-1, keepdim=True)) / n
+    t0, dt0 = normalize(a0, da0)
+    dot = (t0 * a1).sum(-1, keepdim=True)
+    ddot = (dt0 * a1).sum(-1, keepdim=True) + (t0 * da1).sum(-1, keepdim=True)
+    t1, dt1 = normalize(a1 - dot * t0, da1 - ddot * t0 - dot * dt0)
+    t2 = torch.linalg.cross(t0, t1)
+    dt2 = torch.linalg.cross(dt0, t1.expand_as(dt0)) + torch.linalg.cross(t0.expand_as(dt1), dt1)
+    Rt = torch.stack([t0, t1, t2], dim=-1)                               # columns
+    dRt = torch.stack([dt0, dt1, dt2], dim=-1)                            # [3,N,3,3]
+    delta = dRt @ Rt.transpose(-1, -2)                                    # skew: dR' R'^T
+    vec = torch.stack([delta[..., 0, 1], delta[..., 0, 2], delta[..., 1, 2]], dim=-1)   # [3,N,3]
+    return Rt, _det3(vec.transpose(0, 1)).abs().log()
+
+
+def gs9(M, R):
+    """calculate_9 (squeezetrans.py:199-231): Gram-Schmidt of M R, tangent directions R G_k (right multiplication)."""
+    G = _GEN.to(R.dtype)
+    MR = M.reshape(-1, 3, 3) @ R
+    dMR = torch.einsum("nab,kbc->knac", MR, G)
+    return _gram_schmidt_tangent(MR[..., 0], MR[..., 1], dMR[..., 0], dMR[..., 1])
+
+
+def gs36(M, R):
+    """calculate_36 (squeezetrans.py:293-331): the first two columns of R as a 6-vector times M [6,6], Gram-Schmidt; tangent
+    directions G_k R (left multiplication)."""
+    G = _GEN.to(R.dtype)
+    M = M.reshape(-1, 6, 6)
+    dR = torch.einsum("kab,nbc->knac", G, R)
+    v = torch.cat([R[..., 0], R[..., 1]], dim=-1)
+    dv = torch.cat([dR[..., 0], dR[..., 1]], dim=-1)
+    tv = torch.einsum("nab,nb->na", M.expand(R.shape[0], 6, 6), v)
+    dtv = torch.einsum("nab,knb->kna", M.expand(R.shape[0], 6, 6), dv)
+    return _gram_schmidt_tangent(tv[..., :3], tv[..., 3:], dtv[..., :3], dtv[..., 3:])
+
+
+def lu_matrix(p, prefix):
+    """UnconditionLU.forward without the batch axis (squeezetrans.py:85-91)."""
+    g = lambda n: p[f"{prefix}.{n}"]  # noqa: E731
+    return g("w_p") @ (g("w_l") * g("l_mask") + g("l_eye")) @ ((g("w_u") * g("u_mask")) + torch.diag(g("s_sign") * torch.exp(g("w_s"))))
+
+
+def _polar_rotation(X):
+    """U V^T of the SVD X = U S V^T (rottrans.py:73-76, 79-82)."""
+    U, S, Vh = torch.linalg.svd(X)
+    return U @ Vh
+
+
+def svdl9(M, R):
+    """calculate_9_l (rottrans.py:72-76): nearest orthogonal matrix to M R; log-det reported as 0."""
+    return _polar_rotation(M.reshape(-1, 3, 3) @ R), torch.zeros(R.shape[0], dtype=R.dtype)
+
+
+def svdr9(M, R):
+    """calculate_9_r (rottrans.py:79-82): nearest orthogonal matrix to R M."""
+    return _polar_rotation(R @ M.reshape(-1, 3, 3)), torch.zeros(R.shape[0], dtype=R.dtype)
+
+
+def smithr9(M, R, inverse=False):
+    """calculate_9_r_smith (rottrans.py:85-96): R times the Gram-Schmidt rotation of the columns of M (its transpose for the inverse)."""
+    m0 = M[:, 0] / M[:, 0].norm()
+    m1 = M[:, 1] - (m0 * M[:, 1]).sum() * m0
+    m1 = m1 / m1.norm()
+    Q = torch.stack([m0, m1, torch.linalg.cross(m0, m1)], dim=-1)
+    if inverse:
+        Q = Q.transpose(-1, -2)
+    return R @ Q, torch.zeros(R.shape[0], dtype=R.dtype)
+
+
 def cond16_matrix(feature, p, prefix):
     """Condition16Trans (squeezetrans.py:47-48)."""
     return conditioner(feature, p, prefix).reshape(-1, 4, 4) + torch.eye(4, dtype=feature.dtype)[None]
@@ -359,6 +459,18 @@ def flow_forward(cfg, params, R, feature=None, dtype=torch.float32, grad=False):
                 R, l = affine16(lu16_matrix(p, f"layers.{i}.mat"), R)                   # squeezetrans.py:151-152
             elif kind == "rot16":
                 R, l = rot16_apply(rot16_matrix(p, f"layers.{i}.rot"), R)
+            elif kind == "gs9":
+                R, l = gs9(p[f"layers.{i}.mat"], R)                                     # squeezetrans.py:255-257
+            elif kind == "gs9lu":
+                R, l = gs9(lu_matrix(p, f"layers.{i}.mat"), R)                          # squeezetrans.py:269-271
+            elif kind == "gs36":
+                R, l = gs36(p[f"layers.{i}.mat"], R)                                    # squeezetrans.py:355-357
+            elif kind == "svdl9":
+                R, l = svdl9(p[f"layers.{i}.mat"], R)                                   # rottrans.py:99-101
+            elif kind == "svdr9":
+                R, l = svdr9(p[f"layers.{i}.mat"], R)                                   # rottrans.py:129-131
+            elif kind == "smithr9":
+                R, l = smithr9(p[f"layers.{i}.mat"], R)                                 # rottrans.py:159-161
             else:
                 R, l = affine16(cond16_matrix(feature, p, f"layers.{i}.net"), R)
             ldj = ldj + l
@@ -390,6 +502,18 @@ def flow_inverse(cfg, params, R, feature=None, dtype=torch.float32):
                 R, l = affine16(torch.linalg.inv(lu16_matrix(p, f"layers.{i}.mat")), R)   # squeezetrans.py:154-157
             elif kind == "rot16":
                 R, l = rot16_apply(rot16_matrix(p, f"layers.{i}.rot").transpose(-1, -2), R)   # rottrans.py:26-28
+            elif kind == "gs9":
+                R, l = gs9(torch.linalg.inv(p[f"layers.{i}.mat"]), R)                   # squeezetrans.py:259-261
+            elif kind == "gs9lu":
+                R, l = gs9(torch.linalg.inv(lu_matrix(p, f"layers.{i}.mat")), R)        # squeezetrans.py:273-275
+            elif kind == "gs36":
+                R, l = gs36(torch.linalg.inv(p[f"layers.{i}.mat"]), R)                  # squeezetrans.py:359-361
+            elif kind == "svdl9":
+                R, l = svdl9(p[f"layers.{i}.mat"].transpose(-1, -2), R)                 # rottrans.py:103-105
+            elif kind == "svdr9":
+                R, l = svdr9(p[f"layers.{i}.mat"].transpose(-1, -2), R)                 # rottrans.py:133-135
+            elif kind == "smithr9":
+                R, l = smithr9(p[f"layers.{i}.mat"], R, inverse=True)                   # rottrans.py:163-165
             else:
                 R, l = affine16(torch.linalg.inv(cond16_matrix(feature, p, f"layers.{i}.net")), R)  # :51-55
             ldj = ldj + l

@@ -60,18 +60,19 @@ def fill_state_dict(shapes: dict, seed: int = 0, regime: str = "default") -> dic
     for key in sorted(shapes):
         shape = tuple(int(s) for s in shapes[key])
         z = rng.standard_normal(shape).astype(np.float32)
-        if key.endswith(".mat") or key.endswith(".rot"):   # Uncondition16Trans.mat / UnconditionRot.rot [1,4,4]
-            val = np.eye(4, dtype=np.float32)[None] + np.float32(sigma) * z
+        if key.endswith(".mat") or key.endswith(".rot"):   # Uncondition16Trans.mat / UnconditionRot.rot [1,4,4]; 3x3 / 6x6 ablations
+            val = np.eye(shape[-1], dtype=np.float32).reshape((1,) * (len(shape) - 2) + (shape[-1], shape[-1])) + np.float32(sigma) * z
         elif key.endswith(".mat.w_p"):                   # UnconditionLU buffers: fixed, valid structure (the draw is discarded)
-            val = np.eye(4, dtype=np.float32)[[1, 0, 2, 3]]
+            d = shape[-1]
+            val = np.eye(d, dtype=np.float32)[[1, 0] + list(range(2, d))]
         elif key.endswith(".mat.u_mask"):
-            val = np.triu(np.ones((4, 4), dtype=np.float32), 1)
+            val = np.triu(np.ones(shape, dtype=np.float32), 1)
         elif key.endswith(".mat.l_mask"):
-            val = np.triu(np.ones((4, 4), dtype=np.float32), 1).T
+            val = np.triu(np.ones(shape, dtype=np.float32), 1).T
         elif key.endswith(".mat.l_eye"):
-            val = np.eye(4, dtype=np.float32)
+            val = np.eye(shape[-1], dtype=np.float32)
         elif key.endswith(".mat.s_sign"):
-            val = np.array([1, -1, 1, 1], dtype=np.float32)
+            val = np.array([1, -1, 1, 1], dtype=np.float32)[: shape[-1]]
         elif key.endswith(".mat.w_l") or key.endswith(".mat.w_u"):
             val = np.float32(max(sigma, 0.05)) * z
         elif key.endswith(".mat.w_s"):

@@ -40,6 +40,17 @@ CASES = {
                             direction="forward", fisher=None),
     "rot16un_cond":    dict(cfg=dict(layers=3, condition=1, feature_dim=16, rot="16UnRot"), n=512, regime="trained", wseed=18, rseed=64,
                             direction="forward", fisher=None),
+    # 3x3 / 6x6 ablation layers, unconditional (README.md:151-155; flow/squeezetrans.py:176-361, flow/rottrans.py:72-165)
+    "gs9_uncond":      dict(cfg=dict(layers=3, rot="9TransLSmith"), n=1024, regime="trained", wseed=19, rseed=65, direction="forward", fisher=None),
+    "gs9_uncond_inv":  dict(cfg=dict(layers=3, rot="9TransLSmith"), n=512, regime="trained", wseed=19, rseed=66, direction="inverse", fisher=None),
+    "gs9lu_uncond":    dict(cfg=dict(layers=3, rot="9TransLSmith", lu=1), n=512, regime="trained", wseed=20, rseed=67, direction="forward", fisher=None),
+    "gs36_uncond":     dict(cfg=dict(layers=3, rot="36Trans"), n=1024, regime="trained", wseed=21, rseed=68, direction="forward", fisher=None),
+    "gs36_uncond_inv": dict(cfg=dict(layers=3, rot="36Trans"), n=512, regime="trained", wseed=21, rseed=69, direction="inverse", fisher=None),
+    "svdl9_uncond":    dict(cfg=dict(layers=3, rot="9TransLSVD"), n=512, regime="trained", wseed=22, rseed=70, direction="forward", fisher=None),
+    "svdl9_uncond_inv": dict(cfg=dict(layers=3, rot="9TransLSVD"), n=512, regime="trained", wseed=22, rseed=71, direction="inverse", fisher=None),
+    "svdr9_uncond":    dict(cfg=dict(layers=3, rot="9TransRSVD"), n=512, regime="trained", wseed=23, rseed=72, direction="forward", fisher=None),
+    "smithr9_uncond":  dict(cfg=dict(layers=3, rot="9TransRSmith"), n=512, regime="trained", wseed=24, rseed=73, direction="forward", fisher=None),
+    "smithr9_uncond_inv": dict(cfg=dict(layers=3, rot="9TransRSmith"), n=512, regime="trained", wseed=24, rseed=74, direction="inverse", fisher=None),
     "embed_cond":      dict(cfg=dict(layers=3, condition=1, feature_dim=24, embedding=1, embedding_dim=8, rot="16UnTrans", last_affine=1), n=512,
                             regime="default", wseed=14, rseed=58, direction="forward", fisher=None),
 }

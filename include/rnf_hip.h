@@ -39,6 +39,8 @@ extern "C" {
 #define RNF_LAYER_MOBIUS 1        /* flow/mobiusflow.py:27-183  MobiusFlow                                  */
 #define RNF_LAYER_AFFINE16 2      /* flow/squeezetrans.py:161-174 Uncondition16Trans (any constant 4x4 M)   */
 #define RNF_LAYER_AFFINE16_COND 3 /* flow/squeezetrans.py:41-55  Condition16Trans (M = I + MLP(feature))    */
+#define RNF_LAYER_GS9 4           /* flow/squeezetrans.py:250-261 Uncondition9Trans (Gram-Schmidt of M R)      */
+#define RNF_LAYER_GS36 5          /* flow/squeezetrans.py:350-361 Uncondition36Trans (6x6 on two columns)      */
 
 /* ---- arithmetic of the conditioner GEMMs --------------------------------------------------------------------
  * RNF_PREC_FP32  : exact fp32 (v_mfma_f32_32x32x2_f32; bit-for-bit an fp32 fma chain).
@@ -80,6 +82,12 @@ int rnf_pack_affine16(const float *mat16, float *out_layer);
  * caller exactly as the reference does); the layer rotates the quaternion and contributes a log-det of exactly 0.  Same record
  * size and layer kind (RNF_LAYER_AFFINE16) as rnf_pack_affine16; the inverse pass uses the transpose (rottrans.py:26-28). */
 int rnf_pack_rot16(const float *mat16, float *out_layer);
+
+/* Uncondition9Trans (n = 3) / Uncondition36Trans (n = 6), flow/squeezetrans.py:250-261, 350-361 (and their LU
+ * parameterisations, whose assembled matrix is passed here): layer kinds RNF_LAYER_GS9 / RNF_LAYER_GS36.
+ * Record: M row-major, then M^-1 (used by the inverse pass, squeezetrans.py:259-261,359-361). */
+int64_t rnf_gs_packed_floats(int32_t n);
+int rnf_pack_gs(const float *mat, int32_t n, float *out);
 
 /* Condition16Trans.net = ConditionalTransform(F, 16) (flow/squeezetrans.py:42-44). fc_first_w [64,F], fc_last_w [16,64]. */
 int rnf_pack_cond16(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,

@@ -201,6 +201,9 @@ def flow_forward(module, layers, perm_rows, rotation, feature):
     """Differentiable (rotation', ldj) for a stack of layers; called by runtime.run_flow when a gradient is required."""
     if not rotation.is_cuda:
         raise RuntimeError("rotationnormflow_amd runs on the GPU only (HIP kernels, no CPU fallback): got a CPU tensor")
+    for layer in layers:
+        if not hasattr(layer, "_rnf_train_tensors"):
+            raise NotImplementedError(f"{type(layer).__name__} has no backward kernel yet (training path); evaluate it under torch.no_grad()")
     key = (str(rotation.device), runtime.get_precision(), tuple(perm_rows), tuple(l._rnf_shape() for l in layers))
     cached = getattr(module, "_rnf_train_plan", None)
     if cached is None or cached[0] != key:

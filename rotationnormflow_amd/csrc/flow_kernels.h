@@ -588,7 +588,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     auto layer_at = [&](int pos) { return DIR ? (n_layers - 1 - pos) : pos; };
     auto next_mlp = [&](int pos) {
         for (int q = pos + 1; q < n_layers; ++q)
-            if ((args.layers[layer_at(q)].x & 15) != RNF_KIND_AFFINE16) return q;
+            if (kind_has_mlp(args.layers[layer_at(q)].x & 15)) return q;
         return -1;
     };
     auto l_floats = [&](int kind) { return (kind == RNF_KIND_MOBIUS ? KT : 1) * MOB_LAST_TILE_FLOATS; };
@@ -638,6 +638,14 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 for (int i = 0; i < 16; ++i) M[i] = m[i];
                 affine16_apply(M, m[16], R, ldj, params[34] != 0.f);
                 RNF_STAMP(6)                                      // 6: unconditional affine layer
+                continue;
+            }
+            if (kind == RNF_KIND_GS9) {                           // Uncondition9Trans: the inverse pass uses M^-1 (squeezetrans.py:259-261)
+                gs9_apply(params + (DIR ? 9 : 0), R, ldj);
+                continue;
+            }
+            if (kind == RNF_KIND_GS36) {                          // Uncondition36Trans (squeezetrans.py:355-361)
+                gs36_apply(params + (DIR ? 36 : 0), R, ldj);
                 continue;
             }
 

@@ -24,6 +24,11 @@
 // i.e. reference row (c == 0 ? k : K + 3k + c - 1)   (flow/mobiusflow.py:58-61).
 #pragma once
 #include <stdint.h>
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define RNF_LAYOUT_INLINE __host__ __device__ inline constexpr
+#else
+#define RNF_LAYOUT_INLINE inline constexpr
+#endif
 
 namespace rnf {
 
@@ -50,6 +55,10 @@ inline constexpr int64_t mobius_packed_floats(int K) { return MOB_HEAD_FLOATS + 
 // [0..15] M row-major, [16] log|det M|, [17..32] M^-1, [33] log|det M^-1|, [34] 1.0 if M is orthogonal (log-det exactly 0), [35] 0
 constexpr int AFF_FLOATS = 36;
 
+// ---- 3x3 / 6x6 Gram-Schmidt layers (Uncondition9Trans, Uncondition36Trans): [M row-major | M^-1 row-major] ----
+constexpr int GS9_FLOATS = 20;                            // 9 + 9, padded to a multiple of 4
+constexpr int GS36_FLOATS = 72;                           // 36 + 36
+
 // ---- Condition16Trans record: same head as a Moebius layer with an all-zero fc_first image (its whole first layer
 // is the feature projection), then ONE fc_last tile whose rows are M entries: packed row 8g + 4h + c (g = 0,1) is
 // M[2g + h][c]; rows 16..31 are zero padding.
@@ -66,7 +75,8 @@ inline constexpr int64_t featproj_packed_floats(int F) { return F <= 0 ? 0 : (in
 constexpr int G_FLOATS_PER_GROUP = 2 * 4 * 64 * 4;        // 2048 floats = 64 features x 32 samples
 
 // layer kinds (== RNF_LAYER_* of include/rnf_hip.h)
-constexpr int RNF_KIND_MOBIUS = 1, RNF_KIND_AFFINE16 = 2, RNF_KIND_COND16 = 3;
+constexpr int RNF_KIND_MOBIUS = 1, RNF_KIND_AFFINE16 = 2, RNF_KIND_COND16 = 3, RNF_KIND_GS9 = 4, RNF_KIND_GS36 = 5;
+RNF_LAYOUT_INLINE bool kind_has_mlp(int kind) { return kind == RNF_KIND_MOBIUS || kind == RNF_KIND_COND16; }
 
 // layer descriptor columns (include/rnf_hip.h)
 constexpr int D_KIND = 0, D_PERM = 1, D_PARAM = 2, D_SLOT = 3, D_FEAT = 4, D_PREC = 5, D_STRIDE = 6;   // D_PREC: RNF_PREC_* of include/rnf_hip.h

@@ -239,6 +239,42 @@ extern "C" int rnf_pack_affine16(const float *mat16, float *out) {
     return 0;
 }
 
+// n x n inverse in double (Gauss-Jordan with partial pivoting), n <= 6
+static bool invn_double(const double *m, int n, double *inv) {
+    double a[6][12];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) { a[i][j] = m[n * i + j]; a[i][n + j] = (i == j); }
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        for (int r = c + 1; r < n; ++r) if (std::fabs(a[r][c]) > std::fabs(a[p][c])) p = r;
+        if (a[p][c] == 0.0) return false;
+        if (p != c) for (int j = 0; j < 2 * n; ++j) std::swap(a[p][j], a[c][j]);
+        const double ip = 1.0 / a[c][c];
+        for (int j = 0; j < 2 * n; ++j) a[c][j] *= ip;
+        for (int r = 0; r < n; ++r) if (r != c) {
+            const double f = a[r][c];
+            for (int j = 0; j < 2 * n; ++j) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) inv[n * i + j] = a[i][n + j];
+    return true;
+}
+
+// Uncondition9Trans / Uncondition36Trans (flow/squeezetrans.py:250-261, 350-361): [M | M^-1], n = 3 or 6
+extern "C" int rnf_pack_gs(const float *mat, int32_t n, float *out) {
+    if (n != 3 && n != 6) return fail("rnf_pack_gs: n=%d must be 3 or 6", n);
+    if (!mat || !out) return fail("rnf_pack_gs: null pointer");
+    double m[36], inv[36];
+    for (int i = 0; i < n * n; ++i) m[i] = mat[i];
+    if (!invn_double(m, n, inv)) return fail("rnf_pack_gs: singular %dx%d matrix", n, n);
+    const int total = n == 3 ? GS9_FLOATS : GS36_FLOATS;
+    for (int i = 0; i < total; ++i) out[i] = 0.f;
+    for (int i = 0; i < n * n; ++i) { out[i] = mat[i]; out[n * n + i] = (float)inv[i]; }
+    return 0;
+}
+
+extern "C" int64_t rnf_gs_packed_floats(int32_t n) { return n == 3 ? GS9_FLOATS : (n == 6 ? GS36_FLOATS : -1); }
+
 extern "C" int rnf_pack_rot16(const float *mat16, float *out) {
     // orthogonality check in double: M M^T = I within fp32 rounding of a product of SVD factors
     for (int i = 0; i < 4; ++i)
@@ -342,7 +378,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     for (int l = 0; l < n_layers; ++l) {
         const int32_t *d = desc + (size_t)l * D_STRIDE;
         const int kind = d[D_KIND], perm = d[D_PERM], slot = d[D_SLOT];
-        if (kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16 && kind != RNF_KIND_COND16) return fail("layer %d: unknown kind %d", l, kind);
+        if (kind < RNF_KIND_MOBIUS || kind > RNF_KIND_GS36) return fail("layer %d: unknown kind %d", l, kind);
         if (perm < 0 || perm > 5) return fail("layer %d: perm_row %d outside [0,5]", l, perm);
         if (d[D_PARAM] < 0 || d[D_PARAM] % 4) return fail("layer %d: param offset %d must be a non-negative multiple of 4", l, d[D_PARAM]);
         if (kind == RNF_KIND_COND16 && slot < 0) return fail("layer %d: Condition16Trans needs a cond_slot", l);
@@ -352,7 +388,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             fp.feat_off[slot] = d[D_FEAT];
             if (slot + 1 > n_slots) n_slots = slot + 1;
         }
-        if (kind != RNF_KIND_AFFINE16) {
+        if (kind_has_mlp(kind)) {
             any_mlp = true;
             const int p = d[D_PREC];
             if (p != RNF_PREC_FP32 && p != RNF_PREC_F16X2) return fail("layer %d: unknown precision %d", l, p);

@@ -291,6 +291,72 @@ RNF_HD void affine16_apply(const float (&M)[16], float logabsdet, Rot &R, float 
     if (!orthogonal) ldj += logabsdet - 2.0f * logf(l2);
 }
 
+// ---- 3x3 / 6x6 ablation layers: Gram-Schmidt of two transformed columns, log-det from three tangent directions ----------------
+// (calculate_9 / calculate_36, flow/squeezetrans.py:176-231, 293-331).  a0, a1: the two columns; da0[k], da1[k]: their derivatives
+// along tangent direction k.  Forward mode through normalise / project / normalise / cross; the three tangent images
+// vee(dR' R'^T) form a 3x3 matrix whose |det| is the volume change.
+RNF_HD float det3v(v3f a, v3f b, v3f c) { return dot3(a, cross3(b, c)); }
+
+RNF_HD void gram_schmidt_tangent(v3f a0, v3f a1, const v3f (&da0)[3], const v3f (&da1)[3], Rot &R, float &ldj) {
+    const float i0 = hw_rsq(dot3(a0, a0));
+    const v3f t0 = a0 * i0;
+    const float dot = dot3(t0, a1);
+    const v3f b1 = a1 - t0 * dot;
+    const float i1 = hw_rsq(dot3(b1, b1));
+    const v3f t1 = b1 * i1;
+    const v3f t2 = cross3(t0, t1);
+    v3f vec[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const v3f dt0 = (da0[k] - t0 * dot3(t0, da0[k])) * i0;
+        const float ddot = dot3(dt0, a1) + dot3(t0, da1[k]);
+        const v3f db1 = da1[k] - t0 * ddot - dt0 * dot;
+        const v3f dt1 = (db1 - t1 * dot3(t1, db1)) * i1;
+        const v3f dt2 = cross3(dt0, t1) + cross3(t0, dt1);
+        // delta = dR' R'^T with R' = [t0 t1 t2] (columns): delta[a][b] = sum_c dR'[a][c] R'[b][c]
+        vec[k] = v3f{dt0.x * t0.y + dt1.x * t1.y + dt2.x * t2.y,       // delta[0][1]
+                     dt0.x * t0.z + dt1.x * t1.z + dt2.x * t2.z,       // delta[0][2]
+                     dt0.y * t0.z + dt1.y * t1.z + dt2.y * t2.z};      // delta[1][2]
+    }
+    R.c0 = t0; R.c1 = t1; R.c2 = t2;
+    ldj += 0.693147180559945309f * hw_log2(fabsf(det3v(vec[0], vec[1], vec[2])));
+}
+
+RNF_HD v3f mat3_mul(const float *M, v3f a) {          // row-major 3x3 times vector
+    return v3f{fmaf(M[2], a.z, fmaf(M[1], a.y, M[0] * a.x)), fmaf(M[5], a.z, fmaf(M[4], a.y, M[3] * a.x)),
+               fmaf(M[8], a.z, fmaf(M[7], a.y, M[6] * a.x))};
+}
+
+// calculate_9: columns 0, 1 of M R; tangent directions R G_k (right multiplication): (R G_0) = [-r1, r0, 0], (R G_1) = [-r2, 0, r0],
+// (R G_2) = [0, -r2, r1]
+RNF_HD void gs9_apply(const float *M, Rot &R, float &ldj) {
+    const v3f m0 = mat3_mul(M, R.c0), m1 = mat3_mul(M, R.c1), m2 = mat3_mul(M, R.c2);
+    const v3f z = v3f{0.f, 0.f, 0.f};
+    const v3f da0[3] = {m1 * -1.0f, m2 * -1.0f, z};
+    const v3f da1[3] = {m0, z, m2 * -1.0f};
+    gram_schmidt_tangent(m0, m1, da0, da1, R, ldj);
+}
+
+// calculate_36: (r0 (+) r1) as a 6-vector times M [6][6]; tangent directions G_k R (left multiplication):
+// G_0 c = (c.y, -c.x, 0), G_1 c = (c.z, 0, -c.x), G_2 c = (0, c.z, -c.y)
+RNF_HD void mat6_mul(const float *M, v3f u, v3f w, v3f &a0, v3f &a1) {
+    float o[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        o[i] = fmaf(M[6 * i + 5], w.z, fmaf(M[6 * i + 4], w.y, fmaf(M[6 * i + 3], w.x, fmaf(M[6 * i + 2], u.z, fmaf(M[6 * i + 1], u.y, M[6 * i] * u.x)))));
+    a0 = v3f{o[0], o[1], o[2]};
+    a1 = v3f{o[3], o[4], o[5]};
+}
+RNF_HD void gs36_apply(const float *M, Rot &R, float &ldj) {
+    const v3f r0 = R.c0, r1 = R.c1;
+    v3f a0, a1, da0[3], da1[3];
+    mat6_mul(M, r0, r1, a0, a1);
+    mat6_mul(M, v3f{r0.y, -r0.x, 0.f}, v3f{r1.y, -r1.x, 0.f}, da0[0], da1[0]);
+    mat6_mul(M, v3f{r0.z, 0.f, -r0.x}, v3f{r1.z, 0.f, -r1.x}, da0[1], da1[1]);
+    mat6_mul(M, v3f{0.f, r0.z, -r0.y}, v3f{0.f, r1.z, -r1.y}, da0[2], da1[2]);
+    gram_schmidt_tangent(a0, a1, da0, da1, R, ldj);
+}
+
 // 4x4 inverse and determinant by cofactors (Condition16Trans.inverse: torch.linalg.inv, flow/squeezetrans.py:51-55;
 // my_det_4_4: squeezetrans.py:17-22).  Returns det(M); Minv = adj(M)/det.
 RNF_HD float inv4(const float (&m)[16], float (&o)[16]) {

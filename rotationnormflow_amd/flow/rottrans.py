@@ -41,10 +41,114 @@ class UnconditionRot(nn.Module, _SingleLayer):
     def inverse(self, rotation, permute=None, feature=None):
         return self._single(rotation, permute, None, inverse=True)
 
+def _quaternion_of(P):
+    """Unit quaternion (w, x, y, z) of a proper 3x3 rotation, differentiable torch ops on the host (largest-component branch)."""
+    m = P
+    tr = m[0, 0] + m[1, 1] + m[2, 2]
+    cands = torch.stack([1 + tr, 1 + m[0, 0] - m[1, 1] - m[2, 2], 1 - m[0, 0] + m[1, 1] - m[2, 2], 1 - m[0, 0] - m[1, 1] + m[2, 2]])
+    b = int(torch.argmax(cands))
+    if b == 0:
+        q = torch.stack([cands[0], m[2, 1] - m[1, 2], m[0, 2] - m[2, 0], m[1, 0] - m[0, 1]])
+    elif b == 1:
+        q = torch.stack([m[2, 1] - m[1, 2], cands[1], m[0, 1] + m[1, 0], m[0, 2] + m[2, 0]])
+    elif b == 2:
+        q = torch.stack([m[0, 2] - m[2, 0], m[0, 1] + m[1, 0], cands[2], m[1, 2] + m[2, 1]])
+    else:
+        q = torch.stack([m[1, 0] - m[0, 1], m[0, 2] + m[2, 0], m[1, 2] + m[2, 1], cands[3]])
+    return q / q.norm()
+
+
+def _left_matrix(p):
+    """4x4 matrix of q -> p (x) q: the rotation R(p) applied on the LEFT of R(q)."""
+    w, x, y, z = p
+    return torch.stack([torch.stack([w, -x, -y, -z]), torch.stack([x, w, -z, y]), torch.stack([y, z, w, -x]), torch.stack([z, -y, x, w])])
+
+
+def _right_matrix(p):
+    """4x4 matrix of q -> q (x) p: the rotation R(p) applied on the RIGHT of R(q)."""
+    w, x, y, z = p
+    return torch.stack([torch.stack([w, -x, -y, -z]), torch.stack([x, w, z, -y]), torch.stack([y, -z, w, x]), torch.stack([z, y, -x, w])])
+
+
+class _ConstantRotationLayer(nn.Module, _SingleLayer):
+    """The unconditional 3x3 "rotation" ablations (flow/rottrans.py:72-165) multiply R by ONE constant rotation Q(mat) on the left or
+    on the right and report log-det 0:
+
+      * Uncondition9RotL: U V^T of svd(mat R) = polar(mat) R            (R is orthogonal, so the polar factor factorises)
+      * Uncondition9RotR: U V^T of svd(R mat) = R polar(mat)
+      * Uncondition9RotRSmith: R GramSchmidt(mat)
+
+    A constant left / right rotation is a constant orthogonal 4x4 matrix on the quaternion, i.e. exactly the UnconditionRot kernel.
+    The reference runs a batched 3x3 SVD per sample for the first two; here the 3x3 polar factor is parameter preprocessing on the
+    host (one tiny SVD per parameter version, differentiable for training)."""
+
+    _rnf_kind = runtime.KIND_AFFINE16
+    _rnf_orthogonal = True
+    _left = False
+
+    def __init__(self):
+        super().__init__()
+        self.mat = nn.Parameter(torch.eye(3) + torch.randn(3, 3) * 1e-3)
+        self._cache = runtime.PackCache()
+
+    def _rotation(self, m):
+        raise NotImplementedError
+
+    def _quat_matrix(self):
+        Q = self._rotation(self.mat.cpu().float())
+        if float(torch.det(Q.detach())) < 0:
+            raise ValueError(f"{type(self).__name__}: det(mat) < 0, the layer would output reflections")
+        p = _quaternion_of(Q)
+        return (_left_matrix(p) if self._left else _right_matrix(p)).unsqueeze(0)
+
+    def _rnf_pack(self, L, prec=0):
+        with torch.no_grad():
+            return runtime.pack_rot16(L, self._quat_matrix()), None, 0, 0
+
+    def _rnf_shape(self):
+        return (self._rnf_kind, 0, 0)
+
+    def _rnf_train_tensors(self):
+        return [self._quat_matrix()]
+
+    def forward(self, rotation, permute=None, feature=None):
+        return self._single(rotation, permute, None, inverse=False)
+
+    def inverse(self, rotation, permute=None, feature=None):
+        return self._single(rotation, permute, None, inverse=True)
+
+
+def _polar(m):
+    U, S, V = torch.svd(m)
+    return U @ V.transpose(-1, -2)
+
+
+class Uncondition9RotL(_ConstantRotationLayer):
+    """flow/rottrans.py:94-105."""
+    _left = True
+
+    def _rotation(self, m):
+        return _polar(m)
+
+
+class Uncondition9RotR(_ConstantRotationLayer):
+    """flow/rottrans.py:124-135."""
+
+    def _rotation(self, m):
+        return _polar(m)
+
+
+class Uncondition9RotRSmith(_ConstantRotationLayer):
+    """flow/rottrans.py:154-165 (calculate_9_r_smith, :85-96)."""
+
+    def _rotation(self, m):
+        m0 = m[:, 0] / m[:, 0].norm()
+        m1 = m[:, 1] - (m0 * m[:, 1]).sum() * m0
+        m1 = m1 / m1.norm()
+        return torch.stack([m0, m1, torch.linalg.cross(m0, m1)], dim=-1)
+
+
 ConditionRot = _not_built("ConditionRot", "flow/rottrans.py:26-53")
-Uncondition9RotL = _not_built("Uncondition9RotL", "flow/rottrans.py:94-105")
 Condition9RotL = _not_built("Condition9RotL", "flow/rottrans.py:108-121")
-Uncondition9RotR = _not_built("Uncondition9RotR", "flow/rottrans.py:124-135")
 Condition9RotR = _not_built("Condition9RotR", "flow/rottrans.py:138-151")
-Uncondition9RotRSmith = _not_built("Uncondition9RotRSmith", "flow/rottrans.py:154-165")
 Condition9RotRSmith = _not_built("Condition9RotRSmith", "flow/rottrans.py:168-181")

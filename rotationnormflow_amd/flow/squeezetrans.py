@@ -121,22 +121,82 @@ class Uncondition16TransLU(nn.Module, _SingleLayer):
         return self._single(rotation, permute, None, inverse=True)
 
 
+class _GramSchmidtLayer(nn.Module, _SingleLayer):
+    """Shared body of the 3x3 / 6x6 ablation layers: R' = Gram-Schmidt of the transformed first two columns, log-det from three
+    tangent directions (calculate_9 / calculate_36, flow/squeezetrans.py:199-231, 293-331); the inverse pass applies M^-1."""
+
+    _rnf_n = 3
+
+    def _matrix(self):
+        raise NotImplementedError
+
+    def _rnf_pack(self, L, prec=0):
+        with torch.no_grad():
+            return runtime.pack_gs(L, self._matrix(), self._rnf_n), None, 0, 0
+
+    def forward(self, rotation, permute=None, feature=None):
+        return self._single(rotation, permute, None, inverse=False)
+
+    def inverse(self, rotation, permute=None, feature=None):
+        return self._single(rotation, permute, None, inverse=True)
+
+
+class Uncondition9Trans(_GramSchmidtLayer):
+    """calculate_9 with one learned 3x3 matrix (flow/squeezetrans.py:250-261)."""
+
+    _rnf_kind = runtime.KIND_GS9
+
+    def __init__(self):
+        super().__init__()
+        self.mat = nn.Parameter(torch.eye(3) + torch.randn(3, 3) * 1e-3)
+        self._cache = runtime.PackCache()
+
+    def _matrix(self):
+        return self.mat
+
+
+class Uncondition9TransLU(_GramSchmidtLayer):
+    """calculate_9 with the LU-parameterised 3x3 matrix (flow/squeezetrans.py:264-275)."""
+
+    _rnf_kind = runtime.KIND_GS9
+
+    def __init__(self):
+        super().__init__()
+        self.mat = UnconditionLU(3)
+        self._cache = runtime.PackCache()
+
+    def _matrix(self):
+        return self.mat()[0]
+
+
+class Uncondition36Trans(_GramSchmidtLayer):
+    """calculate_36 with one learned 6x6 matrix acting on the first two columns of R (flow/squeezetrans.py:350-361)."""
+
+    _rnf_kind = runtime.KIND_GS36
+    _rnf_n = 6
+
+    def __init__(self):
+        super().__init__()
+        self.mat = nn.Parameter(torch.eye(6) + torch.randn(6, 6) * 1e-3)
+        self._cache = runtime.PackCache()
+
+    def _matrix(self):
+        return self.mat
+
+
 def _not_built(name, where):
     class _Unbuilt(nn.Module):
         def __init__(self, *a, **k):
             super().__init__()
             raise NotImplementedError(
                 f"{name} ({where}) has no HIP kernel yet and rotationnormflow_amd has no PyTorch fallback; "
-                "built affine layers: Uncondition16Trans, Condition16Trans, Uncondition16TransLU, UnconditionRot")
+                "built affine layers: the Uncondition* family and Condition16Trans")
     _Unbuilt.__name__ = _Unbuilt.__qualname__ = name
     return _Unbuilt
 
 
 # declared so that the registry (flow/affineflow.py:5-73) resolves every name; constructing them fails loudly
 Condition16TransLU = _not_built("Condition16TransLU", "flow/squeezetrans.py:130-143")
-Uncondition36Trans = _not_built("Uncondition36Trans", "flow/squeezetrans.py:350-361")
 Condition36Trans = _not_built("Condition36Trans", "flow/squeezetrans.py:334-347")
-Uncondition9Trans = _not_built("Uncondition9Trans", "flow/squeezetrans.py:250-261")
 Condition9Trans = _not_built("Condition9Trans", "flow/squeezetrans.py:234-247")
-Uncondition9TransLU = _not_built("Uncondition9TransLU", "flow/squeezetrans.py:264-275")
 Condition9TransLU = _not_built("Condition9TransLU", "flow/squeezetrans.py:278-291")

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 
-KIND_MOBIUS, KIND_AFFINE16, KIND_COND16 = 1, 2, 3
+KIND_MOBIUS, KIND_AFFINE16, KIND_COND16, KIND_GS9, KIND_GS36 = 1, 2, 3, 4, 5
 DESC_STRIDE = 6
 
 # Arithmetic of the conditioner GEMMs (include/rnf_hip.h RNF_PREC_*): "f16x2" = split-precision fp16 MFMA (22-bit
@@ -194,6 +194,14 @@ def pack_affine16(L, mat):
     rec = np.empty(L.rnf_affine16_packed_floats(), dtype=np.float32)
     m = _np32(mat).reshape(16)
     _lib.check(L.rnf_pack_affine16(m.ctypes.data, rec.ctypes.data))
+    return rec
+
+
+def pack_gs(L, mat, n):
+    """Uncondition9Trans (n=3) / Uncondition36Trans (n=6): [M | M^-1]."""
+    rec = np.empty(L.rnf_gs_packed_floats(n), dtype=np.float32)
+    m = _np32(mat).reshape(n * n)
+    _lib.check(L.rnf_pack_gs(m.ctypes.data, n, rec.ctypes.data))
     return rec
 
 

@@ -93,9 +93,13 @@ def test_registry_table():
     assert isinstance(affineflow.get_affine(mk(rot="16UnTrans", lu=1, condition=1), 8), squeezetrans.Uncondition16TransLU)
     assert isinstance(affineflow.get_affine(mk(rot="16Rot"), 0), rottrans.UnconditionRot)
     assert isinstance(affineflow.get_affine(mk(rot="16UnRot", condition=1), 8), rottrans.UnconditionRot)
-    for rot in ("36Trans", "9TransLSVD", "9TransRSVD", "9TransLSmith", "9TransRSmith"):
-        with pytest.raises(NotImplementedError):                          # declared, no kernel yet: loud, no fallback
-            affineflow.get_affine(mk(rot=rot), 0)
+    for rot, cls in (("36Trans", squeezetrans.Uncondition36Trans), ("9TransLSVD", rottrans.Uncondition9RotL),
+                     ("9TransRSVD", rottrans.Uncondition9RotR), ("9TransLSmith", squeezetrans.Uncondition9Trans),
+                     ("9TransRSmith", rottrans.Uncondition9RotRSmith)):
+        assert isinstance(affineflow.get_affine(mk(rot=rot), 0), cls)
+        with pytest.raises(NotImplementedError):                          # conditional variants: declared, no kernel yet: loud, no fallback
+            affineflow.get_affine(mk(rot=rot, condition=1), 8)
+    assert isinstance(affineflow.get_affine(mk(rot="9TransLSmith", lu=1), 0), squeezetrans.Uncondition9TransLU)
     with pytest.raises(NotImplementedError):
         affineflow.get_affine(mk(rot="16Trans", lu=1, condition=1), 8)   # Condition16TransLU (batch-coupled in the reference)
     with pytest.raises(NotImplementedError):

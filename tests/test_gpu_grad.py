@@ -47,6 +47,10 @@ CASES = {
     "mobius_only": (dict(layers=4, segments=8, rot="None"), 64, "trained"),
     "lu": (dict(layers=2, segments=16, lu=1), 100, "default"),
     "rot": (dict(layers=2, segments=16, rot="UnRot"), 100, "default"),
+    # constant left / right rotations built from a 3x3 parameter on the host (polar factor, Gram-Schmidt): autograd chains dL/dM4x4
+    "svdl9": (dict(layers=2, segments=16, rot="9TransLSVD"), 100, "trained"),
+    "svdr9": (dict(layers=2, segments=16, rot="9TransRSVD"), 70, "trained"),
+    "smithr9": (dict(layers=2, segments=16, rot="9TransRSmith"), 100, "trained"),
 }
 
 
@@ -255,3 +259,14 @@ def test_gradient_blob_sync_hook_is_applied():
     (-ldj).mean().backward()
     for a, p in zip(g1, fl.parameters()):
         assert torch.allclose(p.grad, 0.5 * a, rtol=1e-4, atol=1e-7)
+
+
+def test_gram_schmidt_layers_refuse_training():
+    cfg = orc.make_config(layers=2, segments=16, rot="9TransLSmith")
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=3)
+    fl = product_flow(cfg, w).train()
+    R = torch.from_numpy(synth.uniform_rotations(32, seed=4)).cuda()
+    with pytest.raises(NotImplementedError):
+        fl(R)                                                   # Uncondition9Trans has no backward kernel: loud, no silent detach
+    with torch.no_grad():
+        fl(R)

@@ -95,6 +95,27 @@ def test_affine16_matches_oracle(hm):
     assert np.abs(ldj - wl.numpy()).max() < 2e-6
 
 
+@pytest.mark.parametrize("nm", [3, 6])
+def test_gram_schmidt_layers_match_oracle(hm, nm):
+    """calculate_9 / calculate_36 (3x3 and 6x6 ablation layers): kernel math (host build) against the oracle restatement."""
+    rng = np.random.default_rng(nm)
+    M = f32(np.eye(nm) + 0.3 * rng.standard_normal((nm, nm)))
+    R = synth.uniform_rotations(4096, seed=9 + nm)
+    Ro, ldj = np.empty_like(R), np.empty(4096, np.float32)
+    hm.hm_gs(ptr(M), nm, ptr(R), ptr(Ro), ptr(ldj), 4096)
+    fn = orc.gs9 if nm == 3 else orc.gs36
+    wR, wl = fn(torch.from_numpy(M).double(), torch.from_numpy(R).double())
+    assert np.abs(Ro - wR.numpy()).max() < 3e-6
+    err = np.abs(ldj - wl.numpy())
+    # the log amplifies fp32 rounding where the tangent volume collapses (|det| -> 0; ldj down to -10 with this harsh M): the
+    # yardstick is the oracle's own fp32 evaluation against fp64 (p99 1.4e-5, max 2e-3 on the 6x6 case)
+    ref32 = np.abs(fn(torch.from_numpy(M), torch.from_numpy(R))[1].numpy() - wl.numpy())
+    assert np.quantile(err, 0.99) < max(2.0 * np.quantile(ref32, 0.99), 1e-5)
+    assert err.max() < max(2.0 * ref32.max(), 1e-5)
+    assert np.abs(np.exp(ldj.astype(np.float64)) - np.exp(wl.numpy())).max() < 1e-4
+    assert np.abs(np.einsum("nji,njk->nik", Ro.astype(np.float64), Ro.astype(np.float64)) - np.eye(3)).max() < 2e-6
+
+
 @pytest.mark.parametrize("perm_row", [0, 1, 2, 4])
 def test_inplane_mobius_layer_matches_oracle_3d_formulation(hm, perm_row):
     n, K = 2048, 64

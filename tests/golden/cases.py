@@ -51,6 +51,10 @@ CASES = {
     "svdr9_uncond":    dict(cfg=dict(layers=3, rot="9TransRSVD"), n=512, regime="trained", wseed=23, rseed=72, direction="forward", fisher=None),
     "smithr9_uncond":  dict(cfg=dict(layers=3, rot="9TransRSmith"), n=512, regime="trained", wseed=24, rseed=73, direction="forward", fisher=None),
     "smithr9_uncond_inv": dict(cfg=dict(layers=3, rot="9TransRSmith"), n=512, regime="trained", wseed=24, rseed=74, direction="inverse", fisher=None),
+    # README.md:153-154 ablations on SYMSOL: affine only (--dist noflow), and unconditional 4x4 with --lu 1 behind a conditional first layer is
+    # not constructible here (Condition16TransLU is batch-coupled in the reference: torch.diag of a [N,4] tensor, squeezetrans.py:127)
+    "noflow_affine":   dict(cfg=dict(layers=6, dist="noflow", feature_dim=32, **SYMSOL), n=512, regime="trained", wseed=25, rseed=75, direction="forward", fisher=None),
+    "noflow_affine_inv": dict(cfg=dict(layers=6, dist="noflow", feature_dim=32, **SYMSOL), n=512, regime="trained", wseed=25, rseed=76, direction="inverse", fisher=None),
     "embed_cond":      dict(cfg=dict(layers=3, condition=1, feature_dim=24, embedding=1, embedding_dim=8, rot="16UnTrans", last_affine=1), n=512,
                             regime="default", wseed=14, rseed=58, direction="forward", fisher=None),
 }

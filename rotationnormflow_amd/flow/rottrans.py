@@ -1,5 +1,6 @@
-"""Mirror of the reference's flow/rottrans.py names (SVD / Smith rotation layers, ldj = 0).  None of the BASELINE
-configurations uses them; they are declared for the registry and fail loudly until their kernels are built."""
+"""Mirror of the reference's flow/rottrans.py (SVD / Smith rotation layers, ldj = 0).  The unconditional layers are built: each is a
+constant orthogonal 4x4 on the quaternion, prepared on the host from its 3x3 / 4x4 parameter and run by the quaternion kernel.  The
+conditional ones (a per-sample SVD) are declared for the registry and fail loudly at construction."""
 import torch
 import torch.nn as nn
 

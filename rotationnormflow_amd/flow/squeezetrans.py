@@ -1,5 +1,6 @@
-"""Mirror of the reference's flow/squeezetrans.py (4x4 quaternion-affine family; the other variants are declared
-but not yet built as kernels and fail loudly)."""
+"""Mirror of the reference's flow/squeezetrans.py: the 4x4 quaternion-affine family (constant, LU-parameterised, feature-conditioned)
+and the unconditional 3x3 / 6x6 Gram-Schmidt ablation layers.  The remaining conditional variants are declared for the registry and
+fail loudly at construction."""
 import torch
 import torch.nn as nn
 

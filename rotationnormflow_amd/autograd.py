@@ -88,12 +88,14 @@ class TrainPlan:
     def pack(self, plain, stream):
         """plain blob -> fresh kernel blob, on the device (one launch)."""
         L = _lib.lib()
-        self.check_flags()
+        capturing = torch.cuda.is_current_stream_capturing()      # inside a HIP graph capture: no event queries, no pinned read-back
+        if not capturing:
+            self.check_flags()
         blob = torch.empty(self.blob_floats, dtype=torch.float32, device=plain.device)
         self.flags.zero_()
         _lib.check(L.rnf_pack_flow_device(plain.data_ptr(), self.pack_desc.ctypes.data, self.n_layers, self.segments, self.feat_dim,
                                           self.prec, blob.data_ptr(), self.flags.data_ptr(), stream))
-        if self.flags_event is None:
+        if self.flags_event is None and not capturing:
             self.flags_host.copy_(self.flags, non_blocking=True)
             self.flags_event = torch.cuda.Event()
             self.flags_event.record()

@@ -68,33 +68,96 @@ def save_reference_checkpoint(path, flow: Flow, optimizer, epoch: int, minibatch
     }, path)
 
 
+class GraphedTrainStep:
+    """One training iteration (agent.py:75-92: forward, loss, zero_grad, backward, optimizer step) captured ONCE as a HIP graph and
+    replayed: the iteration is launch-bound on the host (264 parameter tensors go through autograd and the optimizer one by one), the
+    graph replays the same dozen device launches without any of it.
+
+        step = GraphedTrainStep(flow, optimizer, rotation_shape=(1024, 3, 3))          # optimizer: Adam(..., capturable=True)
+        loss = step(batch)                                                             # device tensor, valid until the next call
+
+    Static shapes: every batch must have ``rotation_shape`` (and ``feature_shape``).  ``base``: optional MatrixFisherN with a frozen A
+    (its term is added to the loss as in agent.py:58-65)."""
+
+    def __init__(self, flow: Flow, optimizer, rotation_shape, feature_shape=None, base=None, warmup: int = 3, device="cuda"):
+        from . import runtime
+        self._runtime = runtime
+        self.flow, self.optimizer, self.base = flow, optimizer, base
+        self.rotation = torch.eye(3, device=device).expand(*rotation_shape).contiguous()
+        self.feature = torch.zeros(feature_shape, device=device) if feature_shape is not None else None
+        # The warm-up iterations torch.cuda.graphs needs (lazy optimizer state, allocator pools) run on placeholder data, so the
+        # parameters and the optimizer state are put back IN PLACE afterwards (the graph must keep seeing the same tensors).
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+        saved_params = [p.detach().clone() for p in params]
+        saved_state = {id(p): {k: v.clone() for k, v in optimizer.state.get(p, {}).items() if torch.is_tensor(v)} for p in params}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # off the default stream, as torch.cuda.graphs requires
+            for _ in range(warmup):
+                optimizer.zero_grad(set_to_none=True)
+                self._loss().backward()
+                optimizer.step()
+            with torch.no_grad():
+                for p, old in zip(params, saved_params):
+                    p.copy_(old)
+                    for k, v in optimizer.state.get(p, {}).items():
+                        if torch.is_tensor(v):
+                            before = saved_state[id(p)].get(k)
+                            v.copy_(before) if before is not None else v.zero_()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = self._loss()
+            self.loss.backward()
+            optimizer.step()
+
+    def _loss(self):
+        rot, ldj = self.flow(self.rotation, self.feature)
+        loss = (-ldj).mean()
+        if self.base is not None:
+            loss = loss - self.base._log_prob(rot).mean()
+        return loss
+
+    def __call__(self, rotation, feature=None):
+        self.rotation.copy_(rotation)
+        if self.feature is not None:
+            self.feature.copy_(feature)
+        self.graph.replay()
+        self._runtime.note_training_step()                  # parameters changed: host-packed blobs of the eval path are stale
+        return self.loss
+
+
 def train_uncondition(flow: Flow, train_rotations: torch.Tensor, iterations: int, batch_size: int = 1024, lr: float = 1e-4,
                       seed: int = 42, test_rotations: torch.Tensor = None, val_every: int = 0, ckpt_path=None, save_every: int = 0,
-                      base=None, device="cuda", log=print):
+                      base=None, device="cuda", log=print, graph: bool = True):
     """Maximum-likelihood training of an unconditional flow on a ``raw`` rotation set.  One iteration = the reference's
     ``Agent.train_func`` (agent.py:75-92): loss = mean(-ldj) (- mean base log-prob if ``base`` is given), zero_grad, backward, Adam
-    step -- here three HIP launches (device packer, fused forward, fused backward) plus the optimizer.
+    step -- here three HIP launches (device packer, fused forward, fused backward) plus the optimizer; with ``graph`` (default) the
+    whole iteration is captured once as a HIP graph and replayed (GraphedTrainStep), which removes the per-tensor host work.
     Returns the list of (iteration, train loss) pairs sampled every 100 iterations and the final test log-likelihood (or None)."""
     flow = flow.to(device).train()
     gen = torch.Generator().manual_seed(seed)
     data = train_rotations.to(device)
     n = data.shape[0]
-    try:
-        opt = torch.optim.Adam(flow.parameters(), lr=lr, fused=True)        # one launch instead of a dozen foreach kernels
-    except (TypeError, RuntimeError):                                      # older torch: no fused Adam
-        opt = torch.optim.Adam(flow.parameters(), lr=lr)
+    opt = torch.optim.Adam(flow.parameters(), lr=lr, fused=True, capturable=graph)   # one launch instead of a dozen foreach kernels
+    batch_size = min(batch_size, n)
+    gstep = GraphedTrainStep(flow, opt, (batch_size, 3, 3), base=base, device=device) if graph else None
     history, it, epoch = [], 0, 0
     while it < iterations:
         perm = torch.randperm(n, generator=gen).to(device)
-        for mb, lo in enumerate(range(0, n - batch_size + 1 if n >= batch_size else 1, batch_size)):
+        for mb, lo in enumerate(range(0, n - batch_size + 1, batch_size)):
             batch = data[perm[lo:lo + batch_size]]
-            rot, ldj = flow(batch)
-            loss = (-ldj).mean()
-            if base is not None:
-                loss = loss - base._log_prob(rot).mean()
-            opt.zero_grad(set_to_none=True)
-            loss.backward()
-            opt.step()
+            if gstep is not None:
+                loss = gstep(batch)
+            else:
+                rot, ldj = flow(batch)
+                loss = (-ldj).mean()
+                if base is not None:
+                    loss = loss - base._log_prob(rot).mean()
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
             it += 1
             if it % 100 == 0 or it == iterations:
                 history.append((it, float(loss.detach())))

@@ -270,3 +270,34 @@ def test_gram_schmidt_layers_refuse_training():
         fl(R)                                                   # Uncondition9Trans has no backward kernel: loud, no silent detach
     with torch.no_grad():
         fl(R)
+
+
+def test_graphed_train_step_follows_the_oracle():
+    """harness.GraphedTrainStep (the iteration captured as a HIP graph) must walk the same loss trajectory as fp64 autograd of the
+    oracle with torch.optim.Adam, starting from the untouched initial weights (the capture warm-up must leave no trace)."""
+    from rotationnormflow_amd import harness
+    cfg = orc.make_config(layers=3, segments=16)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=41, regime="default")
+    A = synth.fisher_A("diag531")[0]
+    data = orc.fisher_sample(torch.from_numpy(A).float()[None], 1024).reshape(-1, 3, 3).numpy().astype(np.float32)
+    batches = [data[i * 256:(i + 1) * 256] for i in range(4)]
+    p = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in w.items()}
+    opt_o = torch.optim.Adam(list(p.values()), lr=3e-3)
+    lo = []
+    for b in batches + batches:
+        opt_o.zero_grad()
+        _, ldj = orc.flow_forward(cfg, p, torch.from_numpy(b).double(), None, dtype=torch.float64, grad=True)
+        loss = (-ldj).mean()
+        loss.backward()
+        opt_o.step()
+        lo.append(float(loss.detach()))
+    fl = product_flow(cfg, w).train()
+    opt = torch.optim.Adam(fl.parameters(), lr=3e-3, fused=True, capturable=True)
+    step = harness.GraphedTrainStep(fl, opt, rotation_shape=(256, 3, 3))
+    lp = [float(step(torch.from_numpy(b).cuda()).detach()) for b in batches + batches]
+    assert np.abs(np.array(lo) - np.array(lp)).max() < 2e-4, (lo, lp)
+    # the eval path sees the trained weights (host-packed blobs are invalidated by every replay)
+    with torch.no_grad():
+        _, ldj = fl(torch.from_numpy(batches[0]).cuda())
+    _, ldj_o = orc.flow_forward(cfg, {k: v.detach() for k, v in p.items()}, torch.from_numpy(batches[0]).double(), None, dtype=torch.float64)
+    assert abs(float(ldj.mean()) - float(ldj_o.mean())) < 2e-4

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--cpu-oracle", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="capture the iteration as a HIP graph (harness.GraphedTrainStep) and replay it")
     ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): one optimizer launch instead of foreach kernels")
     a = ap.parse_args()
     cfg = configs.make_config(a.config)
@@ -41,6 +42,23 @@ def main():
     feat = None
     if cfg.condition:
         feat = torch.from_numpy(synth.features(a.batch, fl.feature_dim, seed=2)).cuda()
+
+    if a.graph:
+        from rotationnormflow_amd.harness import GraphedTrainStep
+        opt = torch.optim.Adam(fl.parameters(), lr=1e-4, fused=True, capturable=True)
+        gstep = GraphedTrainStep(fl, opt, tuple(R.shape), None if feat is None else tuple(feat.shape))
+        for _ in range(a.warmup):
+            gstep(R, feat)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss = gstep(R, feat)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        print(json.dumps(dict(metric="training iteration (forward + backward + Adam), HIP graph replay", optimizer="Adam(fused, capturable)",
+                              config=a.config, batch=a.batch, ms_per_iteration=dt * 1e3, rotations_per_s=a.batch / dt,
+                              loss=float(loss.detach()))))
+        return
 
     def step():
         opt.zero_grad(set_to_none=True)

@@ -45,6 +45,8 @@ struct TrainArgs {
     int2 layers[TR_MAX_LAYERS];
 };
 
+struct __attribute__((packed, aligned(4))) Float4U { float x, y, z, w; };      // 16-byte global load from a 4-byte aligned address
+
 // LDS matrix [rows][64 samples], rows padded to 65 floats: conflict free both for "lanes = 32 consecutive samples of one row"
 // and for "lanes = 32 consecutive rows at one sample" (the two MFMA operand patterns), and -- unlike an XOR swizzle -- every
 // unrolled access is base register + immediate offset, so the reads of a product issue back to back
@@ -92,8 +94,13 @@ __device__ __forceinline__ RowsA load_rows64(const float *__restrict__ W, const 
 // D[rho][j] = bias[row] + sum_{k<64} W[row][k] * b(k), k = 32h + m.  b(k): B element (k, this lane's sample).  The B reads of half
 // a product are issued before its first MFMA (sched_barrier), so that the dependent MFMA chain runs back to back instead of paying
 // one LDS latency per step.
-template <class BFn>
-__device__ __forceinline__ f32x16 mfma_rows64(const RowsA &a, int h, BFn b) {
+// B elements are READ first (raw, 16 in flight) and transformed (ReLU) only after a sched_barrier: an op right behind each LDS read
+// makes the compiler reuse one destination register and serialise the reads, exactly as with the global loads.
+struct Identity { __device__ __forceinline__ float operator()(float v) const { return v; } };
+struct Relu { __device__ __forceinline__ float operator()(float v) const { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); } };
+
+template <class BFn, class Post = Identity>
+__device__ __forceinline__ f32x16 mfma_rows64(const RowsA &a, int h, BFn b, Post post = Post()) {
     f32x16 acc = RNF_MFMA(a.bias, h ? 0.f : 1.f, zero16());
 #pragma unroll
     for (int half = 0; half < 2; ++half) {                 // 16 B reads in flight, then 16 MFMAs
@@ -101,6 +108,8 @@ __device__ __forceinline__ f32x16 mfma_rows64(const RowsA &a, int h, BFn b) {
 #pragma unroll
         for (int m = 0; m < 16; ++m) bv[m] = b(32 * h + 16 * half + m);
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) bv[m] = post(bv[m]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             acc = RNF_MFMA(a.w[4 * half + q].x, bv[4 * q], acc);
@@ -144,8 +153,8 @@ __device__ __forceinline__ f32x16 mfma_cols(const ColsA &c, int k0, int h, BFn b
 }
 
 // acc[rho][j] = sum_{s<64} a(s) * b(s): the product over the block's samples (weight gradients), s = 32h + m
-template <class AFn, class BFn>
-__device__ __forceinline__ f32x16 mfma_samples(int h, AFn a, BFn b) {
+template <class AFn, class BFn, class Post = Identity>
+__device__ __forceinline__ f32x16 mfma_samples(int h, AFn a, BFn b, Post post = Post()) {
     f32x16 acc = zero16();
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -153,6 +162,8 @@ __device__ __forceinline__ f32x16 mfma_samples(int h, AFn a, BFn b) {
 #pragma unroll
         for (int m = 0; m < 16; ++m) { av[m] = a(32 * h + 16 * half + m); bv[m] = b(32 * h + 16 * half + m); }
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) bv[m] = post(bv[m]);
 #pragma unroll
         for (int m = 0; m < 16; ++m) acc = RNF_MFMA(av[m], bv[m], acc);
         __builtin_amdgcn_sched_barrier(0);
@@ -194,9 +205,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ void bias_grad(const LMat &G, int n_out, float *gb, int tid) {
     const int q = tid & 3;
     for (int o = tid >> 2; o < n_out; o += TR_WAVES * 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = G.at(o, 16 * q + i);
+        __builtin_amdgcn_sched_barrier(0);                 // all 16 reads in flight before the first add
         float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc += G.at(o, 16 * q + i);
+        for (int i = 0; i < 16; ++i) acc += v[i];
         acc = quad_sum(acc);
         if (q == 0) atomicAdd(gb + o, acc);
     }
@@ -306,21 +321,40 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
             {
                 f32x16 acc = RNF_MFMA(b0[32 * ta + j], h ? 0.f : 1.f, zero16());
                 const float *wrow = W0 + (size_t)(32 * ta + j) * NI;
-                for (int c0 = 0; HAS_FEATURE && c0 < F; c0 += 64) {
-                    for (int m0 = 0; m0 < 32; m0 += 16) {
-                        float a[16], b[16];
+                if (HAS_FEATURE) {
+                    // chunks of 16 K steps (k = 64 (ch / 2) + 32 h + 16 (ch & 1) + u); each lane's 16 operands are one 64-byte run of its row
+                    const float *frow = args.feature + (bvalid ? bsample : 0) * F;
+                    const int nch = (F + 63) / 64 * 2;
+                    auto kof = [&](int ch, int u) { return 64 * (ch >> 1) + 32 * h + 16 * (ch & 1) + u; };
+                    auto load_chunk = [&](int ch, float (&a)[16], float (&b)[16]) {
+                        const int k0 = kof(ch, 0);
+                        if (k0 + 16 <= F) {                       // wave-uniform per half: 4 x 16-byte loads per operand (4-byte aligned)
+                            const Float4U *pa = reinterpret_cast<const Float4U *>(wrow + yo + k0);
+                            const Float4U *pb = reinterpret_cast<const Float4U *>(frow + k0);
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            const int k = c0 + 32 * h + m0 + u, kc = k < F ? k : F - 1;
-                            a[u] = wrow[yo + kc];
-                            b[u] = args.feature[(bvalid ? bsample : 0) * F + kc];
+                            for (int q = 0; q < 4; ++q) {
+                                const Float4U va = pa[q], vb = pb[q];
+                                a[4 * q] = va.x; a[4 * q + 1] = va.y; a[4 * q + 2] = va.z; a[4 * q + 3] = va.w;
+                                b[4 * q] = vb.x; b[4 * q + 1] = vb.y; b[4 * q + 2] = vb.z; b[4 * q + 3] = vb.w;
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) {
+                                const int k = k0 + u, kc = k < F ? k : F - 1;
+                                a[u] = wrow[yo + kc];
+                                b[u] = frow[kc];
+                            }
                         }
+                    };
+                    auto mul_chunk = [&](int ch, const float (&a)[16], const float (&b)[16]) {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) acc = RNF_MFMA(kof(ch, u) < F ? a[u] : 0.f, bvalid ? b[u] : 0.f, acc);
+                    };
+                    for (int ch = 0; ch < nch; ++ch) {
+                        float av[16], bv[16];
+                        load_chunk(ch, av, bv);
                         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            const int k = c0 + 32 * h + m0 + u;
-                            acc = RNF_MFMA(k < F ? a[u] : 0.f, bvalid ? b[u] : 0.f, acc);
-                        }
+                        mul_chunk(ch, av, bv);
                     }
                 }
                 if (mob) {
@@ -337,9 +371,9 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
             {
                 const RowsA w1 = wnext;
                 wnext = load_rows64(W3, b3, 32 * ta + j, 64, h);
-                f32x16 acc = mfma_rows64(w1, h, [&](int k) { return fmaxf(X0.at(k, bs), 0.f); });
+                f32x16 acc = mfma_rows64(w1, h, [&](int k) { return X0.at(k, bs); }, Relu());
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+                for (int r = 0; r < 16; ++r) acc[r] = Relu()(acc[r]);
                 store_tile(H1, 32 * ta, 64, bs, h, acc);
             }
             lds_barrier();
@@ -348,32 +382,33 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                 wnext = load_rows64(W5, b5, 32 * ta + j, 64, h);
                 f32x16 acc = mfma_rows64(w3, h, [&](int k) { return H1.at(k, bs); });
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+                for (int r = 0; r < 16; ++r) acc[r] = Relu()(acc[r]);
                 store_tile(H2, 32 * ta, 64, bs, h, acc);
             }
             lds_barrier();
-            RowsA wA, wB;
             {
                 const RowsA w5 = wnext;
-                wA = load_rows64(WL, bL, 32 * ta + j, NO, h);
+                wnext = load_rows64(WL, bL, 32 * ta + j, NO, h);
                 f32x16 acc = mfma_rows64(w5, h, [&](int k) { return H2.at(k, bs); });
+                {
+                    float xv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r] + X0.at(32 * ta + rho(r, h), bs), 0.f);
+                    for (int r = 0; r < 16; ++r) xv[r] = X0.at(32 * ta + rho(r, h), bs);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = Relu()(acc[r] + xv[r]);
+                }
                 store_tile(H3, 32 * ta, 64, bs, h, acc);
             }
             const LMat &T = H3;
             lds_barrier();
             RNF_TSTAMP(1)
-            for (int rt = ta; rt < ntiles; rt += 4) {     // fc_last: C = WL t + bL, two tiles per trip (A operands ping-pong)
-                const bool has_b = rt + 2 < ntiles;
-                if (has_b) wB = load_rows64(WL, bL, 32 * (rt + 2) + j, NO, h);
-                store_tile(Cm, 32 * rt, NO, bs, h, mfma_rows64(wA, h, [&](int k) { return T.at(k, bs); }));
-                if (has_b) {
-                    if (rt + 4 < ntiles) wA = load_rows64(WL, bL, 32 * (rt + 4) + j, NO, h);
-                    store_tile(Cm, 32 * (rt + 2), NO, bs, h, mfma_rows64(wB, h, [&](int k) { return T.at(k, bs); }));
-                }
+            for (int rt = ta; rt < ntiles; rt += 2) {     // fc_last: C = WL t + bL
+                const RowsA wl = wnext;
+                if (rt + 2 < ntiles) wnext = load_rows64(WL, bL, 32 * (rt + 2) + j, NO, h);
+                store_tile(Cm, 32 * rt, NO, bs, h, mfma_rows64(wl, h, [&](int k) { return T.at(k, bs); }));
             }
-            ColsA cA = load_cols(WL, 64, 0, NO, 32 * ta + j, 64, h), cB;       // first slab of WL^T, needed after the layer math
+            ColsA cnext = load_cols(WL, 64, 0, NO, 32 * ta + j, 64, h);        // first slab of WL^T, needed after the layer math
             lds_barrier();
             RNF_TSTAMP(2)
             // ================= layer math: forward sums + backward; dL/dC overwrites C =================
@@ -442,40 +477,44 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
             RNF_TSTAMP(4)
             {
                 f32x16 acc = zero16();
-                for (int k0 = 0; k0 < NO; k0 += 128) {    // two 64-row slabs of WL^T per trip (A operands ping-pong)
-                    const bool has_b = k0 + 64 < NO;
-                    if (has_b) cB = load_cols(WL, 64, k0 + 64, NO, 32 * ta + j, 64, h);
-                    else cB = load_cols(W5, 64, 0, 64, 32 * ta + j, 64, h);                // ahead: W5^T for the first hidden step
-                    acc = mfma_cols(cA, k0, h, [&](int k) { return Cm.at(k, bs); }, acc);
-                    if (has_b) {
-                        if (k0 + 128 < NO) cA = load_cols(WL, 64, k0 + 128, NO, 32 * ta + j, 64, h);
-                        else cA = load_cols(W5, 64, 0, 64, 32 * ta + j, 64, h);
-                        acc = mfma_cols(cB, k0 + 64, h, [&](int k) { return Cm.at(k, bs); }, acc);
-                    } else {
-                        cA = cB;
-                    }
+                for (int k0 = 0; k0 < NO; k0 += 64) {     // 64-row slabs of WL^T; the next slab (or W5^T for the first hidden step) loads ahead
+                    const ColsA cur = cnext;
+                    if (k0 + 64 < NO) cnext = load_cols(WL, 64, k0 + 64, NO, 32 * ta + j, 64, h);
+                    else cnext = load_cols(W5, 64, 0, 64, 32 * ta + j, 64, h);
+                    acc = mfma_cols(cur, k0, h, [&](int k) { return Cm.at(k, bs); }, acc);
                 }
+                {                                         // through t = relu(x0 + h3): this is dL/dh3 and the residual part of dL/dx0
+                    float tv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r)              // through t = relu(x0 + h3): this is dL/dh3 and the residual part of dL/dx0
-                    acc[r] = T.at(32 * ta + rho(r, h), bs) > 0.f ? acc[r] : 0.f;
+                    for (int r = 0; r < 16; ++r) tv[r] = T.at(32 * ta + rho(r, h), bs);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = tv[r] > 0.f ? acc[r] : 0.f;
+                }
                 lds_barrier();                            // `red` (inside GA) is no longer read
                 store_tile(GA, 32 * ta, 64, bs, h, acc);
             }
             lds_barrier();
             RNF_TSTAMP(5)
             // hidden layers, last to first.  (g_out, act_in) -> gW, gb, g_in masked by the ReLU of its pre-activation.
-            // cA holds the transposed weights of this step; Wnext: the matrix of the FOLLOWING step (loaded ahead), or nullptr
+            // cnext holds the transposed weights of this step; Wnext: the matrix of the FOLLOWING step (loaded ahead), or nullptr
             auto hidden_backward = [&](float *gW, float *gb, const LMat &Gout, const LMat &PreIn, const LMat &Gin, const float *Wnext) {
-                if (Wnext) cB = load_cols(Wnext, 64, 0, 64, 32 * ta + j, 64, h);
-                const f32x16 wg = mfma_samples(h, [&](int s) { return Gout.at(32 * ta + j, s); }, [&](int s) { return fmaxf(PreIn.at(32 * tb + j, s), 0.f); });
+                const ColsA cur = cnext;
+                if (Wnext) cnext = load_cols(Wnext, 64, 0, 64, 32 * ta + j, 64, h);
+                const f32x16 wg = mfma_samples(h, [&](int s) { return Gout.at(32 * ta + j, s); }, [&](int s) { return PreIn.at(32 * tb + j, s); }, Relu());
                 scatter_add(gW, 64, 32 * ta, 64, 32 * tb + j, true, h, wg);
                 bias_grad(Gout, 64, gb, tid);
-                f32x16 acc = mfma_cols(cA, 0, h, [&](int k) { return Gout.at(k, bs); }, zero16());
+                f32x16 acc = mfma_cols(cur, 0, h, [&](int k) { return Gout.at(k, bs); }, zero16());
+                {
+                    float pv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = PreIn.at(32 * ta + rho(r, h), bs) > 0.f ? acc[r] : 0.f;
+                    for (int r = 0; r < 16; ++r) pv[r] = PreIn.at(32 * ta + rho(r, h), bs);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = pv[r] > 0.f ? acc[r] : 0.f;
+                }
                 lds_barrier();                            // Gin may alias a buffer other waves were still reading
                 store_tile(Gin, 32 * ta, 64, bs, h, acc);
-                if (Wnext) cA = cB;
                 lds_barrier();
             };
             // (each activation buffer is free once its ReLU mask has been applied, and takes the next gradient)
@@ -484,7 +523,14 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
             hidden_backward(gW1, gb1, H2, X0, H1, nullptr);   // g_h1  -> chain part of g_x0 (H1's storage)
             RNF_TSTAMP(6)
             const LMat GB = H3;                           // total dL/dx0 = chain + residual
-            for (int o = 16 * wave; o < 16 * wave + 16; ++o) GB.at(o, lane) = H1.at(o, lane) + GA.at(o, lane);
+            {
+                float c1[16], c2[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { c1[i] = H1.at(16 * wave + i, lane); c2[i] = GA.at(16 * wave + i, lane); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) GB.at(16 * wave + i, lane) = c1[i] + c2[i];
+            }
             lds_barrier();
             // fc_first: x0 = W0 (y (+) f) + b0
             bias_grad(GB, 64, gb0, tid);
@@ -494,12 +540,18 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                     scatter_add(gW0, NI, 32 * wave, 64, j, j < 3, h, acc);
                 }
                 float gy0 = 0.f, gy1 = 0.f, gy2 = 0.f;                      // the conditioner-input path of dL/dy (every wave, all rows)
-#pragma unroll 8
-                for (int o = 0; o < 64; ++o) {
-                    const float go = GB.at(o, lane);
-                    gy0 = fmaf(W0[(size_t)o * NI], go, gy0);
-                    gy1 = fmaf(W0[(size_t)o * NI + 1], go, gy1);
-                    gy2 = fmaf(W0[(size_t)o * NI + 2], go, gy2);
+                for (int o0 = 0; o0 < 64; o0 += 16) {
+                    float gv[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) gv[i] = GB.at(o0 + i, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float *wr = W0 + (size_t)(o0 + i) * NI;
+                        gy0 = fmaf(wr[0], gv[i], gy0);
+                        gy1 = fmaf(wr[1], gv[i], gy1);
+                        gy2 = fmaf(wr[2], gv[i], gy2);
+                    }
                 }
                 set_col(gRin, p1, get_col(gRin, p1) + v3f{gy0, gy1, gy2});
             }
@@ -512,31 +564,48 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                     f32x16 acc = zero16();
                     const long long r0 = blk * 64 + 32 * h;
                     const float *fp = args.feature + (r0 < args.n ? r0 : args.n - 1) * F + (c < F ? c : F - 1);   // row 32h + m of the block, column c
-                    for (int m0 = 0; m0 < 32; m0 += 8) {
-                        float b[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {                      // (rows of padding rotations: their g is exactly 0)
+                    for (int half = 0; half < 2; ++half) {                   // (rows of padding rotations: their g is exactly 0)
+                        float b[16], gq[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) {
                             b[u] = *fp;
-                            if (blk * 64 + 32 * h + m0 + u + 1 < args.n) fp += F;
+                            if (blk * 64 + 32 * h + 16 * half + u + 1 < args.n) fp += F;
+                            gq[u] = GB.at(32 * rt + j, 32 * h + 16 * half + u);
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) acc = RNF_MFMA(GB.at(32 * rt + j, 32 * h + m0 + u), b[u], acc);
+                        for (int u = 0; u < 16; ++u) acc = RNF_MFMA(gq[u], b[u], acc);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     scatter_add(gW0 + yo, NI, 32 * rt, 64, c, c < F, h, acc);
                 }
+                asm volatile("" ::: "memory");       // keeps the two tile loops apart (hoisting the second loop's loads over the first spills)
                 if (args.g_feature) {
-                    // g_f[c][s] = sum_o W0[o][yo + c] g[o][s]: tiles ceil(F/32) (feature rows) x 2 (sample columns)
+                    // g_f[s][c] = sum_o g[o][s] W0[o][yo + c]: tiles 2 (sample rows) x ceil(F/32) (feature columns); A = g^T from LDS,
+                    // B = rows of W0 (coalesced over the feature index), and the tile lands feature-contiguous for the read-modify-write
                     for (int t = wave; t < 2 * ctiles; t += TR_WAVES) {
                         const int st = t & 1, ct = t >> 1;
-                        const int c = 32 * ct + j, sc = 32 * st + j;
-                        const ColsA wf = load_cols(W0 + yo, NI, 0, 64, c, F, h);
-                        const f32x16 acc = mfma_cols(wf, 0, h, [&](int k) { return GB.at(k, sc); }, zero16());
-                        const long long smp = blk * 64 + sc;
+                        const int c = 32 * ct + j, cc = c < F ? c : F - 1;
+                        f32x16 acc = zero16();
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            float av[16], bv[16];
+#pragma unroll
+                            for (int m = 0; m < 16; ++m) {
+                                const int o = 32 * h + 16 * half + m;
+                                av[m] = GB.at(o, 32 * st + j);
+                                bv[m] = W0[(size_t)o * NI + yo + cc];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int m = 0; m < 16; ++m) acc = RNF_MFMA(av[m], bv[m], acc);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int cc = 32 * ct + rho(r, h);
-                            if (cc < F && smp < args.n) args.g_feature[smp * F + cc] += acc[r];
+                            const long long smp = blk * 64 + 32 * st + rho(r, h);
+                            if (c < F && smp < args.n) args.g_feature[smp * F + c] += acc[r];
                         }
                     }
                 }

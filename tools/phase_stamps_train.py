@@ -56,9 +56,14 @@ def main():
         torch.cuda.synchronize()
     s = stamps.cpu().numpy().astype(float)
     blocks = (args.batch + 63) // 64
-    print(f"preset={args.preset} batch={args.batch}: wave-0 cycles per block (s_memtime ticks, 100 MHz), {blocks} blocks")
-    for name, v in zip(PHASES, s):
-        print(f"{name:40s} {100 * v / s.sum():6.1f} %   {v / blocks:12.0f}")
+    n_mlp = sum(1 for layer in fl.layers if hasattr(layer, "conditioner") or hasattr(layer, "net"))
+    n_aff = len(fl.layers) - n_mlp
+    print(f"preset={args.preset} batch={args.batch}: wave-0 shader-clock cycles (s_memtime), {blocks} workgroups, "
+          f"{n_mlp} conditioner layers + {n_aff} constant affine layers")
+    print(f"{'phase':40s} {'share':>8s} {'cycles/workgroup':>18s} {'cycles/layer':>14s}")
+    for i, (name, v) in enumerate(zip(PHASES, s)):
+        per = v / blocks / (n_aff if i == 8 else (1 if i == 9 else n_mlp)) if (n_aff if i == 8 else n_mlp) else 0.0
+        print(f"{name:40s} {100 * v / s.sum():6.1f} %   {v / blocks:16.0f} {per:14.0f}")
 
 
 if __name__ == "__main__":

@@ -107,39 +107,48 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
                         bl[s][2 * q] = pl[0]; bl[s][2 * q + 1] = pl[1];
                     }
                 }
-                for (int slot = 0; slot < args.n_slots; ++slot) {
+                // weight tiles (slot, out tile) stream through two LDS buffers by LDS-DMA: tile t + 1 lands while tile t multiplies,
+                // one barrier per tile (the synchronous copy with two barriers per tile was 5x the MFMA time of the tile)
+                const int n_t = 2 * args.n_slots;
+                constexpr int BUF = (FP_KCHUNK / 16) * 512;
+                auto tile_src = [&](int t) {
+                    return args.blob + args.feat_off[t >> 1] + ((size_t)(t & 1) * nsteps_all + kc / 16) * 512;
+                };
+                __syncthreads();                                   // every wave has finished with both buffers (previous chunk / tile)
+                dma_floats(lds, tile_src(0), ns * 512, wave, lane, NW);
+                for (int t = 0; t < n_t; ++t) {
+                    const int slot = t >> 1, ot = t & 1;
                     const float *rec = args.blob + args.feat_off[slot];
-                    for (int ot = 0; ot < 2; ++ot) {
-                        __syncthreads();
-                        stage_floats(lds, rec + ((size_t)ot * nsteps_all + kc / 16) * 512, ns * 512, tid, NT);
-                        __syncthreads();
-                        float *g = args.G + (((size_t)slot * args.g_groups + group) * 2 + ot) * (4 * 64 * 4);
-                        f32x16 acc1, acc2;
-                        if (kc == 0) {
-                            const float *bias = rec + (size_t)2 * nsteps_all * 512 + (ot * 2 + h) * 16;
+                    const float *wl = lds + (t & 1) * BUF;
+                    dma_wait_all();
+                    __syncthreads();                               // tile t is complete; nobody still reads the other buffer
+                    if (t + 1 < n_t) dma_floats(lds + ((t + 1) & 1) * BUF, tile_src(t + 1), ns * 512, wave, lane, NW);
+                    float *g = args.G + (((size_t)slot * args.g_groups + group) * 2 + ot) * (4 * 64 * 4);
+                    f32x16 acc1, acc2;
+                    if (kc == 0) {
+                        const float *bias = rec + (size_t)2 * nsteps_all * 512 + (ot * 2 + h) * 16;
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc1[r] = bias[r];
-                        } else {
-                            acc1 = load_g16(g, lane);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-#pragma unroll
-                        for (int s = 0; s < FP_KCHUNK / 16; ++s) {
-                            if (s < ns) {
-                                const h8 ah = lds_h8(lds, (s * 2 + 0) * 64 + lane);
-                                const h8 al = lds_h8(lds, (s * 2 + 1) * 64 + lane);
-                                acc1 = RNF_MFMA_H(ah, bh[s], acc1);
-                                acc2 = RNF_MFMA_H(ah, bl[s], acc2);
-                                acc2 = RNF_MFMA_H(al, bh[s], acc2);
-                            }
-                        }
-                        float4 *g4 = reinterpret_cast<float4 *>(g);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            g4[q * 64 + lane] = make_float4(fmaf(acc2[4 * q], kLoInv, acc1[4 * q]), fmaf(acc2[4 * q + 1], kLoInv, acc1[4 * q + 1]),
-                                                            fmaf(acc2[4 * q + 2], kLoInv, acc1[4 * q + 2]), fmaf(acc2[4 * q + 3], kLoInv, acc1[4 * q + 3]));
+                        for (int r = 0; r < 16; ++r) acc1[r] = bias[r];
+                    } else {
+                        acc1 = load_g16(g, lane);
                     }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < FP_KCHUNK / 16; ++s) {
+                        if (s < ns) {
+                            const h8 ah = lds_h8(wl, (s * 2 + 0) * 64 + lane);
+                            const h8 al = lds_h8(wl, (s * 2 + 1) * 64 + lane);
+                            acc1 = RNF_MFMA_H(ah, bh[s], acc1);
+                            acc2 = RNF_MFMA_H(ah, bl[s], acc2);
+                            acc2 = RNF_MFMA_H(al, bh[s], acc2);
+                        }
+                    }
+                    float4 *g4 = reinterpret_cast<float4 *>(g);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        g4[q * 64 + lane] = make_float4(fmaf(acc2[4 * q], kLoInv, acc1[4 * q]), fmaf(acc2[4 * q + 1], kLoInv, acc1[4 * q + 1]),
+                                                        fmaf(acc2[4 * q + 2], kLoInv, acc1[4 * q + 2]), fmaf(acc2[4 * q + 3], kLoInv, acc1[4 * q + 3]));
                 }
             }
         }

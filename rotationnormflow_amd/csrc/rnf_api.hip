@@ -464,7 +464,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             fp.F = F;
             fp.n_slots = n_slots;
             const int kchunk = F < FP_KCHUNK ? F : FP_KCHUNK;
-            size_t fl = sizeof(float) * (prec ? (size_t)((kchunk + 15) / 16) * 512 : (size_t)kchunk / 8 * 256);
+            size_t fl = sizeof(float) * (prec ? (size_t)2 * (FP_KCHUNK / 16) * 512 : (size_t)kchunk / 8 * 256);   // f16x2: two DMA buffers
             if (prec) {
                 auto kern = featproj_kernel<NW, 1>;
                 HIP_TRY(allow_lds(kern, fl));

@@ -147,7 +147,7 @@ class _FlowForwardFn(torch.autograd.Function):
                                                     states.data_ptr(), ws.data_ptr(), ws.numel(), stream))
         feat_plain = None
         if plan.n_cond:
-            feat_plain = feature.reshape(n, -1).to(device=dev, dtype=torch.float32).contiguous()
+            feat_plain = feature.reshape(n, plan.feat_dim).to(device=dev, dtype=torch.float32).contiguous()
         ctx.plan = plan
         ctx.grad_sync = grad_sync
         ctx.rot_shape = rotation.shape

@@ -275,7 +275,7 @@ def _check_inputs(rotation, feature, packed: PackedFlow):
     feat = None
     if packed.n_cond:
         assert feature is not None, "The input feature is needed in this module"          # mobiusflow.py:48-49
-        feat = feature.reshape(rot.shape[0], -1)
+        feat = feature.reshape(rot.shape[0], -1) if rot.shape[0] else feature.reshape(0, packed.feat_dim)   # (-1 is ambiguous for 0 rows)
         if feat.shape[1] != packed.feat_dim:
             raise ValueError(f"feature has {feat.shape[1]} columns, flow expects {packed.feat_dim}")
         feat = feat.to(device=rot.device, dtype=torch.float32)

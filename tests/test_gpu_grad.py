@@ -301,3 +301,24 @@ def test_graphed_train_step_follows_the_oracle():
         _, ldj = fl(torch.from_numpy(batches[0]).cuda())
     _, ldj_o = orc.flow_forward(cfg, {k: v.detach() for k, v in p.items()}, torch.from_numpy(batches[0]).double(), None, dtype=torch.float64)
     assert abs(float(ldj.mean()) - float(ldj_o.mean())) < 2e-4
+
+
+@pytest.mark.parametrize("n", [0, 1, 65])
+def test_training_on_tiny_and_ragged_batches(n):
+    """Empty batch: zero gradients, no launch.  1 and 65 rotations: one nearly empty workgroup / one full + one with a single lane."""
+    cfg, w, R, feat, gR, gl = _make("cond_first_affine")
+    fl = product_flow(cfg, w).train()
+    Rd = torch.from_numpy(R[:n]).cuda().requires_grad_(True)
+    fd = torch.from_numpy(feat[:n]).cuda().requires_grad_(True)
+    Ro, ldj = fl(Rd, fd)
+    assert Ro.shape == (n, 3, 3) and ldj.shape == (n,)
+    (ldj.sum() + Ro.sum()).backward()
+    torch.cuda.synchronize()
+    if n == 0:
+        assert all(float(p.grad.abs().max()) == 0.0 for p in fl.parameters())
+        return
+    want, want_gR, want_gf, _, _ = oracle_grads(cfg, w, R[:n], feat[:n], np.ones((n, 3, 3), np.float32), np.ones(n, np.float32))
+    for k, p in fl.named_parameters():
+        g = p.grad.cpu().numpy().astype(np.float64)
+        assert np.abs(g - want[k]).max() / max(np.abs(want[k]).max(), 1e-3) < REL, k
+    assert np.abs(fd.grad.cpu().numpy() - want_gf).max() / max(np.abs(want_gf).max(), 1e-3) < REL

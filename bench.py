@@ -93,11 +93,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    # RNF_BENCH_SHARED_GPU=1 (test rig only: a 1-GPU box): every rank uses cuda:0 and the collective runs over gloo, so that the
+    # N > 1 control flow of this script can be exercised without N GPUs.  The driver never sets it.
+    shared_gpu = os.environ.get("RNF_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 

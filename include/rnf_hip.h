@@ -147,7 +147,8 @@ int rnf_flow_forward_train(const float *rotation_dev, const float *feature_dev, 
 
 /* Reverse sweep of Flow.forward (what autograd does for the reference, agent.py:79-80).
  * In : g_rotation_out_dev [n][9] (NULL = zeros), g_ldj_dev [n].
- * Out: grads_dev (plain layout, ACCUMULATED into: zero it first), g_rotation_in_dev [n][9],
+ * Out: grads_dev (plain layout, ACCUMULATED into: zero it first; NULL = skip every parameter gradient, for callers that only
+ *      differentiate w.r.t. the inputs: pose refinement, eval.py:464-478), g_rotation_in_dev [n][9],
  *      g_feature_dev [n][F] (accumulated into; may be NULL).
  * Scratch: layer_scratch_dev float[n_layers], zeroed by the caller (batch sums of dL/dldj for the d log|det M| / dM term).
  * Segments <= 64, n_layers <= 200. */

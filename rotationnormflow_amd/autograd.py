@@ -165,7 +165,8 @@ class _FlowForwardFn(torch.autograd.Function):
         n = states.shape[1]
         dev = states.device
         L = _lib.lib()
-        grads = torch.zeros_like(plain)
+        want_w = any(ctx.needs_input_grad[4:])            # no parameter requires grad: input gradients only, weight products skipped
+        grads = torch.zeros_like(plain) if want_w else None
         g_rot_in = torch.zeros((n, 9), dtype=torch.float32, device=dev)
         want_gfeat = feat_plain is not None and ctx.needs_input_grad[3]
         g_feat = torch.zeros_like(feat_plain) if want_gfeat else None
@@ -179,17 +180,18 @@ class _FlowForwardFn(torch.autograd.Function):
                 stream = torch.cuda.current_stream(dev).cuda_stream
                 _lib.check(L.rnf_flow_backward(states.data_ptr(), ptr(feat_plain), n, plan.feat_dim, plain.data_ptr(),
                                                plan.train_desc.ctypes.data, plan.n_layers, plan.segments, ptr(g_rot_c),
-                                               g_ldj_c.data_ptr(), grads.data_ptr(), g_rot_in.data_ptr(), ptr(g_feat),
+                                               g_ldj_c.data_ptr(), ptr(grads), g_rot_in.data_ptr(), ptr(g_feat),
                                                scratch.data_ptr(), stream))
-        runtime.note_training_step()                      # an optimizer step follows: host-packed blobs are stale from now on
-        if ctx.grad_sync is not None:                     # data-parallel training: ONE collective for every parameter gradient
-            ctx.grad_sync(grads)
         needs = ctx.needs_input_grad
-        pieces = torch.split(grads, ctx.sizes) if ctx.sizes else ()
+        if want_w:
+            runtime.note_training_step()                  # an optimizer step follows: host-packed blobs are stale from now on
+            if ctx.grad_sync is not None:                 # data-parallel training: ONE collective for every parameter gradient
+                ctx.grad_sync(grads)
+        pieces = torch.split(grads, ctx.sizes) if (ctx.sizes and want_w) else ()
         outs = []
         for i, (shape, device, dtype) in enumerate(ctx.shapes):
             g = None
-            if needs[4 + i]:
+            if want_w and needs[4 + i]:
                 g = pieces[i].view(shape)
                 if device != dev or dtype is not torch.float32:
                     g = g.to(device=device, dtype=dtype)

@@ -571,7 +571,7 @@ extern "C" int rnf_flow_backward(const float *states, const float *feat, int64_t
     if (K < 1 || K > 64) return fail("training path supports 1..64 segments, got %d", K);
     if (F < 0) return fail("feature_dim %d is negative", F);
     if (n == 0) return 0;
-    if (!states || !plain || !tdesc || !g_ldj || !grads || !g_rot_in || !g_ldj_sum) return fail("null pointer argument");
+    if (!states || !plain || !tdesc || !g_ldj || !g_rot_in || !g_ldj_sum) return fail("null pointer argument");
     TrainArgs a;
     std::memset(&a, 0, sizeof(a));
     for (int l = 0; l < n_layers; ++l) {

@@ -32,7 +32,8 @@ struct TrainArgs {
     const float *states;      // [n_layers][n][9] rotation at the input of layer (iteration position) p
     const float *feature;     // [n][F] or nullptr
     const float *plain;       // plain parameter blob
-    float *grads;             // gradient blob (same layout), zeroed by the caller
+    float *grads;             // gradient blob (same layout), zeroed by the caller; nullptr: input gradients only (pose refinement,
+                              // eval.py:464-478), every weight-gradient product is skipped
     const float *g_rot_out;   // [n][9] dL/dR_out or nullptr (zeros)
     const float *g_ldj;       // [n]   dL/dldj
     float *g_rot_in;          // [n][9]
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
     const int j = lane & 31, h = lane >> 5;
     const int ta = wave >> 1, tb = wave & 1;              // this wave's 32x32 tile of a 64 x 64 product
     const int K = args.K, F = HAS_FEATURE ? args.F : 0;
+    const bool want_w = args.grads != nullptr;            // wave-uniform
     // LDS: X0, H1, H2, H3 (pre-activations, later reused for gradients), GA (gradient / reduction scratch), C (conditioner output,
     // then its gradient)
     const LMat X0{lds}, H1{lds + 64 * LROW}, H2{lds + 2 * 64 * LROW}, H3{lds + 3 * 64 * LROW}, GA{lds + 4 * 64 * LROW},
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                 for (int i = 0; i < 16; ++i) gM[i] = 0.f;
                 const bool orth = (d.x >> 8) & 1;         // UnconditionRot: ldj = 0 (flow/rottrans.py:21)
                 affine16_backward(M, sv, gR, g_ldj, orth, gM, gRin);
-                if (wave == 0) {                          // batch sums through LDS: lane 4v + q adds 16 rotations of entry v
+                if (wave == 0 && want_w) {                // batch sums through LDS: lane 4v + q adds 16 rotations of entry v
 #pragma unroll
                     for (int i = 0; i < 16; ++i) GA.at(i, lane) = valid ? gM[i] : 0.f;
                     const int v = lane >> 2, q = lane & 3;
@@ -469,11 +471,11 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
             RNF_TSTAMP(3)
             // ================= conditioner backward =================
             // fc_last: gWL += g_c t^T, gbL += rowsum(g_c), g_t = WL^T g_c
-            for (int rt = ta; rt < ntiles; rt += 2) {
+            for (int rt = ta; want_w && rt < ntiles; rt += 2) {
                 const f32x16 acc = mfma_samples(h, [&](int s) { return Cm.at(32 * rt + j, s); }, [&](int s) { return T.at(32 * tb + j, s); });
                 scatter_add(gWL, 64, 32 * rt, NO, 32 * tb + j, true, h, acc);
             }
-            bias_grad(Cm, NO, gbL, tid);
+            if (want_w) bias_grad(Cm, NO, gbL, tid);
             RNF_TSTAMP(4)
             {
                 f32x16 acc = zero16();
@@ -501,9 +503,11 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
             auto hidden_backward = [&](float *gW, float *gb, const LMat &Gout, const LMat &PreIn, const LMat &Gin, const float *Wnext) {
                 const ColsA cur = cnext;
                 if (Wnext) cnext = load_cols(Wnext, 64, 0, 64, 32 * ta + j, 64, h);
-                const f32x16 wg = mfma_samples(h, [&](int s) { return Gout.at(32 * ta + j, s); }, [&](int s) { return PreIn.at(32 * tb + j, s); }, Relu());
-                scatter_add(gW, 64, 32 * ta, 64, 32 * tb + j, true, h, wg);
-                bias_grad(Gout, 64, gb, tid);
+                if (want_w) {
+                    const f32x16 wg = mfma_samples(h, [&](int s) { return Gout.at(32 * ta + j, s); }, [&](int s) { return PreIn.at(32 * tb + j, s); }, Relu());
+                    scatter_add(gW, 64, 32 * ta, 64, 32 * tb + j, true, h, wg);
+                    bias_grad(Gout, 64, gb, tid);
+                }
                 f32x16 acc = mfma_cols(cur, 0, h, [&](int k) { return Gout.at(k, bs); }, zero16());
                 {
                     float pv[16];
@@ -533,9 +537,9 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
             }
             lds_barrier();
             // fc_first: x0 = W0 (y (+) f) + b0
-            bias_grad(GB, 64, gb0, tid);
+            if (want_w) bias_grad(GB, 64, gb0, tid);
             if (mob) {
-                if (wave < 2) {                           // gW0[:, 0:3] += g y^T: two row tiles, columns 0..2 of a 32-column tile
+                if (wave < 2 && want_w) {                 // gW0[:, 0:3] += g y^T: two row tiles, columns 0..2 of a 32-column tile
                     const f32x16 acc = mfma_samples(h, [&](int s) { return GB.at(32 * wave + j, s); }, [&](int s) { return j < 3 ? YL.at(j, s) : 0.f; });
                     scatter_add(gW0, NI, 32 * wave, 64, j, j < 3, h, acc);
                 }
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
             if (HAS_FEATURE) {
                 // gW0[o][yo + c] += sum_s g[o][s] f[s][c]: tiles 2 (rows) x ceil(F/32) (columns), 4 waves
                 const int ctiles = (F + 31) / 32;
-                for (int t = wave; t < 2 * ctiles; t += TR_WAVES) {
+                for (int t = wave; want_w && t < 2 * ctiles; t += TR_WAVES) {
                     const int rt = t & 1, ct = t >> 1;
                     const int c = 32 * ct + j;
                     f32x16 acc = zero16();
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
 // d log|det M| / dM = M^-T, weighted by the batch sum of dL/dldj (Uncondition16Trans, flow/squeezetrans.py:33-38,57-66)
 __global__ void affine_logdet_grad_kernel(const TrainArgs args) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= args.n_layers) return;
+    if (l >= args.n_layers || !args.grads) return;
     const int2 d = args.layers[l];
     if ((d.x & 15) != RNF_KIND_AFFINE16 || ((d.x >> 8) & 1)) return;
     float M[16], Mi[16];

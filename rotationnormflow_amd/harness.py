@@ -231,3 +231,45 @@ def estimate_rotations(flow: Flow, feature: torch.Tensor, queries: torch.Tensor 
         best = torch.argmax(log_prob, dim=-1)
         est = samples.reshape(B, Q, 3, 3)[torch.arange(B, device=best.device), best]
     return est, log_prob
+
+
+def matrix_to_quaternion(R: torch.Tensor) -> torch.Tensor:
+    """[B,3,3] rotations -> unit quaternions [B,4] (real part first), largest-component branch per row."""
+    m = R.reshape(-1, 3, 3)
+    m00, m11, m22 = m[:, 0, 0], m[:, 1, 1], m[:, 2, 2]
+    cand = torch.stack([
+        torch.stack([1 + m00 + m11 + m22, m[:, 2, 1] - m[:, 1, 2], m[:, 0, 2] - m[:, 2, 0], m[:, 1, 0] - m[:, 0, 1]], -1),
+        torch.stack([m[:, 2, 1] - m[:, 1, 2], 1 + m00 - m11 - m22, m[:, 0, 1] + m[:, 1, 0], m[:, 0, 2] + m[:, 2, 0]], -1),
+        torch.stack([m[:, 0, 2] - m[:, 2, 0], m[:, 0, 1] + m[:, 1, 0], 1 - m00 + m11 - m22, m[:, 1, 2] + m[:, 2, 1]], -1),
+        torch.stack([m[:, 1, 0] - m[:, 0, 1], m[:, 0, 2] + m[:, 2, 0], m[:, 1, 2] + m[:, 2, 1], 1 - m00 - m11 + m22], -1)], 1)
+    best = torch.argmax(torch.stack([cand[:, i, i] for i in range(4)], -1), -1)
+    q = cand[torch.arange(m.shape[0], device=m.device), best]
+    return q / q.norm(dim=-1, keepdim=True)
+
+
+def refine_rotations(flow: Flow, feature, rotations: torch.Tensor, steps: int = 100, lr: float = 1e-4, base=None):
+    """Pose refinement of ``eval.py``'s ``nll_grad`` mode (eval.py:464-480): gradient ascent of the log-density over the query
+    rotation, parameterised by a quaternion; every step is the FIRST step of a fresh Adam (eval.py:470-471 re-creates the optimizer
+    inside the loop), i.e. q <- q - lr * g / (|g| + 1e-8), followed by renormalisation.  The gradient w.r.t. the rotation comes from
+    the backward sweep with the parameter gradients switched off (the flow's parameters are frozen for the duration).
+    rotations [B,3,3], feature [B,F] or None.  Returns the refined rotations [B,3,3]."""
+    from .utils.fisher import quaternion_to_matrix
+    flags = [p.requires_grad for p in flow.parameters()]
+    for p in flow.parameters():
+        p.requires_grad_(False)
+    try:
+        q = matrix_to_quaternion(rotations.detach()).to(torch.float32)
+        for _ in range(steps):
+            q = q.detach().requires_grad_(True)
+            with torch.enable_grad():
+                rot, ldj = flow(quaternion_to_matrix(q), feature)
+                loss = -ldj.mean()
+                if base is not None:
+                    loss = loss - base._log_prob(rot).mean()
+                (g,) = torch.autograd.grad(loss, q)
+            q = q.detach() - lr * g / (g.abs() + 1e-8)
+            q = q / q.norm(dim=-1, keepdim=True)
+        return quaternion_to_matrix(q.detach())
+    finally:
+        for p, f in zip(flow.parameters(), flags):
+            p.requires_grad_(f)

@@ -332,7 +332,7 @@ __device__ __forceinline__ void mobius_begin(const Rot &R, int perm_row, MobiusC
 
 __device__ __forceinline__ void segments4(const f32x16 &o, const MobiusCtx &c, float &S, float &A, float &J) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) segment_full(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, c.zc, c.zs, c.zth, S, A, J);
+    for (int g = 0; g < 4; ++g) segment_fwd_pi(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, S, A, J);
 }
 
 // forward, all fc_last tiles resident (K <= 64): software pipelined BY HAND.  Tile tau+1's 32 dependent MFMAs (64

@@ -242,6 +242,27 @@ RNF_HD void segment_full(float s_raw, float w0, float w1, float w2, const Frame 
     seg_stage<7>(g, s_raw, w0, w1, w2, f, zc, zs, ztheta, S, A, J);
 }
 
+// The forward segment with the layer's input point fixed at z = (-1, 0), theta = pi: x expressed in its own frame IS (-1, 0)
+// (r = -x/|x|, v orthogonal to x; the reference's atan2(x.v, x.r) returns pi up to rounding, mobiusflow.py:104-108), so
+// a = -ur, b = -uv and phi = pi + 2 atan(uv / (1 + ur)).  softplus without the argument-splitting / log1p-residue terms of
+// softplus(): their contribution is below 1e-8 absolute on a term that is then divided by the sum of K such terms.
+// 44 VALU instructions (6 transcendental) instead of 57; used by the split-precision forward kernel, which is VALU-issue bound.
+RNF_HD void segment_fwd_pi(float s_raw, float w0, float w1, float w2, const Frame &f, float &S, float &A, float &J) {
+    const float wr = fmaf(w2, f.r.z, fmaf(w1, f.r.y, w0 * f.r.x));
+    const float wv = fmaf(w2, f.v.z, fmaf(w1, f.v.y, w0 * f.v.x));
+    const float sc = 0.7f * hw_rcp(1.0f + hw_sqrt(fmaf(wv, wv, wr * wr)));
+    const float ur = wr * sc, uv = wv * sc;
+    const float e1 = 1.0f + ur;
+    const float t = uv * hw_rcp(e1);
+    const float c = (1.0f - fmaf(uv, uv, ur * ur)) * hw_rcp(fmaf(uv, uv, e1 * e1));
+    const float phi = fmaf(2.0f, atan_unit(t), kPi);
+    const float e = hw_exp2(-1.44269504088896341f * fabsf(s_raw));
+    const float sp = fmaf(hw_log2(1.0f + e), 0.693147180559945309f, fmaxf(s_raw, 0.0f));
+    S += sp;
+    A = fmaf(sp, phi, A);
+    J = fmaf(sp, c, J);
+}
+
 // pytorch3d.transforms.matrix_to_quaternion (published 0.7.5 rule; call site flow/squeezetrans.py:34):
 // four candidates from sqrt(max(0, 1 +- m00 +- m11 +- m22)), keep the one with the largest |q_i| (first on ties),
 // denominators floored at 0.1.  Real part first.

@@ -172,8 +172,9 @@ __device__ __forceinline__ void split_act(const f32x16 (&x)[2], ActFrag &f) {
                 v.y = __builtin_amdgcn_fmed3f(v.y, 0.f, __builtin_inff());
             }
             const h2 ph = __builtin_convertvector(v, h2);                 // v_cvt_pk_f16_f32 (RN)
-            const f2 back = __builtin_convertvector(ph, f2);              // 2 x v_cvt_f32_f16
-            const h2 pl = __builtin_convertvector((v - back) * kLoScale, h2);
+            // (v - hi) * 4096 as fma(-4096, hi, 4096 v): the fp16 operand feeds v_fma_mix_f32 directly, no v_cvt_f32_f16 / v_sub
+            const f2 t = v * kLoScale;
+            const h2 pl = {(_Float16)__builtin_fmaf(-kLoScale, (float)ph[0], t.x), (_Float16)__builtin_fmaf(-kLoScale, (float)ph[1], t.y)};
             f.hi[s][j] = ph[0]; f.hi[s][j + 1] = ph[1];
             f.lo[s][j] = pl[0]; f.lo[s][j + 1] = pl[1];
         }

@@ -140,6 +140,16 @@ def train_uncondition(flow: Flow, train_rotations: torch.Tensor, iterations: int
     gen = torch.Generator().manual_seed(seed)
     data = train_rotations.to(device)
     n = data.shape[0]
+    # data parallel: every rank draws the SAME global mini-batch (same seed) and trains on its own contiguous slice of it; the
+    # gradient blob is averaged over the ranks by one all-reduce inside backward (dist.data_parallel_training), so each rank takes
+    # the optimizer step of the global batch and the replicas stay identical.  Collectives are not captured into the HIP graph.
+    import torch.distributed as tdist
+    world = tdist.get_world_size() if (tdist.is_available() and tdist.is_initialized()) else 1
+    rank = tdist.get_rank() if world > 1 else 0
+    if world > 1:
+        from .dist import data_parallel_training, shard_bounds
+        data_parallel_training(flow)
+        graph = False
     opt = torch.optim.Adam(flow.parameters(), lr=lr, fused=True, capturable=graph)   # one launch instead of a dozen foreach kernels
     batch_size = min(batch_size, n)
     gstep = GraphedTrainStep(flow, opt, (batch_size, 3, 3), base=base, device=device) if graph else None
@@ -148,6 +158,9 @@ def train_uncondition(flow: Flow, train_rotations: torch.Tensor, iterations: int
         perm = torch.randperm(n, generator=gen).to(device)
         for mb, lo in enumerate(range(0, n - batch_size + 1, batch_size)):
             batch = data[perm[lo:lo + batch_size]]
+            if world > 1:
+                b0, b1 = shard_bounds(batch.shape[0], rank, world)
+                batch = batch[b0:b1]
             if gstep is not None:
                 loss = gstep(batch)
             else:

@@ -174,6 +174,10 @@ int rnf_flow_log_prob(const float *rotation_dev, const float *feature_dev, int64
 int rnf_fisher_log_prob(const float *rotation_dev, int64_t n, const float *fisher_A_dev, const float *fisher_c_dev,
                         int64_t fisher_B, float *out_dev, void *stream);
 
+/* Log-constants c[b] of MatrixFisherN(A[b]) with the default normaliser approximation (utils/fisher.py:67-76 proper singular
+ * values, :93-97 norm_type = 1): log p(R) = tr(A^T R) - c.  A_dev float[B][9], c_out_dev float[B]; fp64 inside. */
+int rnf_fisher_log_const(const float *A_dev, int64_t B, float *c_out_dev, void *stream);
+
 /* Gradient of rnf_fisher_log_prob w.r.t. the rotations (training with a matrix-Fisher base, agent.py:58-64):
  * g_rotation[i] = g_logp[i] * A[i / (n/B)].  (The gradient w.r.t. A needs the derivative of the normaliser and is not built.) */
 int rnf_fisher_log_prob_backward(const float *g_logp_dev, int64_t n, const float *A_dev, int64_t B, float *g_rotation_dev,

@@ -657,6 +657,57 @@ extern "C" int rnf_fisher_log_prob(const float *rot, int64_t n, const float *A, 
     return 0;
 }
 
+// log-constants of MatrixFisherN(A) (utils/fisher.py:67-76,93-97): c = s0 + s1 + s2 + log norm with the PROPER singular values of A
+// (the smallest one carries the sign of det A) and norm = 1 / sqrt(8 pi (s0+s1)(s1+s2)(s0+s2)).  One thread per matrix, fp64:
+// eigenvalues of A^T A by cyclic Jacobi (robust for repeated singular values), so that a per-sample A coming out of a network never
+// goes through a host SVD and a device->host sync.
+__global__ void fisher_log_const_kernel(const float *A, long long B, float *c_out) {
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double a[3][3], m[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a[i][j] = A[b * 9 + 3 * i + j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) m[i][j] = a[0][i] * a[0][j] + a[1][i] * a[1][j] + a[2][i] * a[2][j];
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        const double off = fabs(m[0][1]) + fabs(m[0][2]) + fabs(m[1][2]);
+        if (off <= 1e-300 || off <= 1e-18 * (fabs(m[0][0]) + fabs(m[1][1]) + fabs(m[2][2]))) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (m[p][q] == 0.0) continue;
+                const double theta = (m[q][q] - m[p][p]) / (2.0 * m[p][q]);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 3; ++k) {               // M <- M J
+                    const double mkp = m[k][p], mkq = m[k][q];
+                    m[k][p] = cs * mkp - sn * mkq;
+                    m[k][q] = sn * mkp + cs * mkq;
+                }
+                for (int k = 0; k < 3; ++k) {               // M <- J^T M
+                    const double mpk = m[p][k], mqk = m[q][k];
+                    m[p][k] = cs * mpk - sn * mqk;
+                    m[q][k] = sn * mpk + cs * mqk;
+                }
+            }
+    }
+    double s0 = sqrt(fmax(m[0][0], 0.0)), s1 = sqrt(fmax(m[1][1], 0.0)), s2 = sqrt(fmax(m[2][2], 0.0)), t;
+    if (s0 < s1) { t = s0; s0 = s1; s1 = t; }
+    if (s1 < s2) { t = s1; s1 = s2; s2 = t; }
+    if (s0 < s1) { t = s0; s0 = s1; s1 = t; }
+    const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                       a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+    if (det < 0.0) s2 = -s2;
+    const double norm = 1.0 / sqrt(8.0 * 3.14159265358979323846 * (s0 + s1) * (s2 + s1) * (s0 + s2));
+    c_out[b] = (float)(s0 + s1 + s2 + log(norm));
+}
+
+extern "C" int rnf_fisher_log_const(const float *A, int64_t B, float *c_out, void *stream) {
+    if (!A || !c_out) return fail("rnf_fisher_log_const: null pointer");
+    if (B <= 0) return fail("rnf_fisher_log_const: B=%lld", (long long)B);
+    hipLaunchKernelGGL(fisher_log_const_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), A, (long long)B, c_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // d(tr(A^T R) - c)/dR = A: g_rot[i] = g_logp[i] * A[row(i)]
 __global__ void fisher_log_prob_backward_kernel(const float *g_logp, long long n, const float *A, long long div, float *g_rot) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -66,10 +66,28 @@ class MatrixFisherN(torch.nn.Module):
         if norm_type != 1:
             raise NotImplementedError("only the default normaliser approximation norm_type=1 is built (utils/fisher.py:93-97)")
         self.A = A.reshape(-1, 3, 3)
-        S = proper_singular_values(self.A)
-        norm = 1.0 / torch.sqrt(8 * math.pi * (S[:, 0] + S[:, 1]) * (S[:, 2] + S[:, 1]) * (S[:, 0] + S[:, 2]))
-        self.norm = norm.to(device=self.A.device, dtype=self.A.dtype)
-        self._c = (S.sum(-1) + norm.log()).to(torch.float32)      # log p = tr(A^T R) - c
+        if self.A.is_cuda:
+            # per-sample A from a network (agent.py:57-60): constants on the device, no host SVD and no device->host sync
+            A32 = self.A.detach().to(torch.float32).contiguous()
+            self._c = torch.empty(A32.shape[0], dtype=torch.float32, device=A32.device)
+            with torch.cuda.device(A32.device):
+                _lib.check(_lib.lib().rnf_fisher_log_const(A32.data_ptr(), A32.shape[0], self._c.data_ptr(),
+                                                           torch.cuda.current_stream(A32.device).cuda_stream))
+            self._norm = None
+        else:
+            S = proper_singular_values(self.A)
+            norm = 1.0 / torch.sqrt(8 * math.pi * (S[:, 0] + S[:, 1]) * (S[:, 2] + S[:, 1]) * (S[:, 0] + S[:, 2]))
+            self._norm = norm.to(dtype=self.A.dtype)
+            self._c = (S.sum(-1) + norm.log()).to(torch.float32)      # log p = tr(A^T R) - c
+
+    @property
+    def norm(self):
+        """The reference's ``self.norm`` (utils/fisher.py:215); computed lazily when A lives on the GPU (needs the singular values)."""
+        if self._norm is None:
+            S = proper_singular_values(self.A)
+            self._norm = (1.0 / torch.sqrt(8 * math.pi * (S[:, 0] + S[:, 1]) * (S[:, 2] + S[:, 1]) * (S[:, 0] + S[:, 2]))).to(
+                device=self.A.device, dtype=self.A.dtype)
+        return self._norm
 
     def log_const(self):
         return self._c

@@ -72,3 +72,24 @@ def test_sample_then_inverse_pipeline():
     with torch.no_grad():
         logp_chk = fl.log_prob(x, base=base)["logp"]
     assert (logp_x - logp_chk).abs().mean().item() < 1e-3
+
+
+def test_log_constants_on_device_match_host_svd():
+    """MatrixFisherN(A) with A on the GPU (per-sample A from a network, agent.py:57-60) computes its log-constants with
+    rnf_fisher_log_const (fp64 Jacobi on the device, no host SVD / sync); the CPU-tensor path keeps the torch SVD.  Both must agree,
+    including negative determinants (the smallest proper singular value is negative) and repeated singular values."""
+    import numpy as np
+    from rotationnormflow_amd.utils.fisher import MatrixFisherN
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((300, 3, 3)) * rng.uniform(0.2, 8.0, (300, 1, 1))
+    A[:20] = np.stack([np.diag([5.0, 3.0, 1.0])] * 20) @ synth.uniform_rotations(20, seed=4).astype(np.float64)      # rotated diag(5,3,1)
+    A[20:30] = np.stack([np.diag([4.0, 4.0, 1.5])] * 10)                                                              # repeated
+    A[30:40] = -A[:10]                                                                                               # det < 0
+    A = torch.from_numpy(A.astype(np.float32))
+    host = MatrixFisherN(A).log_const().numpy().astype(np.float64)
+    dev = MatrixFisherN(A.cuda()).log_const().cpu().numpy().astype(np.float64)
+    assert np.abs(dev - host).max() < 2e-6 * np.maximum(1.0, np.abs(host)).max()
+    R = torch.from_numpy(synth.uniform_rotations(300 * 4, seed=5)).cuda()
+    lp_dev = MatrixFisherN(A.cuda())._log_prob(R).cpu().numpy()
+    lp_host = MatrixFisherN(A)._log_prob(R).cpu().numpy()
+    assert np.abs(lp_dev - lp_host).max() < 2e-5

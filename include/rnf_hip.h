@@ -174,6 +174,10 @@ int rnf_flow_log_prob(const float *rotation_dev, const float *feature_dev, int64
 int rnf_fisher_log_prob(const float *rotation_dev, int64_t n, const float *fisher_A_dev, const float *fisher_c_dev,
                         int64_t fisher_B, float *out_dev, void *stream);
 
+/* Pose-accuracy epilogue of Agent.eval_acc (agent.py:266-283; utils/utils.py:231-235 min_geodesic_distance_rotmats): angle (radians)
+ * between estimate i and the closest of its k ground-truth rotations.  est_dev float[n][9], gt_dev float[n][k][9], out_dev float[n]. */
+int rnf_min_geodesic(const float *est_dev, const float *gt_dev, int64_t n, int32_t k, float *out_dev, void *stream);
+
 /* Log-constants c[b] of MatrixFisherN(A[b]) with the default normaliser approximation (utils/fisher.py:67-76 proper singular
  * values, :93-97 norm_type = 1): log p(R) = tr(A^T R) - c.  A_dev float[B][9], c_out_dev float[B]; fp64 inside. */
 int rnf_fisher_log_const(const float *A_dev, int64_t B, float *c_out_dev, void *stream);

@@ -44,6 +44,7 @@ _SIGNATURES = {
                                     c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnf_fisher_log_prob": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_void_p]),
+    "rnf_min_geodesic": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_void_p]),
     "rnf_fisher_log_const": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p]),
     "rnf_fisher_log_prob_backward": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_void_p]),
     "rnf_fisher_sample": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_uint64, c_f32p, C.c_void_p, C.c_void_p]),

@@ -657,6 +657,32 @@ extern "C" int rnf_fisher_log_prob(const float *rot, int64_t n, const float *A, 
     return 0;
 }
 
+// eval_acc epilogue (agent.py:266-283, utils/utils.py:231-235): geodesic angle between an estimate and the closest of its K ground-truth
+// rotations (K > 1: symmetric objects): acos(clip((max_k tr(E^T G_k) - 1) / 2, -1, 1)), one thread per estimate
+__global__ void min_geodesic_kernel(const float *est, const float *gt, long long n, int k, float *out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float e[9];
+    for (int c = 0; c < 9; ++c) e[c] = est[i * 9 + c];
+    float best = -4.0f;
+    for (int q = 0; q < k; ++q) {
+        const float *g = gt + ((size_t)i * k + q) * 9;
+        float tr = 0.f;
+        for (int c = 0; c < 9; ++c) tr = fmaf(e[c], g[c], tr);
+        best = fmaxf(best, tr);
+    }
+    out[i] = acosf(fminf(fmaxf((best - 1.0f) * 0.5f, -1.0f), 1.0f));
+}
+
+extern "C" int rnf_min_geodesic(const float *est, const float *gt, int64_t n, int32_t k, float *out, void *stream) {
+    if (n < 0 || k <= 0) return fail("rnf_min_geodesic: n=%lld k=%d", (long long)n, k);
+    if (n == 0) return 0;
+    if (!est || !gt || !out) return fail("rnf_min_geodesic: null pointer");
+    hipLaunchKernelGGL(min_geodesic_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), est, gt, (long long)n, k, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // log-constants of MatrixFisherN(A) (utils/fisher.py:67-76,93-97): c = s0 + s1 + s2 + log norm with the PROPER singular values of A
 // (the smallest one carries the sign of det A) and norm = 1 / sqrt(8 pi (s0+s1)(s1+s2)(s0+s2)).  One thread per matrix, fp64:
 // eigenvalues of A^T A by cyclic Jacobi (robust for repeated singular values), so that a per-sample A coming out of a network never

@@ -286,3 +286,26 @@ def refine_rotations(flow: Flow, feature, rotations: torch.Tensor, steps: int = 
     finally:
         for p, f in zip(flow.parameters(), flags):
             p.requires_grad_(f)
+
+
+def min_geodesic_distance(est_rotation: torch.Tensor, gt_rotation: torch.Tensor) -> torch.Tensor:
+    """utils/utils.py:231-235: angle (radians) between each estimate [B,3,3] and the closest of its ground truths [B,K,3,3] (or [B,3,3])."""
+    from . import _lib
+    est = est_rotation.reshape(-1, 3, 3).to(torch.float32).contiguous()
+    n = est.shape[0]
+    gt = gt_rotation.reshape(n, -1, 3, 3).to(device=est.device, dtype=torch.float32).contiguous()
+    if not est.is_cuda:
+        raise RuntimeError("rotationnormflow_amd runs on the GPU only (no CPU fallback)")
+    out = torch.empty(n, dtype=torch.float32, device=est.device)
+    with torch.cuda.device(est.device):
+        _lib.check(_lib.lib().rnf_min_geodesic(est.data_ptr(), gt.data_ptr(), n, gt.shape[1], out.data_ptr(),
+                                               torch.cuda.current_stream(est.device).cuda_stream))
+    return out
+
+
+def pose_accuracy(flow: Flow, feature, gt_rotation, queries=None, base=None, number_queries: int = 500, thresholds_deg=(15.0, 30.0)):
+    """What ``Agent.eval_acc`` + ``eval.py`` report per batch (agent.py:238-283, utils/utils.py:208-209): arg-max pose estimate, geodesic
+    error in degrees against the (possibly several) ground truths, accuracy at the thresholds.  -> dict(err_deg, est_rotation, acc)"""
+    est, _ = estimate_rotations(flow, feature, queries=queries, base=base, number_queries=number_queries)
+    err_deg = torch.rad2deg(min_geodesic_distance(est, gt_rotation))
+    return dict(err_deg=err_deg, est_rotation=est, acc={t: float((err_deg <= t).float().mean()) for t in thresholds_deg})

@@ -50,6 +50,14 @@ def _affine_kind(cfg, first_layer_condition=False):
             return "lu16" if lu else "uncond16"
         if rot == "16UnRot":                                    # affineflow.py:43-44
             return "rot16"
+        if rot == "9TransLSmith" and not lu:                    # affineflow.py:34-38
+            return "cgs9"
+        if rot == "9TransRSmith":                               # affineflow.py:39-40
+            return "csmithr9"
+        if rot == "9TransLSVD":                                 # affineflow.py:30-31
+            return "csvdl9"
+        if rot == "9TransRSVD":                                 # affineflow.py:32-33
+            return "csvdr9"
     else:
         if rot == "16Trans":                                    # affineflow.py:50-54
             return "lu16" if lu else "uncond16"
@@ -119,6 +127,8 @@ def state_shapes(cfg):
             shapes[f"layers.{i}.mat"] = (1, 4, 4)
         elif kind == "cond16":
             mlp(f"layers.{i}.net", fd, 16)
+        elif kind in ("cgs9", "csmithr9", "csvdl9", "csvdr9"):  # squeezetrans.py:237, rottrans.py:111,141,171
+            mlp(f"layers.{i}.net", fd, 9)
         elif kind == "lu16":                                    # UnconditionLU(4), squeezetrans.py:76-83
             for name, shp in (("w_p", (4, 4)), ("u_mask", (4, 4)), ("l_mask", (4, 4)), ("s_sign", (4,)), ("l_eye", (4, 4)),
                               ("w_l", (4, 4)), ("w_s", (4,)), ("w_u", (4, 4))):
@@ -416,14 +426,20 @@ def svdr9(M, R):
 
 
 def smithr9(M, R, inverse=False):
-    """calculate_9_r_smith (rottrans.py:85-96): R times the Gram-Schmidt rotation of the columns of M (its transpose for the inverse)."""
-    m0 = M[:, 0] / M[:, 0].norm()
-    m1 = M[:, 1] - (m0 * M[:, 1]).sum() * m0
-    m1 = m1 / m1.norm()
+    """calculate_9_r_smith (rottrans.py:85-96): R times the Gram-Schmidt rotation of the columns of M (its transpose for the inverse).
+    M [3,3] or [N,3,3]."""
+    m0 = M[..., :, 0] / M[..., :, 0].norm(dim=-1, keepdim=True)
+    m1 = M[..., :, 1] - (m0 * M[..., :, 1]).sum(-1, keepdim=True) * m0
+    m1 = m1 / m1.norm(dim=-1, keepdim=True)
     Q = torch.stack([m0, m1, torch.linalg.cross(m0, m1)], dim=-1)
     if inverse:
         Q = Q.transpose(-1, -2)
     return R @ Q, torch.zeros(R.shape[0], dtype=R.dtype)
+
+
+def cond9_matrix(feature, p, prefix):
+    """Condition9Trans / Condition9Rot* (squeezetrans.py:240-241, rottrans.py:114-115): I + reshape(net(feature), 3, 3)."""
+    return conditioner(feature, p, prefix).reshape(-1, 3, 3) + torch.eye(3, dtype=feature.dtype)[None]
 
 
 def cond16_matrix(feature, p, prefix):
@@ -471,6 +487,14 @@ def flow_forward(cfg, params, R, feature=None, dtype=torch.float32, grad=False):
                 R, l = svdr9(p[f"layers.{i}.mat"], R)                                   # rottrans.py:129-131
             elif kind == "smithr9":
                 R, l = smithr9(p[f"layers.{i}.mat"], R)                                 # rottrans.py:159-161
+            elif kind == "cgs9":
+                R, l = gs9(cond9_matrix(feature, p, f"layers.{i}.net"), R)              # squeezetrans.py:239-242
+            elif kind == "csmithr9":
+                R, l = smithr9(cond9_matrix(feature, p, f"layers.{i}.net"), R)          # rottrans.py:173-176
+            elif kind == "csvdl9":
+                R, l = svdl9(cond9_matrix(feature, p, f"layers.{i}.net"), R)            # rottrans.py:113-116
+            elif kind == "csvdr9":
+                R, l = svdr9(cond9_matrix(feature, p, f"layers.{i}.net"), R)            # rottrans.py:143-146
             else:
                 R, l = affine16(cond16_matrix(feature, p, f"layers.{i}.net"), R)
             ldj = ldj + l
@@ -514,6 +538,14 @@ def flow_inverse(cfg, params, R, feature=None, dtype=torch.float32):
                 R, l = svdr9(p[f"layers.{i}.mat"].transpose(-1, -2), R)                 # rottrans.py:133-135
             elif kind == "smithr9":
                 R, l = smithr9(p[f"layers.{i}.mat"], R, inverse=True)                   # rottrans.py:163-165
+            elif kind == "cgs9":
+                R, l = gs9(torch.linalg.inv(cond9_matrix(feature, p, f"layers.{i}.net")), R)        # squeezetrans.py:244-247
+            elif kind == "csmithr9":
+                R, l = smithr9(cond9_matrix(feature, p, f"layers.{i}.net"), R, inverse=True)        # rottrans.py:178-181
+            elif kind == "csvdl9":
+                R, l = svdl9(cond9_matrix(feature, p, f"layers.{i}.net").transpose(-1, -2), R)      # rottrans.py:118-121
+            elif kind == "csvdr9":
+                R, l = svdr9(cond9_matrix(feature, p, f"layers.{i}.net").transpose(-1, -2), R)      # rottrans.py:148-151
             else:
                 R, l = affine16(torch.linalg.inv(cond16_matrix(feature, p, f"layers.{i}.net")), R)  # :51-55
             ldj = ldj + l

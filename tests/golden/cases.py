@@ -55,6 +55,15 @@ CASES = {
     # not constructible here (Condition16TransLU is batch-coupled in the reference: torch.diag of a [N,4] tensor, squeezetrans.py:127)
     "noflow_affine":   dict(cfg=dict(layers=6, dist="noflow", feature_dim=32, **SYMSOL), n=512, regime="trained", wseed=25, rseed=75, direction="forward", fisher=None),
     "noflow_affine_inv": dict(cfg=dict(layers=6, dist="noflow", feature_dim=32, **SYMSOL), n=512, regime="trained", wseed=25, rseed=76, direction="inverse", fisher=None),
+    # conditional 3x3 ablation layers (per-sample matrix I + MLP(feature)): Gram-Schmidt with tangent log-det, Smith and polar rotations
+    "cgs9_cond":       dict(cfg=dict(layers=3, condition=1, feature_dim=24, rot="9TransLSmith"), n=512, regime="trained", wseed=26, rseed=77, direction="forward", fisher=None),
+    "cgs9_cond_inv":   dict(cfg=dict(layers=3, condition=1, feature_dim=24, rot="9TransLSmith"), n=512, regime="trained", wseed=26, rseed=78, direction="inverse", fisher=None),
+    "csmithr9_cond":   dict(cfg=dict(layers=3, condition=1, feature_dim=24, rot="9TransRSmith", last_affine=1), n=512, regime="trained", wseed=27, rseed=79, direction="forward", fisher=None),
+    "csmithr9_cond_inv": dict(cfg=dict(layers=3, condition=1, feature_dim=24, rot="9TransRSmith"), n=512, regime="trained", wseed=27, rseed=80, direction="inverse", fisher=None),
+    "csvdl9_cond":     dict(cfg=dict(layers=3, condition=1, feature_dim=24, rot="9TransLSVD"), n=512, regime="trained", wseed=28, rseed=81, direction="forward", fisher=None),
+    "csvdl9_cond_inv": dict(cfg=dict(layers=3, condition=1, feature_dim=24, rot="9TransLSVD"), n=512, regime="trained", wseed=28, rseed=82, direction="inverse", fisher=None),
+    "csvdr9_cond":     dict(cfg=dict(layers=3, condition=1, feature_dim=24, rot="9TransRSVD", frequent_permute=1), n=512, regime="trained", wseed=29, rseed=83, direction="forward", fisher=None),
+    "csvdr9_cond_inv": dict(cfg=dict(layers=3, condition=1, feature_dim=24, rot="9TransRSVD"), n=512, regime="trained", wseed=29, rseed=84, direction="inverse", fisher=None),
     "embed_cond":      dict(cfg=dict(layers=3, condition=1, feature_dim=24, embedding=1, embedding_dim=8, rot="16UnTrans", last_affine=1), n=512,
                             regime="default", wseed=14, rseed=58, direction="forward", fisher=None),
 }

@@ -41,6 +41,11 @@ extern "C" {
 #define RNF_LAYER_AFFINE16_COND 3 /* flow/squeezetrans.py:41-55  Condition16Trans (M = I + MLP(feature))    */
 #define RNF_LAYER_GS9 4           /* flow/squeezetrans.py:250-261 Uncondition9Trans (Gram-Schmidt of M R)      */
 #define RNF_LAYER_GS36 5          /* flow/squeezetrans.py:350-361 Uncondition36Trans (6x6 on two columns)      */
+/* conditional 3x3 layers, M = I + reshape(MLP(feature), 3, 3) per sample (records from rnf_pack_cond9): */
+#define RNF_LAYER_COND9_GS 6      /* flow/squeezetrans.py:234-247 Condition9Trans                              */
+#define RNF_LAYER_COND9_SMITH 7   /* flow/rottrans.py:168-181     Condition9RotRSmith                          */
+#define RNF_LAYER_COND9_POLAR_L 8 /* flow/rottrans.py:108-121     Condition9RotL                               */
+#define RNF_LAYER_COND9_POLAR_R 9 /* flow/rottrans.py:138-151     Condition9RotR                               */
 
 /* ---- arithmetic of the conditioner GEMMs --------------------------------------------------------------------
  * RNF_PREC_FP32  : exact fp32 (v_mfma_f32_32x32x2_f32; bit-for-bit an fp32 fma chain).
@@ -91,6 +96,12 @@ int rnf_pack_gs(const float *mat, int32_t n, float *out);
 
 /* Condition16Trans.net = ConditionalTransform(F, 16) (flow/squeezetrans.py:42-44). fc_first_w [64,F], fc_last_w [16,64]. */
 int rnf_pack_cond16(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
+                    const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
+                    const float *fc_last_w, const float *fc_last_b, int32_t feature_dim, int32_t precision,
+                    float *out_layer, float *out_feat);
+
+/* Same record for the conditional 3x3 layers (RNF_LAYER_COND9_*): fc_last has 9 rows. */
+int rnf_pack_cond9(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
                     const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
                     const float *fc_last_w, const float *fc_last_b, int32_t feature_dim, int32_t precision,
                     float *out_layer, float *out_feat);

@@ -534,6 +534,47 @@ __device__ __forceinline__ void cond16_finish(const f32x16 &o, int h, Rot &R, fl
     else affine16_apply(M, logf(fabsf(det)), R, ldj);
 }
 
+// Conditional 3x3 layers (extended instantiation only): M = I + reshape(outputs 0..8, 3, 3); output i sits where output i of
+// Condition16Trans sits (rows 0..3: lane-half 0 registers 0..3, rows 4..7: lane-half 1 registers 0..3, row 8: lane-half 0 register 4).
+template <bool INVERSE>
+__device__ __forceinline__ void cond9_finish(int kind, const f32x16 &o, int h, Rot &R, float &ldj) {
+    float m[9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float mine = o[c], other = __shfl_xor(mine, 32, 64);
+        m[c] = h ? other : mine;
+        m[4 + c] = h ? mine : other;
+    }
+    {
+        const float mine = o[4], other = __shfl_xor(mine, 32, 64);
+        m[8] = h ? other : mine;
+    }
+    m[0] += 1.f; m[4] += 1.f; m[8] += 1.f;
+    if (kind == RNF_KIND_COND9_GS) {                       // Condition9Trans (squeezetrans.py:239-247)
+        if (INVERSE) {
+            float mi[9];
+            inv3(m, mi);
+            gs9_apply(mi, R, ldj);
+        } else {
+            gs9_apply(m, R, ldj);
+        }
+    } else if (kind == RNF_KIND_COND9_SMITH) {             // Condition9RotRSmith (rottrans.py:173-181): R GS(M), inverse R GS(M)^T
+        v3f q0, q1, q2;
+        smith3(m, q0, q1, q2);
+        if (INVERSE) right_mul_cols(v3f{q0.x, q1.x, q2.x}, v3f{q0.y, q1.y, q2.y}, v3f{q0.z, q1.z, q2.z}, R);
+        else right_mul_cols(q0, q1, q2, R);
+    } else {                                               // Condition9RotL / 9RotR (rottrans.py:113-121, 143-151): polar(M) R, R polar(M)
+        v3f p0, p1, p2;                                    // rows of P = polar(M); the inverse uses M^T, whose polar factor is P^T
+        polar3(m, p0, p1, p2);
+        const v3f t0 = v3f{p0.x, p1.x, p2.x}, t1 = v3f{p0.y, p1.y, p2.y}, t2 = v3f{p0.z, p1.z, p2.z};     // rows of P^T = columns of P
+        if (kind == RNF_KIND_COND9_POLAR_L) {
+            if (INVERSE) left_mul_rows(t0, t1, t2, R); else left_mul_rows(p0, p1, p2, R);
+        } else {
+            if (INVERSE) right_mul_cols(p0, p1, p2, R); else right_mul_cols(t0, t1, t2, R);   // columns of P^T are the rows of P
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // weight staging
 //   SYNC: before each MLP layer all waves copy the layer's record global(L2) -> LDS between two barriers (any K).
@@ -568,7 +609,7 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 #define RNF_STAMP_FLUSH
 #endif
 
-template <int DIR, int KT_INV, int NW, bool PIPE, int PREC>
+template <int DIR, int KT_INV, int NW, bool PIPE, int PREC, bool EXT = false>
 __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -709,7 +750,8 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             } else {
                 const f32x16 o16 = Mlp<PREC>::last(lds + MOB_LAST, lane, h, tt);
                 barrier2();
-                cond16_finish<DIR != 0>(o16, h, R, ldj);
+                if (EXT && kind != RNF_KIND_COND16) cond9_finish<DIR != 0>(kind, o16, h, R, ldj);
+                else cond16_finish<DIR != 0>(o16, h, R, ldj);
             }
             RNF_STAMP(5)                                          // 5: layer finish (bisection for the inverse)
         }

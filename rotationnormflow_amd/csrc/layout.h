@@ -76,7 +76,10 @@ constexpr int G_FLOATS_PER_GROUP = 2 * 4 * 64 * 4;        // 2048 floats = 64 fe
 
 // layer kinds (== RNF_LAYER_* of include/rnf_hip.h)
 constexpr int RNF_KIND_MOBIUS = 1, RNF_KIND_AFFINE16 = 2, RNF_KIND_COND16 = 3, RNF_KIND_GS9 = 4, RNF_KIND_GS36 = 5;
-RNF_LAYOUT_INLINE bool kind_has_mlp(int kind) { return kind == RNF_KIND_MOBIUS || kind == RNF_KIND_COND16; }
+// conditional 3x3 layers: M = I + reshape(MLP(feature), 3, 3) per sample (Condition9Trans, Condition9RotRSmith, Condition9RotL, Condition9RotR)
+constexpr int RNF_KIND_COND9_GS = 6, RNF_KIND_COND9_SMITH = 7, RNF_KIND_COND9_POLAR_L = 8, RNF_KIND_COND9_POLAR_R = 9, RNF_KIND_COND9_LAST = 9;
+RNF_LAYOUT_INLINE bool kind_is_cond9(int kind) { return kind >= RNF_KIND_COND9_GS && kind <= RNF_KIND_COND9_LAST; }
+RNF_LAYOUT_INLINE bool kind_has_mlp(int kind) { return kind == RNF_KIND_MOBIUS || kind == RNF_KIND_COND16 || kind_is_cond9(kind); }
 
 // layer descriptor columns (include/rnf_hip.h)
 constexpr int D_KIND = 0, D_PERM = 1, D_PARAM = 2, D_SLOT = 3, D_FEAT = 4, D_PREC = 5, D_STRIDE = 6;   // D_PREC: RNF_PREC_* of include/rnf_hip.h

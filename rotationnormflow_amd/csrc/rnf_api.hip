@@ -178,10 +178,29 @@ extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b,
     return 0;
 }
 
+static int pack_cond(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b, const float *l3_w,
+                     const float *l3_b, const float *l5_w, const float *l5_b, const float *fc_last_w, const float *fc_last_b, int32_t F,
+                     int32_t prec, int32_t n_out, float *out, float *out_feat);
+
 extern "C" int rnf_pack_cond16(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
                                const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
                                const float *fc_last_w, const float *fc_last_b, int32_t F, int32_t prec, float *out,
                                float *out_feat) {
+    return pack_cond(fc_first_w, fc_first_b, l1_w, l1_b, l3_w, l3_b, l5_w, l5_b, fc_last_w, fc_last_b, F, prec, 16, out, out_feat);
+}
+
+// Condition9Trans / Condition9RotL / Condition9RotR / Condition9RotRSmith (flow/squeezetrans.py:234-247, flow/rottrans.py:108-181): the
+// same record with a 9-row fc_last; output i sits where output i of Condition16Trans sits, so the kernels gather both the same way.
+extern "C" int rnf_pack_cond9(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
+                              const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
+                              const float *fc_last_w, const float *fc_last_b, int32_t F, int32_t prec, float *out,
+                              float *out_feat) {
+    return pack_cond(fc_first_w, fc_first_b, l1_w, l1_b, l3_w, l3_b, l5_w, l5_b, fc_last_w, fc_last_b, F, prec, 9, out, out_feat);
+}
+
+static int pack_cond(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b, const float *l3_w,
+                     const float *l3_b, const float *l5_w, const float *l5_b, const float *fc_last_w, const float *fc_last_b, int32_t F,
+                     int32_t prec, int32_t n_out, float *out, float *out_feat) {
     if (F <= 0 || F % 8) return fail("rnf_pack_cond16: feature_dim=%d must be a positive multiple of 8", F);
     if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2) return fail("rnf_pack_cond16: unknown precision %d", prec);
     g_half_overflow = false;
@@ -189,11 +208,13 @@ extern "C" int rnf_pack_cond16(const float *fc_first_w, const float *fc_first_b,
     const float *hw[3] = {l1_w, l3_w, l5_w};
     const float *hb[3] = {l1_b, l3_b, l5_b};
     pack_hidden(out, hw, hb, prec);
-    // one fc_last tile: packed row 8g + 4h + c (g = 0,1) <-> M[2g + h][c] = output 4*(2g+h) + c; rows >= 16 zero
+    // one fc_last tile: packed row 8g + 4h + c (g = 0,1) <-> output 4*(2g+h) + c (= M[2g + h][c] of the 4x4); rows >= 16 and outputs
+    // >= n_out are zero
     auto src_row = [&](int row) {
         if (row >= 16) return -1;
         const int g = row >> 3, h = (row >> 2) & 1, c = row & 3;
-        return 4 * (2 * g + h) + c;
+        const int o = 4 * (2 * g + h) + c;
+        return o < n_out ? o : -1;
     };
     float *rec = out + MOB_LAST;
     auto row_of = [&](int, int i) { int s = src_row(i); return s < 0 ? (const float *)nullptr : fc_last_w + (size_t)s * 64; };
@@ -339,10 +360,10 @@ static bool staging_dma() {
     return mode == 1;
 }
 
-template <int DIR, int KT_INV, bool PIPE, int PREC>
+template <int DIR, int KT_INV, bool PIPE, int PREC, bool EXT = false>
 static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream) {
     constexpr int NWK = (DIR == 0 && PREC == 1) ? NW_FWD_H : NW;
-    auto kern = flow_stack_kernel<DIR, KT_INV, NWK, PIPE, PREC>;
+    auto kern = flow_stack_kernel<DIR, KT_INV, NWK, PIPE, PREC, EXT>;
     HIP_TRY(allow_lds(kern, lds_bytes));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWK * 64), lds_bytes, stream, a);
     HIP_TRY(hipGetLastError());
@@ -373,15 +394,16 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     FeatProjArgs fp;
     std::memset(&fp, 0, sizeof(fp));
     int n_slots = 0;
-    bool any_mlp = false;
+    bool any_mlp = false, ext = false;       // ext: the flow contains a layer kind only the extended kernel instantiation carries
     int prec = -1;
     for (int l = 0; l < n_layers; ++l) {
         const int32_t *d = desc + (size_t)l * D_STRIDE;
         const int kind = d[D_KIND], perm = d[D_PERM], slot = d[D_SLOT];
-        if (kind < RNF_KIND_MOBIUS || kind > RNF_KIND_GS36) return fail("layer %d: unknown kind %d", l, kind);
+        if (kind < RNF_KIND_MOBIUS || kind > RNF_KIND_COND9_LAST) return fail("layer %d: unknown kind %d", l, kind);
         if (perm < 0 || perm > 5) return fail("layer %d: perm_row %d outside [0,5]", l, perm);
         if (d[D_PARAM] < 0 || d[D_PARAM] % 4) return fail("layer %d: param offset %d must be a non-negative multiple of 4", l, d[D_PARAM]);
-        if (kind == RNF_KIND_COND16 && slot < 0) return fail("layer %d: Condition16Trans needs a cond_slot", l);
+        if ((kind == RNF_KIND_COND16 || kind_is_cond9(kind)) && slot < 0) return fail("layer %d: a conditional affine layer needs a cond_slot", l);
+        if (kind_is_cond9(kind)) ext = true;
         if (slot >= 0) {
             if (slot >= MAX_SLOTS) return fail("layer %d: cond_slot %d >= %d", l, slot, MAX_SLOTS);
             if (d[D_FEAT] < 0 || d[D_FEAT] % 4) return fail("layer %d: feat offset %d invalid", l, d[D_FEAT]);
@@ -488,8 +510,11 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         int rc;
         // (inverse with K = 64: 96 segment registers + the DMA bookkeeping spill under the 256-VGPR cap; it is VALU-bound in
         //  the bisection anyway, so it keeps the synchronous staging)
-        const bool pipe = staging_dma() && KT <= MOB_MAX_TILES_IN_LDS && !(o.dir == 1 && KT == 8);
+        // (flows with a conditional 3x3 layer run the extended instantiation, which is only built with the synchronous staging)
+        const bool pipe = staging_dma() && KT <= MOB_MAX_TILES_IN_LDS && !(o.dir == 1 && KT == 8) && !ext;
 #define RNF_LAUNCH(DIR_, KT_)                                                                                   \
+    ext ? (prec ? launch_stack<DIR_, KT_, false, 1, true>(a, grid, lds_bytes, stream)                          \
+                : launch_stack<DIR_, KT_, false, 0, true>(a, grid, lds_bytes, stream)) :                       \
     (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1>(a, grid, lds_bytes, stream)                               \
                   : launch_stack<DIR_, KT_, true, 0>(a, grid, lds_bytes, stream))                              \
           : (prec ? launch_stack<DIR_, KT_, false, 1>(a, grid, lds_bytes, stream)                              \

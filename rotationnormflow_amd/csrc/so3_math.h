@@ -378,6 +378,53 @@ RNF_HD void gs36_apply(const float *M, Rot &R, float &ldj) {
     gram_schmidt_tangent(a0, a1, da0, da1, R, ldj);
 }
 
+// ---- conditional 3x3 layers: per-sample M (row-major) ---------------------------------------------------------------------------
+// inverse by cofactors (torch.linalg.inv of squeezetrans.py:245)
+RNF_HD void inv3(const float (&m)[9], float (&o)[9]) {
+    const float c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const float id = 1.0f / (m[0] * c00 + m[1] * c01 + m[2] * c02);
+    o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+// Gram-Schmidt rotation of the COLUMNS of M (calculate_9_r_smith, rottrans.py:85-91), returned as columns q0, q1, q2
+RNF_HD void smith3(const float (&m)[9], v3f &q0, v3f &q1, v3f &q2) {
+    const v3f a0 = v3f{m[0], m[3], m[6]}, a1 = v3f{m[1], m[4], m[7]};
+    q0 = a0 * hw_rsq(dot3(a0, a0));
+    const v3f b1 = a1 - q0 * dot3(q0, a1);
+    q1 = b1 * hw_rsq(dot3(b1, b1));
+    q2 = cross3(q0, q1);
+}
+
+// Orthogonal polar factor U V^T of M (calculate_9_l / calculate_9_r, rottrans.py:72-82 take it from a batched SVD) by the Newton
+// iteration X <- (X + X^-T) / 2, X^-T = cof(X) / det(X): quadratically convergent, M = I + MLP output is well conditioned.
+// Rows of the result in p0, p1, p2.
+RNF_HD void polar3(const float (&m)[9], v3f &p0, v3f &p1, v3f &p2) {
+    p0 = v3f{m[0], m[1], m[2]}; p1 = v3f{m[3], m[4], m[5]}; p2 = v3f{m[6], m[7], m[8]};
+#pragma unroll 1
+    for (int it = 0; it < 10; ++it) {
+        const v3f c0 = cross3(p1, p2), c1 = cross3(p2, p0), c2 = cross3(p0, p1);      // rows of the cofactor matrix
+        const float hid = 0.5f / dot3(p0, c0);
+        p0 = p0 * 0.5f + c0 * hid;
+        p1 = p1 * 0.5f + c1 * hid;
+        p2 = p2 * 0.5f + c2 * hid;
+    }
+}
+
+// R <- P R for a matrix given by its rows; R <- R Q for a matrix given by its columns (or rows = Q^T when transposed)
+RNF_HD void left_mul_rows(v3f p0, v3f p1, v3f p2, Rot &R) {
+    R.c0 = v3f{dot3(p0, R.c0), dot3(p1, R.c0), dot3(p2, R.c0)};
+    R.c1 = v3f{dot3(p0, R.c1), dot3(p1, R.c1), dot3(p2, R.c1)};
+    R.c2 = v3f{dot3(p0, R.c2), dot3(p1, R.c2), dot3(p2, R.c2)};
+}
+RNF_HD void right_mul_cols(v3f q0, v3f q1, v3f q2, Rot &R) {          // (R Q)[:, c] = sum_k R[:, k] Q[k][c], q_c = column c of Q
+    const v3f r0 = R.c0, r1 = R.c1, r2 = R.c2;
+    R.c0 = r0 * q0.x + r1 * q0.y + r2 * q0.z;
+    R.c1 = r0 * q1.x + r1 * q1.y + r2 * q1.z;
+    R.c2 = r0 * q2.x + r1 * q2.y + r2 * q2.z;
+}
+
 // 4x4 inverse and determinant by cofactors (Condition16Trans.inverse: torch.linalg.inv, flow/squeezetrans.py:51-55;
 // my_det_4_4: squeezetrans.py:17-22).  Returns det(M); Minv = adj(M)/det.
 RNF_HD float inv4(const float (&m)[16], float (&o)[16]) {

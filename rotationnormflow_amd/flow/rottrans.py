@@ -149,7 +149,22 @@ class Uncondition9RotRSmith(_ConstantRotationLayer):
         return torch.stack([m0, m1, torch.linalg.cross(m0, m1)], dim=-1)
 
 
+from .squeezetrans import _Conditional9  # noqa: E402
+
+
+class Condition9RotL(_Conditional9):
+    """Polar rotation of the per-sample matrix applied on the left (flow/rottrans.py:108-121); log-det 0."""
+    _rnf_kind = runtime.KIND_COND9_POLAR_L
+
+
+class Condition9RotR(_Conditional9):
+    """Polar rotation of the per-sample matrix applied on the right (flow/rottrans.py:138-151); log-det 0."""
+    _rnf_kind = runtime.KIND_COND9_POLAR_R
+
+
+class Condition9RotRSmith(_Conditional9):
+    """R times the Gram-Schmidt rotation of the per-sample matrix, its transpose for the inverse (flow/rottrans.py:168-181); log-det 0."""
+    _rnf_kind = runtime.KIND_COND9_SMITH
+
+
 ConditionRot = _not_built("ConditionRot", "flow/rottrans.py:26-53")
-Condition9RotL = _not_built("Condition9RotL", "flow/rottrans.py:108-121")
-Condition9RotR = _not_built("Condition9RotR", "flow/rottrans.py:138-151")
-Condition9RotRSmith = _not_built("Condition9RotRSmith", "flow/rottrans.py:168-181")

@@ -168,6 +168,17 @@ int rnf_flow_backward(const float *states_dev, const float *feature_dev, int64_t
                       const float *g_rotation_out_dev, const float *g_ldj_dev, float *grads_dev, float *g_rotation_in_dev,
                       float *g_feature_dev, float *layer_scratch_dev, void *stream);
 
+/* Shared feature rows: feature_dev holds n / feature_div rows and row r conditions rotations [r * feature_div, (r + 1) * feature_div)
+ * -- the pose-estimation pattern of Agent.eval_acc (agent.py:238-263), where the reference materialises feature.repeat(number_queries).
+ * The feature projection runs once per row; workspace from rnf_workspace_bytes_shared.  n must be a multiple of feature_div. */
+size_t rnf_workspace_bytes_shared(int64_t n, int32_t n_cond_layers, int64_t feature_div);
+int rnf_flow_forward_shared(const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim, int64_t feature_div,
+                            const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments,
+                            float *rotation_out_dev, float *ldj_out_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+int rnf_flow_inverse_shared(const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim, int64_t feature_div,
+                            const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments,
+                            float *rotation_out_dev, float *ldj_out_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* Fused density evaluation: Flow.forward + MatrixFisherN(A)._log_prob(R') + the NLL accumulation
  * (agent.py:54-65,217-229; utils/fisher.py:217-232).
  *   fisher_A_dev [B,3,3], fisher_c_dev [B] with c_b = sum(S_b) + log(norm_b) (host precomputes the proper singular

@@ -22,7 +22,37 @@ struct FeatProjArgs {
     long long g_groups;
     int F;
     int n_slots;
+    int row_mode;            // 1: the "samples" are shared feature rows; G holds a 64-float record per (slot, row), see flow_kernels.h GFrag
     int feat_off[MAX_SLOTS]; // blob offset (floats) of each slot's featproj record
+};
+
+// where one lane's 16 accumulator registers of (slot, out tile) live in G: fragment order per 32-sample group (coalesced 1 KiB wave
+// transactions), or -- row mode -- inside the 64-float record of the lane's feature row
+struct GOut {
+    float4 *p;
+    int stride;      // float4 between consecutive register quads
+    bool ok;
+    __device__ __forceinline__ GOut(const FeatProjArgs &a, int slot, long long group, long long sample, bool valid, int ot, int lane, int h) {
+        if (a.row_mode) {
+            p = reinterpret_cast<float4 *>(a.G + ((size_t)slot * a.n + (valid ? sample : 0)) * 64 + (ot * 2 + h) * 16);
+            stride = 1;
+            ok = valid;
+        } else {
+            p = reinterpret_cast<float4 *>(a.G + (((size_t)slot * a.g_groups + group) * 2 + ot) * (4 * 64 * 4)) + lane;
+            stride = 64;
+            ok = true;
+        }
+    }
+    __device__ __forceinline__ void store(int q, float4 v) const { if (ok) p[q * stride] = v; }
+    __device__ __forceinline__ f32x16 load() const {
+        const float4 b0 = p[0], b1 = p[stride], b2 = p[2 * stride], b3 = p[3 * stride];
+        f32x16 c;
+        c[0] = b0.x; c[1] = b0.y; c[2] = b0.z; c[3] = b0.w;
+        c[4] = b1.x; c[5] = b1.y; c[6] = b1.z; c[7] = b1.w;
+        c[8] = b2.x; c[9] = b2.y; c[10] = b2.z; c[11] = b2.w;
+        c[12] = b3.x; c[13] = b3.y; c[14] = b3.z; c[15] = b3.w;
+        return c;
+    }
 };
 
 template <int NW, int PREC>
@@ -57,14 +87,14 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
                         __syncthreads();
                         stage_floats(lds, rec + ((size_t)ot * ngroups_k + kc / 8) * 256, nu * 256, tid, NT);
                         __syncthreads();
-                        float *g = args.G + (((size_t)slot * args.g_groups + group) * 2 + ot) * (4 * 64 * 4);
+                        const GOut gout(args, slot, group, sample, valid, ot, lane, h);
                         f32x16 acc;
                         if (kc == 0) {
                             const float *bias = rec + (size_t)2 * ngroups_k * 256 + (ot * 2 + h) * 16;
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[r] = bias[r];
                         } else {
-                            acc = load_g16(g, lane);
+                            acc = gout.load();
                         }
 #pragma unroll
                         for (int u = 0; u < FP_KCHUNK / 8; ++u) {
@@ -76,10 +106,8 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
                                 acc = RNF_MFMA(a.w, bf[u].w, acc);
                             }
                         }
-                        float4 *g4 = reinterpret_cast<float4 *>(g);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            g4[q * 64 + lane] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                        for (int q = 0; q < 4; ++q) gout.store(q, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
                     }
                 }
             } else {
@@ -123,14 +151,14 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
                     dma_wait_all();
                     __syncthreads();                               // tile t is complete; nobody still reads the other buffer
                     if (t + 1 < n_t) dma_floats(lds + ((t + 1) & 1) * BUF, tile_src(t + 1), ns * 512, wave, lane, NW);
-                    float *g = args.G + (((size_t)slot * args.g_groups + group) * 2 + ot) * (4 * 64 * 4);
+                    const GOut gout(args, slot, group, sample, valid, ot, lane, h);
                     f32x16 acc1, acc2;
                     if (kc == 0) {
                         const float *bias = rec + (size_t)2 * nsteps_all * 512 + (ot * 2 + h) * 16;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc1[r] = bias[r];
                     } else {
-                        acc1 = load_g16(g, lane);
+                        acc1 = gout.load();
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
@@ -144,11 +172,10 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
                             acc2 = RNF_MFMA_H(al, bh[s], acc2);
                         }
                     }
-                    float4 *g4 = reinterpret_cast<float4 *>(g);
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        g4[q * 64 + lane] = make_float4(fmaf(acc2[4 * q], kLoInv, acc1[4 * q]), fmaf(acc2[4 * q + 1], kLoInv, acc1[4 * q + 1]),
-                                                        fmaf(acc2[4 * q + 2], kLoInv, acc1[4 * q + 2]), fmaf(acc2[4 * q + 3], kLoInv, acc1[4 * q + 3]));
+                        gout.store(q, make_float4(fmaf(acc2[4 * q], kLoInv, acc1[4 * q]), fmaf(acc2[4 * q + 1], kLoInv, acc1[4 * q + 1]),
+                                                  fmaf(acc2[4 * q + 2], kLoInv, acc1[4 * q + 2]), fmaf(acc2[4 * q + 3], kLoInv, acc1[4 * q + 3])));
                 }
             }
         }

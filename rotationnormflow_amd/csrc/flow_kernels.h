@@ -34,6 +34,8 @@ struct FlowArgs {
     long long sample_base;    // global index of sample 0 (for the Fisher row lookup)
     long long fisher_div;     // samples per Fisher row (n_total / B)
     long long g_groups;       // 32-sample groups per cond slot in G
+    long long g_div;          // > 0: feature rows are SHARED, row = (sample_base + sample) / g_div, and G holds one 64-float record per
+    long long g_rows;         //      (slot, feature row) instead of one fragment tile per (slot, 32-sample group)
     int fair_off;                // >= 0: float offset in LDS of the per-wave progress words (SIMD fairness governor on)
     unsigned long long *stamps;  // diagnostic builds only (RNF_STAMPS): per-phase cycle sums, else nullptr
     float *states;            // training forward: [n_layers][states_n][9] rotation at the input of every layer, else nullptr
@@ -76,6 +78,28 @@ __device__ __forceinline__ f32x16 load_g16(const float *g_tile /* [4][64] float4
     c[12] = b3.x; c[13] = b3.y; c[14] = b3.z; c[15] = b3.w;
     return c;
 }
+
+// Where a wave finds its feature-projection values.  ROWS = false (default kernels): fragment tiles of its 32-sample group (p = tile of
+// out tile 0).  ROWS = true (extended instantiation): feature rows may be shared by runs of consecutive samples (pose estimation: one
+// image feature, many query rotations) and `rows` selects the 64-float record of each lane's own feature row,
+// [out tile][lane half][16 accumulator registers].
+template <bool ROWS>
+struct GFrag {
+    const float *p;
+    bool rows;
+    __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
+    __device__ __forceinline__ f32x16 load(int ot, int lane, int h) const {
+        if (!ROWS || !rows) return load_g16(p + ot * (4 * 64 * 4), lane);
+        const float4 *q = reinterpret_cast<const float4 *>(p + (ot * 2 + h) * 16);
+        const float4 b0 = q[0], b1 = q[1], b2 = q[2], b3 = q[3];
+        f32x16 c;
+        c[0] = b0.x; c[1] = b0.y; c[2] = b0.z; c[3] = b0.w;
+        c[4] = b1.x; c[5] = b1.y; c[6] = b1.z; c[7] = b1.w;
+        c[8] = b2.x; c[9] = b2.y; c[10] = b2.z; c[11] = b2.w;
+        c[12] = b3.x; c[13] = b3.y; c[14] = b3.z; c[15] = b3.w;
+        return c;
+    }
+};
 
 // one 64 -> 32 output tile: acc += W_tile[32 x 64] . relu?(in)   (in = two f32x16 register tiles)
 template <bool RELU>
@@ -229,12 +253,13 @@ template <>
 struct Mlp<0> {
     struct Act { f32x16 t[2]; };
     // g: this wave's feature-projection fragments for the layer (global memory), or nullptr for an unconditional layer
+    template <class GF>
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
-                                                const float *g, Act &out, Fair &) {
+                                                const GF &g, Act &out, Fair &) {
         f32x16 cinit[2];
         if (g) {
-            cinit[0] = load_g16(g, lane);
-            cinit[1] = load_g16(g + 4 * 64 * 4, lane);
+            cinit[0] = g.load(0, lane, h);
+            cinit[1] = g.load(1, lane, h);
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { cinit[0][r] = 0.f; cinit[1][r] = 0.f; }
@@ -257,8 +282,9 @@ struct Mlp<1> {
         c = RNF_MFMA(a.x, bA, c);
         return RNF_MFMA(a.y, bB, c);
     }
+    template <class GF>
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
-                                                const float *g, Act &out, Fair &fair) {
+                                                const GF &g, Act &out, Fair &fair) {
         const float bA = h ? y1 : y0;
         const float bB = h ? 1.0f : y2;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -266,7 +292,7 @@ struct Mlp<1> {
         {
             f32x16 x0[2];
 #pragma unroll
-            for (int ot = 0; ot < 2; ++ot) x0[ot] = first_tile(lds, ot, lane, bA, bB, g ? load_g16(g + ot * (4 * 64 * 4), lane) : zero);
+            for (int ot = 0; ot < 2; ++ot) x0[ot] = first_tile(lds, ot, lane, bA, bB, g ? g.load(ot, lane, h) : zero);
             split_act<true>(x0, f);
         }
         f32x16 hcur[2];
@@ -284,7 +310,7 @@ struct Mlp<1> {
         for (int ot = 0; ot < 2; ++ot) {                        // residual x0 + h3 (flow/condition.py:29)
             hcur[ot] = first_tile(lds, ot, lane, bA, bB, hcur[ot]);
             if (g) {
-                const f32x16 gg = load_g16(g + ot * (4 * 64 * 4), lane);
+                const f32x16 gg = g.load(ot, lane, h);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hcur[ot][r] += gg[r];
             }
@@ -692,7 +718,16 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             }
 
             // ---- layers with a conditioner MLP ----
-            const float *gfrag = slot >= 0 ? args.G + ((size_t)slot * args.g_groups + group) * G_FLOATS_PER_GROUP : nullptr;
+            GFrag<EXT> gfrag{nullptr, EXT && args.g_div > 0};
+            if (slot >= 0) {
+                if (EXT && args.g_div > 0) {
+                    long long row = (args.sample_base + (valid ? sample : 0)) / args.g_div;
+                    if (row >= args.g_rows) row = args.g_rows - 1;
+                    gfrag.p = args.G + ((size_t)slot * args.g_rows + row) * 64;
+                } else {
+                    gfrag.p = args.G + ((size_t)slot * args.g_groups + group) * G_FLOATS_PER_GROUP;
+                }
+            }
             // where the NEXT image comes from (DMA mode): next MLP layer of this tile, else the first one of the next tile
             int nxt_off = -1, nxt_kind = 0;
             if (PIPE) {

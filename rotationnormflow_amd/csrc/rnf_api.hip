@@ -333,6 +333,12 @@ static int device_cus() {
     return cus;
 }
 
+extern "C" size_t rnf_workspace_bytes_shared(int64_t n, int32_t n_cond_layers, int64_t feature_div) {
+    if (feature_div <= 0) return rnf_workspace_bytes(n, n_cond_layers);
+    const size_t rows = (size_t)((n + feature_div - 1) / feature_div);
+    return PARTIALS_BYTES + (size_t)n_cond_layers * rows * 64 * sizeof(float);
+}
+
 extern "C" size_t rnf_workspace_bytes(int64_t n, int32_t n_cond_layers) {
     size_t bytes = PARTIALS_BYTES;
     if (n_cond_layers > 0) {
@@ -377,6 +383,7 @@ struct RunOpts {
     float *logp_out;
     double *sum_out;
     float *states = nullptr;  // training forward: per-layer input rotations [n_layers][n][9]
+    int64_t feature_div = 0;  // > 0: feature row r serves rotations [r * feature_div, (r + 1) * feature_div)
 };
 
 static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, const float *blob, const int32_t *desc,
@@ -428,8 +435,11 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         if (o.sum_out) { hipLaunchKernelGGL(nll_finalize_kernel, dim3(1), dim3(256), 0, stream, (const double *)nullptr, 0, 0.0, o.sum_out, 0); }
         return 0;
     }
-    if (ws_bytes < rnf_workspace_bytes(n, n_slots) && (n_slots > 0 || o.sum_out))
-        return fail("workspace of %zu bytes is smaller than rnf_workspace_bytes()=%zu", ws_bytes, rnf_workspace_bytes(n, n_slots));
+    const bool shared = o.feature_div > 0 && n_slots > 0;
+    if (shared) ext = true;                              // shared feature rows are read by the extended instantiation only
+    if (shared && n % o.feature_div) return fail("n=%lld not divisible by feature_div=%lld", (long long)n, (long long)o.feature_div);
+    const size_t ws_need = shared ? rnf_workspace_bytes_shared(n, n_slots, o.feature_div) : rnf_workspace_bytes(n, n_slots);
+    if (ws_bytes < ws_need && (n_slots > 0 || o.sum_out)) return fail("workspace of %zu bytes is smaller than the %zu needed", ws_bytes, ws_need);
     if ((n_slots > 0 || o.sum_out) && !ws) return fail("workspace pointer is null");
 
     const int KT = K / 8;
@@ -451,7 +461,10 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         }
     }
     const int cus = device_cus();
-    const long long chunk_cap = n_slots ? CHUNK_SAMPLES : n;
+    const long long chunk_cap = (n_slots && !shared) ? CHUNK_SAMPLES : n;      // shared feature rows: the projection scratch is tiny
+    const long long feat_rows = shared ? n / o.feature_div : 0;
+    a.g_div = shared ? o.feature_div : 0;
+    a.g_rows = feat_rows;
 
     a.blob = blob;
 #ifdef RNF_STAMPS
@@ -477,24 +490,28 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         const long long groups = (ntiles * nwk > ntiles_fp * NW) ? ntiles * nwk : ntiles_fp * NW;
         int grid = (int)(ntiles < cus ? ntiles : cus);
         const int grid_fp = (int)(ntiles_fp < cus ? ntiles_fp : cus);
-        if (n_slots) {
-            fp.feat = feat + base * F;
+        if (n_slots && (!shared || base == 0)) {          // shared rows: ONE projection of the feature rows, before the first chunk
+            const long long pn = shared ? feat_rows : cn;
+            const long long pt = (pn + NW * 32 - 1) / (NW * 32);
+            const int grid_p = shared ? (int)(pt < cus ? pt : cus) : grid_fp;
+            fp.feat = shared ? feat : feat + base * F;
             fp.blob = blob;
             fp.G = G;
-            fp.n = cn;
+            fp.n = pn;
             fp.g_groups = groups;
             fp.F = F;
             fp.n_slots = n_slots;
+            fp.row_mode = shared ? 1 : 0;
             const int kchunk = F < FP_KCHUNK ? F : FP_KCHUNK;
             size_t fl = sizeof(float) * (prec ? (size_t)2 * (FP_KCHUNK / 16) * 512 : (size_t)kchunk / 8 * 256);   // f16x2: two DMA buffers
             if (prec) {
                 auto kern = featproj_kernel<NW, 1>;
                 HIP_TRY(allow_lds(kern, fl));
-                hipLaunchKernelGGL(kern, dim3(grid_fp), dim3(NW * 64), fl, stream, fp);
+                hipLaunchKernelGGL(kern, dim3(grid_p), dim3(NW * 64), fl, stream, fp);
             } else {
                 auto kern = featproj_kernel<NW, 0>;
                 HIP_TRY(allow_lds(kern, fl));
-                hipLaunchKernelGGL(kern, dim3(grid_fp), dim3(NW * 64), fl, stream, fp);
+                hipLaunchKernelGGL(kern, dim3(grid_p), dim3(NW * 64), fl, stream, fp);
             }
             HIP_TRY(hipGetLastError());
         }
@@ -539,6 +556,25 @@ extern "C" int rnf_flow_forward(const float *rot, const float *feat, int64_t n, 
                                 const int32_t *desc, int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, void *ws,
                                 size_t ws_bytes, void *stream) {
     RunOpts o{0, nullptr, nullptr, 0, nullptr, nullptr};
+    return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
+}
+
+// Shared feature rows (pose estimation, agent.py:238-263: every image feature is evaluated against number_queries rotations; the
+// reference materialises feature.repeat): feature_dev has n / feature_div rows, row r serves rotations [r * feature_div, (r+1) * feature_div).
+// The feature projection then runs once per ROW and its scratch is one 64-float record per (layer, row).
+extern "C" int rnf_flow_forward_shared(const float *rot, const float *feat, int64_t n, int32_t F, int64_t feature_div, const float *blob,
+                                       const int32_t *desc, int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, void *ws,
+                                       size_t ws_bytes, void *stream) {
+    RunOpts o{0, nullptr, nullptr, 0, nullptr, nullptr};
+    o.feature_div = feature_div;
+    return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
+}
+
+extern "C" int rnf_flow_inverse_shared(const float *rot, const float *feat, int64_t n, int32_t F, int64_t feature_div, const float *blob,
+                                       const int32_t *desc, int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, void *ws,
+                                       size_t ws_bytes, void *stream) {
+    RunOpts o{1, nullptr, nullptr, 0, nullptr, nullptr};
+    o.feature_div = feature_div;
     return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
 }
 
@@ -812,7 +848,7 @@ __global__ __launch_bounds__(NWc * 64) void conditioner_kernel(const float *y, l
         __syncthreads();
         typename Mlp<PREC>::Act tt;
         Fair nofair{lds, wave, -1, 0};
-        Mlp<PREC>::head(lds, lane, h, y0, y1, y2, nullptr, tt, nofair);
+        Mlp<PREC>::head(lds, lane, h, y0, y1, y2, GFrag<false>{nullptr, false}, tt, nofair);
         for (int tau = 0; tau < KT; ++tau) {
             __syncthreads();
             stage_floats(lds + MOB_LAST, layer + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS, MOB_LAST_TILE_FLOATS, tid, NWc * 64);

@@ -82,18 +82,20 @@ class Flow(nn.Module):
         return self._cache.get(self, device, build)
 
     # ---- reference API ----------------------------------------------------------------------------------------------
-    def forward(self, rotation, feature=None, inverse=False, draw=False):
+    def forward(self, rotation, feature=None, inverse=False, draw=False, feature_repeat=None):
+        """``feature_repeat`` = Q (extension): ``feature`` holds N / Q rows, row r conditioning rotations [r Q, (r + 1) Q) -- what the
+        reference expresses by materialising ``feature.repeat`` (agent.py:240-244); evaluation only."""
         if inverse:
-            return self.inverse(rotation, feature, draw)
+            return self.inverse(rotation, feature, draw, feature_repeat=feature_repeat)
         if not self.condition:
             feature = None
         return runtime.run_flow(self, lambda: self._packed(rotation.device), rotation, feature, inverse=False,
-                                train_layers=list(self.layers), train_rows=self._forward_rows())
+                                train_layers=list(self.layers), train_rows=self._forward_rows(), feature_repeat=feature_repeat)
 
-    def inverse(self, rotation, feature=None, draw=False):
+    def inverse(self, rotation, feature=None, draw=False, feature_repeat=None):
         if not self.condition:
             feature = None
-        return runtime.run_flow(self, self._packed(rotation.device), rotation, feature, inverse=True)
+        return runtime.run_flow(self, self._packed(rotation.device), rotation, feature, inverse=True, feature_repeat=feature_repeat)
 
     # ---- fused density evaluation (agent.py:54-65,217-229 + utils/fisher.py:217-232) -------------------------
     def log_prob(self, rotation, feature=None, base=None, return_rotation=False):

@@ -238,8 +238,8 @@ def estimate_rotations(flow: Flow, feature: torch.Tensor, queries: torch.Tensor 
             Q = queries.shape[0]
             sample = queries[None].expand(B, Q, 3, 3).reshape(-1, 3, 3).contiguous()    # agent.py:253-258
             base_ll = torch.zeros(B, Q, device=feature.device)
-        feat = feature[:, None, :].expand(B, Q, feature.shape[1]).reshape(B * Q, -1).contiguous()   # agent.py:240-244
-        samples, ldj = flow.inverse(sample, feat)
+        # agent.py:240-244 repeats every feature row Q times; here the rows are shared inside the kernels (one projection per image)
+        samples, ldj = flow.inverse(sample, feature, feature_repeat=Q)
         log_prob = -ldj.reshape(B, Q) + base_ll                                         # agent.py:262-263
         best = torch.argmax(log_prob, dim=-1)
         est = samples.reshape(B, Q, 3, 3)[torch.arange(B, device=best.device), best]

@@ -265,7 +265,7 @@ def workspace(device, nbytes: int) -> torch.Tensor:
 
 
 # ---- launch ---------------------------------------------------------------------------------------------------------
-def _check_inputs(rotation, feature, packed: PackedFlow):
+def _check_inputs(rotation, feature, packed: PackedFlow, feature_repeat=None):
     if not rotation.is_cuda:
         raise RuntimeError("rotationnormflow_amd runs on the GPU only (HIP kernels, no CPU fallback): got a CPU tensor")
     if rotation.dim() < 2 or rotation.shape[-1] != 3 or rotation.shape[-2] != 3:
@@ -277,7 +277,12 @@ def _check_inputs(rotation, feature, packed: PackedFlow):
     feat = None
     if packed.n_cond:
         assert feature is not None, "The input feature is needed in this module"          # mobiusflow.py:48-49
-        feat = feature.reshape(rot.shape[0], -1) if rot.shape[0] else feature.reshape(0, packed.feat_dim)   # (-1 is ambiguous for 0 rows)
+        if feature_repeat:
+            if rot.shape[0] % feature_repeat:
+                raise ValueError(f"{rot.shape[0]} rotations are not a multiple of feature_repeat={feature_repeat}")
+            feat = feature.reshape(rot.shape[0] // feature_repeat, packed.feat_dim)
+        else:
+            feat = feature.reshape(rot.shape[0], -1) if rot.shape[0] else feature.reshape(0, packed.feat_dim)   # (-1 is ambiguous for 0 rows)
         if feat.shape[1] != packed.feat_dim:
             raise ValueError(f"feature has {feat.shape[1]} columns, flow expects {packed.feat_dim}")
         feat = feat.to(device=rot.device, dtype=torch.float32)
@@ -301,33 +306,44 @@ def _refuse_autograd(rotation, feature, module, what):
             "torch.no_grad() -- there is deliberately no PyTorch fallback path")
 
 
-def run_flow(module, packed, rotation, feature, inverse=False, train_layers=None, train_rows=None):
+def run_flow(module, packed, rotation, feature, inverse=False, train_layers=None, train_rows=None, feature_repeat=None):
     """-> (rotation' [N,3,3], ldj [N]) through rnf_flow_forward / rnf_flow_inverse.
     When a gradient is required (training, agent.py:75-92) the forward direction goes through autograd.flow_forward, which
     needs the layer modules and their permutation rows (``train_layers``, ``train_rows``) and packs on the device itself.
-    ``packed`` may be a callable that builds the host-packed flow on demand."""
+    ``packed`` may be a callable that builds the host-packed flow on demand.
+    ``feature_repeat`` = Q: ``feature`` has N / Q rows and row r conditions rotations [r Q, (r + 1) Q) (pose estimation, agent.py:238-263;
+    evaluation only) -- the feature projection then runs once per row instead of once per rotation."""
     if _needs_grad(rotation, feature, module):
         if inverse:
             _refuse_autograd(rotation, feature, module, "Flow.inverse")
+        if feature_repeat:
+            _refuse_autograd(rotation, feature, module, "a flow call with shared feature rows (feature_repeat)")
         from . import autograd
         return autograd.flow_forward(module, train_layers, train_rows, rotation, feature)
     if callable(packed):
         packed = packed()
-    rot, feat = _check_inputs(rotation, feature, packed)
+    shared = bool(feature_repeat) and packed.n_cond > 0
+    rot, feat = _check_inputs(rotation, feature, packed, feature_repeat if shared else None)
     n = rot.shape[0]
     L = _lib.lib()
     out_rot = torch.empty_like(rot)
     out_ldj = torch.empty(n, dtype=torch.float32, device=rot.device)
     if n == 0:                                             # empty batch: nothing to launch (data_ptr() would be null)
         return out_rot.reshape(rotation.shape), out_ldj
-    wbytes = L.rnf_workspace_bytes(n, packed.n_cond)
-    ws = workspace(rot.device, wbytes)
-    fn = L.rnf_flow_inverse if inverse else L.rnf_flow_forward
     with torch.cuda.device(rot.device):
         stream = torch.cuda.current_stream(rot.device).cuda_stream
-        _lib.check(fn(rot.data_ptr(), feat.data_ptr() if feat is not None else None, n, packed.feat_padded,
-                      packed.blob.data_ptr(), packed.desc.ctypes.data, packed.n_layers, packed.segments,
-                      out_rot.data_ptr(), out_ldj.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+        if shared:
+            ws = workspace(rot.device, L.rnf_workspace_bytes_shared(n, packed.n_cond, feature_repeat))
+            fn = L.rnf_flow_inverse_shared if inverse else L.rnf_flow_forward_shared
+            _lib.check(fn(rot.data_ptr(), feat.data_ptr(), n, packed.feat_padded, feature_repeat, packed.blob.data_ptr(),
+                          packed.desc.ctypes.data, packed.n_layers, packed.segments, out_rot.data_ptr(), out_ldj.data_ptr(),
+                          ws.data_ptr(), ws.numel(), stream))
+        else:
+            ws = workspace(rot.device, L.rnf_workspace_bytes(n, packed.n_cond))
+            fn = L.rnf_flow_inverse if inverse else L.rnf_flow_forward
+            _lib.check(fn(rot.data_ptr(), feat.data_ptr() if feat is not None else None, n, packed.feat_padded,
+                          packed.blob.data_ptr(), packed.desc.ctypes.data, packed.n_layers, packed.segments,
+                          out_rot.data_ptr(), out_ldj.data_ptr(), ws.data_ptr(), ws.numel(), stream))
     return out_rot.reshape(rotation.shape), out_ldj
 
 

@@ -167,3 +167,29 @@ def test_errors_are_loud():
             fl(R.cpu(), torch.zeros(8, 16))                         # no CPU fallback
     with pytest.raises(NotImplementedError):
         fl.inverse(R, torch.zeros(8, 16, device="cuda"))           # no backward for the inverse: refuses instead of detaching
+
+
+@pytest.mark.parametrize("direction", ["forward", "inverse"])
+@pytest.mark.parametrize("Q", [500, 37])
+def test_shared_feature_rows_equal_materialised_repeat(direction, Q):
+    """feature_repeat=Q (pose estimation: one image feature against Q query rotations, agent.py:238-263) must give what the reference's
+    pattern gives -- every feature row repeated Q times -- including runs that straddle 32-rotation wave tiles (Q = 37, 500).  The two
+    calls go through different instantiations of the stack kernel (shared rows live in the extended one), whose fused-multiply-add
+    contraction differs in places: agreement is to fp32 rounding, not bit for bit."""
+    cfg = orc.make_config(layers=4, segments=16, condition=1, feature_dim=40, rot="16UnTrans", last_affine=1, frequent_permute=1)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=8, regime="trained")
+    fl = product_flow(cfg, w)
+    B = 9
+    R = torch.from_numpy(synth.uniform_rotations(B * Q, seed=9)).cuda()
+    f = torch.from_numpy(synth.features(B, 40, seed=10)).cuda()
+    frep = f[:, None, :].expand(B, Q, 40).reshape(B * Q, 40).contiguous()
+    with torch.no_grad():
+        if direction == "forward":
+            a = fl(R, f, feature_repeat=Q)
+            b = fl(R, frep)
+        else:
+            a = fl.inverse(R, f, feature_repeat=Q)
+            b = fl.inverse(R, frep)
+    assert (a[0] - b[0]).abs().max().item() < 2e-5 and (a[1] - b[1]).abs().max().item() < 5e-5
+    with torch.no_grad(), pytest.raises(ValueError):
+        fl(R[:-1], f, feature_repeat=Q)

@@ -179,6 +179,12 @@ int rnf_flow_inverse_shared(const float *rotation_dev, const float *feature_dev,
                             const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments,
                             float *rotation_out_dev, float *ldj_out_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* rnf_flow_log_prob with shared feature rows (density of one image on a grid of rotations, eval.py:444-462). */
+int rnf_flow_log_prob_shared(const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim, int64_t feature_div,
+                             const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments, const float *fisher_A,
+                             const float *fisher_c, int64_t fisher_B, float *rotation_out_dev, float *ldj_out_dev, float *logp_out_dev,
+                             double *sum_out, void *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* Fused density evaluation: Flow.forward + MatrixFisherN(A)._log_prob(R') + the NLL accumulation
  * (agent.py:54-65,217-229; utils/fisher.py:217-232).
  *   fisher_A_dev [B,3,3], fisher_c_dev [B] with c_b = sum(S_b) + log(norm_b) (host precomputes the proper singular

@@ -46,6 +46,9 @@ _SIGNATURES = {
                                           c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnf_flow_inverse_shared": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int64, c_f32p, c_i32p, C.c_int32, C.c_int32,
                                           c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnf_flow_log_prob_shared": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int64, c_f32p, c_i32p, C.c_int32, C.c_int32,
+                                           c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p,
+                                           C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnf_flow_log_prob": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
                                     c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -692,6 +692,16 @@ extern "C" int rnf_flow_log_prob(const float *rot, const float *feat, int64_t n,
     return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
 }
 
+extern "C" int rnf_flow_log_prob_shared(const float *rot, const float *feat, int64_t n, int32_t F, int64_t feature_div, const float *blob,
+                                        const int32_t *desc, int32_t n_layers, int32_t K, const float *fisher_A, const float *fisher_c,
+                                        int64_t fisher_B, float *rot_out, float *ldj_out, float *logp_out, double *sum_out, void *ws,
+                                        size_t ws_bytes, void *stream) {
+    if ((fisher_A == nullptr) != (fisher_c == nullptr)) return fail("fisher_A and fisher_c must both be given or both be null");
+    RunOpts o{0, fisher_A, fisher_c, fisher_B, logp_out, sum_out};
+    o.feature_div = feature_div;
+    return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // small standalone kernels
 // ------------------------------------------------------------------------------------------------------------

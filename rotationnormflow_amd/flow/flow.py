@@ -98,7 +98,7 @@ class Flow(nn.Module):
         return runtime.run_flow(self, self._packed(rotation.device), rotation, feature, inverse=True, feature_repeat=feature_repeat)
 
     # ---- fused density evaluation (agent.py:54-65,217-229 + utils/fisher.py:217-232) -------------------------
-    def log_prob(self, rotation, feature=None, base=None, return_rotation=False):
+    def log_prob(self, rotation, feature=None, base=None, return_rotation=False, feature_repeat=None):
         """Per-sample log p(R) = ldj + base(R') and {sum, count} in fp64, in one launch.
         ``base``: None (uniform) or a ``MatrixFisherN``.  Returns dict(logp, sum, rotation, ldj)."""
         if not self.condition:
@@ -107,4 +107,4 @@ class Flow(nn.Module):
         if base is not None:
             A, c = base.A, base.log_const()
         return runtime.run_log_prob(self, self._packed(rotation.device), rotation, feature, A, c,
-                                    want_rotation=return_rotation, want_ldj=False, want_logp=True)
+                                    want_rotation=return_rotation, want_ldj=False, want_logp=True, feature_repeat=feature_repeat)

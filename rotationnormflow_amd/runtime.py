@@ -348,10 +348,11 @@ def run_flow(module, packed, rotation, feature, inverse=False, train_layers=None
 
 
 def run_log_prob(module, packed: PackedFlow, rotation, feature, fisher_A=None, fisher_c=None,
-                 want_rotation=False, want_ldj=False, want_logp=True):
+                 want_rotation=False, want_ldj=False, want_logp=True, feature_repeat=None):
     """Fused Flow.forward + base log-density + NLL sum.  -> dict(logp, sum [2] float64 device tensor, rotation, ldj)"""
     _refuse_autograd(rotation, feature, module, "the fused log_prob evaluation")
-    rot, feat = _check_inputs(rotation, feature, packed)
+    shared = bool(feature_repeat) and packed.n_cond > 0
+    rot, feat = _check_inputs(rotation, feature, packed, feature_repeat if shared else None)
     n = rot.shape[0]
     L = _lib.lib()
     dev = rot.device
@@ -366,12 +367,19 @@ def run_log_prob(module, packed: PackedFlow, rotation, feature, fisher_A=None, f
         fisher_A = fisher_A.reshape(-1, 3, 3).to(device=dev, dtype=torch.float32).contiguous()
         fisher_c = fisher_c.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
         B = fisher_A.shape[0]
-    ws = workspace(dev, L.rnf_workspace_bytes(n, packed.n_cond))
     ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(L.rnf_flow_log_prob(rot.data_ptr(), ptr(feat), n, packed.feat_padded, packed.blob.data_ptr(),
-                                       packed.desc.ctypes.data, packed.n_layers, packed.segments,
-                                       ptr(fisher_A), ptr(fisher_c), B, ptr(out_rot), ptr(out_ldj), ptr(out_lp),
-                                       out_sum.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+        if shared:
+            ws = workspace(dev, L.rnf_workspace_bytes_shared(n, packed.n_cond, feature_repeat))
+            _lib.check(L.rnf_flow_log_prob_shared(rot.data_ptr(), ptr(feat), n, packed.feat_padded, feature_repeat, packed.blob.data_ptr(),
+                                                  packed.desc.ctypes.data, packed.n_layers, packed.segments,
+                                                  ptr(fisher_A), ptr(fisher_c), B, ptr(out_rot), ptr(out_ldj), ptr(out_lp),
+                                                  out_sum.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+        else:
+            ws = workspace(dev, L.rnf_workspace_bytes(n, packed.n_cond))
+            _lib.check(L.rnf_flow_log_prob(rot.data_ptr(), ptr(feat), n, packed.feat_padded, packed.blob.data_ptr(),
+                                           packed.desc.ctypes.data, packed.n_layers, packed.segments,
+                                           ptr(fisher_A), ptr(fisher_c), B, ptr(out_rot), ptr(out_ldj), ptr(out_lp),
+                                           out_sum.data_ptr(), ws.data_ptr(), ws.numel(), stream))
     return dict(logp=out_lp, sum=out_sum, rotation=out_rot, ldj=out_ldj)

@@ -193,3 +193,19 @@ def test_shared_feature_rows_equal_materialised_repeat(direction, Q):
     assert (a[0] - b[0]).abs().max().item() < 2e-5 and (a[1] - b[1]).abs().max().item() < 5e-5
     with torch.no_grad(), pytest.raises(ValueError):
         fl(R[:-1], f, feature_repeat=Q)
+
+
+def test_fused_log_prob_with_shared_feature_rows():
+    """Density of a few images on a grid of rotations (eval.py:444-462): flow.log_prob(grid, feature, feature_repeat=Q) against the
+    materialised repeat."""
+    cfg = orc.make_config(layers=3, segments=16, condition=1, feature_dim=24, rot="16UnTrans", last_affine=1)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=12, regime="trained")
+    fl = product_flow(cfg, w)
+    B, Q = 5, 333
+    R = torch.from_numpy(synth.uniform_rotations(B * Q, seed=13)).cuda()
+    f = torch.from_numpy(synth.features(B, 24, seed=14)).cuda()
+    with torch.no_grad():
+        a = fl.log_prob(R, f, feature_repeat=Q)
+        b = fl.log_prob(R, f[:, None, :].expand(B, Q, 24).reshape(B * Q, 24).contiguous())
+    assert (a["logp"] - b["logp"]).abs().max().item() < 5e-5
+    assert abs(float(a["sum"][0] - b["sum"][0])) < 1e-3 and float(a["sum"][1]) == B * Q

@@ -46,6 +46,7 @@ extern "C" {
 #define RNF_LAYER_COND9_SMITH 7   /* flow/rottrans.py:168-181     Condition9RotRSmith                          */
 #define RNF_LAYER_COND9_POLAR_L 8 /* flow/rottrans.py:108-121     Condition9RotL                               */
 #define RNF_LAYER_COND9_POLAR_R 9 /* flow/rottrans.py:138-151     Condition9RotR                               */
+#define RNF_LAYER_COND36 10       /* flow/squeezetrans.py:334-347 Condition36Trans (record from rnf_pack_cond36) */
 
 /* ---- arithmetic of the conditioner GEMMs --------------------------------------------------------------------
  * RNF_PREC_FP32  : exact fp32 (v_mfma_f32_32x32x2_f32; bit-for-bit an fp32 fma chain).
@@ -102,6 +103,13 @@ int rnf_pack_cond16(const float *fc_first_w, const float *fc_first_b, const floa
 
 /* Same record for the conditional 3x3 layers (RNF_LAYER_COND9_*): fc_last has 9 rows. */
 int rnf_pack_cond9(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
+                    const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
+                    const float *fc_last_w, const float *fc_last_b, int32_t feature_dim, int32_t precision,
+                    float *out_layer, float *out_feat);
+
+/* Condition36Trans (RNF_LAYER_COND36): fc_last has 36 rows in two tiles; record length rnf_cond36_packed_floats(). */
+int64_t rnf_cond36_packed_floats(void);
+int rnf_pack_cond36(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
                     const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
                     const float *fc_last_w, const float *fc_last_b, int32_t feature_dim, int32_t precision,
                     float *out_layer, float *out_feat);

@@ -50,6 +50,8 @@ def _affine_kind(cfg, first_layer_condition=False):
             return "lu16" if lu else "uncond16"
         if rot == "16UnRot":                                    # affineflow.py:43-44
             return "rot16"
+        if rot == "36Trans":                                    # affineflow.py:26-27
+            return "cgs36"
         if rot == "9TransLSmith" and not lu:                    # affineflow.py:34-38
             return "cgs9"
         if rot == "9TransRSmith":                               # affineflow.py:39-40
@@ -129,6 +131,8 @@ def state_shapes(cfg):
             mlp(f"layers.{i}.net", fd, 16)
         elif kind in ("cgs9", "csmithr9", "csvdl9", "csvdr9"):  # squeezetrans.py:237, rottrans.py:111,141,171
             mlp(f"layers.{i}.net", fd, 9)
+        elif kind == "cgs36":                                   # squeezetrans.py:337
+            mlp(f"layers.{i}.net", fd, 36)
         elif kind == "lu16":                                    # UnconditionLU(4), squeezetrans.py:76-83
             for name, shp in (("w_p", (4, 4)), ("u_mask", (4, 4)), ("l_mask", (4, 4)), ("s_sign", (4,)), ("l_eye", (4, 4)),
                               ("w_l", (4, 4)), ("w_s", (4,)), ("w_u", (4, 4))):
@@ -398,8 +402,9 @@ def gs36(M, R):
     dR = torch.einsum("kab,nbc->knac", G, R)
     v = torch.cat([R[..., 0], R[..., 1]], dim=-1)
     dv = torch.cat([dR[..., 0], dR[..., 1]], dim=-1)
-    tv = torch.einsum("nab,nb->na", M.expand(R.shape[0], 6, 6), v)
-    dtv = torch.einsum("nab,knb->kna", M.expand(R.shape[0], 6, 6), dv)
+    Mn = M.expand(R.shape[0], 6, 6)                                     # one shared matrix or one per sample
+    tv = torch.einsum("nab,nb->na", Mn, v)
+    dtv = torch.einsum("nab,knb->kna", Mn, dv)
     return _gram_schmidt_tangent(tv[..., :3], tv[..., 3:], dtv[..., :3], dtv[..., 3:])
 
 
@@ -440,6 +445,11 @@ def smithr9(M, R, inverse=False):
 def cond9_matrix(feature, p, prefix):
     """Condition9Trans / Condition9Rot* (squeezetrans.py:240-241, rottrans.py:114-115): I + reshape(net(feature), 3, 3)."""
     return conditioner(feature, p, prefix).reshape(-1, 3, 3) + torch.eye(3, dtype=feature.dtype)[None]
+
+
+def cond36_matrix(feature, p, prefix):
+    """Condition36Trans (squeezetrans.py:339-341): I + reshape(net(feature), 6, 6)."""
+    return conditioner(feature, p, prefix).reshape(-1, 6, 6) + torch.eye(6, dtype=feature.dtype)[None]
 
 
 def cond16_matrix(feature, p, prefix):
@@ -489,6 +499,8 @@ def flow_forward(cfg, params, R, feature=None, dtype=torch.float32, grad=False):
                 R, l = smithr9(p[f"layers.{i}.mat"], R)                                 # rottrans.py:159-161
             elif kind == "cgs9":
                 R, l = gs9(cond9_matrix(feature, p, f"layers.{i}.net"), R)              # squeezetrans.py:239-242
+            elif kind == "cgs36":
+                R, l = gs36(cond36_matrix(feature, p, f"layers.{i}.net"), R)            # squeezetrans.py:339-342
             elif kind == "csmithr9":
                 R, l = smithr9(cond9_matrix(feature, p, f"layers.{i}.net"), R)          # rottrans.py:173-176
             elif kind == "csvdl9":
@@ -540,6 +552,8 @@ def flow_inverse(cfg, params, R, feature=None, dtype=torch.float32):
                 R, l = smithr9(p[f"layers.{i}.mat"], R, inverse=True)                   # rottrans.py:163-165
             elif kind == "cgs9":
                 R, l = gs9(torch.linalg.inv(cond9_matrix(feature, p, f"layers.{i}.net")), R)        # squeezetrans.py:244-247
+            elif kind == "cgs36":
+                R, l = gs36(torch.linalg.inv(cond36_matrix(feature, p, f"layers.{i}.net")), R)      # squeezetrans.py:344-347
             elif kind == "csmithr9":
                 R, l = smithr9(cond9_matrix(feature, p, f"layers.{i}.net"), R, inverse=True)        # rottrans.py:178-181
             elif kind == "csvdl9":

@@ -30,6 +30,8 @@ _SIGNATURES = {
     "rnf_pack_gs": (C.c_int, [c_f32p, C.c_int32, c_f32p]),
     "rnf_pack_cond16": (C.c_int, [c_f32p] * 10 + [C.c_int32, C.c_int32, c_f32p, c_f32p]),
     "rnf_pack_cond9": (C.c_int, [c_f32p] * 10 + [C.c_int32, C.c_int32, c_f32p, c_f32p]),
+    "rnf_cond36_packed_floats": (C.c_int64, []),
+    "rnf_pack_cond36": (C.c_int, [c_f32p] * 10 + [C.c_int32, C.c_int32, c_f32p, c_f32p]),
     "rnf_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "rnf_flow_forward": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
                                    c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),

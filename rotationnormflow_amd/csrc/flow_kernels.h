@@ -601,6 +601,35 @@ __device__ __forceinline__ void cond9_finish(int kind, const f32x16 &o, int h, R
     }
 }
 
+// Condition36Trans (extended instantiation only): M = I + reshape(outputs 0..35, 6, 6) from two fc_last tiles.  Packed row P of tile 0 is
+// output P (register 4g + c of lane-half hh holds packed row 8g + 4hh + c), rows 0..3 of tile 1 are outputs 32..35 (lane-half 0).
+template <bool INVERSE>
+__device__ __forceinline__ void cond36_finish(const f32x16 &o0, const f32x16 &o1, int h, Rot &R, float &ldj) {
+    float m[36];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float mine = o0[4 * g + c], other = __shfl_xor(mine, 32, 64);
+            m[8 * g + c] = h ? other : mine;              // packed rows 8g + c belong to lane-half 0
+            m[8 * g + 4 + c] = h ? mine : other;          // packed rows 8g + 4 + c to lane-half 1
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float mine = o1[c], other = __shfl_xor(mine, 32, 64);
+        m[32 + c] = h ? other : mine;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) m[7 * i] += 1.0f;
+    if (INVERSE) {
+        float mi[36];
+        inv6(m, mi);
+        gs36_apply(mi, R, ldj);
+    } else {
+        gs36_apply(m, R, ldj);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // weight staging
 //   SYNC: before each MLP layer all waves copy the layer's record global(L2) -> LDS between two barriers (any K).
@@ -659,7 +688,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             if (kind_has_mlp(args.layers[layer_at(q)].x & 15)) return q;
         return -1;
     };
-    auto l_floats = [&](int kind) { return (kind == RNF_KIND_MOBIUS ? KT : 1) * MOB_LAST_TILE_FLOATS; };
+    auto l_floats = [&](int kind) { return kind_last_tiles(kind, KT) * MOB_LAST_TILE_FLOATS; };
     const int first_mlp = next_mlp(-1);
 
     if (args.fair_off >= 0 && tid < NW) reinterpret_cast<int *>(lds + args.fair_off)[tid] = 0;
@@ -736,7 +765,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 if (q >= 0) { const int2 dn = args.layers[layer_at(q)]; nxt_off = dn.y; nxt_kind = dn.x & 15; }
             } else {
                 __syncthreads();                                   // everyone is done with the previous image
-                const int tiles_now = (kind == RNF_KIND_MOBIUS) ? min(KT, MOB_MAX_TILES_IN_LDS) : 1;
+                const int tiles_now = min(kind_last_tiles(kind, KT), MOB_MAX_TILES_IN_LDS);
                 stage_floats(lds, params, MOB_HEAD_FLOATS + tiles_now * MOB_LAST_TILE_FLOATS, tid, NT);
                 __syncthreads();
             }
@@ -784,9 +813,15 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 }
             } else {
                 const f32x16 o16 = Mlp<PREC>::last(lds + MOB_LAST, lane, h, tt);
-                barrier2();
-                if (EXT && kind != RNF_KIND_COND16) cond9_finish<DIR != 0>(kind, o16, h, R, ldj);
-                else cond16_finish<DIR != 0>(o16, h, R, ldj);
+                if (EXT && kind == RNF_KIND_COND36) {
+                    const f32x16 o16b = Mlp<PREC>::last(lds + MOB_LAST + MOB_LAST_TILE_FLOATS, lane, h, tt);
+                    barrier2();
+                    cond36_finish<DIR != 0>(o16, o16b, h, R, ldj);
+                } else {
+                    barrier2();
+                    if (EXT && kind != RNF_KIND_COND16) cond9_finish<DIR != 0>(kind, o16, h, R, ldj);
+                    else cond16_finish<DIR != 0>(o16, h, R, ldj);
+                }
             }
             RNF_STAMP(5)                                          // 5: layer finish (bisection for the inverse)
         }

@@ -63,6 +63,7 @@ constexpr int GS36_FLOATS = 72;                           // 36 + 36
 // is the feature projection), then ONE fc_last tile whose rows are M entries: packed row 8g + 4h + c (g = 0,1) is
 // M[2g + h][c]; rows 16..31 are zero padding.
 constexpr int64_t COND16_FLOATS = MOB_HEAD_FLOATS + MOB_LAST_TILE_FLOATS;
+constexpr int64_t COND36_FLOATS = MOB_HEAD_FLOATS + 2 * MOB_LAST_TILE_FLOATS;
 
 // ---- feature projection record (per layer that consumes the feature vector), F padded to a multiple of 8 ----
 // [2][F/8][64] float4 weight image of W0[:, 3:] (or W0 for Condition16Trans), then bias image [2][2][16]
@@ -78,8 +79,13 @@ constexpr int G_FLOATS_PER_GROUP = 2 * 4 * 64 * 4;        // 2048 floats = 64 fe
 constexpr int RNF_KIND_MOBIUS = 1, RNF_KIND_AFFINE16 = 2, RNF_KIND_COND16 = 3, RNF_KIND_GS9 = 4, RNF_KIND_GS36 = 5;
 // conditional 3x3 layers: M = I + reshape(MLP(feature), 3, 3) per sample (Condition9Trans, Condition9RotRSmith, Condition9RotL, Condition9RotR)
 constexpr int RNF_KIND_COND9_GS = 6, RNF_KIND_COND9_SMITH = 7, RNF_KIND_COND9_POLAR_L = 8, RNF_KIND_COND9_POLAR_R = 9, RNF_KIND_COND9_LAST = 9;
+// Condition36Trans: M = I + reshape(MLP(feature), 6, 6) per sample; TWO fc_last tiles (packed row P of tile 0 is output P, rows 0..3 of
+// tile 1 are outputs 32..35)
+constexpr int RNF_KIND_COND36 = 10, RNF_KIND_LAST = 10;
 RNF_LAYOUT_INLINE bool kind_is_cond9(int kind) { return kind >= RNF_KIND_COND9_GS && kind <= RNF_KIND_COND9_LAST; }
-RNF_LAYOUT_INLINE bool kind_has_mlp(int kind) { return kind == RNF_KIND_MOBIUS || kind == RNF_KIND_COND16 || kind_is_cond9(kind); }
+RNF_LAYOUT_INLINE bool kind_has_mlp(int kind) { return kind == RNF_KIND_MOBIUS || kind == RNF_KIND_COND16 || kind_is_cond9(kind) || kind == RNF_KIND_COND36; }
+// fc_last tiles of one layer record (KT = segments / 8 for a Moebius layer)
+RNF_LAYOUT_INLINE int kind_last_tiles(int kind, int KT) { return kind == RNF_KIND_MOBIUS ? KT : (kind == RNF_KIND_COND36 ? 2 : 1); }
 
 // layer descriptor columns (include/rnf_hip.h)
 constexpr int D_KIND = 0, D_PERM = 1, D_PARAM = 2, D_SLOT = 3, D_FEAT = 4, D_PREC = 5, D_STRIDE = 6;   // D_PREC: RNF_PREC_* of include/rnf_hip.h

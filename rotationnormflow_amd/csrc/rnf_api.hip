@@ -198,13 +198,22 @@ extern "C" int rnf_pack_cond9(const float *fc_first_w, const float *fc_first_b, 
     return pack_cond(fc_first_w, fc_first_b, l1_w, l1_b, l3_w, l3_b, l5_w, l5_b, fc_last_w, fc_last_b, F, prec, 9, out, out_feat);
 }
 
+// Condition36Trans (flow/squeezetrans.py:334-347): two fc_last tiles, packed row P of tile 0 = output P, rows 0..3 of tile 1 = outputs 32..35
+extern "C" int rnf_pack_cond36(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
+                               const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
+                               const float *fc_last_w, const float *fc_last_b, int32_t F, int32_t prec, float *out,
+                               float *out_feat) {
+    return pack_cond(fc_first_w, fc_first_b, l1_w, l1_b, l3_w, l3_b, l5_w, l5_b, fc_last_w, fc_last_b, F, prec, 36, out, out_feat);
+}
+extern "C" int64_t rnf_cond36_packed_floats(void) { return COND36_FLOATS; }
+
 static int pack_cond(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b, const float *l3_w,
                      const float *l3_b, const float *l5_w, const float *l5_b, const float *fc_last_w, const float *fc_last_b, int32_t F,
                      int32_t prec, int32_t n_out, float *out, float *out_feat) {
     if (F <= 0 || F % 8) return fail("rnf_pack_cond16: feature_dim=%d must be a positive multiple of 8", F);
     if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2) return fail("rnf_pack_cond16: unknown precision %d", prec);
     g_half_overflow = false;
-    std::memset(out, 0, sizeof(float) * COND16_FLOATS);        // zero fc_first image: x0 comes from the projection
+    std::memset(out, 0, sizeof(float) * (n_out == 36 ? COND36_FLOATS : COND16_FLOATS));   // zero fc_first image: x0 comes from the projection
     const float *hw[3] = {l1_w, l3_w, l5_w};
     const float *hb[3] = {l1_b, l3_b, l5_b};
     pack_hidden(out, hw, hb, prec);
@@ -216,10 +225,13 @@ static int pack_cond(const float *fc_first_w, const float *fc_first_b, const flo
         const int o = 4 * (2 * g + h) + c;
         return o < n_out ? o : -1;
     };
-    float *rec = out + MOB_LAST;
-    auto row_of = [&](int, int i) { int s = src_row(i); return s < 0 ? (const float *)nullptr : fc_last_w + (size_t)s * 64; };
-    if (prec) pack_w64_h(rec, 1, row_of); else pack_w64(rec, 1, row_of);
-    pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) { int s = src_row(row); return s < 0 ? 0.f : fc_last_b[s]; });
+    for (int tau = 0; tau < (n_out == 36 ? 2 : 1); ++tau) {
+        auto src = [&](int row) { return n_out == 36 ? (tau == 0 ? row : (row < 4 ? 32 + row : -1)) : src_row(row); };
+        float *rec = out + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS;
+        auto row_of = [&](int, int i) { int s = src(i); return s < 0 ? (const float *)nullptr : fc_last_w + (size_t)s * 64; };
+        if (prec) pack_w64_h(rec, 1, row_of); else pack_w64(rec, 1, row_of);
+        pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) { int s = src(row); return s < 0 ? 0.f : fc_last_b[s]; });
+    }
     if (prec) pack_featproj_h(out_feat, fc_first_w, F, 0, F, fc_first_b); else pack_featproj(out_feat, fc_first_w, F, 0, F, fc_first_b);
     if (prec && g_half_overflow) return fail("rnf_pack_cond16: a weight is outside the fp16 range; use RNF_PREC_FP32") + 1;
     return 0;
@@ -401,16 +413,19 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     FeatProjArgs fp;
     std::memset(&fp, 0, sizeof(fp));
     int n_slots = 0;
+    int min_tiles = 1;                       // fc_last tiles the largest non-Moebius record needs resident in LDS
     bool any_mlp = false, ext = false;       // ext: the flow contains a layer kind only the extended kernel instantiation carries
     int prec = -1;
     for (int l = 0; l < n_layers; ++l) {
         const int32_t *d = desc + (size_t)l * D_STRIDE;
         const int kind = d[D_KIND], perm = d[D_PERM], slot = d[D_SLOT];
-        if (kind < RNF_KIND_MOBIUS || kind > RNF_KIND_COND9_LAST) return fail("layer %d: unknown kind %d", l, kind);
+        if (kind < RNF_KIND_MOBIUS || kind > RNF_KIND_LAST) return fail("layer %d: unknown kind %d", l, kind);
         if (perm < 0 || perm > 5) return fail("layer %d: perm_row %d outside [0,5]", l, perm);
         if (d[D_PARAM] < 0 || d[D_PARAM] % 4) return fail("layer %d: param offset %d must be a non-negative multiple of 4", l, d[D_PARAM]);
-        if ((kind == RNF_KIND_COND16 || kind_is_cond9(kind)) && slot < 0) return fail("layer %d: a conditional affine layer needs a cond_slot", l);
-        if (kind_is_cond9(kind)) ext = true;
+        if ((kind == RNF_KIND_COND16 || kind_is_cond9(kind) || kind == RNF_KIND_COND36) && slot < 0)
+            return fail("layer %d: a conditional affine layer needs a cond_slot", l);
+        if (kind_is_cond9(kind) || kind == RNF_KIND_COND36) ext = true;
+        if (kind == RNF_KIND_COND36) min_tiles = 2;
         if (slot >= 0) {
             if (slot >= MAX_SLOTS) return fail("layer %d: cond_slot %d >= %d", l, slot, MAX_SLOTS);
             if (d[D_FEAT] < 0 || d[D_FEAT] % 4) return fail("layer %d: feat offset %d invalid", l, d[D_FEAT]);
@@ -448,7 +463,8 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
 
     double *partials = reinterpret_cast<double *>(ws);
     float *G = n_slots ? reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + PARTIALS_BYTES) : nullptr;
-    const int tiles_in_lds = any_mlp ? (KT < MOB_MAX_TILES_IN_LDS ? KT : MOB_MAX_TILES_IN_LDS) : 0;
+    int tiles_in_lds = any_mlp ? (KT < MOB_MAX_TILES_IN_LDS ? KT : MOB_MAX_TILES_IN_LDS) : 0;
+    if (any_mlp && tiles_in_lds < min_tiles) tiles_in_lds = min_tiles;
     size_t lds_bytes = any_mlp ? sizeof(float) * (MOB_HEAD_FLOATS + (size_t)tiles_in_lds * MOB_LAST_TILE_FLOATS) : 0;
     if (lds_bytes < NW_FWD_H * sizeof(double)) lds_bytes = NW_FWD_H * sizeof(double) * 2;
     {   // SIMD fairness governor (flow_kernels.h struct Fair): forward split-precision kernel; RNF_FAIR=0 switches it off

@@ -425,6 +425,37 @@ RNF_HD void right_mul_cols(v3f q0, v3f q1, v3f q2, Rot &R) {          // (R Q)[:
     R.c2 = r0 * q2.x + r1 * q2.y + r2 * q2.z;
 }
 
+// 6x6 inverse (torch.linalg.inv of squeezetrans.py:345) by Gauss-Jordan with partial pivoting, everything in registers: the pivot row is
+// brought into place by compare-and-swap of whole rows (selects, no dynamic indexing -- a dynamically indexed register array would go to
+// scratch memory).  About 1.3 k VALU instructions per matrix; only the inverse pass of Condition36Trans pays it.
+RNF_HD void inv6(float (&a)[36], float (&b)[36]) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) b[i] = (i % 7 == 0) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) {                 // bubble the largest |a[r][c]| up to row c
+            const bool sw = fabsf(a[6 * r + c]) > fabsf(a[6 * c + c]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float ac = a[6 * c + k], ar = a[6 * r + k], bc = b[6 * c + k], br = b[6 * r + k];
+                a[6 * c + k] = sw ? ar : ac; a[6 * r + k] = sw ? ac : ar;
+                b[6 * c + k] = sw ? br : bc; b[6 * r + k] = sw ? bc : br;
+            }
+        }
+        const float ip = 1.0f / a[6 * c + c];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { a[6 * c + k] *= ip; b[6 * c + k] *= ip; }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            if (r == c) continue;
+            const float f = a[6 * r + c];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { a[6 * r + k] = fmaf(-f, a[6 * c + k], a[6 * r + k]); b[6 * r + k] = fmaf(-f, b[6 * c + k], b[6 * r + k]); }
+        }
+    }
+}
+
 // 4x4 inverse and determinant by cofactors (Condition16Trans.inverse: torch.linalg.inv, flow/squeezetrans.py:51-55;
 // my_det_4_4: squeezetrans.py:17-22).  Returns det(M); Minv = adj(M)/det.
 RNF_HD float inv4(const float (&m)[16], float (&o)[16]) {

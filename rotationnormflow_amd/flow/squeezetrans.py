@@ -189,14 +189,16 @@ class _Conditional9(nn.Module, _SingleLayer):
     """Shared body of the conditional 3x3 ablation layers: M = I + reshape(MLP(feature), 3, 3) per sample; the per-sample map (Gram-Schmidt
     with tangent log-det, Smith rotation, polar rotation) runs in the extended instantiation of the fused stack kernel."""
 
+    _rnf_outputs = 9
+
     def __init__(self, feature_dim):
         super().__init__()
         self.feature_dim = feature_dim
-        self.net = ConditionalTransform(feature_dim, 9)
+        self.net = ConditionalTransform(feature_dim, self._rnf_outputs)
         self._cache = runtime.PackCache()
 
     def _rnf_pack(self, L, prec=0):
-        rec, frec = runtime.pack_cond16(L, self.net, self.feature_dim, prec, n_out=9)
+        rec, frec = runtime.pack_cond16(L, self.net, self.feature_dim, prec, n_out=self._rnf_outputs)
         return rec, frec, self.feature_dim, 0
 
     def forward(self, rotation, permute=None, feature=None):
@@ -204,6 +206,13 @@ class _Conditional9(nn.Module, _SingleLayer):
 
     def inverse(self, rotation, permute=None, feature=None):
         return self._single(rotation, permute, feature, inverse=True)
+
+
+class Condition36Trans(_Conditional9):
+    """calculate_36 with a per-sample 6x6 matrix I + reshape(MLP(feature), 6, 6); the inverse pass inverts it per sample in registers
+    (flow/squeezetrans.py:334-347)."""
+    _rnf_kind = runtime.KIND_COND36
+    _rnf_outputs = 36
 
 
 class Condition9Trans(_Conditional9):
@@ -224,5 +233,4 @@ def _not_built(name, where):
 
 # declared so that the registry (flow/affineflow.py:5-73) resolves every name; constructing them fails loudly
 Condition16TransLU = _not_built("Condition16TransLU", "flow/squeezetrans.py:130-143")
-Condition36Trans = _not_built("Condition36Trans", "flow/squeezetrans.py:334-347")
 Condition9TransLU = _not_built("Condition9TransLU", "flow/squeezetrans.py:278-291")

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 
 KIND_MOBIUS, KIND_AFFINE16, KIND_COND16, KIND_GS9, KIND_GS36 = 1, 2, 3, 4, 5
-KIND_COND9_GS, KIND_COND9_SMITH, KIND_COND9_POLAR_L, KIND_COND9_POLAR_R = 6, 7, 8, 9
+KIND_COND9_GS, KIND_COND9_SMITH, KIND_COND9_POLAR_L, KIND_COND9_POLAR_R, KIND_COND36 = 6, 7, 8, 9, 10
 DESC_STRIDE = 6
 
 # Arithmetic of the conditioner GEMMs (include/rnf_hip.h RNF_PREC_*): "f16x2" = split-precision fp16 MFMA (22-bit
@@ -181,13 +181,13 @@ def pack_mobius(L, cond, K, feature_dim, prec=_lib.PREC_FP32):
 def pack_cond16(L, net, feature_dim, prec=_lib.PREC_FP32, n_out=16):
     F = feature_dim
     Fp = pad8(F)
-    rec = np.empty(L.rnf_cond16_packed_floats(), dtype=np.float32)
+    rec = np.empty(L.rnf_cond36_packed_floats() if n_out == 36 else L.rnf_cond16_packed_floats(), dtype=np.float32)
     frec = np.empty(L.rnf_featproj_packed_floats(Fp), dtype=np.float32)
     arrs = [_pad_cols(_np32(net.fc_first.weight), 0, F, Fp), _np32(net.fc_first.bias)]
     for j in (1, 3, 5):
         arrs += [_np32(net.layers[j].weight), _np32(net.layers[j].bias)]
     arrs += [_np32(net.fc_last.weight), _np32(net.fc_last.bias)]
-    fn = L.rnf_pack_cond16 if n_out == 16 else L.rnf_pack_cond9
+    fn = {16: L.rnf_pack_cond16, 9: L.rnf_pack_cond9, 36: L.rnf_pack_cond36}[n_out]
     _check_pack(L, fn(*[a.ctypes.data for a in arrs], Fp, prec, rec.ctypes.data, frec.ctypes.data))
     return rec, frec
 

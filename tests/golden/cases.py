@@ -64,6 +64,8 @@ CASES = {
     "csvdl9_cond_inv": dict(cfg=dict(layers=3, condition=1, feature_dim=24, rot="9TransLSVD"), n=512, regime="trained", wseed=28, rseed=82, direction="inverse", fisher=None),
     "csvdr9_cond":     dict(cfg=dict(layers=3, condition=1, feature_dim=24, rot="9TransRSVD", frequent_permute=1), n=512, regime="trained", wseed=29, rseed=83, direction="forward", fisher=None),
     "csvdr9_cond_inv": dict(cfg=dict(layers=3, condition=1, feature_dim=24, rot="9TransRSVD"), n=512, regime="trained", wseed=29, rseed=84, direction="inverse", fisher=None),
+    "cgs36_cond":      dict(cfg=dict(layers=3, condition=1, feature_dim=24, rot="36Trans"), n=512, regime="trained", wseed=30, rseed=85, direction="forward", fisher=None),
+    "cgs36_cond_inv":  dict(cfg=dict(layers=3, condition=1, feature_dim=24, rot="36Trans", last_affine=1), n=512, regime="trained", wseed=30, rseed=86, direction="inverse", fisher=None),
     "embed_cond":      dict(cfg=dict(layers=3, condition=1, feature_dim=24, embedding=1, embedding_dim=8, rot="16UnTrans", last_affine=1), n=512,
                             regime="default", wseed=14, rseed=58, direction="forward", fisher=None),
 }

@@ -98,9 +98,10 @@ def test_registry_table():
                      ("9TransRSmith", rottrans.Uncondition9RotRSmith)):
         assert isinstance(affineflow.get_affine(mk(rot=rot), 0), cls)
     for rot, cls in (("9TransLSVD", rottrans.Condition9RotL), ("9TransRSVD", rottrans.Condition9RotR),
-                     ("9TransLSmith", squeezetrans.Condition9Trans), ("9TransRSmith", rottrans.Condition9RotRSmith)):
+                     ("9TransLSmith", squeezetrans.Condition9Trans), ("9TransRSmith", rottrans.Condition9RotRSmith),
+                     ("36Trans", squeezetrans.Condition36Trans)):
         assert isinstance(affineflow.get_affine(mk(rot=rot, condition=1), 8), cls)
-    for kw in (dict(rot="36Trans"), dict(rot="9TransLSmith", lu=1), dict(rot="16Rot")):
+    for kw in (dict(rot="9TransLSmith", lu=1), dict(rot="16Rot")):
         with pytest.raises(NotImplementedError):                          # declared, not built: loud, no fallback
             affineflow.get_affine(mk(condition=1, **kw), 8)
     assert isinstance(affineflow.get_affine(mk(rot="9TransLSmith", lu=1), 0), squeezetrans.Uncondition9TransLU)

@@ -159,3 +159,35 @@ def test_fisher_constants_match_oracle():
         want = orc.fisher_log_prob(R, A, torch.float64)
         got = (R * A.double().reshape(1, 3, 3)).sum((-1, -2)) - d.log_const().double()
         assert (got - want).abs().max() < 2e-6
+
+
+def test_argument_validation_happens_before_any_gpu_work():
+    """Every entry point checks its arguments on the host first: these calls return an error code (and a message) without a GPU."""
+    import numpy as np
+    L = _lib.lib()
+    err = lambda: L.rnf_last_error().decode()  # noqa: E731
+    buf = np.zeros(128, np.float32)
+    # host packers
+    assert L.rnf_pack_gs(buf.ctypes.data, 4, buf.ctypes.data) != 0 and "3 or 6" in err()
+    assert L.rnf_pack_gs(np.zeros(9, np.float32).ctypes.data, 3, buf.ctypes.data) != 0 and "singular" in err()
+    assert L.rnf_gs_packed_floats(3) == 20 and L.rnf_gs_packed_floats(6) == 72 and L.rnf_gs_packed_floats(5) == -1
+    assert L.rnf_cond36_packed_floats() == L.rnf_cond16_packed_floats() + 2080
+    # training entry points
+    tdesc = np.array([[1, 0, 0]], np.int32)
+    args = (None, None, 64, 0, None, tdesc.ctypes.data, 1, 72, None, None, None, None, None, None, None)
+    assert L.rnf_flow_backward(*args) != 0 and "segments" in err()
+    args = (None, None, 64, 0, None, tdesc.ctypes.data, 300, 64, None, None, None, None, None, None, None)
+    assert L.rnf_flow_backward(*args) != 0 and "n_layers" in err()
+    args = (None, None, 0, 0, None, tdesc.ctypes.data, 1, 64, None, None, None, None, None, None, None)
+    assert L.rnf_flow_backward(*args) == 0                                  # empty batch: nothing to do
+    pdesc = np.array([[11, 0, 0, -1]], np.int32)
+    assert L.rnf_pack_flow_device(buf.ctypes.data, pdesc.ctypes.data, 1, 64, 0, 1, buf.ctypes.data, buf.ctypes.data, None) != 0 and "kind" in err()
+    assert L.rnf_pack_flow_device(buf.ctypes.data, pdesc.ctypes.data, 1, 60, 0, 1, buf.ctypes.data, buf.ctypes.data, None) != 0 and "multiple of 8" in err()
+    assert L.rnf_plain_layer_floats(1, 64, 0) == 29376 and L.rnf_plain_layer_floats(2, 64, 0) == 16
+    assert L.rnf_plain_layer_floats(3, 64, 40) == 64 * 40 + 64 + 3 * 4160 + 16 * 65
+    # shared feature rows
+    assert L.rnf_workspace_bytes_shared(1 << 20, 42, 512) == 4096 * 8 + 42 * 2048 * 64 * 4
+    assert L.rnf_workspace_bytes_shared(1 << 20, 42, 0) == L.rnf_workspace_bytes(1 << 20, 42)
+    # small kernels
+    assert L.rnf_min_geodesic(None, None, 5, 0, None, None) != 0
+    assert L.rnf_fisher_log_const(None, 3, None, None) != 0

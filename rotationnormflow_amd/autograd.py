@@ -53,6 +53,8 @@ class TrainPlan:
                 size = L.rnf_mobius_packed_floats(self.segments)
             elif kind == runtime.KIND_COND16:
                 size = L.rnf_cond16_packed_floats()
+            elif kind == runtime.KIND_GS9:
+                size = L.rnf_gs_packed_floats(3)
             else:
                 size = L.rnf_affine16_packed_floats()
             rec_sizes.append(size)

@@ -137,6 +137,19 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
         out[34] = out[35] = 0.f;
         return;
     }
+    if (kind == RNF_KIND_GS9) {                                        // rnf_pack_gs(n = 3): [M | M^-1], cofactor inverse in double
+        if (tid != 0) return;
+        double m[9], c[9];
+        for (int i = 0; i < 9; ++i) m[i] = P[i];
+        c[0] = m[4] * m[8] - m[5] * m[7]; c[1] = m[2] * m[7] - m[1] * m[8]; c[2] = m[1] * m[5] - m[2] * m[4];
+        c[3] = m[5] * m[6] - m[3] * m[8]; c[4] = m[0] * m[8] - m[2] * m[6]; c[5] = m[2] * m[3] - m[0] * m[5];
+        c[6] = m[3] * m[7] - m[4] * m[6]; c[7] = m[1] * m[6] - m[0] * m[7]; c[8] = m[0] * m[4] - m[1] * m[3];
+        const double det = m[0] * c[0] + m[1] * c[3] + m[2] * c[6];
+        if (det == 0.0) atomicOr(args.flags, PK_FLAG_SINGULAR);
+        for (int i = 0; i < 9; ++i) { out[i] = P[i]; out[9 + i] = (float)(c[i] / det); }
+        out[18] = out[19] = 0.f;
+        return;
+    }
     const bool mob = kind == RNF_KIND_MOBIUS;
     const int yo = mob ? 3 : 0, ni = yo + F, NO = mob ? 4 * K : 16;
     const float *W0 = P, *b0 = W0 + 64 * ni;

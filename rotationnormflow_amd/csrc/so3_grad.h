@@ -267,4 +267,46 @@ RNF_HD void affine16_backward(const float (&M)[16], const AffineSaved &sv, const
     gRin.c2 = v3f{r02, r12, r22};
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// calculate_9 (flow/squeezetrans.py:199-231) backward, on the closed form of so3_math.h gs9_apply: X = M R, q0 = x0/|x0|,
+// b1 = x1 - (q0.x1) q0, q1 = b1/|b1|, q2 = q0 x q1, u22 = q2.x2, ldj = 2 log|u22| - 2 log|x0|.
+// gM (9, accumulated into) and dL/dR (columns).
+// ---------------------------------------------------------------------------------------------------------------------
+RNF_HD void gs9_backward(const float (&M)[9], const Rot &R, const Rot &gRout, float g_ldj, float (&gM)[9], Rot &gRin) {
+    const v3f x0 = mat3_mul(M, R.c0), x1 = mat3_mul(M, R.c1), x2 = mat3_mul(M, R.c2);
+    const float iu00 = 1.0f / sqrtf(dot3(x0, x0));
+    const v3f q0 = x0 * iu00;
+    const float d = dot3(q0, x1);
+    const v3f b1 = x1 - q0 * d;
+    const float iu11 = 1.0f / sqrtf(dot3(b1, b1));
+    const v3f q1 = b1 * iu11;
+    const v3f q2 = cross3(q0, q1);
+    const float u22 = dot3(q2, x2);
+    // ldj = 2 log|u22| - 2 log u00
+    const float g_u22 = 2.0f * g_ldj / u22;
+    v3f g_q2 = gRout.c2 + x2 * g_u22;
+    const v3f g_x2 = q2 * g_u22;
+    // q2 = q0 x q1
+    v3f g_q0 = gRout.c0 + cross3(q1, g_q2);
+    const v3f g_q1 = gRout.c1 + cross3(g_q2, q0);
+    // q1 = b1 / |b1|, b1 = x1 - d q0, d = q0 . x1
+    const v3f g_b1 = normalize_bwd(q1, iu11, g_q1);
+    const float g_d = -dot3(g_b1, q0);
+    g_q0 = g_q0 - g_b1 * d + x1 * g_d;
+    const v3f g_x1 = g_b1 + q0 * g_d;
+    // q0 = x0 / |x0|;  -2 log u00
+    const v3f g_x0 = normalize_bwd(q0, iu00, g_q0) - q0 * (2.0f * g_ldj * iu00);
+    // X = M R: gM[i][j] += sum_c gX[i][c] R[j][c];  gR[:, c] = M^T gX[:, c]
+    const v3f gx[3] = {g_x0, g_x1, g_x2};
+    const v3f rc[3] = {R.c0, R.c1, R.c2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        gM[0] += gx[c].x * rc[c].x; gM[1] += gx[c].x * rc[c].y; gM[2] += gx[c].x * rc[c].z;
+        gM[3] += gx[c].y * rc[c].x; gM[4] += gx[c].y * rc[c].y; gM[5] += gx[c].y * rc[c].z;
+        gM[6] += gx[c].z * rc[c].x; gM[7] += gx[c].z * rc[c].y; gM[8] += gx[c].z * rc[c].z;
+    }
+    auto mt = [&](v3f g) { return v3f{M[0] * g.x + M[3] * g.y + M[6] * g.z, M[1] * g.x + M[4] * g.y + M[7] * g.z, M[2] * g.x + M[5] * g.y + M[8] * g.z}; };
+    gRin.c0 = mt(g_x0); gRin.c1 = mt(g_x1); gRin.c2 = mt(g_x2);
+}
+
 }  // namespace rnf

@@ -348,14 +348,20 @@ RNF_HD v3f mat3_mul(const float *M, v3f a) {          // row-major 3x3 times vec
                fmaf(M[8], a.z, fmaf(M[7], a.y, M[6] * a.x))};
 }
 
-// calculate_9: columns 0, 1 of M R; tangent directions R G_k (right multiplication): (R G_0) = [-r1, r0, 0], (R G_1) = [-r2, 0, r0],
-// (R G_2) = [0, -r2, r1]
+// calculate_9 (squeezetrans.py:199-231): Gram-Schmidt of X = M R.  With X = Q U (U upper triangular, u00 = |x0|, u22 = q2 . x2) the
+// reference's tangent-space determinant (three directions R G_k pushed through normalise / project / normalise / cross) is, in closed
+// form,  ldj = 2 log|u22| - 2 log u00  (checked against the forward-mode restatement in oracle.gs9 to 1e-14 in fp64,
+// tests/test_oracle_golden.py); only the 6x6 variant needs the tangent machinery above.
 RNF_HD void gs9_apply(const float *M, Rot &R, float &ldj) {
-    const v3f m0 = mat3_mul(M, R.c0), m1 = mat3_mul(M, R.c1), m2 = mat3_mul(M, R.c2);
-    const v3f z = v3f{0.f, 0.f, 0.f};
-    const v3f da0[3] = {m1 * -1.0f, m2 * -1.0f, z};
-    const v3f da1[3] = {m0, z, m2 * -1.0f};
-    gram_schmidt_tangent(m0, m1, da0, da1, R, ldj);
+    const v3f x0 = mat3_mul(M, R.c0), x1 = mat3_mul(M, R.c1), x2 = mat3_mul(M, R.c2);
+    const float n0 = dot3(x0, x0);
+    const v3f q0 = x0 * hw_rsq(n0);
+    const v3f b1 = x1 - q0 * dot3(q0, x1);
+    const v3f q1 = b1 * hw_rsq(dot3(b1, b1));
+    const v3f q2 = cross3(q0, q1);
+    const float u22 = dot3(q2, x2);
+    R.c0 = q0; R.c1 = q1; R.c2 = q2;
+    ldj += 0.693147180559945309f * hw_log2(u22 * u22 * hw_rcp(n0));
 }
 
 // calculate_36: (r0 (+) r1) as a 6-vector times M [6][6]; tangent directions G_k R (left multiplication):

@@ -15,6 +15,7 @@
 //   Moebius (NI = 3 + F, NO = 4K) / Condition16Trans (NI = F, NO = 16) conditioner MLP (flow/condition.py):
 //       W0 [64][NI] | b0 [64] | W1 [64][64] | b1 | W3 | b3 | W5 | b5 | WL [NO][64] | bL [NO]
 //   Uncondition16Trans:              M [16]
+//   Uncondition9Trans (+LU):         M [9] + 3 floats of padding (every layer starts 16-byte aligned)
 // The gradient blob has the same layout.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -297,6 +298,28 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                     if (q == 0) atomicAdd(Gp + v, tot);
                     const float gl = wave_sum(valid && !orth ? g_ldj : 0.f);
                     if (lane == 0) atomicAdd(args.g_ldj_sum + pos, gl);
+                }
+                gR = gRin;
+                RNF_TSTAMP(8)
+                continue;
+            }
+            if (kind == RNF_KIND_GS9) {                   // Uncondition9Trans / 9TransLU: M [9] (+3 pad) in the plain blob
+                float M[9], gM[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { M[i] = P[i]; gM[i] = 0.f; }
+                Rot gRin;
+                gs9_backward(M, Rin, gR, g_ldj, gM, gRin);
+                if (wave == 0 && want_w) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) GA.at(i, lane) = valid ? gM[i] : 0.f;
+#pragma unroll
+                    for (int i = 9; i < 16; ++i) GA.at(i, lane) = 0.f;
+                    const int v = lane >> 2, q = lane & 3;
+                    float tot = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) tot += GA.at(v, 16 * q + i);
+                    tot = quad_sum(tot);
+                    if (q == 0 && v < 9) atomicAdd(Gp + v, tot);
                 }
                 gR = gRin;
                 RNF_TSTAMP(8)

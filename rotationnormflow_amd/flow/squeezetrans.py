@@ -135,6 +135,15 @@ class _GramSchmidtLayer(nn.Module, _SingleLayer):
         with torch.no_grad():
             return runtime.pack_gs(L, self._matrix(), self._rnf_n), None, 0, 0
 
+    def _rnf_shape(self):
+        return (self._rnf_kind, 0, 0)
+
+    def _train_tensors(self):
+        """3x3 only: the plain blob holds M [9] + 3 floats of padding (the log-det has a closed form, csrc/so3_math.h gs9_apply, whose
+        reverse mode is csrc/so3_grad.h gs9_backward); the 6x6 layer has no backward kernel."""
+        m = self._matrix()
+        return [m.reshape(9), m.new_zeros(3)]
+
     def forward(self, rotation, permute=None, feature=None):
         return self._single(rotation, permute, None, inverse=False)
 
@@ -155,6 +164,9 @@ class Uncondition9Trans(_GramSchmidtLayer):
     def _matrix(self):
         return self.mat
 
+    def _rnf_train_tensors(self):
+        return self._train_tensors()
+
 
 class Uncondition9TransLU(_GramSchmidtLayer):
     """calculate_9 with the LU-parameterised 3x3 matrix (flow/squeezetrans.py:264-275)."""
@@ -168,6 +180,9 @@ class Uncondition9TransLU(_GramSchmidtLayer):
 
     def _matrix(self):
         return self.mat()[0]
+
+    def _rnf_train_tensors(self):
+        return self._train_tensors()            # autograd chains dL/dM through the LU assembly
 
 
 class Uncondition36Trans(_GramSchmidtLayer):

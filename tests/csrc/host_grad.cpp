@@ -44,4 +44,19 @@ void hg_affine(const float *M, float logabsdet, const float *Rin, const float *g
     }
     for (int k = 0; k < 16; ++k) gM[k] = gm[k];
 }
+void hg_gs9(const float *M, const float *Rin, const float *gRout, const float *g_ldj, int n, float *Rout, float *ldj, float *gM, float *gRin) {
+    float m[9], gm[9];
+    for (int k = 0; k < 9; ++k) { m[k] = M[k]; gm[k] = 0.f; }
+    for (int i = 0; i < n; ++i) {
+        Rot R = load_rot(Rin + 9 * i), gi;
+        const Rot Rin0 = R;
+        float l = 0.f;
+        gs9_apply(m, R, l);
+        store_rot(R, Rout + 9 * i);
+        ldj[i] = l;
+        gs9_backward(m, Rin0, load_rot(gRout + 9 * i), g_ldj[i], gm, gi);
+        store_rot(gi, gRin + 9 * i);
+    }
+    for (int k = 0; k < 9; ++k) gM[k] = gm[k];
+}
 }

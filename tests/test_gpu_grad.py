@@ -51,6 +51,9 @@ CASES = {
     "svdl9": (dict(layers=2, segments=16, rot="9TransLSVD"), 100, "trained"),
     "svdr9": (dict(layers=2, segments=16, rot="9TransRSVD"), 70, "trained"),
     "smithr9": (dict(layers=2, segments=16, rot="9TransRSmith"), 100, "trained"),
+    # Gram-Schmidt 3x3 layers: closed-form log-det, analytic backward
+    "gs9": (dict(layers=2, segments=16, rot="9TransLSmith"), 130, "trained"),
+    "gs9lu": (dict(layers=2, segments=16, rot="9TransLSmith", lu=1), 90, "default"),
 }
 
 
@@ -262,12 +265,12 @@ def test_gradient_blob_sync_hook_is_applied():
 
 
 def test_gram_schmidt_layers_refuse_training():
-    cfg = orc.make_config(layers=2, segments=16, rot="9TransLSmith")
+    cfg = orc.make_config(layers=2, segments=16, rot="36Trans")
     w = synth.fill_state_dict(orc.state_shapes(cfg), seed=3)
     fl = product_flow(cfg, w).train()
     R = torch.from_numpy(synth.uniform_rotations(32, seed=4)).cuda()
     with pytest.raises(NotImplementedError):
-        fl(R)                                                   # Uncondition9Trans has no backward kernel: loud, no silent detach
+        fl(R)                                                   # Uncondition36Trans has no backward kernel: loud, no silent detach
     with torch.no_grad():
         fl(R)
 

@@ -104,3 +104,24 @@ def test_affine16_backward(hg):
     assert np.abs(gM_full - gMw.numpy()[0]).max() < 3e-4 * max(1.0, float(gMw.abs().max()))
     tw, tg = tangent(R.astype(np.float64), gRw.numpy()), tangent(R.astype(np.float64), gRin.astype(np.float64))
     assert np.abs(tg - tw).max() < 3e-4 * max(1.0, np.abs(tw).max())
+
+
+def test_gram_schmidt_3x3_backward(hg):
+    """calculate_9 backward (closed-form log-det) against autograd of the oracle's forward-mode restatement."""
+    n = 512
+    rng = np.random.default_rng(5)
+    M = f32(np.eye(3) + 0.3 * rng.standard_normal((3, 3)))
+    R = synth.uniform_rotations(n, seed=31)
+    gR = f32(rng.standard_normal((n, 3, 3)))
+    gl = f32(rng.standard_normal(n))
+    Ro, ldj, gM, gRin = np.empty_like(R), np.empty(n, np.float32), np.empty(9, np.float32), np.empty_like(R)
+    hg.hg_gs9(ptr(M), ptr(R), ptr(gR), ptr(gl), n, ptr(Ro), ptr(ldj), ptr(gM), ptr(gRin))
+    Mt = torch.from_numpy(M).double().requires_grad_(True)
+    Rt = torch.from_numpy(R).double().requires_grad_(True)
+    Rw, lw = orc.gs9(Mt, Rt)
+    assert np.abs(Ro - Rw.detach().numpy()).max() < 5e-6 and np.abs(ldj - lw.detach().numpy()).max() < 2e-5
+    loss = (Rw * torch.from_numpy(gR).double()).sum() + (lw * torch.from_numpy(gl).double()).sum()
+    gMw, gRw = torch.autograd.grad(loss, (Mt, Rt))
+    assert np.abs(gM.reshape(3, 3) - gMw.numpy()).max() / np.abs(gMw.numpy()).max() < 2e-5
+    tg, tw = tangent(R.astype(np.float64), gRin.astype(np.float64)), tangent(R.astype(np.float64), gRw.numpy())
+    assert np.abs(tg - tw).max() / np.abs(tw).max() < 2e-5

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const h2 ph = __builtin_convertvector(v[q], h2);
-                        const h2 pl = __builtin_convertvector((v[q] - __builtin_convertvector(ph, f2)) * kLoScale, h2);
+                        const h2 pl = __builtin_convertvector((v[q] - __builtin_convertvector(ph, f2)) * FEAT_LO_SCALE, h2);
                         bh[s][2 * q] = ph[0]; bh[s][2 * q + 1] = ph[1];
                         bl[s][2 * q] = pl[0]; bl[s][2 * q + 1] = pl[1];
                     }
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        gout.store(q, make_float4(fmaf(acc2[4 * q], kLoInv, acc1[4 * q]), fmaf(acc2[4 * q + 1], kLoInv, acc1[4 * q + 1]),
-                                                  fmaf(acc2[4 * q + 2], kLoInv, acc1[4 * q + 2]), fmaf(acc2[4 * q + 3], kLoInv, acc1[4 * q + 3])));
+                        gout.store(q, make_float4(fmaf(acc2[4 * q], (1.0f / FEAT_LO_SCALE), acc1[4 * q]), fmaf(acc2[4 * q + 1], (1.0f / FEAT_LO_SCALE), acc1[4 * q + 1]),
+                                                  fmaf(acc2[4 * q + 2], (1.0f / FEAT_LO_SCALE), acc1[4 * q + 2]), fmaf(acc2[4 * q + 3], (1.0f / FEAT_LO_SCALE), acc1[4 * q + 3])));
                 }
             }
         }

@@ -176,7 +176,6 @@ __device__ __forceinline__ f32x16 last_tile(const float *tile_rec, int lane, int
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #define RNF_MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
-constexpr float kLoScale = 4096.0f, kLoInv = 1.0f / 4096.0f;
 
 struct ActFrag {
     h8 hi[4], lo[4];          // B fragments of one 64-feature activation, k-step s = 2*tile + half
@@ -186,19 +185,22 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <bool RELU>
 __device__ __forceinline__ void split_act(const f32x16 (&x)[2], ActFrag &f) {
+    // -1.0 the optimiser cannot see through: fma(m1, hi, v) then stays one v_fma_mixlo/mixhi_f16 that takes the fp16 `hi` directly
+    // (a literal -1 is folded into v - float(hi): v_cvt_f32_f16 + v_sub_f32 + a second v_cvt_pk_f16_f32)
+    float m1 = -1.0f;
+    asm("" : "+s"(m1));
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
             f2 v = {x[s >> 1][8 * (s & 1) + j], x[s >> 1][8 * (s & 1) + j + 1]};
-            if (RELU) {       // med3(x, 0, +inf): one instruction (fmaxf costs two: it first quiets a possible sNaN)
-                v.x = __builtin_amdgcn_fmed3f(v.x, 0.f, __builtin_inff());
-                v.y = __builtin_amdgcn_fmed3f(v.y, 0.f, __builtin_inff());
+            if (RELU) {       // integer max(bits, 0) IS relu on the bit pattern (negative floats are negative integers): one instruction,
+                              // where fmaxf / fmed3 cost two (they first quiet a possible sNaN)
+                v.x = __int_as_float(max(__float_as_int(v.x), 0));
+                v.y = __int_as_float(max(__float_as_int(v.y), 0));
             }
             const h2 ph = __builtin_convertvector(v, h2);                 // v_cvt_pk_f16_f32 (RN)
-            // (v - hi) * 4096 as fma(-4096, hi, 4096 v): the fp16 operand feeds v_fma_mix_f32 directly, no v_cvt_f32_f16 / v_sub
-            const f2 t = v * kLoScale;
-            const h2 pl = {(_Float16)__builtin_fmaf(-kLoScale, (float)ph[0], t.x), (_Float16)__builtin_fmaf(-kLoScale, (float)ph[1], t.y)};
+            const h2 pl = {(_Float16)__builtin_fmaf(m1, (float)ph[0], v.x), (_Float16)__builtin_fmaf(m1, (float)ph[1], v.y)};
             f.hi[s][j] = ph[0]; f.hi[s][j + 1] = ph[1];
             f.lo[s][j] = pl[0]; f.lo[s][j + 1] = pl[1];
         }
@@ -210,27 +212,24 @@ __device__ __forceinline__ h8 lds_h8(const float *base, int idx16) {
 }
 
 // one 64 -> 32 output tile in split precision; w_tile = [4 k-steps][hi, lo][64 lanes] h8  (2048 floats, as in fp32)
-__device__ __forceinline__ f32x16 gemm_tile64_h(const float *w_tile, int lane, const ActFrag &in, f32x16 acc1) {
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 acc2;
+__device__ __forceinline__ f32x16 gemm_tile64_h(const float *w_tile, int lane, const ActFrag &in, f32x16 acc) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const h8 ah = lds_h8(w_tile, (s * 2 + 0) * 64 + lane);
         const h8 al = lds_h8(w_tile, (s * 2 + 1) * 64 + lane);
-        acc1 = RNF_MFMA_H(ah, in.hi[s], acc1);
-        acc2 = RNF_MFMA_H(ah, in.lo[s], s == 0 ? zero : acc2);     // s == 0: inline-constant 0 as the C operand
-        acc2 = RNF_MFMA_H(al, in.hi[s], acc2);
+        acc = RNF_MFMA_H(ah, in.hi[s], acc);
+        acc = RNF_MFMA_H(ah, in.lo[s], acc);
+        acc = RNF_MFMA_H(al, in.hi[s], acc);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[r] = fmaf(acc2[r], kLoInv, acc1[r]);
-    return acc1;
+    return acc;
 }
 
 // SIMD fairness governor.  The two waves a workgroup places on one SIMD (w and w^4) run the same instruction stream; the
 // hardware arbitrates by age, so the older one runs ahead, reaches the layer barrier early and leaves its partner to finish
 // alone (a single wave cannot fill the VALU: every instruction waits for the previous one of its dependent chain).  Each wave
 // publishes a progress counter in LDS at a few points per layer and takes the lower issue priority while it is ahead of its
-// partner, so the pair advances together and the barrier wait shrinks.  Only changes timing, never results.
+// partner, so the pair advances together and the barrier wait shrinks.  Only changes timing, never results.  (8-wave workgroups
+// only: with 16 waves, four per SIMD, the hardware arbitration alone measured 2 % faster than any governor.)
 struct Fair {
     float *lds;
     int wave, off, prog;
@@ -393,6 +392,37 @@ __device__ __forceinline__ void tile_pipe(const float *rec, int lane, int h, con
     tile_step<0>(nxt, a, tt, cur, seg, c, S, A, J);
 }
 
+// split-precision counterpart of tile_step: slot m = 3 * (segment g) + (slice st) carries matrix instruction m of the next tile
+// (k-step m / 3; term hi.hi, hi.lo, lo.hi) and slice st of segment g of the finished tile.  Left to itself the compiler emits the
+// 12 matrix instructions back to back; while they queue for the matrix pipe they hold the VALU issue port of the SIMD.
+template <int M>
+__device__ __forceinline__ void tile_step_h(const float *rec, int lane, f32x16 &nxt, h8 (&ah)[2], h8 (&al)[2], const ActFrag &in,
+                                            const f32x16 &cur, SegPi (&seg)[4], const MobiusCtx &c, float &S, float &A, float &J) {
+    constexpr int ks = M / 3, term = M % 3, b = ks & 1;
+    if constexpr (term == 0 && ks + 1 < 4) {          // operands of the next k-step: in flight during this one (two 4-register pairs)
+        ah[b ^ 1] = lds_h8(rec, ((ks + 1) * 2 + 0) * 64 + lane);
+        al[b ^ 1] = lds_h8(rec, ((ks + 1) * 2 + 1) * 64 + lane);
+    }
+    if constexpr (term == 0) nxt = RNF_MFMA_H(ah[b], in.hi[ks], nxt);
+    else if constexpr (term == 1) nxt = RNF_MFMA_H(ah[b], in.lo[ks], nxt);
+    else nxt = RNF_MFMA_H(al[b], in.hi[ks], nxt);
+    constexpr int g = M / 3, st = M % 3;
+    seg_pi_stage<st>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, S, A, J);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (M + 1 < 12) tile_step_h<M + 1>(rec, lane, nxt, ah, al, in, cur, seg, c, S, A, J);
+}
+
+__device__ __forceinline__ void tile_pipe_h(const float *rec, int lane, int h, const ActFrag &tt, f32x16 &nxt, const f32x16 &cur,
+                                            const MobiusCtx &c, float &S, float &A, float &J) {
+    nxt = load_bias16(rec + MOB_LAST_TILE_BIAS + h * 16);
+    h8 ah[2], al[2];
+    ah[0] = lds_h8(rec, 0 * 64 + lane);
+    al[0] = lds_h8(rec, 1 * 64 + lane);
+    SegPi seg[4];
+    __builtin_amdgcn_sched_barrier(0);
+    tile_step_h<0>(rec, lane, nxt, ah, al, tt, cur, seg, c, S, A, J);
+}
+
 template <int PREC>
 __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int lane, int h, const typename Mlp<PREC>::Act &tt,
                                                  const MobiusCtx &c, float &S, float &A, float &J, Fair &fair) {
@@ -411,12 +441,12 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int l
             segments4(bufA, c, S, A, J);
         }
     } else {
-        // software pipeline: tile tau+1's 12 matrix instructions are in flight on the matrix cores while the VALU runs
-        // the segment math of tile tau
+        // software pipeline BY HAND: each of tile tau+1's 12 matrix instructions is issued in front of one ~15-instruction slice of
+        // tile tau's segment math (tile_pipe_h)
         f32x16 cur = Mlp<1>::last(rec, lane, h, tt);
         for (int tau = 1; tau < KT; ++tau) {
-            f32x16 nxt = Mlp<1>::last(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt);
-            segments4(cur, c, S, A, J);
+            f32x16 nxt;
+            tile_pipe_h(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt, nxt, cur, c, S, A, J);
             cur = nxt;
             fair.tick();
         }
@@ -729,11 +759,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             }
 
             if (kind == RNF_KIND_AFFINE16) {
-                float M[16];
-                const float *m = params + (DIR ? 17 : 0);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) M[i] = m[i];
-                affine16_apply(M, m[16], R, ldj, params[34] != 0.f);
+                affine16_table_apply(params + (DIR ? AFF_TABLE_INV : AFF_TABLE_FWD), params[DIR ? 33 : 16], R, ldj, params[34] != 0.f);
                 RNF_STAMP(6)                                      // 6: unconditional affine layer
                 continue;
             }

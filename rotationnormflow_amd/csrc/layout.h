@@ -32,6 +32,13 @@
 
 namespace rnf {
 
+// split-precision operand pairs x = hi + lo / SCALE (flow_kernels.h): the 64-wide conditioner GEMMs keep lo UNSCALED (it lives in
+// the fp16 subnormal range, absolute resolution 2^-24) so that all three products accumulate into ONE MFMA accumulator; the
+// feature projection scales lo by 2^12 and combines two accumulators.
+constexpr float W_LO_SCALE = 1.0f;
+constexpr float FEAT_LO_SCALE = 4096.0f;
+
+
 constexpr int HID = 64;                   // flow/condition.py:9
 constexpr int WAVE = 64;
 constexpr int TILE_SAMPLES = 32;          // samples per wave (one MFMA column tile)
@@ -52,8 +59,10 @@ constexpr int MOB_MAX_TILES_IN_LDS = 8;                   // fc_last tiles resid
 inline constexpr int64_t mobius_packed_floats(int K) { return MOB_HEAD_FLOATS + (int64_t)(K / 8) * MOB_LAST_TILE_FLOATS; }
 
 // ---- unconditional 4x4 affine record ----
-// [0..15] M row-major, [16] log|det M|, [17..32] M^-1, [33] log|det M^-1|, [34] 1.0 if M is orthogonal (log-det exactly 0), [35] 0
-constexpr int AFF_FLOATS = 36;
+// [0..15] M row-major, [16] log|det M|, [17..32] M^-1, [33] log|det M^-1|, [34] 1.0 if M is orthogonal (log-det exactly 0), [35] 0,
+// [36..135] the 10x10 table of M (so3_math.h affine16_table), [136..235] the table of M^-1, [236..239] 0
+constexpr int AFF_TABLE_FWD = 36, AFF_TABLE_INV = 136;
+constexpr int AFF_FLOATS = 240;
 
 // ---- 3x3 / 6x6 Gram-Schmidt layers (Uncondition9Trans, Uncondition36Trans): [M row-major | M^-1 row-major] ----
 constexpr int GS9_FLOATS = 20;                            // 9 + 9, padded to a multiple of 4

@@ -28,10 +28,10 @@ struct PackArgs {
     PackLayer layers[PK_MAX_LAYERS];
 };
 
-__device__ __forceinline__ float half_part(float w, int lo, int *flags) {
+__device__ __forceinline__ float half_part(float w, int lo, float lo_scale, int *flags) {
     if (!(fabsf(w) < 65504.0f)) atomicOr(flags, PK_FLAG_HALF_RANGE);      // also catches NaN / inf
     const _Float16 wh = (_Float16)w;
-    return lo ? (w - (float)wh) * 4096.0f : (float)wh;
+    return lo ? (w - (float)wh) * lo_scale : (float)wh;
 }
 
 __device__ __forceinline__ float pack2(float a, float b) {           // two fp16 in one 32-bit word, first element in the low half
@@ -55,7 +55,7 @@ __device__ __forceinline__ float w64_image(int r, int prec, RowFn row_of, int *f
         const int ot = e >> 12, s = (e >> 10) & 3, lo = (e >> 9) & 1, lane = (e >> 3) & 63, j = e & 7;
         const float *row = row_of(ot, lane & 31);
         const float w = row ? row[16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)] : 0.f;
-        v[q] = half_part(w, lo, flags);
+        v[q] = half_part(w, lo, W_LO_SCALE, flags);
     }
     return pack2(v[0], v[1]);
 }
@@ -78,7 +78,7 @@ __device__ __forceinline__ float featproj_image(int r, int prec, const float *W,
         const int s = rem >> 10, lo = (rem >> 9) & 1, lane = (rem >> 3) & 63, j = rem & 7;
         const int k = 16 * s + 8 * (lane >> 5) + j;
         const float w = k < F ? W[(size_t)(32 * ot + (lane & 31)) * ldw + col0 + k] : 0.f;
-        v[q] = half_part(w, lo, flags);
+        v[q] = half_part(w, lo, FEAT_LO_SCALE, flags);
     }
     return pack2(v[0], v[1]);
 }
@@ -123,6 +123,12 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 4; ++j) { out[4 * i + j] = P[4 * i + j]; out[17 + 4 * i + j] = P[4 * j + i]; }
             out[16] = 0.f; out[33] = 0.f; out[34] = 1.f; out[35] = 0.f;
+            double m[16], mt[16];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) { m[4 * i + j] = P[4 * i + j]; mt[4 * i + j] = P[4 * j + i]; }
+            affine16_table(m, out + AFF_TABLE_FWD);
+            affine16_table(mt, out + AFF_TABLE_INV);
+            for (int i = AFF_TABLE_INV + 100; i < AFF_FLOATS; ++i) out[i] = 0.f;
             return;
         }
         double m[16], inv[16], det = 0.0;
@@ -135,6 +141,9 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
         out[16] = (float)log(fabs(det));
         out[33] = (float)(-log(fabs(det)));
         out[34] = out[35] = 0.f;
+        affine16_table(m, out + AFF_TABLE_FWD);
+        affine16_table(inv, out + AFF_TABLE_INV);
+        for (int i = AFF_TABLE_INV + 100; i < AFF_FLOATS; ++i) out[i] = 0.f;
         return;
     }
     if (kind == RNF_KIND_GS9) {                                        // rnf_pack_gs(n = 3): [M | M^-1], cofactor inverse in double

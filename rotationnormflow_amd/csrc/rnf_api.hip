@@ -83,7 +83,7 @@ static void pack_w64_h(float *img, int n_ot, RowFn row_of) {
                     if (!(std::fabs(w) < 65504.0f)) g_half_overflow = true;      // also catches NaN / inf
                     const _Float16 wh = (_Float16)w;
                     hi[j] = wh;
-                    lo[j] = (_Float16)((w - (float)wh) * 4096.0f);
+                    lo[j] = (_Float16)((w - (float)wh) * W_LO_SCALE);
                 }
             }
 }
@@ -123,7 +123,7 @@ static void pack_featproj_h(float *out, const float *W, int ldw, int col0, int F
                     if (!(std::fabs(w) < 65504.0f)) g_half_overflow = true;
                     const _Float16 wh = (_Float16)w;
                     hi[j] = wh;
-                    lo[j] = (_Float16)((w - (float)wh) * 4096.0f);
+                    lo[j] = (_Float16)((w - (float)wh) * FEAT_LO_SCALE);
                 }
             }
     pack_bias(out + (size_t)2 * ns * 512, 2, [&](int ot, int row) { return b0[32 * ot + row]; });
@@ -269,6 +269,9 @@ extern "C" int rnf_pack_affine16(const float *mat16, float *out) {
     out[16] = (float)std::log(std::fabs(det));
     out[33] = (float)(-std::log(std::fabs(det)));
     out[34] = out[35] = 0.f;
+    affine16_table(m, out + AFF_TABLE_FWD);
+    affine16_table(inv, out + AFF_TABLE_INV);
+    for (int i = AFF_TABLE_INV + 100; i < AFF_FLOATS; ++i) out[i] = 0.f;
     return 0;
 }
 
@@ -322,6 +325,12 @@ extern "C" int rnf_pack_rot16(const float *mat16, float *out) {
     out[33] = 0.f;
     out[34] = 1.f;
     out[35] = 0.f;
+    double m[16], mt[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { m[4 * i + j] = mat16[4 * i + j]; mt[4 * i + j] = mat16[4 * j + i]; }
+    affine16_table(m, out + AFF_TABLE_FWD);
+    affine16_table(mt, out + AFF_TABLE_INV);
+    for (int i = AFF_TABLE_INV + 100; i < AFF_FLOATS; ++i) out[i] = 0.f;
     return 0;
 }
 
@@ -329,7 +338,9 @@ extern "C" int rnf_pack_rot16(const float *mat16, float *out) {
 // launchers
 // ------------------------------------------------------------------------------------------------------------
 constexpr int NW = 8;                                   // waves per workgroup (2 per SIMD): exact-fp32 and inverse kernels, featproj
-constexpr int NW_FWD_H = 8;                             // forward split-precision kernel (12 waves = 3 per SIMD fits in 161 VGPRs but measured slower: barrier skew)
+constexpr int NW_FWD_H = 8;                             // forward split-precision kernel small launches
+constexpr int NW_FWD_WIDE = 16;                         // same kernel, 4 waves per SIMD (fits in 128 VGPRs): launches that fill every CU with
+                                                        // 512-rotation workgroups; +12 % over 8 waves (profiles/r1/nw_sweep.txt)
 constexpr long long CHUNK_SAMPLES = 1LL << 18;          // samples per launch when a feature projection scratch is needed
 constexpr size_t PARTIALS_BYTES = 4096 * sizeof(double);
 
@@ -356,8 +367,8 @@ extern "C" size_t rnf_workspace_bytes(int64_t n, int32_t n_cond_layers) {
     if (n_cond_layers > 0) {
         long long chunk = n < CHUNK_SAMPLES ? n : CHUNK_SAMPLES;
         long long groups = (chunk + 255) / 256 * 8;     // whole workgroup tiles, for either workgroup size
-        const long long g12 = (chunk + 32 * NW_FWD_H - 1) / (32 * NW_FWD_H) * NW_FWD_H;
-        if (g12 > groups) groups = g12;
+        const long long g16 = (chunk + 32 * NW_FWD_WIDE - 1) / (32 * NW_FWD_WIDE) * NW_FWD_WIDE;
+        if (g16 > groups) groups = g16;
         bytes += (size_t)n_cond_layers * groups * G_FLOATS_PER_GROUP * sizeof(float);
     }
     return bytes;
@@ -366,6 +377,16 @@ extern "C" size_t rnf_workspace_bytes(int64_t n, int32_t n_cond_layers) {
 template <typename K>
 static hipError_t allow_lds(K kernel, size_t bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// RNF_WIDE=0 keeps the forward kernel at 8 waves per workgroup (measurement switch)
+static bool wide_allowed() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = std::getenv("RNF_WIDE");
+        mode = (e && e[0] == '0') ? 0 : 1;
+    }
+    return mode == 1;
 }
 
 // staging mode: DMA (LDS-DMA double-phase prefetch, needs segments <= 64) unless RNF_STAGING=sync
@@ -379,8 +400,18 @@ static bool staging_dma() {
 }
 
 template <int DIR, int KT_INV, bool PIPE, int PREC, bool EXT = false>
-static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream) {
+static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream, int nwk) {
+    if constexpr (DIR == 0 && PREC == 1 && PIPE && !EXT) {
+        if (nwk == NW_FWD_WIDE) {
+            auto kern = flow_stack_kernel<DIR, KT_INV, NW_FWD_WIDE, PIPE, PREC, EXT>;
+            HIP_TRY(allow_lds(kern, lds_bytes));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_FWD_WIDE * 64), lds_bytes, stream, a);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+    }
     constexpr int NWK = (DIR == 0 && PREC == 1) ? NW_FWD_H : NW;
+    if (nwk != NWK) return fail("internal: no %d-wave instantiation of this stack kernel", nwk);
     auto kern = flow_stack_kernel<DIR, KT_INV, NWK, PIPE, PREC, EXT>;
     HIP_TRY(allow_lds(kern, lds_bytes));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWK * 64), lds_bytes, stream, a);
@@ -466,7 +497,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     int tiles_in_lds = any_mlp ? (KT < MOB_MAX_TILES_IN_LDS ? KT : MOB_MAX_TILES_IN_LDS) : 0;
     if (any_mlp && tiles_in_lds < min_tiles) tiles_in_lds = min_tiles;
     size_t lds_bytes = any_mlp ? sizeof(float) * (MOB_HEAD_FLOATS + (size_t)tiles_in_lds * MOB_LAST_TILE_FLOATS) : 0;
-    if (lds_bytes < NW_FWD_H * sizeof(double)) lds_bytes = NW_FWD_H * sizeof(double) * 2;
+    if (lds_bytes < NW_FWD_WIDE * sizeof(double) * 2) lds_bytes = NW_FWD_WIDE * sizeof(double) * 2;
     {   // SIMD fairness governor (flow_kernels.h struct Fair): forward split-precision kernel; RNF_FAIR=0 switches it off
         static int fair = -1;
         if (fair < 0) { const char *e = std::getenv("RNF_FAIR"); fair = (e && e[0] == '0') ? 0 : 1; }
@@ -497,10 +528,19 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     a.fisher_c = o.fisher_c;
     a.fisher_div = o.fisher_A ? n / o.fisher_B : 1;
 
+    // (inverse with K = 64: 96 segment registers + the DMA bookkeeping spill under the 256-VGPR cap; it is VALU-bound in
+    //  the bisection anyway, so it keeps the synchronous staging)
+    // (flows with a conditional 3x3 layer run the extended instantiation, which is only built with the synchronous staging)
+    const bool pipe = staging_dma() && KT <= MOB_MAX_TILES_IN_LDS && !(o.dir == 1 && KT == 8) && !ext;
+    const int fair_off = a.fair_off;
     bool first = true;
     for (long long base = 0; base < n; base += chunk_cap) {
         const long long cn = (n - base) < chunk_cap ? (n - base) : chunk_cap;
-        const int nwk = (o.dir == 0 && prec == 1) ? NW_FWD_H : NW;          // waves per workgroup of the stack kernel
+        // waves per workgroup of the stack kernel: the forward split-precision kernel goes 16 wide once 8-wave workgroups would
+        // no longer fit the CUs in one round
+        const bool wide = o.dir == 0 && prec == 1 && pipe && !ext && wide_allowed() && cn > (long long)cus * NW_FWD_H * 32;
+        const int nwk = wide ? NW_FWD_WIDE : ((o.dir == 0 && prec == 1) ? NW_FWD_H : NW);
+        a.fair_off = wide ? -1 : fair_off;                                   // the governor pairs two waves per SIMD
         const long long ntiles = (cn + nwk * 32 - 1) / (nwk * 32);
         const long long ntiles_fp = (cn + NW * 32 - 1) / (NW * 32);          // the feature projection keeps 8 waves
         const long long groups = (ntiles * nwk > ntiles_fp * NW) ? ntiles * nwk : ntiles_fp * NW;
@@ -541,17 +581,13 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         a.sample_base = base;
         a.g_groups = groups;
         int rc;
-        // (inverse with K = 64: 96 segment registers + the DMA bookkeeping spill under the 256-VGPR cap; it is VALU-bound in
-        //  the bisection anyway, so it keeps the synchronous staging)
-        // (flows with a conditional 3x3 layer run the extended instantiation, which is only built with the synchronous staging)
-        const bool pipe = staging_dma() && KT <= MOB_MAX_TILES_IN_LDS && !(o.dir == 1 && KT == 8) && !ext;
 #define RNF_LAUNCH(DIR_, KT_)                                                                                   \
-    ext ? (prec ? launch_stack<DIR_, KT_, false, 1, true>(a, grid, lds_bytes, stream)                          \
-                : launch_stack<DIR_, KT_, false, 0, true>(a, grid, lds_bytes, stream)) :                       \
-    (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1>(a, grid, lds_bytes, stream)                               \
-                  : launch_stack<DIR_, KT_, true, 0>(a, grid, lds_bytes, stream))                              \
-          : (prec ? launch_stack<DIR_, KT_, false, 1>(a, grid, lds_bytes, stream)                              \
-                  : launch_stack<DIR_, KT_, false, 0>(a, grid, lds_bytes, stream)))
+    ext ? (prec ? launch_stack<DIR_, KT_, false, 1, true>(a, grid, lds_bytes, stream, nwk)                          \
+                : launch_stack<DIR_, KT_, false, 0, true>(a, grid, lds_bytes, stream, nwk)) :                       \
+    (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1>(a, grid, lds_bytes, stream, nwk)                               \
+                  : launch_stack<DIR_, KT_, true, 0>(a, grid, lds_bytes, stream, nwk))                              \
+          : (prec ? launch_stack<DIR_, KT_, false, 1>(a, grid, lds_bytes, stream, nwk)                              \
+                  : launch_stack<DIR_, KT_, false, 0>(a, grid, lds_bytes, stream, nwk)))
         if (o.dir == 0) rc = RNF_LAUNCH(0, 0);
         else if (KT == 1) rc = RNF_LAUNCH(1, 1);
         else if (KT == 2) rc = RNF_LAUNCH(1, 2);

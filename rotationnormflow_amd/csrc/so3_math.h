@@ -263,6 +263,44 @@ RNF_HD void segment_fwd_pi(float s_raw, float w0, float w1, float w2, const Fram
     J = fmaf(sp, c, J);
 }
 
+// segment_fwd_pi cut into three slices of ~15 VALU instructions: the split-precision forward kernel issues ONE matrix instruction of
+// the next fc_last tile in front of every slice (flow_kernels.h tile_pipe_h), so that a wave never queues matrix instructions back to
+// back -- a matrix instruction waiting for the matrix pipe holds the SIMD's VALU issue port and stalls the other waves' segment math
+// (profiles/r1/mfma_f16_valu_overlap_microbench.txt).
+struct SegPi {
+    float ur, uv, t, c, p, z;
+};
+template <int STAGE>
+RNF_HD void seg_pi_stage(SegPi &g, float s_raw, float w0, float w1, float w2, const Frame &f, float &S, float &A, float &J) {
+    if constexpr (STAGE == 0) {
+        const float wr = fmaf(w2, f.r.z, fmaf(w1, f.r.y, w0 * f.r.x));
+        const float wv = fmaf(w2, f.v.z, fmaf(w1, f.v.y, w0 * f.v.x));
+        const float sc = 0.7f * hw_rcp(1.0f + hw_sqrt(fmaf(wv, wv, wr * wr)));
+        g.ur = wr * sc;
+        g.uv = wv * sc;
+    } else if constexpr (STAGE == 1) {
+        const float e1 = 1.0f + g.ur;
+        g.t = g.uv * hw_rcp(e1);
+        g.c = (1.0f - fmaf(g.uv, g.uv, g.ur * g.ur)) * hw_rcp(fmaf(g.uv, g.uv, e1 * e1));
+        g.z = g.t * g.t;
+        float p = fmaf(2.456724578e-03f, g.z, -1.440135792e-02f);
+        p = fmaf(p, g.z, 3.978122362e-02f);
+        p = fmaf(p, g.z, -7.234857378e-02f);
+        g.p = fmaf(p, g.z, 1.049894609e-01f);
+    } else {
+        float p = fmaf(g.p, g.z, -1.416122920e-01f);
+        p = fmaf(p, g.z, 1.998590677e-01f);
+        p = fmaf(p, g.z, -3.333259703e-01f);
+        p = fmaf(p, g.z, 9.999998864e-01f);
+        const float phi = fmaf(2.0f, p * g.t, kPi);
+        const float e = hw_exp2(-1.44269504088896341f * fabsf(s_raw));
+        const float sp = fmaf(hw_log2(1.0f + e), 0.693147180559945309f, fmaxf(s_raw, 0.0f));
+        S += sp;
+        A = fmaf(sp, phi, A);
+        J = fmaf(sp, g.c, J);
+    }
+}
+
 // pytorch3d.transforms.matrix_to_quaternion (published 0.7.5 rule; call site flow/squeezetrans.py:34):
 // four candidates from sqrt(max(0, 1 +- m00 +- m11 +- m22)), keep the one with the largest |q_i| (first on ties),
 // denominators floored at 0.1.  Real part first.
@@ -310,6 +348,75 @@ RNF_HD void affine16_apply(const float (&M)[16], float logabsdet, Rot &R, float 
     float l2 = fmaf(t[3], t[3], fmaf(t[2], t[2], fmaf(t[1], t[1], t[0] * t[0])));
     quat_to_rot(t, l2, R);
     if (!orthogonal) ldj += logabsdet - 2.0f * logf(l2);
+}
+
+// calculate_16 for a CONSTANT matrix without the quaternion detour.  For a unit quaternion every product q_i q_j is an affine
+// function of the rotation entries (w^2 = (1 + R00 + R11 + R22) / 4, w x = (R21 - R12) / 4, x y = (R01 + R10) / 4, ...), so
+// q' q'^T = M (q q^T) M^T is affine in R too, and both |q'|^2 and |q'|^2 R(q'/|q'|) are linear in q' q'^T: the whole layer is
+//     [ |q'|^2 ; |q'|^2 R' (row-major) ] = T . [ 1 ; R (row-major) ]       with one 10x10 table T(M) built by the packer (in double),
+// 90 fma + 1 rcp + 9 mul + log instead of the 4-candidate square-root selection, matrix-vector product and re-expansion (~330 VALU).
+// Same result as affine16_apply up to fp32 rounding (the quaternion's sign and the candidate choice never mattered).
+RNF_HD void affine16_table(const double *M /* 4x4 row-major */, float *T /* [10][10] */) {
+#pragma clang fp contract(off)
+    for (int k = 0; k < 10; ++k) {
+        double in[10];
+        for (int i = 0; i < 10; ++i) in[i] = (i == k) ? 1.0 : 0.0;
+        const double one = in[0];
+        const double *r = in + 1;
+        double Q[4][4];
+        Q[0][0] = 0.25 * (one + r[0] + r[4] + r[8]);
+        Q[1][1] = 0.25 * (one + r[0] - r[4] - r[8]);
+        Q[2][2] = 0.25 * (one - r[0] + r[4] - r[8]);
+        Q[3][3] = 0.25 * (one - r[0] - r[4] + r[8]);
+        Q[0][1] = Q[1][0] = 0.25 * (r[7] - r[5]);
+        Q[0][2] = Q[2][0] = 0.25 * (r[2] - r[6]);
+        Q[0][3] = Q[3][0] = 0.25 * (r[3] - r[1]);
+        Q[1][2] = Q[2][1] = 0.25 * (r[1] + r[3]);
+        Q[1][3] = Q[3][1] = 0.25 * (r[2] + r[6]);
+        Q[2][3] = Q[3][2] = 0.25 * (r[5] + r[7]);
+        double MQ[4][4], P[4][4];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double a = 0.0;
+                for (int l = 0; l < 4; ++l) a += M[4 * i + l] * Q[l][j];
+                MQ[i][j] = a;
+            }
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double a = 0.0;
+                for (int l = 0; l < 4; ++l) a += MQ[i][l] * M[4 * j + l];
+                P[i][j] = a;
+            }
+        double o[10];
+        o[0] = P[0][0] + P[1][1] + P[2][2] + P[3][3];
+        o[1] = P[0][0] + P[1][1] - P[2][2] - P[3][3];
+        o[2] = 2.0 * (P[1][2] - P[0][3]);
+        o[3] = 2.0 * (P[1][3] + P[0][2]);
+        o[4] = 2.0 * (P[1][2] + P[0][3]);
+        o[5] = P[0][0] - P[1][1] + P[2][2] - P[3][3];
+        o[6] = 2.0 * (P[2][3] - P[0][1]);
+        o[7] = 2.0 * (P[1][3] - P[0][2]);
+        o[8] = 2.0 * (P[2][3] + P[0][1]);
+        o[9] = P[0][0] - P[1][1] - P[2][2] + P[3][3];
+        for (int i = 0; i < 10; ++i) T[10 * i + k] = (float)o[i];
+    }
+}
+
+RNF_HD void affine16_table_apply(const float *T, float logabsdet, Rot &R, float &ldj, bool orthogonal) {
+    const float r[9] = {R.c0.x, R.c1.x, R.c2.x, R.c0.y, R.c1.y, R.c2.y, R.c0.z, R.c1.z, R.c2.z};
+    float o[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        float a = T[10 * i];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a = fmaf(T[10 * i + 1 + k], r[k], a);
+        o[i] = a;
+    }
+    const float inv = hw_rcp(o[0]);
+    R.c0.x = o[1] * inv; R.c1.x = o[2] * inv; R.c2.x = o[3] * inv;
+    R.c0.y = o[4] * inv; R.c1.y = o[5] * inv; R.c2.y = o[6] * inv;
+    R.c0.z = o[7] * inv; R.c1.z = o[8] * inv; R.c2.z = o[9] * inv;
+    if (!orthogonal) ldj += fmaf(-2.0f * 0.693147180559945309f, hw_log2(o[0]), logabsdet);
 }
 
 // ---- 3x3 / 6x6 ablation layers: Gram-Schmidt of two transformed columns, log-det from three tangent directions ----------------

@@ -132,22 +132,22 @@ def split_act(x2, relu=True):
         if relu:
             vals = np.maximum(vals, 0)
         h = vals.astype(np.float16)
-        l = ((vals - h.astype(np.float32)) * np.float32(4096.0)).astype(np.float16)
+        l = (vals - h.astype(np.float32)).astype(np.float16)       # unscaled: lands in the fp16 subnormal range, floor 2^-24
         hi.append(h.astype(np.float64))
         lo.append(l.astype(np.float64))
     return hi, lo
 
 
-def gemm_tile64_h(rec32, off_floats, act, acc1):
-    """rec32: the packed record as float32 array; weights at float offset `off_floats`: [4 s][hi,lo][64 lanes] 8 x fp16."""
+def gemm_tile64_h(rec32, off_floats, act, acc):
+    """rec32: the packed record as float32 array; weights at float offset `off_floats`: [4 s][hi,lo][64 lanes] 8 x fp16.
+    One accumulator takes all three products (hi.hi, hi.lo, lo.hi) as in flow_kernels.h gemm_tile64_h."""
     halves = rec32[off_floats: off_floats + 2048].view(np.float16).astype(np.float64).reshape(4, 2, 64, 8)
     hi, lo = act
-    acc2 = np.zeros((16, 64))
     for s in range(4):
-        acc1 = mfma_h(halves[s, 0], hi[s], acc1)
-        acc2 = mfma_h(halves[s, 0], lo[s], acc2)
-        acc2 = mfma_h(halves[s, 1], hi[s], acc2)
-    return acc1 + acc2 / 4096.0
+        acc = mfma_h(halves[s, 0], hi[s], acc)
+        acc = mfma_h(halves[s, 0], lo[s], acc)
+        acc = mfma_h(halves[s, 1], hi[s], acc)
+    return acc
 
 
 def conditioner_from_record_h(rec32, y, K):

@@ -83,13 +83,15 @@ def test_inv4(hm):
     assert np.abs(np.einsum("nij,njk->nik", o.astype(np.float64), m64) - np.eye(4))[ok].max() < 5e-5
 
 
-def test_affine16_matches_oracle(hm):
+@pytest.mark.parametrize("entry", ["hm_affine16", "hm_affine16_table"])
+def test_affine16_matches_oracle(hm, entry):
+    """calculate_16 with a constant M: the quaternion form (conditional layers) and the packer's 10x10 table form (unconditional layers)."""
     rng = np.random.default_rng(2)
     M = f32(np.eye(4) + 0.25 * rng.standard_normal((4, 4)))
     R = synth.uniform_rotations(4096, seed=8)
     Ro, ldj = np.empty_like(R), np.empty(4096, np.float32)
     lad = float(np.log(abs(np.linalg.det(M.astype(np.float64)))))
-    hm.hm_affine16(ptr(M), C.c_float(lad), ptr(R), ptr(Ro), ptr(ldj), 4096)
+    getattr(hm, entry)(ptr(M), C.c_float(lad), ptr(R), ptr(Ro), ptr(ldj), 4096)
     wR, wl = orc.affine16(torch.from_numpy(M).double()[None], torch.from_numpy(R).double())
     assert np.abs(Ro - wR.numpy()).max() < 2e-6
     assert np.abs(ldj - wl.numpy()).max() < 2e-6

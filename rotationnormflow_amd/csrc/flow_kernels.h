@@ -42,7 +42,8 @@ struct FlowArgs {
     long long states_n;       // rotations in the whole call (chunks write at sample_base)
     int n_layers;
     int KT;                   // fc_last tiles = segments / 8
-    // per layer: x = kind | perm_row << 4 | (cond_slot + 1) << 8 ; y = param offset (floats)
+    int tab_off;              // >= 0 (DMA staging): float offset in LDS of two AFF_TABLE_LDS_STRIDE-float buffers for constant-affine blocks
+    // per layer: x = kind | perm_row << 4 | (cond_slot + 1) << 8 | (position of the next MLP layer + 1) << 16 ; y = param offset (floats)
     int2 layers[MAX_LAYERS];
 };
 
@@ -356,9 +357,11 @@ __device__ __forceinline__ void mobius_begin(const Rot &R, int perm_row, MobiusC
     }
 }
 
+// HALF (split-precision kernels): A accumulates sp * atan(t), mobius_fwd_finish<true> adds the constant part (so3_math.h)
+template <bool HALF>
 __device__ __forceinline__ void segments4(const f32x16 &o, const MobiusCtx &c, float &S, float &A, float &J) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) segment_fwd_pi(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, S, A, J);
+    for (int g = 0; g < 4; ++g) segment_fwd_pi<HALF>(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, S, A, J);
 }
 
 // forward, all fc_last tiles resident (K <= 64): software pipelined BY HAND.  Tile tau+1's 32 dependent MFMAs (64
@@ -436,9 +439,9 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int l
         }
         if (tau < KT) {
             tile_pipe(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt.t, bufB, bufA, c, S, A, J);
-            segments4(bufB, c, S, A, J);
+            segments4<false>(bufB, c, S, A, J);
         } else {
-            segments4(bufA, c, S, A, J);
+            segments4<false>(bufA, c, S, A, J);
         }
     } else {
         // software pipeline BY HAND: each of tile tau+1's 12 matrix instructions is issued in front of one ~15-instruction slice of
@@ -450,7 +453,7 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int l
             cur = nxt;
             fair.tick();
         }
-        segments4(cur, c, S, A, J);
+        segments4<true>(cur, c, S, A, J);
     }
 }
 
@@ -468,17 +471,20 @@ __device__ __forceinline__ void mobius_fwd_tiles_restage(float *lds, const float
             __syncthreads();
         }
         f32x16 o = Mlp<PREC>::last(lds + MOB_LAST + (tau % MOB_MAX_TILES_IN_LDS) * MOB_LAST_TILE_FLOATS, lane, h, tt);
-        segments4(o, c, S, A, J);
+        segments4<PREC == 1>(o, c, S, A, J);
     }
 }
 
+template <bool HALF>
 __device__ __forceinline__ void mobius_fwd_finish(const MobiusCtx &c, float S, float A, float J, Rot &R, float &ldj) {
     S = pair_sum(S);
     A = pair_sum(A);
     J = pair_sum(J);
     const float invS = hw_rcp(S);
     float sn, cs;
-    sincos_small(A * invS, sn, cs);
+    // HALF: theta' = pi + 2 A / S, and sin / cos of pi + d are -sin d, -cos d
+    sincos_small(HALF ? 2.0f * A * invS : A * invS, sn, cs);
+    if (HALF) { sn = -sn; cs = -cs; }
     const v3f tx = c.f.v * sn + c.f.r * cs;
     const v3f tz = normalize3(c.cyc ? cross3(tx, c.y) : cross3(c.y, tx));               // mobiusflow.py:75-79
     set_col(R, c.p0, tx);
@@ -720,12 +726,26 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     };
     auto l_floats = [&](int kind) { return kind_last_tiles(kind, KT) * MOB_LAST_TILE_FLOATS; };
     const int first_mlp = next_mlp(-1);
+    // DMA staging: the block of the constant-affine layer right behind the MLP layer at position q rides with that layer's fc_last
+    // image into LDS buffer `parity` (two buffers: a slow wave may still read the previous block while the next one lands)
+    auto stage_table = [&](int q, int parity) {
+        if (args.tab_off < 0 || q < 0 || q + 1 >= n_layers) return;
+        const int2 da = args.layers[layer_at(q + 1)];
+        if ((da.x & 15) != RNF_KIND_AFFINE16 || wave != 0 || lane >= AFF_TABLE_FLOATS / 4) return;
+        const float *t = args.blob + da.y + (DIR ? AFF_TABLE_INV : AFF_TABLE_FWD) + 4 * lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)t,
+                                         (__attribute__((address_space(3))) void *)(lds + args.tab_off + AFF_TABLE_LDS_STRIDE * parity), 16, 0, 0);
+    };
+    auto has_table = [&](int q) { return args.tab_off >= 0 && q + 1 < n_layers && (args.layers[layer_at(q + 1)].x & 15) == RNF_KIND_AFFINE16; };
+    int seq = 0;                                                      // MLP layers this wave has been through (across tiles)
+    int tab_parity = -1;                                              // >= 0: the next affine layer's block sits in LDS buffer tab_parity
 
     if (args.fair_off >= 0 && tid < NW) reinterpret_cast<int *>(lds + args.fair_off)[tid] = 0;
     if (PIPE && first_mlp >= 0) {                                  // prologue: image of the first MLP layer
         const int2 d = args.layers[layer_at(first_mlp)];
         dma_floats(lds, args.blob + d.y, MOB_HEAD_FLOATS, wave, lane, NW);
         dma_floats(lds + MOB_LAST, args.blob + d.y + MOB_LAST, l_floats(d.x & 15), wave, lane, NW);
+        stage_table(first_mlp, 0);
         dma_wait_all();
         __syncthreads();
     }
@@ -749,7 +769,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
 
         for (int pos = 0; pos < n_layers; ++pos) {
             const int2 d = args.layers[layer_at(pos)];
-            const int kind = d.x & 15, perm_row = (d.x >> 4) & 15, slot = (d.x >> 8) - 1;
+            const int kind = d.x & 15, perm_row = (d.x >> 4) & 15, slot = ((d.x >> 8) & 255) - 1;
             const float *params = args.blob + d.y;
             if (DIR == 0 && args.states && valid && h == 0) {       // saved for train_kernels.h (backward recomputes from here)
                 float *dst = args.states + ((size_t)pos * args.states_n + args.sample_base + sample) * 9;
@@ -759,7 +779,12 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             }
 
             if (kind == RNF_KIND_AFFINE16) {
-                affine16_table_apply(params + (DIR ? AFF_TABLE_INV : AFF_TABLE_FWD), params[DIR ? 33 : 16], R, ldj, params[34] != 0.f);
+                if (PIPE && tab_parity >= 0) {                    // block staged in LDS together with the previous layer's fc_last image
+                    affine16_table_apply(lds + args.tab_off + AFF_TABLE_LDS_STRIDE * tab_parity, R, ldj);
+                    tab_parity = -1;
+                } else {                                          // scalar loads (one ~2 us round trip per layer: 104 floats do not fit the SGPRs at once)
+                    affine16_table_apply(params + (DIR ? AFF_TABLE_INV : AFF_TABLE_FWD), R, ldj);
+                }
                 RNF_STAMP(6)                                      // 6: unconditional affine layer
                 continue;
             }
@@ -784,10 +809,11 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 }
             }
             // where the NEXT image comes from (DMA mode): next MLP layer of this tile, else the first one of the next tile
-            int nxt_off = -1, nxt_kind = 0;
+            int nxt_off = -1, nxt_kind = 0, nxt_q = -1;
             if (PIPE) {
-                int q = next_mlp(pos);
+                int q = ((d.x >> 16) & 1023) - 1;                  // next layer with an MLP image (host-filled, rnf_api.hip run_flow)
                 if (q < 0 && more_tiles) q = first_mlp;
+                nxt_q = q;
                 if (q >= 0) { const int2 dn = args.layers[layer_at(q)]; nxt_off = dn.y; nxt_kind = dn.x & 15; }
             } else {
                 __syncthreads();                                   // everyone is done with the previous image
@@ -820,6 +846,9 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     dma_wait_all();
                     __syncthreads();
                     if (nxt_off >= 0) dma_floats(lds + MOB_LAST, args.blob + nxt_off + MOB_LAST, l_floats(nxt_kind), wave, lane, NW);
+                    tab_parity = has_table(pos) ? (seq & 1) : -1;
+                    ++seq;
+                    stage_table(nxt_q, seq & 1);
                 }
                 RNF_STAMP(4)                                      // 4: barrier B2 (+ DMA issue)
             };
@@ -835,7 +864,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC>(lds, KT, lane, h, tt, ctx, S, A, J, fair);
                     else mobius_fwd_tiles_restage<PREC>(lds, params, KT, lane, h, tt, ctx, S, A, J, tid, NT);
                     barrier2();
-                    mobius_fwd_finish(ctx, S, A, J, R, ldj);
+                    mobius_fwd_finish<PREC == 1>(ctx, S, A, J, R, ldj);
                 }
             } else {
                 const f32x16 o16 = Mlp<PREC>::last(lds + MOB_LAST, lane, h, tt);

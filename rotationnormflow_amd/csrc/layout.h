@@ -60,9 +60,11 @@ inline constexpr int64_t mobius_packed_floats(int K) { return MOB_HEAD_FLOATS + 
 
 // ---- unconditional 4x4 affine record ----
 // [0..15] M row-major, [16] log|det M|, [17..32] M^-1, [33] log|det M^-1|, [34] 1.0 if M is orthogonal (log-det exactly 0), [35] 0,
-// [36..135] the 10x10 table of M (so3_math.h affine16_table), [136..235] the table of M^-1, [236..239] 0
-constexpr int AFF_TABLE_FWD = 36, AFF_TABLE_INV = 136;
-constexpr int AFF_FLOATS = 240;
+// [36..139] forward block: the 10x10 table of M (so3_math.h affine16_table), log|det M|, the orthogonal flag, 0, 0;
+// [140..243] the same block for M^-1 (the inverse pass).  The forward kernel stages one block in LDS next to the layer images.
+constexpr int AFF_TABLE_FWD = 36, AFF_TABLE_INV = 140, AFF_TABLE_FLOATS = 104;
+constexpr int AFF_FLOATS = 244;
+constexpr int AFF_TABLE_LDS_STRIDE = 112;                 // floats between the two blocks staged in LDS (AFF_TABLE_FLOATS rounded up)
 
 // ---- 3x3 / 6x6 Gram-Schmidt layers (Uncondition9Trans, Uncondition36Trans): [M row-major | M^-1 row-major] ----
 constexpr int GS9_FLOATS = 20;                            // 9 + 9, padded to a multiple of 4

@@ -126,9 +126,8 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
             double m[16], mt[16];
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 4; ++j) { m[4 * i + j] = P[4 * i + j]; mt[4 * i + j] = P[4 * j + i]; }
-            affine16_table(m, out + AFF_TABLE_FWD);
-            affine16_table(mt, out + AFF_TABLE_INV);
-            for (int i = AFF_TABLE_INV + 100; i < AFF_FLOATS; ++i) out[i] = 0.f;
+            affine16_table(m, 0.f, true, out + AFF_TABLE_FWD);
+            affine16_table(mt, 0.f, true, out + AFF_TABLE_INV);
             return;
         }
         double m[16], inv[16], det = 0.0;
@@ -141,9 +140,8 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
         out[16] = (float)log(fabs(det));
         out[33] = (float)(-log(fabs(det)));
         out[34] = out[35] = 0.f;
-        affine16_table(m, out + AFF_TABLE_FWD);
-        affine16_table(inv, out + AFF_TABLE_INV);
-        for (int i = AFF_TABLE_INV + 100; i < AFF_FLOATS; ++i) out[i] = 0.f;
+        affine16_table(m, out[16], false, out + AFF_TABLE_FWD);
+        affine16_table(inv, out[33], false, out + AFF_TABLE_INV);
         return;
     }
     if (kind == RNF_KIND_GS9) {                                        // rnf_pack_gs(n = 3): [M | M^-1], cofactor inverse in double

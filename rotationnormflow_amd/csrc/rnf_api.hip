@@ -269,9 +269,8 @@ extern "C" int rnf_pack_affine16(const float *mat16, float *out) {
     out[16] = (float)std::log(std::fabs(det));
     out[33] = (float)(-std::log(std::fabs(det)));
     out[34] = out[35] = 0.f;
-    affine16_table(m, out + AFF_TABLE_FWD);
-    affine16_table(inv, out + AFF_TABLE_INV);
-    for (int i = AFF_TABLE_INV + 100; i < AFF_FLOATS; ++i) out[i] = 0.f;
+    affine16_table(m, out[16], false, out + AFF_TABLE_FWD);
+    affine16_table(inv, out[33], false, out + AFF_TABLE_INV);
     return 0;
 }
 
@@ -328,9 +327,8 @@ extern "C" int rnf_pack_rot16(const float *mat16, float *out) {
     double m[16], mt[16];
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) { m[4 * i + j] = mat16[4 * i + j]; mt[4 * i + j] = mat16[4 * j + i]; }
-    affine16_table(m, out + AFF_TABLE_FWD);
-    affine16_table(mt, out + AFF_TABLE_INV);
-    for (int i = AFF_TABLE_INV + 100; i < AFF_FLOATS; ++i) out[i] = 0.f;
+    affine16_table(m, 0.f, true, out + AFF_TABLE_FWD);
+    affine16_table(mt, 0.f, true, out + AFF_TABLE_INV);
     return 0;
 }
 
@@ -473,6 +471,15 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         a.layers[l] = make_int2(kind | (perm << 4) | ((slot + 1) << 8), d[D_PARAM]);
     }
     if (prec < 0) prec = 0;
+    {   // bits 16..25 of x: iteration position + 1 of the next layer with an MLP image behind this one (0 = none), in the order the
+        // pass walks the layers -- saves the kernel a dependent chain of scalar loads per layer
+        int nxt = 0;
+        for (int pos = n_layers - 1; pos >= 0; --pos) {
+            const int l = o.dir ? n_layers - 1 - pos : pos;
+            a.layers[l].x |= nxt << 16;
+            if (kind_has_mlp(a.layers[l].x & 15)) nxt = pos + 1;
+        }
+    }
     if (n_slots > 0) {
         if (!feat) return fail("this flow consumes a feature vector but feature pointer is null (flow/mobiusflow.py:48-49)");
         if (F <= 0 || F % 8) return fail("feature_dim=%d must be a positive multiple of 8 (pad on the host)", F);
@@ -532,6 +539,12 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     //  the bisection anyway, so it keeps the synchronous staging)
     // (flows with a conditional 3x3 layer run the extended instantiation, which is only built with the synchronous staging)
     const bool pipe = staging_dma() && KT <= MOB_MAX_TILES_IN_LDS && !(o.dir == 1 && KT == 8) && !ext;
+    a.tab_off = -1;
+    if (pipe && any_mlp) {                                     // two LDS buffers for the blocks of constant-affine layers (flow_kernels.h stage_table)
+        lds_bytes = (lds_bytes + 15) / 16 * 16;
+        a.tab_off = (int)(lds_bytes / sizeof(float));
+        lds_bytes += sizeof(float) * 2 * AFF_TABLE_LDS_STRIDE;
+    }
     const int fair_off = a.fair_off;
     bool first = true;
     for (long long base = 0; base < n; base += chunk_cap) {

@@ -247,6 +247,8 @@ RNF_HD void segment_full(float s_raw, float w0, float w1, float w2, const Frame 
 // a = -ur, b = -uv and phi = pi + 2 atan(uv / (1 + ur)).  softplus without the argument-splitting / log1p-residue terms of
 // softplus(): their contribution is below 1e-8 absolute on a term that is then divided by the sum of K such terms.
 // 44 VALU instructions (6 transcendental) instead of 57; used by the split-precision forward kernel, which is VALU-issue bound.
+// HALF: A accumulates sp * atan(t) only -- the caller adds the constant part once per layer (sum sp * phi = pi * S + 2 * that).
+template <bool HALF = false>
 RNF_HD void segment_fwd_pi(float s_raw, float w0, float w1, float w2, const Frame &f, float &S, float &A, float &J) {
     const float wr = fmaf(w2, f.r.z, fmaf(w1, f.r.y, w0 * f.r.x));
     const float wv = fmaf(w2, f.v.z, fmaf(w1, f.v.y, w0 * f.v.x));
@@ -255,7 +257,8 @@ RNF_HD void segment_fwd_pi(float s_raw, float w0, float w1, float w2, const Fram
     const float e1 = 1.0f + ur;
     const float t = uv * hw_rcp(e1);
     const float c = (1.0f - fmaf(uv, uv, ur * ur)) * hw_rcp(fmaf(uv, uv, e1 * e1));
-    const float phi = fmaf(2.0f, atan_unit(t), kPi);
+    const float at = atan_unit(t);
+    const float phi = HALF ? at : fmaf(2.0f, at, kPi);
     const float e = hw_exp2(-1.44269504088896341f * fabsf(s_raw));
     const float sp = fmaf(hw_log2(1.0f + e), 0.693147180559945309f, fmaxf(s_raw, 0.0f));
     S += sp;
@@ -263,7 +266,7 @@ RNF_HD void segment_fwd_pi(float s_raw, float w0, float w1, float w2, const Fram
     J = fmaf(sp, c, J);
 }
 
-// segment_fwd_pi cut into three slices of ~15 VALU instructions: the split-precision forward kernel issues ONE matrix instruction of
+// segment_fwd_pi<true> cut into three slices of ~15 VALU instructions: the split-precision forward kernel issues ONE matrix instruction of
 // the next fc_last tile in front of every slice (flow_kernels.h tile_pipe_h), so that a wave never queues matrix instructions back to
 // back -- a matrix instruction waiting for the matrix pipe holds the SIMD's VALU issue port and stalls the other waves' segment math
 // (profiles/r1/mfma_f16_valu_overlap_microbench.txt).
@@ -292,11 +295,10 @@ RNF_HD void seg_pi_stage(SegPi &g, float s_raw, float w0, float w1, float w2, co
         p = fmaf(p, g.z, 1.998590677e-01f);
         p = fmaf(p, g.z, -3.333259703e-01f);
         p = fmaf(p, g.z, 9.999998864e-01f);
-        const float phi = fmaf(2.0f, p * g.t, kPi);
         const float e = hw_exp2(-1.44269504088896341f * fabsf(s_raw));
         const float sp = fmaf(hw_log2(1.0f + e), 0.693147180559945309f, fmaxf(s_raw, 0.0f));
         S += sp;
-        A = fmaf(sp, phi, A);
+        A = fmaf(sp, p * g.t, A);                  // HALF convention: sp * atan(t)
         J = fmaf(sp, g.c, J);
     }
 }
@@ -356,8 +358,11 @@ RNF_HD void affine16_apply(const float (&M)[16], float logabsdet, Rot &R, float 
 //     [ |q'|^2 ; |q'|^2 R' (row-major) ] = T . [ 1 ; R (row-major) ]       with one 10x10 table T(M) built by the packer (in double),
 // 90 fma + 1 rcp + 9 mul + log instead of the 4-candidate square-root selection, matrix-vector product and re-expansion (~330 VALU).
 // Same result as affine16_apply up to fp32 rounding (the quaternion's sign and the candidate choice never mattered).
-RNF_HD void affine16_table(const double *M /* 4x4 row-major */, float *T /* [10][10] */) {
+RNF_HD void affine16_table(const double *M /* 4x4 row-major */, float logabsdet, bool orthogonal, float *T /* AFF_TABLE_FLOATS */) {
 #pragma clang fp contract(off)
+    T[100] = logabsdet;
+    T[101] = orthogonal ? 1.0f : 0.0f;
+    T[102] = T[103] = 0.0f;
     for (int k = 0; k < 10; ++k) {
         double in[10];
         for (int i = 0; i < 10; ++i) in[i] = (i == k) ? 1.0 : 0.0;
@@ -402,7 +407,7 @@ RNF_HD void affine16_table(const double *M /* 4x4 row-major */, float *T /* [10]
     }
 }
 
-RNF_HD void affine16_table_apply(const float *T, float logabsdet, Rot &R, float &ldj, bool orthogonal) {
+RNF_HD void affine16_table_apply(const float *T, Rot &R, float &ldj) {
     const float r[9] = {R.c0.x, R.c1.x, R.c2.x, R.c0.y, R.c1.y, R.c2.y, R.c0.z, R.c1.z, R.c2.z};
     float o[10];
 #pragma unroll
@@ -416,7 +421,7 @@ RNF_HD void affine16_table_apply(const float *T, float logabsdet, Rot &R, float 
     R.c0.x = o[1] * inv; R.c1.x = o[2] * inv; R.c2.x = o[3] * inv;
     R.c0.y = o[4] * inv; R.c1.y = o[5] * inv; R.c2.y = o[6] * inv;
     R.c0.z = o[7] * inv; R.c1.z = o[8] * inv; R.c2.z = o[9] * inv;
-    if (!orthogonal) ldj += fmaf(-2.0f * 0.693147180559945309f, hw_log2(o[0]), logabsdet);
+    if (T[101] == 0.0f) ldj += fmaf(-2.0f * 0.693147180559945309f, hw_log2(o[0]), T[100]);
 }
 
 // ---- 3x3 / 6x6 ablation layers: Gram-Schmidt of two transformed columns, log-det from three tangent directions ----------------

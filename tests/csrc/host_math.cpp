@@ -35,14 +35,14 @@ void hm_affine16(const float *M, float logabsdet, const float *Rin, float *Rout,
 void hm_affine16_table(const float *M, float logabsdet, const float *Rin, float *Rout, float *ldj, int n) {
     double m[16];
     for (int k = 0; k < 16; ++k) m[k] = M[k];
-    float T[100];
-    affine16_table(m, T);
+    float T[AFF_TABLE_FLOATS];
+    affine16_table(m, logabsdet, false, T);
     for (int i = 0; i < n; ++i) {
         const float *s = Rin + 9 * i;
         Rot R;
         R.c0 = v3f{s[0], s[3], s[6]}; R.c1 = v3f{s[1], s[4], s[7]}; R.c2 = v3f{s[2], s[5], s[8]};
         float l = 0.f;
-        affine16_table_apply(T, logabsdet, R, l, false);
+        affine16_table_apply(T, R, l);
         float *d = Rout + 9 * i;
         d[0] = R.c0.x; d[1] = R.c1.x; d[2] = R.c2.x; d[3] = R.c0.y; d[4] = R.c1.y; d[5] = R.c2.y; d[6] = R.c0.z; d[7] = R.c1.z; d[8] = R.c2.z;
         ldj[i] = l;

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
 def test_packed_sizes_match_parameter_counts():
     L = _lib.lib()
     assert L.rnf_mobius_packed_floats(64) == 29376           # == parameter count of an unconditional Moebius layer
-    assert L.rnf_affine16_packed_floats() == 240
+    assert L.rnf_affine16_packed_floats() == 244
     assert L.rnf_featproj_packed_floats(256) == 64 * 256 + 64
     assert L.rnf_featproj_packed_floats(40) == 2 * 3 * 512 + 64          # k-steps of 16, zero padded (f16x2 image)
     assert L.rnf_workspace_bytes(1 << 20, 0) == 4096 * 8

@@ -95,7 +95,7 @@ def test_affine16_record():
     rng = np.random.default_rng(0)
     M = (np.eye(4) + 0.3 * rng.standard_normal((4, 4))).astype(np.float32)
     rec = runtime.pack_affine16(_lib.lib(), torch.from_numpy(M)[None])
-    assert rec.size == 240
+    assert rec.size == 244
     assert np.array_equal(rec[:16], M.ravel())
     assert abs(rec[16] - np.log(abs(np.linalg.det(M.astype(np.float64))))) < 1e-6
     assert np.abs(rec[17:33].reshape(4, 4) - np.linalg.inv(M.astype(np.float64))).max() < 1e-6
@@ -103,14 +103,14 @@ def test_affine16_record():
     # the 10x10 tables: [|q'|^2 ; |q'|^2 R'] = T [1 ; R] for q' = M q(R), checked against the quaternion formulas in fp64
     from oracle import flow_oracle as orc
     R = synth.uniform_rotations(64, seed=4).astype(np.float64)
-    for off, mat in ((36, M.astype(np.float64)), (136, np.linalg.inv(M.astype(np.float64)))):
+    for off, mat in ((36, M.astype(np.float64)), (140, np.linalg.inv(M.astype(np.float64)))):
         T = rec[off:off + 100].reshape(10, 10).astype(np.float64)
         out = np.concatenate([np.ones((64, 1)), R.reshape(64, 9)], axis=1) @ T.T
         q = orc.matrix_to_quaternion(torch.from_numpy(R)).numpy() @ mat.T
         want = orc.quaternion_to_matrix(torch.from_numpy(q)).numpy()
         assert np.abs(out[:, 0] - (q * q).sum(1)).max() < 1e-6
         assert np.abs(out[:, 1:] / out[:, :1] - want.reshape(64, 9)).max() < 1e-6
-    assert np.abs(rec[236:]).max() == 0.0
+        assert rec[off + 100] == rec[16 if off == 36 else 33] and np.abs(rec[off + 101:off + 104]).max() == 0.0
 
 
 @pytest.mark.parametrize("K", [8, 64])

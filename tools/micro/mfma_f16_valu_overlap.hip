@@ -10,10 +10,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
-// ROLE bit 0: the MFMA waves work; bit 1: the VALU waves work
+// ROLE bit 0: the MFMA waves work; bit 1: the VALU waves work; bit 2: VALU waves at s_setprio 3, MFMA waves at 0;
+// bit 3: an s_nop 7 + s_nop 7 pad behind every MFMA; bit 4: the VALU waves are the OLDER ones (waves 0-3)
 template <int ROLE>
 __global__ void specialised(float *out, unsigned long long *cyc, int iters, float c1, float c2) {
-    const int wave = threadIdx.x >> 6;
+    const int wave = (ROLE & 16) ? 7 - (int)(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
     f32x16 acc[4];
     for (int q = 0; q < 4; ++q)
         for (int r = 0; r < 16; ++r) acc[q][r] = threadIdx.x * 0.001f + r + q;
@@ -24,14 +25,19 @@ __global__ void specialised(float *out, unsigned long long *cyc, int iters, floa
     __syncthreads();
     unsigned long long t0 = clock64();
     if (wave < 4) {
+        if (ROLE & 4) __builtin_amdgcn_s_setprio(0);
         if (ROLE & 1)
             for (int it = 0; it < iters; ++it) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = MFMA_H(a, b, acc[q]);      // 16 MFMAs, 4 independent chains
+                    for (int q = 0; q < 4; ++q) {
+                        acc[q] = MFMA_H(a, b, acc[q]);      // 16 MFMAs, 4 independent chains
+                        if (ROLE & 8) { asm volatile("s_nop 7\n\ts_nop 7"); __builtin_amdgcn_sched_barrier(0); }
+                    }
             }
     } else {
+        if (ROLE & 4) __builtin_amdgcn_s_setprio(3);
         if (ROLE & 2)
             for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -118,7 +124,13 @@ int main() {
     run_spec<1>("specialised, only the MFMA waves work");
     run_spec<2>("specialised, only the VALU waves work");
     run_spec<3>("specialised, both work (overlap => max, no overlap => sum)");
-    for (int t = 256; t <= 1024; t *= 2) {
+    run_spec<3 + 4>("both work, VALU waves prio 3 / MFMA waves prio 0");
+    run_spec<3 + 8>("both work, s_nop pads behind every MFMA");
+    run_spec<1 + 8>("only MFMA waves, s_nop pads");
+    run_spec<3 + 4 + 8>("both work, prio + pads");
+    run_spec<3 + 16>("both work, VALU waves are the older ones");
+    run_spec<3 + 16 + 8>("both work, VALU waves older + pads");
+    for (int t = 1024; t <= 1024; t *= 2) {
         run_same<4, 0>(t);
         run_same<0, 32>(t);
         run_same<4, 16>(t);

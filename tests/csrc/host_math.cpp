@@ -35,7 +35,7 @@ void hm_affine16(const float *M, float logabsdet, const float *Rin, float *Rout,
 void hm_affine16_table(const float *M, float logabsdet, const float *Rin, float *Rout, float *ldj, int n) {
     double m[16];
     for (int k = 0; k < 16; ++k) m[k] = M[k];
-    float T[AFF_TABLE_FLOATS];
+    float T[104];                                 // AFF_TABLE_FLOATS (layout.h)
     affine16_table(m, logabsdet, false, T);
     for (int i = 0; i < n; ++i) {
         const float *s = Rin + 9 * i;

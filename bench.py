@@ -80,6 +80,18 @@ def cpu_baseline(cfg, weights, A, budget_s=12.0):
                        f"{threads} threads, one pass of {dt:.1f} s")
 
 
+def pmc_traffic(precision, n):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this workload (FETCH_SIZE and WRITE_SIZE
+    are collected in their own runs, tools/profile_round.sh; gfx950 correction applied by tools/pmc_summary.py).  None when the run is
+    not the profiled configuration."""
+    path = os.path.join(ROOT, "profiles", "r1", f"pmc_flow_stack_kernel_{precision}_end.json")
+    if n != 1 << 20 or not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
+        d = json.load(fh)
+    return d.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,20 +168,24 @@ def main():
         value = total_rot / elapsed
         achieved_tflops = FLOP_PER_ROTATION * n / (kernel_ms * 1e-3) / 1e12
         precision = get_precision()
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+        nw = 16 if (precision == "f16x2" and n > cus * 256 and os.environ.get("RNF_WIDE") != "0") else 8
+        traffic, traffic_src = pmc_traffic(precision, n)
         if precision == "f16x2":
             # the conditioner GEMMs run on the fp16 matrix cores (3 fp16 MFMAs with fp32 accumulate per fp32 product-sum),
             # so the MFMA roofline of this kernel is the dense fp16 peak; `achieved` stays the ALGORITHMIC fp32 FLOP rate
             # (executed matrix FLOPs are 3x that).  The kernel is VALU-issue bound (segment math), see DESIGN.md section 3.
             roofline = {"bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved_tflops / PEAK_F16_MFMA_TFLOPS, "traffic": None,
-                        "kernel": "rnf::flow_stack_kernel<0,0,8,true,1>", "kernel_ms": kernel_ms,
+                        "frac": achieved_tflops / PEAK_F16_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                        "kernel": f"rnf::flow_stack_kernel<0,0,{nw},true,1>", "kernel_ms": kernel_ms,
                         "algorithmic_flop_per_rotation": FLOP_PER_ROTATION, "executed_mfma_tflops": 3 * achieved_tflops,
                         "frac_of_fp32_mfma_peak": achieved_tflops / PEAK_FP32_MFMA_TFLOPS,
-                        "note": "fp32 operands split into two fp16 terms (22 bits), fp16 MFMA + fp32 accumulate; binding "
-                                "limit is VALU issue of the per-segment trig/softplus math, not MFMA and not HBM"}
+                        "note": "fp32 operands split into two fp16 terms (hi + unscaled lo, 2^-24 absolute floor), three fp16 MFMAs into "
+                                "one fp32 accumulator; binding limit is VALU issue of the per-segment trig/softplus math, not MFMA "
+                                "and not HBM"}
         else:
             roofline = {"bound": "mfma", "achieved": achieved_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                        "frac": achieved_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                         "kernel": "rnf::flow_stack_kernel<0,0,8,true,0>", "kernel_ms": kernel_ms,
                         "algorithmic_flop_per_rotation": FLOP_PER_ROTATION,
                         "note": "exact fp32-input MFMA; shares the FMA datapath with the VALU segment math on gfx950"}

@@ -399,16 +399,16 @@ __device__ __forceinline__ void tile_pipe(const float *rec, int lane, int h, con
 // (k-step m / 3; term hi.hi, hi.lo, lo.hi) and slice st of segment g of the finished tile.  Left to itself the compiler emits the
 // 12 matrix instructions back to back; while they queue for the matrix pipe they hold the VALU issue port of the SIMD.
 template <int M>
-__device__ __forceinline__ void tile_step_h(const float *rec, int lane, f32x16 &nxt, h8 (&ah)[2], h8 (&al)[2], const ActFrag &in,
+__device__ __forceinline__ void tile_step_h(const float *rec, int lane, f32x16 &nxt, h8 &ah, h8 &al, const ActFrag &in,
                                             const f32x16 &cur, SegPi (&seg)[4], const MobiusCtx &c, float &S, float &A, float &J) {
-    constexpr int ks = M / 3, term = M % 3, b = ks & 1;
-    if constexpr (term == 0 && ks + 1 < 4) {          // operands of the next k-step: in flight during this one (two 4-register pairs)
-        ah[b ^ 1] = lds_h8(rec, ((ks + 1) * 2 + 0) * 64 + lane);
-        al[b ^ 1] = lds_h8(rec, ((ks + 1) * 2 + 1) * 64 + lane);
+    constexpr int ks = M / 3, term = M % 3;
+    if constexpr (term == 0) nxt = RNF_MFMA_H(ah, in.hi[ks], nxt);
+    else if constexpr (term == 1) nxt = RNF_MFMA_H(ah, in.lo[ks], nxt);
+    else nxt = RNF_MFMA_H(al, in.hi[ks], nxt);
+    if constexpr (term == 2 && ks + 1 < 4) {          // operands of the next k-step: the matrix instruction has read its registers at
+        ah = lds_h8(rec, ((ks + 1) * 2 + 0) * 64 + lane);     // issue, the slice below and the other waves cover the LDS latency
+        al = lds_h8(rec, ((ks + 1) * 2 + 1) * 64 + lane);
     }
-    if constexpr (term == 0) nxt = RNF_MFMA_H(ah[b], in.hi[ks], nxt);
-    else if constexpr (term == 1) nxt = RNF_MFMA_H(ah[b], in.lo[ks], nxt);
-    else nxt = RNF_MFMA_H(al[b], in.hi[ks], nxt);
     constexpr int g = M / 3, st = M % 3;
     seg_pi_stage<st>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, S, A, J);
     __builtin_amdgcn_sched_barrier(0);
@@ -418,9 +418,8 @@ __device__ __forceinline__ void tile_step_h(const float *rec, int lane, f32x16 &
 __device__ __forceinline__ void tile_pipe_h(const float *rec, int lane, int h, const ActFrag &tt, f32x16 &nxt, const f32x16 &cur,
                                             const MobiusCtx &c, float &S, float &A, float &J) {
     nxt = load_bias16(rec + MOB_LAST_TILE_BIAS + h * 16);
-    h8 ah[2], al[2];
-    ah[0] = lds_h8(rec, 0 * 64 + lane);
-    al[0] = lds_h8(rec, 1 * 64 + lane);
+    h8 ah = lds_h8(rec, 0 * 64 + lane);
+    h8 al = lds_h8(rec, 1 * 64 + lane);
     SegPi seg[4];
     __builtin_amdgcn_sched_barrier(0);
     tile_step_h<0>(rec, lane, nxt, ah, al, tt, cur, seg, c, S, A, J);
@@ -713,7 +712,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     const long long ntiles = (args.n + TILE - 1) / TILE;
     const int KT = DIR ? KT_INV : args.KT;
     const int n_layers = args.n_layers;
-    double dsum = 0.0;
+    double dsum = 0.0;                                               // wave-uniform running sum of log p (kept in scalar registers)
     Fair fair{lds, wave, args.fair_off, 0};
     RNF_STAMP_DECL
 
@@ -732,7 +731,9 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
         if (args.tab_off < 0 || q < 0 || q + 1 >= n_layers) return;
         const int2 da = args.layers[layer_at(q + 1)];
         if ((da.x & 15) != RNF_KIND_AFFINE16 || wave != 0 || lane >= AFF_TABLE_FLOATS / 4) return;
-        const float *t = args.blob + da.y + (DIR ? AFF_TABLE_INV : AFF_TABLE_FWD) + 4 * lane;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                                  // keeps the per-lane address out of the long-lived registers
+        const float *t = args.blob + da.y + (DIR ? AFF_TABLE_INV : AFF_TABLE_FWD) + 4 * ln;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)t,
                                          (__attribute__((address_space(3))) void *)(lds + args.tab_off + AFF_TABLE_LDS_STRIDE * parity), 16, 0, 0);
     };
@@ -752,14 +753,21 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
 
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long group = tile * NW + wave;                 // 32-sample group index inside this launch
-        const long long sample = group * TILE_SAMPLES + j;
-        const bool valid = sample < args.n;
+        const long long sample0 = group * TILE_SAMPLES;           // wave uniform
+        const bool valid = sample0 + j < args.n;
+        // this lane's sample index, re-derived where it is used: a 64-bit index (and the addresses the compiler pre-computes from it)
+        // kept live across the layer stack costs register pairs that end up in scratch in the 128-register instantiation
+        auto sample_now = [&]() {
+            int jj = j;
+            asm volatile("" : "+v"(jj));
+            return sample0 + jj;
+        };
         const bool more_tiles = tile + gridDim.x < ntiles;
 
         Rot R;
         R.c0 = v3f{1.f, 0.f, 0.f}; R.c1 = v3f{0.f, 1.f, 0.f}; R.c2 = v3f{0.f, 0.f, 1.f};
         if (valid) {
-            const float *src = args.rot_in + sample * 9;      // row-major [3][3]
+            const float *src = args.rot_in + (sample0 + j) * 9;      // row-major [3][3]
             R.c0 = v3f{src[0], src[3], src[6]};
             R.c1 = v3f{src[1], src[4], src[7]};
             R.c2 = v3f{src[2], src[5], src[8]};
@@ -772,7 +780,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             const int kind = d.x & 15, perm_row = (d.x >> 4) & 15, slot = ((d.x >> 8) & 255) - 1;
             const float *params = args.blob + d.y;
             if (DIR == 0 && args.states && valid && h == 0) {       // saved for train_kernels.h (backward recomputes from here)
-                float *dst = args.states + ((size_t)pos * args.states_n + args.sample_base + sample) * 9;
+                float *dst = args.states + ((size_t)pos * args.states_n + args.sample_base + sample_now()) * 9;
                 dst[0] = R.c0.x; dst[1] = R.c1.x; dst[2] = R.c2.x;
                 dst[3] = R.c0.y; dst[4] = R.c1.y; dst[5] = R.c2.y;
                 dst[6] = R.c0.z; dst[7] = R.c1.z; dst[8] = R.c2.z;
@@ -801,7 +809,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             GFrag<EXT> gfrag{nullptr, EXT && args.g_div > 0};
             if (slot >= 0) {
                 if (EXT && args.g_div > 0) {
-                    long long row = (args.sample_base + (valid ? sample : 0)) / args.g_div;
+                    long long row = (args.sample_base + (valid ? sample_now() : 0)) / args.g_div;
                     if (row >= args.g_rows) row = args.g_rows - 1;
                     gfrag.p = args.G + ((size_t)slot * args.g_rows + row) * 64;
                 } else {
@@ -882,7 +890,9 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
         }
 
         // epilogue: outputs + fused base density + NLL partial (utils/fisher.py:217-232, agent.py:55-65)
+        double lp_d = 0.0;
         if (valid && h == 0) {
+            const long long sample = sample_now();
             if (args.rot_out) {
                 float *dst = args.rot_out + sample * 9;
                 dst[0] = R.c0.x; dst[1] = R.c1.x; dst[2] = R.c2.x;
@@ -902,14 +912,19 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     lp += tr - args.fisher_c[row];
                 }
                 if (args.logp_out) args.logp_out[sample] = lp;
-                dsum += (double)lp;
+                lp_d = (double)lp;
             }
+        }
+        if (args.partials) {  // fixed-order wave sum per tile; the running sum is wave uniform (a per-lane double across the whole
+                              // layer stack costs a register pair, which the 128-register instantiation would keep in scratch)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) lp_d += __shfl_xor(lp_d, off, 64);
+            const double t = dsum + lp_d;
+            dsum = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(t)), __builtin_amdgcn_readfirstlane(__double2loint(t)));
         }
     }
 
     if (args.partials) {      // deterministic block partial: wave shuffle tree -> LDS -> thread 0
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dsum += __shfl_down(dsum, off, 64);
         __syncthreads();
         double *red = reinterpret_cast<double *>(lds);
         if (lane == 0) red[wave] = dsum;

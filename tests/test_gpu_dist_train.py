@@ -39,7 +39,8 @@ def _worker(rank, world, port, q):
     try:
         fl = _make_flow()
         harness.train_uncondition(fl, _data(), iterations=6, batch_size=256, lr=2e-3, seed=3, log=lambda *a: None)
-        q.put((rank, torch.cat([p.detach().reshape(-1) for p in fl.parameters()]).cpu().numpy()))
+        ll = harness.mean_log_likelihood(fl, _data()[:1024], device="cuda")
+        q.put((rank, (torch.cat([p.detach().reshape(-1) for p in fl.parameters()]).cpu().numpy(), ll)))
     finally:
         dist.destroy_process_group()
 
@@ -54,14 +55,24 @@ def test_two_ranks_train_like_one():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=150) for _ in range(2))
+    got = dict(q.get(timeout=600) for _ in range(2))      # generous: a cold box pages torch in for every spawned rank
     for p in procs:
         p.join(60)
-    assert np.array_equal(got[0], got[1])                                   # replicas identical bit for bit
+    (got0, ll0), (got1, ll1) = got[0], got[1]
+    assert np.array_equal(got0, got1)                                       # replicas identical bit for bit
+    got = {0: got0}
     fl = _make_flow()
     harness.train_uncondition(fl, _data(), iterations=6, batch_size=256, lr=2e-3, seed=3, graph=False, log=lambda *a: None)
     want = torch.cat([p.detach().reshape(-1) for p in fl.parameters()]).cpu().numpy()
     start = torch.cat([p.detach().reshape(-1) for p in _make_flow().parameters()]).numpy()
     moved = np.abs(want - start).max()
     assert moved > 5e-3                                                      # six Adam steps at lr 2e-3 moved the weights
-    assert np.abs(got[0] - want).max() < 2e-2 * moved, (np.abs(got[0] - want).max(), moved)
+    # Adam's first steps move every parameter by ~lr in the direction of sign(g): a parameter whose gradient is at the rounding-noise level
+    # (the two-rank sum is associated differently from the single-process sum, and float atomics add in a different order every run)
+    # can go either way, so a small fraction of outliers up to the largest movement is legitimate; 99 % of the parameters must agree
+    # to 2 % of it, and the trained densities must agree
+    diff = np.abs(got[0] - want)
+    assert np.quantile(diff, 0.99) < 2e-2 * moved, (np.quantile(diff, 0.99), moved)
+    assert diff.max() <= 1.5 * moved, (diff.max(), moved)
+    ll = harness.mean_log_likelihood(fl, _data()[:1024], device="cuda")
+    assert abs(ll0 - ll) < 2e-3 and ll0 == ll1, (ll0, ll1, ll)

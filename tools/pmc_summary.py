@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes for one kernel: mean counter value per dispatch (over the dispatches of the LARGEST grid, i.e.
+the benchmark launches, not the parity spot check), plus the HBM traffic per launch with the gfx950 correction of
+MI355X_MICROARCH.md (FETCH_SIZE counts 64 B per 128-B request: x2; both counters are in KiB).
+
+    python tools/pmc_summary.py <out.csv> <out.json> <kernel substring> <rocprofv3 output dir> [more dirs ...]
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def main():
+    out_csv, out_json, needle = sys.argv[1:4]
+    rows = defaultdict(list)          # counter -> [(grid, value)]
+    meta = {}
+    for d in sys.argv[4:]:
+        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            per_dispatch = defaultdict(float)
+            info = {}
+            with open(path, newline="") as fh:
+                for r in csv.DictReader(fh):
+                    if needle not in r["Kernel_Name"]:
+                        continue
+                    key = (r["Dispatch_Id"], r["Counter_Name"])
+                    per_dispatch[key] += float(r["Counter_Value"])
+                    info[r["Dispatch_Id"]] = (int(r["Grid_Size"]), int(r["Workgroup_Size"]), int(r["VGPR_Count"]), int(r["LDS_Block_Size"]),
+                                              r["Kernel_Name"])
+            for (disp, name), v in per_dispatch.items():
+                rows[name].append((info[disp][0], v))
+                meta[name] = info[disp]
+    with open(out_csv, "w") as fh:
+        fh.write("counter,mean_per_dispatch,dispatches,grid_size\n")
+        summary = {}
+        for name in sorted(rows):
+            gmax = max(g for g, _ in rows[name])
+            vals = [v for g, v in rows[name] if g == gmax]
+            summary[name] = sum(vals) / len(vals)
+            fh.write(f"{name},{summary[name]:.1f},{len(vals)},{gmax}\n")
+    out = {"kernel": next(iter(meta.values()))[4] if meta else None, "counters": summary}
+    if meta:
+        g, wg, vgpr, lds, _ = next(iter(meta.values()))
+        out.update(workgroup_size=wg, vgpr_count=vgpr, lds_block_size=lds)
+    if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+        out["hbm_fetch_bytes_per_launch"] = summary["FETCH_SIZE"] * 1024 * 2
+        out["hbm_write_bytes_per_launch"] = summary["WRITE_SIZE"] * 1024
+        out["hbm_bytes_per_launch"] = out["hbm_fetch_bytes_per_launch"] + out["hbm_write_bytes_per_launch"]
+    with open(out_json, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

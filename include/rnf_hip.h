@@ -50,9 +50,9 @@ extern "C" {
 
 /* ---- arithmetic of the conditioner GEMMs --------------------------------------------------------------------
  * RNF_PREC_FP32  : exact fp32 (v_mfma_f32_32x32x2_f32; bit-for-bit an fp32 fma chain).
- * RNF_PREC_F16X2 : every fp32 operand carried as two fp16 terms (22 significant bits), three fp16 MFMAs with fp32
- *                  accumulation per product-sum; indistinguishable from fp32 at the parity bar of this path,
- *                  ~2.5x faster because the fp16 matrix cores co-execute with the VALU segment math.  Operands must be
+ * RNF_PREC_F16X2 : every fp32 operand carried as two fp16 terms (hi + unscaled lo: 22 significant bits, absolute floor 2^-24),
+ *                  three fp16 MFMAs into one fp32 accumulator per product-sum; indistinguishable from fp32 at the parity bar of
+ *                  this path, ~2.8x faster than the fp32-input MFMA, which shares the VALU's FMA datapath.  Operands must be
  *                  inside the fp16 range (|x| < 65504): rnf_pack_* returns 2 for such weights (pack FP32 instead).
  */
 #define RNF_PREC_FP32 0

@@ -159,13 +159,16 @@ __device__ __forceinline__ f32x16 last_tile(const float *tile_rec, int lane, int
 
 // ------------------------------------------------------------------------------------------------------------
 // Split-precision path (PREC = 1, "f16x2"): every fp32 operand x of the 64-wide GEMMs is carried as two fp16 terms
-//     x = hi + 2^-12 * lo,   hi = fp16(x) (RN),  lo = fp16((x - hi) * 2^12)        (22 significant bits)
-// and each fp32 product-sum as THREE v_mfma_f32_32x32x16_f16 (fp32 accumulate):
-//     acc1 += Ahi.Bhi        acc2 += Ahi.Blo + Alo.Bhi        result = acc1 + 2^-12 * acc2        (Alo.Blo ~ 2^-24 dropped)
+//     x = hi + lo,   hi = fp16(x) (RN),  lo = fp16(x - hi)   (unscaled: lo lives in the fp16 subnormal range, whose spacing 2^-24 is
+//                                                              the absolute floor of the pair; 22 significant bits above 2^-2)
+// and each fp32 product-sum as THREE v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator:
+//     acc += Ahi.Bhi;  acc += Ahi.Blo;  acc += Alo.Bhi                                      (Alo.Blo ~ 2^-24 dropped)
+// (gfx950's fp16 MFMA keeps subnormal inputs; with lo pre-scaled by 2^12 instead, a second accumulator and 16 combining FMAs per
+// tile were needed: +9 % run time and +29 registers.)
 // Why: on gfx950 the f32-input MFMA runs on the same FMA datapath as the VALU (measured: VALU issue stalls for the
 // ~48-64 cycles an f32 MFMA occupies, profiles/r1/mfma_valu_coissue_microbench.txt), so the exact-fp32 kernel can never
-// overlap the segment math with the conditioner GEMMs; the f16 MFMA runs on the real matrix cores at 16x the rate and
-// co-executes with the VALU.  Measured effect on parity: none beyond fp32 rounding noise.
+// overlap the segment math with the conditioner GEMMs; the f16 MFMA runs on the real matrix cores at 16x the rate.
+// Measured effect on parity: none beyond fp32 rounding noise.
 // Range: an activation or weight >= 65520 in magnitude overflows fp16 and the result turns into inf/NaN (loudly); the
 // host packer refuses weights outside the fp16 range and falls back to the exact PREC = 0 kernels.
 //

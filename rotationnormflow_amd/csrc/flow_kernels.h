@@ -211,6 +211,17 @@ __device__ __forceinline__ void split_act(const f32x16 (&x)[2], ActFrag &f) {
     }
 }
 
+// one value pair of an accumulator tile -> element pair `e` (0..3) of one k-step fragment (the 5 instructions of split_act)
+__device__ __forceinline__ void split_pair(float a, float b, float m1, h8 &hi, h8 &lo, int e) {
+    a = __int_as_float(max(__float_as_int(a), 0));
+    b = __int_as_float(max(__float_as_int(b), 0));
+    const f2 v = {a, b};
+    const h2 ph = __builtin_convertvector(v, h2);
+    const h2 pl = {(_Float16)__builtin_fmaf(m1, (float)ph[0], a), (_Float16)__builtin_fmaf(m1, (float)ph[1], b)};
+    hi[2 * e] = ph[0]; hi[2 * e + 1] = ph[1];
+    lo[2 * e] = pl[0]; lo[2 * e + 1] = pl[1];
+}
+
 __device__ __forceinline__ h8 lds_h8(const float *base, int idx16) {
     return reinterpret_cast<const h8 *>(base)[idx16];
 }
@@ -226,6 +237,50 @@ __device__ __forceinline__ f32x16 gemm_tile64_h(const float *w_tile, int lane, c
         acc = RNF_MFMA_H(al, in.hi[s], acc);
     }
     return acc;
+}
+
+// Hidden layers, software pipelined BY HAND (split-precision path).  The operand split of an output tile (8 value pairs x 5 VALU)
+// rides behind the matrix instructions of the NEXT tile instead of standing between two matrix bursts:
+//   FILL 1 (tile 0 of a layer): the previous layer's tile 1 (`src`) becomes fragments f[2], f[3] during k-steps 0 and 1 -- which only
+//           need f[0], f[1]; k-steps 2, 3 then consume the fresh fragments;
+//   FILL 2 (tile 1 of a layer): this layer's tile 0 (`src`) becomes f[0] during k-step 1 and f[1] during k-step 2 -- each fragment is
+//           overwritten right after the last matrix instruction that reads its previous content has been issued, so the fragments
+//           need no second set of registers.
+// Matrix instruction m = 3 * k-step + term; one sched_barrier per slot keeps the order (the compiler would cluster the 12 MFMAs).
+template <int M, int FILL>
+__device__ __forceinline__ void hidden_slot(const float *w_tile, int lane, ActFrag &f, f32x16 &acc, const f32x16 &src, float m1, h8 &ah,
+                                            h8 &al) {
+    constexpr int ks = M / 3, term = M % 3;
+    if constexpr (term == 0) acc = RNF_MFMA_H(ah, f.hi[ks], acc);
+    else if constexpr (term == 1) acc = RNF_MFMA_H(ah, f.lo[ks], acc);
+    else acc = RNF_MFMA_H(al, f.hi[ks], acc);
+    if constexpr (term == 2 && ks + 1 < 4) {
+        ah = lds_h8(w_tile, ((ks + 1) * 2 + 0) * 64 + lane);
+        al = lds_h8(w_tile, ((ks + 1) * 2 + 1) * 64 + lane);
+    }
+    // which fragment this k-step group fills (-1: none) and from which half of `src`
+    constexpr int dst = FILL == 1 ? (ks == 0 ? 2 : (ks == 1 ? 3 : -1)) : (FILL == 2 ? (ks == 1 ? 0 : (ks == 2 ? 1 : -1)) : -1);
+    if constexpr (dst >= 0) {
+        constexpr int half = dst & 1;                              // fragment 2t + half <- registers 8 * half .. 8 * half + 7 of tile t
+        if constexpr (term == 0) {
+            split_pair(src[8 * half + 0], src[8 * half + 1], m1, f.hi[dst], f.lo[dst], 0);
+        } else if constexpr (term == 1) {
+            split_pair(src[8 * half + 2], src[8 * half + 3], m1, f.hi[dst], f.lo[dst], 1);
+        } else {
+            split_pair(src[8 * half + 4], src[8 * half + 5], m1, f.hi[dst], f.lo[dst], 2);
+            split_pair(src[8 * half + 6], src[8 * half + 7], m1, f.hi[dst], f.lo[dst], 3);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (M + 1 < 12) hidden_slot<M + 1, FILL>(w_tile, lane, f, acc, src, m1, ah, al);
+}
+
+template <int FILL>
+__device__ __forceinline__ void hidden_tile(const float *w_tile, int lane, ActFrag &f, f32x16 &acc, const f32x16 &src, float m1) {
+    h8 ah = lds_h8(w_tile, 0 * 64 + lane);
+    h8 al = lds_h8(w_tile, 1 * 64 + lane);
+    __builtin_amdgcn_sched_barrier(0);
+    hidden_slot<0, FILL>(w_tile, lane, f, acc, src, m1, ah, al);
 }
 
 // SIMD fairness governor.  The two waves a workgroup places on one SIMD (w and w^4) run the same instruction stream; the
@@ -291,34 +346,50 @@ struct Mlp<1> {
         const float bA = h ? y1 : y0;
         const float bB = h ? 1.0f : y2;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        ActFrag f;
+        float m1 = -1.0f;
+        asm("" : "+s"(m1));                                     // see split_act
+        ActFrag &f = out;                                       // the fragments are rewritten in place, layer after layer
         {
             f32x16 x0[2];
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) x0[ot] = first_tile(lds, ot, lane, bA, bB, g ? g.load(ot, lane, h) : zero);
             split_act<true>(x0, f);
         }
-        f32x16 hcur[2];
+        auto w = [&](int L, int ot) { return lds + MOB_HID + (L * 2 + ot) * (8 * 64 * 4); };
+        auto bias = [&](int L, int ot) { return load_bias16(lds + MOB_HB + ((L * 2 + ot) * 2 + h) * 16); };
+        // layer 0: tile 0 bare (its input is complete), tile 1 carries the split of tile 0
+        f32x16 a0 = bias(0, 0), a1 = bias(0, 1);
+        hidden_tile<0>(w(0, 0), lane, f, a0, a0, m1);
+        hidden_tile<2>(w(0, 1), lane, f, a1, a0, m1);
+        fair.tick();
+        // layer 1: tile 0 carries the split of layer 0's tile 1, tile 1 the split of its own tile 0
+        f32x16 b0 = bias(1, 0), b1 = bias(1, 1);
+        hidden_tile<1>(w(1, 0), lane, f, b0, a1, m1);
+        hidden_tile<2>(w(1, 1), lane, f, b1, b0, m1);
+        fair.tick();
+        // layer 2, then the residual x0 + h3 (flow/condition.py:29) tile by tile: tile 0's residual + split ride behind tile 1's MFMAs
+        a0 = bias(2, 0);
+        a1 = bias(2, 1);
+        hidden_tile<1>(w(2, 0), lane, f, a0, b1, m1);
+        a0 = first_tile(lds, 0, lane, bA, bB, a0);
+        if (g) {
+            const f32x16 gg = g.load(0, lane, h);
 #pragma unroll
-        for (int L = 0; L < 3; ++L) {
+            for (int r = 0; r < 16; ++r) a0[r] += gg[r];
+        }
+        hidden_tile<2>(w(2, 1), lane, f, a1, a0, m1);
+        fair.tick();
+        a1 = first_tile(lds, 1, lane, bA, bB, a1);
+        if (g) {
+            const f32x16 gg = g.load(1, lane, h);
 #pragma unroll
-            for (int ot = 0; ot < 2; ++ot) {
-                f32x16 c = load_bias16(lds + MOB_HB + ((L * 2 + ot) * 2 + h) * 16);
-                hcur[ot] = gemm_tile64_h(lds + MOB_HID + (L * 2 + ot) * (8 * 64 * 4), lane, f, c);
-            }
-            if (L < 2) split_act<true>(hcur, f);
-            fair.tick();
+            for (int r = 0; r < 16; ++r) a1[r] += gg[r];
         }
 #pragma unroll
-        for (int ot = 0; ot < 2; ++ot) {                        // residual x0 + h3 (flow/condition.py:29)
-            hcur[ot] = first_tile(lds, ot, lane, bA, bB, hcur[ot]);
-            if (g) {
-                const f32x16 gg = g.load(ot, lane, h);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hcur[ot][r] += gg[r];
-            }
+        for (int e = 0; e < 4; ++e) {
+            split_pair(a1[2 * e], a1[2 * e + 1], m1, f.hi[2], f.lo[2], e);
+            split_pair(a1[8 + 2 * e], a1[8 + 2 * e + 1], m1, f.hi[3], f.lo[3], e);
         }
-        split_act<true>(hcur, out);
     }
     static __device__ __forceinline__ f32x16 last(const float *tile_rec, int lane, int h, const Act &a) {
         f32x16 c = load_bias16(tile_rec + MOB_LAST_TILE_BIAS + h * 16);

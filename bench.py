@@ -92,6 +92,23 @@ def pmc_traffic(precision, n):
     return d.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
 
 
+def pmc_busy(precision, n):
+    """VALU / matrix-pipe busy fractions of the dominant kernel from the same committed PMC passes (what actually bounds it)."""
+    path = os.path.join(ROOT, "profiles", "r1", f"pmc_flow_stack_kernel_{precision}_end.json")
+    if n != 1 << 20 or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        c = json.load(fh)["counters"]
+    try:
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0                      # the counter sums the 8 XCDs
+        simds = 1024.0
+        return {"valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (simds * cycles),     # quad-cycles -> cycles
+                "matrix_pipe_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (simds * cycles),
+                "valu_instructions": c["SQ_INSTS_VALU"], "mfma_instructions": c["SQ_INSTS_MFMA"]}
+    except KeyError:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +206,9 @@ def main():
                         "kernel": "rnf::flow_stack_kernel<0,0,8,true,0>", "kernel_ms": kernel_ms,
                         "algorithmic_flop_per_rotation": FLOP_PER_ROTATION,
                         "note": "exact fp32-input MFMA; shares the FMA datapath with the VALU segment math on gfx950"}
+        busy = pmc_busy(precision, n)
+        if busy:
+            roofline["pmc"] = busy
         out = {
             "metric": "rotation log_prob evals/s (24-layer MobiusAffine + matrix-Fisher base), mean NLL alongside",
             "value": value, "unit": "rotations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

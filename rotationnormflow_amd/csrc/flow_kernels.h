@@ -239,8 +239,9 @@ __device__ __forceinline__ f32x16 gemm_tile64_h(const float *w_tile, int lane, c
     return acc;
 }
 
-// Hidden layers, software pipelined BY HAND (split-precision path).  The operand split of an output tile (8 value pairs x 5 VALU)
-// rides behind the matrix instructions of the NEXT tile instead of standing between two matrix bursts:
+// Hidden layers in slot order (split-precision path).  The operand split of an output tile (8 value pairs x 5 VALU) is written behind
+// the matrix instructions of the NEXT tile instead of between two matrix bursts (where the compiler actually places the FILL 2 work:
+// see the note at RNF_PIN_H):
 //   FILL 1 (tile 0 of a layer): the previous layer's tile 1 (`src`) becomes fragments f[2], f[3] during k-steps 0 and 1 -- which only
 //           need f[0], f[1]; k-steps 2, 3 then consume the fresh fragments;
 //   FILL 2 (tile 1 of a layer): this layer's tile 0 (`src`) becomes f[0] during k-step 1 and f[1] during k-step 2 -- each fragment is
@@ -270,6 +271,9 @@ __device__ __forceinline__ void hidden_slot(const float *w_tile, int lane, ActFr
             split_pair(src[8 * half + 4], src[8 * half + 5], m1, f.hi[dst], f.lo[dst], 2);
             split_pair(src[8 * half + 6], src[8 * half + 7], m1, f.hi[dst], f.lo[dst], 3);
         }
+#ifdef RNF_PIN_H                                                    // FILL 2 results are consumed by the next layer only: unpinned, the optimiser
+        asm volatile("" : "+v"(f.hi[dst]), "+v"(f.lo[dst]));       // moves that split behind the tile (see tile_step_h); pinned: 0.8 % slower
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (M + 1 < 12) hidden_slot<M + 1, FILL>(w_tile, lane, f, acc, src, m1, ah, al);
@@ -470,8 +474,8 @@ __device__ __forceinline__ void tile_pipe(const float *rec, int lane, int h, con
 }
 
 // split-precision counterpart of tile_step: slot m = 3 * (segment g) + (slice st) carries matrix instruction m of the next tile
-// (k-step m / 3; term hi.hi, hi.lo, lo.hi) and slice st of segment g of the finished tile.  Left to itself the compiler emits the
-// 12 matrix instructions back to back; while they queue for the matrix pipe they hold the VALU issue port of the SIMD.
+// (k-step m / 3; term hi.hi, hi.lo, lo.hi) and slice st of segment g of the finished tile; the operands of k-step s + 1 are fetched
+// behind the last matrix instruction of k-step s into the same registers (one look-ahead, 8 registers instead of 32).
 template <int M>
 __device__ __forceinline__ void tile_step_h(const float *rec, int lane, f32x16 &nxt, h8 &ah, h8 &al, const ActFrag &in,
                                             const f32x16 &cur, SegPi (&seg)[4], const MobiusCtx &c, float &S, float &A, float &J) {
@@ -485,6 +489,14 @@ __device__ __forceinline__ void tile_step_h(const float *rec, int lane, f32x16 &
     }
     constexpr int g = M / 3, st = M % 3;
     seg_pi_stage<st>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, S, A, J);
+    // NOTE: the slice's results are only consumed slots later, and sched_barrier orders the machine scheduler, not the IR passes: the
+    // optimiser sinks this arithmetic past the fences into one VALU block behind the 12 matrix instructions.  Pinning each slice in
+    // its slot (-DRNF_PIN_L) gives the interleaved stream the source suggests and measured 0.8 % SLOWER, so the shipped build does not.
+#ifdef RNF_PIN_L
+    if constexpr (st == 0) asm volatile("" : "+v"(seg[g].ur), "+v"(seg[g].uv));
+    else if constexpr (st == 1) asm volatile("" : "+v"(seg[g].t), "+v"(seg[g].c), "+v"(seg[g].p), "+v"(seg[g].z));
+    else asm volatile("" : "+v"(S), "+v"(A), "+v"(J));
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (M + 1 < 12) tile_step_h<M + 1>(rec, lane, nxt, ah, al, in, cur, seg, c, S, A, J);
 }
@@ -517,8 +529,7 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int l
             segments4<false>(bufA, c, S, A, J);
         }
     } else {
-        // software pipeline BY HAND: each of tile tau+1's 12 matrix instructions is issued in front of one ~15-instruction slice of
-        // tile tau's segment math (tile_pipe_h)
+        // tile tau+1's 12 matrix instructions and tile tau's segment math in one loop body (tile_pipe_h)
         f32x16 cur = Mlp<1>::last(rec, lane, h, tt);
         for (int tau = 1; tau < KT; ++tau) {
             f32x16 nxt;

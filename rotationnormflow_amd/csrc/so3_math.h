@@ -266,10 +266,8 @@ RNF_HD void segment_fwd_pi(float s_raw, float w0, float w1, float w2, const Fram
     J = fmaf(sp, c, J);
 }
 
-// segment_fwd_pi<true> cut into three slices of ~15 VALU instructions: the split-precision forward kernel issues ONE matrix instruction of
-// the next fc_last tile in front of every slice (flow_kernels.h tile_pipe_h), so that a wave never queues matrix instructions back to
-// back -- a matrix instruction waiting for the matrix pipe holds the SIMD's VALU issue port and stalls the other waves' segment math
-// (profiles/r1/mfma_f16_valu_overlap_microbench.txt).
+// segment_fwd_pi<true> cut into three slices of ~15 VALU instructions, one per matrix instruction of the next fc_last tile
+// (flow_kernels.h tile_pipe_h; whether the slices really sit between the matrix instructions is a build switch there).
 struct SegPi {
     float ur, uv, t, c, p, z;
 };

@@ -950,8 +950,11 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     InvSegs<KTI> sg;
                     float S = 0.f;
                     mobius_inv_tiles<KTI, PREC>(lds, lane, h, tt, ctx, sg, S);
-                    barrier2();
+                    // B2 (and the DMA issue of the next fc_last image) AFTER the root finder: issued in front of it, the DMA address
+                    // arithmetic would sit on top of the 96 live segment registers (36 spills at K = 64); the image still has the whole
+                    // hidden-layer phase of the next layer to land
                     mobius_inv_finish<KTI>(ctx, sg, S, R, ldj);
+                    barrier2();
                 } else {
                     float S = 0.f, A = 0.f, J = 0.f;
                     if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC>(lds, KT, lane, h, tt, ctx, S, A, J, fair);

@@ -536,10 +536,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     a.fisher_c = o.fisher_c;
     a.fisher_div = o.fisher_A ? n / o.fisher_B : 1;
 
-    // (inverse with K = 64: 96 segment registers + the DMA bookkeeping spill under the 256-VGPR cap; it is VALU-bound in
-    //  the bisection anyway, so it keeps the synchronous staging)
-    // (flows with a conditional 3x3 layer run the extended instantiation, which is only built with the synchronous staging)
-    const bool pipe = staging_dma() && KT <= MOB_MAX_TILES_IN_LDS && !(o.dir == 1 && KT == 8) && !ext;
+    const bool pipe = staging_dma() && KT <= MOB_MAX_TILES_IN_LDS;
     a.tab_off = -1;
     if (pipe && any_mlp) {                                     // two LDS buffers for the blocks of constant-affine layers (flow_kernels.h stage_table)
         lds_bytes = (lds_bytes + 15) / 16 * 16;
@@ -596,8 +593,10 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         a.g_groups = groups;
         int rc;
 #define RNF_LAUNCH(DIR_, KT_)                                                                                   \
-    ext ? (prec ? launch_stack<DIR_, KT_, false, 1, true>(a, grid, lds_bytes, stream, nwk)                          \
-                : launch_stack<DIR_, KT_, false, 0, true>(a, grid, lds_bytes, stream, nwk)) :                       \
+    ext ? (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1, true>(a, grid, lds_bytes, stream, nwk)                   \
+                        : launch_stack<DIR_, KT_, true, 0, true>(a, grid, lds_bytes, stream, nwk))                  \
+                : (prec ? launch_stack<DIR_, KT_, false, 1, true>(a, grid, lds_bytes, stream, nwk)                  \
+                        : launch_stack<DIR_, KT_, false, 0, true>(a, grid, lds_bytes, stream, nwk))) :              \
     (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1>(a, grid, lds_bytes, stream, nwk)                               \
                   : launch_stack<DIR_, KT_, true, 0>(a, grid, lds_bytes, stream, nwk))                              \
           : (prec ? launch_stack<DIR_, KT_, false, 1>(a, grid, lds_bytes, stream, nwk)                              \

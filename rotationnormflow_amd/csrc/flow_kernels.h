@@ -580,6 +580,7 @@ __device__ __forceinline__ void mobius_fwd_finish(const MobiusCtx &c, float S, f
 template <int KT>
 struct InvSegs {
     float sp[4 * KT], ur[4 * KT], uv[4 * KT];
+    float q[4 * KT];          // sp * (1 - |u|^2): the theta-independent numerator of the segment's derivative term
 };
 
 template <int KT, int PREC>
@@ -593,6 +594,7 @@ __device__ __forceinline__ void mobius_inv_tiles(const float *lds, int lane, int
         for (int g = 0; g < 4; ++g) {
             squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, sg.ur[4 * tau + g], sg.uv[4 * tau + g]);
             sg.sp[4 * tau + g] = softplus(o[4 * g]);
+            sg.q[4 * tau + g] = sg.sp[4 * tau + g] * (1.0f - fmaf(sg.uv[4 * tau + g], sg.uv[4 * tau + g], sg.ur[4 * tau + g] * sg.ur[4 * tau + g]));
             S += sg.sp[4 * tau + g];
         }
         // keep the tiles in order: letting the scheduler hoist all 8 tiles' MFMAs (8 x 16 accumulators) on top of the
@@ -620,15 +622,18 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
     for (int it = 0; it < 16; ++it) {
         float sn, cs;
         sincos_small(th, sn, cs);
+        // per segment (so3_math.h mobius_angle): phi = th + 2 atan(-b / (1 - a)), c = (1 - |u|^2) / (b^2 + (1 - a)^2), (a, b) = u conj(z);
+        // the constant parts are hoisted: sum sp phi = th S + 2 sum sp atan(.), sum sp c = sum q / (b^2 + (1 - a)^2)   (21 + 2 instead of 27 + 2)
         float acc = 0.f, der = 0.f;
 #pragma unroll
         for (int s = 0; s < 4 * KT; ++s) {
-            float phi, cc;
-            mobius_angle(cs, sn, th, sg.ur[s], sg.uv[s], phi, cc);
-            acc = fmaf(sg.sp[s], phi, acc);
-            der = fmaf(sg.sp[s], cc, der);
+            const float a = fmaf(sg.uv[s], sn, sg.ur[s] * cs);
+            const float b = fmaf(sg.uv[s], cs, -sg.ur[s] * sn);
+            const float e1 = 1.0f - a;
+            acc = fmaf(sg.sp[s], atan_unit(-b * hw_rcp(e1)), acc);
+            der = fmaf(sg.q[s], hw_rcp(fmaf(b, b, e1 * e1)), der);
         }
-        const float fx = pair_sum(acc) * invS - c.target;
+        const float fx = fmaf(2.0f * pair_sum(acc), invS, th) - c.target;
         const float dfx = pair_sum(der) * invS;
         if (fx < 0.f) lo = th; else hi = th;
         float nt = th - fx * hw_rcp(dfx);
@@ -647,9 +652,10 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
     float J = 0.f;
 #pragma unroll
     for (int s = 0; s < 4 * KT; ++s) {
-        float phi, cc;
-        mobius_angle(cs, sn, mid, sg.ur[s], sg.uv[s], phi, cc);
-        J = fmaf(sg.sp[s], cc, J);
+        const float a = fmaf(sg.uv[s], sn, sg.ur[s] * cs);
+        const float b = fmaf(sg.uv[s], cs, -sg.ur[s] * sn);
+        const float e1 = 1.0f - a;
+        J = fmaf(sg.q[s], hw_rcp(fmaf(b, b, e1 * e1)), J);
     }
     J = pair_sum(J);
     const v3f xx = c.f.v * sn + c.f.r * cs;
@@ -932,12 +938,16 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             }
             RNF_STAMP(2)                                          // 2: barrier B1 (+ DMA issue)
 
-            // B2 (DMA mode): every wave is past the L part and the next layer's H part has landed
-            auto barrier2 = [&]() {
+            // B2 (DMA mode): every wave is past the L part and the next layer's H part has landed; then the next L part is requested
+            auto b2_sync = [&]() {
                 RNF_STAMP(3)                                      // 3: fc_last tiles + segment math (L part)
                 if (PIPE) {
                     dma_wait_all();
                     __syncthreads();
+                }
+            };
+            auto b2_issue = [&]() {
+                if (PIPE) {
                     if (nxt_off >= 0) dma_floats(lds + MOB_LAST, args.blob + nxt_off + MOB_LAST, l_floats(nxt_kind), wave, lane, NW);
                     tab_parity = has_table(pos) ? (seq & 1) : -1;
                     ++seq;
@@ -945,16 +955,19 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 }
                 RNF_STAMP(4)                                      // 4: barrier B2 (+ DMA issue)
             };
+            auto barrier2 = [&]() { b2_sync(); b2_issue(); };
             if (kind == RNF_KIND_MOBIUS) {
                 if constexpr (DIR != 0) {
                     InvSegs<KTI> sg;
                     float S = 0.f;
                     mobius_inv_tiles<KTI, PREC>(lds, lane, h, tt, ctx, sg, S);
-                    // B2 (and the DMA issue of the next fc_last image) AFTER the root finder: issued in front of it, the DMA address
-                    // arithmetic would sit on top of the 96 live segment registers (36 spills at K = 64); the image still has the whole
-                    // hidden-layer phase of the next layer to land
+                    // the barrier right behind the tiles (the root finder does not touch LDS, and its pass count differs from wave to wave:
+                    // a barrier behind it was 19 % of the wave time), the DMA request of the next fc_last image behind the root finder:
+                    // in front of it the DMA address arithmetic would sit on top of the 96 live segment registers (36 spills at K = 64);
+                    // the image still has the whole hidden-layer phase of the next layer to land
+                    b2_sync();
                     mobius_inv_finish<KTI>(ctx, sg, S, R, ldj);
-                    barrier2();
+                    b2_issue();
                 } else {
                     float S = 0.f, A = 0.f, J = 0.f;
                     if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC>(lds, KT, lane, h, tt, ctx, S, A, J, fair);

@@ -593,7 +593,7 @@ __device__ __forceinline__ void mobius_inv_tiles(const float *lds, int lane, int
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, sg.ur[4 * tau + g], sg.uv[4 * tau + g]);
-            sg.sp[4 * tau + g] = softplus(o[4 * g]);
+            sg.sp[4 * tau + g] = PREC == 1 ? softplus_lean(o[4 * g]) : softplus(o[4 * g]);
             sg.q[4 * tau + g] = sg.sp[4 * tau + g] * (1.0f - fmaf(sg.uv[4 * tau + g], sg.uv[4 * tau + g], sg.ur[4 * tau + g] * sg.ur[4 * tau + g]));
             S += sg.sp[4 * tau + g];
         }

@@ -42,6 +42,13 @@ RNF_HD float softplus(float x) {
     return fmaxf(x, 0.0f) + l;
 }
 
+// softplus without the argument split and the log1p residue: those terms are < 1e-8 absolute on a weight that is then divided by the sum
+// of K such weights (the split-precision kernels use this form in both directions, so forward and inverse see the same weights)
+RNF_HD float softplus_lean(float x) {
+    const float e = hw_exp2(-1.44269504088896341f * fabsf(x));
+    return fmaf(hw_log2(1.0f + e), 0.693147180559945309f, fmaxf(x, 0.0f));
+}
+
 // atan2(y, x) mapped to [0, 2pi) (the wrap of flow/mobiusflow.py:98-99 folded in).  Octant reduction to a in [0,1],
 // then the classic single-precision arctangent: |t| <= tan(pi/8) via t = (a-1)/(a+1), odd degree-9 minimax (~2 ulp).
 // first half: octant + tan(pi/8) reduction -> t with |t| <= tan(pi/8) and the "added pi/4" flag

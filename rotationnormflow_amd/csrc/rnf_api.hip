@@ -340,6 +340,10 @@ constexpr int NW = 8;                                   // waves per workgroup (
 constexpr int NW_FWD_H = 8;                             // forward split-precision kernel small launches
 constexpr int NW_FWD_WIDE = 16;                         // same kernel, 4 waves per SIMD (fits in 128 VGPRs): launches that fill every CU with
                                                         // 512-rotation workgroups; +12 % over 8 waves (profiles/r1/nw_sweep.txt)
+#ifndef RNF_NW_FP
+#define RNF_NW_FP 8
+#endif
+constexpr int NW_FP = RNF_NW_FP;                        // waves per workgroup of the feature projection (workgroups per CU: 8 / NW_FP)
 constexpr long long CHUNK_SAMPLES = 1LL << 18;          // samples per launch when a feature projection scratch is needed
 constexpr size_t PARTIALS_BYTES = 4096 * sizeof(double);
 
@@ -553,14 +557,15 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         const int nwk = wide ? NW_FWD_WIDE : ((o.dir == 0 && prec == 1) ? NW_FWD_H : NW);
         a.fair_off = wide ? -1 : fair_off;                                   // the governor pairs two waves per SIMD
         const long long ntiles = (cn + nwk * 32 - 1) / (nwk * 32);
-        const long long ntiles_fp = (cn + NW * 32 - 1) / (NW * 32);          // the feature projection keeps 8 waves
-        const long long groups = (ntiles * nwk > ntiles_fp * NW) ? ntiles * nwk : ntiles_fp * NW;
+        const long long ntiles_fp = (cn + NW_FP * 32 - 1) / (NW_FP * 32);
+        const long long groups = (ntiles * nwk > ntiles_fp * NW_FP) ? ntiles * nwk : ntiles_fp * NW_FP;
         int grid = (int)(ntiles < cus ? ntiles : cus);
-        const int grid_fp = (int)(ntiles_fp < cus ? ntiles_fp : cus);
+        const int cus_fp = cus * (8 / NW_FP);
+        const int grid_fp = (int)(ntiles_fp < cus_fp ? ntiles_fp : cus_fp);
         if (n_slots && (!shared || base == 0)) {          // shared rows: ONE projection of the feature rows, before the first chunk
             const long long pn = shared ? feat_rows : cn;
-            const long long pt = (pn + NW * 32 - 1) / (NW * 32);
-            const int grid_p = shared ? (int)(pt < cus ? pt : cus) : grid_fp;
+            const long long pt = (pn + NW_FP * 32 - 1) / (NW_FP * 32);
+            const int grid_p = shared ? (int)(pt < cus_fp ? pt : cus_fp) : grid_fp;
             fp.feat = shared ? feat : feat + base * F;
             fp.blob = blob;
             fp.G = G;
@@ -572,13 +577,13 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             const int kchunk = F < FP_KCHUNK ? F : FP_KCHUNK;
             size_t fl = sizeof(float) * (prec ? (size_t)2 * (FP_KCHUNK / 16) * 512 : (size_t)kchunk / 8 * 256);   // f16x2: two DMA buffers
             if (prec) {
-                auto kern = featproj_kernel<NW, 1>;
+                auto kern = featproj_kernel<NW_FP, 1>;
                 HIP_TRY(allow_lds(kern, fl));
-                hipLaunchKernelGGL(kern, dim3(grid_p), dim3(NW * 64), fl, stream, fp);
+                hipLaunchKernelGGL(kern, dim3(grid_p), dim3(NW_FP * 64), fl, stream, fp);
             } else {
-                auto kern = featproj_kernel<NW, 0>;
+                auto kern = featproj_kernel<NW_FP, 0>;
                 HIP_TRY(allow_lds(kern, fl));
-                hipLaunchKernelGGL(kern, dim3(grid_p), dim3(NW * 64), fl, stream, fp);
+                hipLaunchKernelGGL(kern, dim3(grid_p), dim3(NW_FP * 64), fl, stream, fp);
             }
             HIP_TRY(hipGetLastError());
         }

@@ -186,7 +186,9 @@ def main():
         achieved_tflops = FLOP_PER_ROTATION * n / (kernel_ms * 1e-3) / 1e12
         precision = get_precision()
         cus = torch.cuda.get_device_properties(device).multi_processor_count
-        nw = 16 if (precision == "f16x2" and n > cus * 256 and os.environ.get("RNF_WIDE") != "0") else 8
+        nw = 8                                                   # waves per workgroup the library picks for this launch (rnf_api.hip run_flow)
+        if precision == "f16x2" and os.environ.get("RNF_WIDE") != "0":
+            nw = 16 if n > cus * 256 else (4 if n <= cus * 128 else 8)
         traffic, traffic_src = pmc_traffic(precision, n)
         if precision == "f16x2":
             # the conditioner GEMMs run on the fp16 matrix cores (3 fp16 MFMAs with fp32 accumulate per fp32 product-sum),

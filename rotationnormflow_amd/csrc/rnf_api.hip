@@ -338,6 +338,8 @@ extern "C" int rnf_pack_rot16(const float *mat16, float *out) {
 // ------------------------------------------------------------------------------------------------------------
 constexpr int NW = 8;                                   // waves per workgroup (2 per SIMD): exact-fp32 and inverse kernels, featproj
 constexpr int NW_FWD_H = 8;                             // forward split-precision kernel small launches
+constexpr int NW_FWD_NARROW = 4;                        // same kernel, 1 wave per SIMD: launches that leave half of the CUs empty at 8 waves (small
+                                                        // batches, training: forward latency 0.41 -> 0.34 ms at 1024 rotations)
 constexpr int NW_FWD_WIDE = 16;                         // same kernel, 4 waves per SIMD (fits in 128 VGPRs): launches that fill every CU with
                                                         // 512-rotation workgroups; +12 % over 8 waves (profiles/r1/nw_sweep.txt)
 #ifndef RNF_NW_FP
@@ -409,6 +411,13 @@ static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream
             auto kern = flow_stack_kernel<DIR, KT_INV, NW_FWD_WIDE, PIPE, PREC, EXT>;
             HIP_TRY(allow_lds(kern, lds_bytes));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_FWD_WIDE * 64), lds_bytes, stream, a);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+        if (nwk == NW_FWD_NARROW) {
+            auto kern = flow_stack_kernel<DIR, KT_INV, NW_FWD_NARROW, PIPE, PREC, EXT>;
+            HIP_TRY(allow_lds(kern, lds_bytes));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_FWD_NARROW * 64), lds_bytes, stream, a);
             HIP_TRY(hipGetLastError());
             return 0;
         }
@@ -554,8 +563,9 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         // waves per workgroup of the stack kernel: the forward split-precision kernel goes 16 wide once 8-wave workgroups would
         // no longer fit the CUs in one round
         const bool wide = o.dir == 0 && prec == 1 && pipe && !ext && wide_allowed() && cn > (long long)cus * NW_FWD_H * 32;
-        const int nwk = wide ? NW_FWD_WIDE : ((o.dir == 0 && prec == 1) ? NW_FWD_H : NW);
-        a.fair_off = wide ? -1 : fair_off;                                   // the governor pairs two waves per SIMD
+        const bool narrow = o.dir == 0 && prec == 1 && pipe && !ext && wide_allowed() && cn <= (long long)cus * NW_FWD_NARROW * 32;
+        const int nwk = wide ? NW_FWD_WIDE : (narrow ? NW_FWD_NARROW : ((o.dir == 0 && prec == 1) ? NW_FWD_H : NW));
+        a.fair_off = (wide || narrow) ? -1 : fair_off;                       // the governor pairs two waves per SIMD
         const long long ntiles = (cn + nwk * 32 - 1) / (nwk * 32);
         const long long ntiles_fp = (cn + NW_FP * 32 - 1) / (NW_FP * 32);
         const long long groups = (ntiles * nwk > ntiles_fp * NW_FP) ? ntiles * nwk : ntiles_fp * NW_FP;

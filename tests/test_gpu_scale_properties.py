@@ -47,10 +47,13 @@ def test_fisher24_full_batch_independence_additivity_determinism():
     with torch.no_grad():
         sub = fl.log_prob(R[idx].contiguous(), base=base)["logp"]
     assert torch.equal(sub, lp[idx])
-    # a small launch runs the 8-wave instantiation of the stack kernel, the launches above the 16-wave one: same arithmetic
+    # small launches run the 4-wave instantiation of the stack kernel, mid-sized ones the 8-wave one, the launches above the 16-wave
+    # one: same arithmetic
     with torch.no_grad():
         small = fl.log_prob(R[:4096].contiguous(), base=base)["logp"]
+        mid = fl.log_prob(R[:40000].contiguous(), base=base)["logp"]
     assert (small - lp[:4096]).abs().max().item() < 2e-6
+    assert (mid - lp[:40000]).abs().max().item() < 2e-6
     # spot check against the oracle (fp64) on a few hundred of those rows
     pick = idx[:512].cpu()
     want, _ = orc.log_prob(cfg, w, R[pick.cuda()].cpu().numpy(), None, synth.fisher_A("diag531"), torch.float64)

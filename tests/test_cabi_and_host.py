@@ -191,3 +191,32 @@ def test_argument_validation_happens_before_any_gpu_work():
     # small kernels
     assert L.rnf_min_geodesic(None, None, 5, 0, None, None) != 0
     assert L.rnf_fisher_log_const(None, 3, None, None) != 0
+
+
+def test_pmc_summary_tool(tmp_path):
+    """tools/pmc_summary.py: mean per dispatch over the largest grid only, gfx950 x2 correction on FETCH_SIZE, KiB units."""
+    import json
+    import subprocess
+    import sys
+    d = tmp_path / "pass1"
+    d.mkdir()
+    head = ('"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name",'
+            '"Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value",'
+            '"Start_Timestamp","End_Timestamp"\n')
+    rows = []
+    for disp, grid, fetch, write in ((1, 4096, 10.0, 1.0), (2, 262144, 100.0, 8.0), (3, 262144, 300.0, 8.0)):
+        for xcd_part in (0.25, 0.75):                                  # rocprofv3 emits one row per counter instance
+            rows.append(f'{disp},{disp},"Agent 2",1,1,1,{grid},7,"void rnf::flow_stack_kernel<0, 0, 16, true, 1, false>(rnf::FlowArgs)",1024,0,0,64,64,96,'
+                        f'"FETCH_SIZE",{fetch * xcd_part},1,2\n')
+        rows.append(f'{disp},{disp},"Agent 2",1,1,1,{grid},7,"void rnf::flow_stack_kernel<0, 0, 16, true, 1, false>(rnf::FlowArgs)",1024,0,0,64,64,96,'
+                    f'"WRITE_SIZE",{write},1,2\n')
+        rows.append(f'{disp},{disp},"Agent 2",1,1,1,{grid},9,"other_kernel",64,0,0,8,0,16,"FETCH_SIZE",999.0,1,2\n')
+    (d / "run_counter_collection.csv").write_text(head + "".join(rows))
+    out_csv, out_json = tmp_path / "s.csv", tmp_path / "s.json"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), str(out_csv), str(out_json), "flow_stack_kernel", str(d)],
+                   check=True, capture_output=True)
+    s = json.loads(out_json.read_text())
+    assert s["counters"]["FETCH_SIZE"] == 200.0 and s["counters"]["WRITE_SIZE"] == 8.0        # the two big-grid dispatches only
+    assert s["hbm_fetch_bytes_per_launch"] == 200.0 * 1024 * 2 and s["hbm_write_bytes_per_launch"] == 8.0 * 1024
+    assert s["workgroup_size"] == 1024

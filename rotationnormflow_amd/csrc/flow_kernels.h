@@ -529,7 +529,9 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int l
             segments4<false>(bufA, c, S, A, J);
         }
     } else {
-        // tile tau+1's 12 matrix instructions and tile tau's segment math in one loop body (tile_pipe_h)
+        // tile tau+1's 12 matrix instructions and tile tau's segment math in one loop body (tile_pipe_h).  (`cur = nxt` costs 8
+        // v_mov_b64 per tile; the two-tiles-per-trip ping-pong of the fp32 path avoids them but spills 10 registers under the 128
+        // budget of the 16-wave instantiation and measured 1 % slower.)
         f32x16 cur = Mlp<1>::last(rec, lane, h, tt);
         for (int tau = 1; tau < KT; ++tau) {
             f32x16 nxt;

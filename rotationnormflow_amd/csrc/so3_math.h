@@ -42,11 +42,21 @@ RNF_HD float softplus(float x) {
     return fmaxf(x, 0.0f) + l;
 }
 
+// max(x, 0) as an integer max on the bit pattern (negative floats are negative integers): ONE instruction on the device, where
+// fmaxf(x, 0) on a matrix-instruction result costs two (the compiler first quiets a possible signalling NaN with v_max x, x)
+RNF_HD float relu_bits(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __int_as_float(max(__float_as_int(x), 0));
+#else
+    return x > 0.0f ? x : 0.0f;
+#endif
+}
+
 // softplus without the argument split and the log1p residue: those terms are < 1e-8 absolute on a weight that is then divided by the sum
 // of K such weights (the split-precision kernels use this form in both directions, so forward and inverse see the same weights)
 RNF_HD float softplus_lean(float x) {
     const float e = hw_exp2(-1.44269504088896341f * fabsf(x));
-    return fmaf(hw_log2(1.0f + e), 0.693147180559945309f, fmaxf(x, 0.0f));
+    return fmaf(hw_log2(1.0f + e), 0.693147180559945309f, relu_bits(x));
 }
 
 // atan2(y, x) mapped to [0, 2pi) (the wrap of flow/mobiusflow.py:98-99 folded in).  Octant reduction to a in [0,1],
@@ -267,7 +277,7 @@ RNF_HD void segment_fwd_pi(float s_raw, float w0, float w1, float w2, const Fram
     const float at = atan_unit(t);
     const float phi = HALF ? at : fmaf(2.0f, at, kPi);
     const float e = hw_exp2(-1.44269504088896341f * fabsf(s_raw));
-    const float sp = fmaf(hw_log2(1.0f + e), 0.693147180559945309f, fmaxf(s_raw, 0.0f));
+    const float sp = fmaf(hw_log2(1.0f + e), 0.693147180559945309f, relu_bits(s_raw));
     S += sp;
     A = fmaf(sp, phi, A);
     J = fmaf(sp, c, J);
@@ -301,7 +311,7 @@ RNF_HD void seg_pi_stage(SegPi &g, float s_raw, float w0, float w1, float w2, co
         p = fmaf(p, g.z, -3.333259703e-01f);
         p = fmaf(p, g.z, 9.999998864e-01f);
         const float e = hw_exp2(-1.44269504088896341f * fabsf(s_raw));
-        const float sp = fmaf(hw_log2(1.0f + e), 0.693147180559945309f, fmaxf(s_raw, 0.0f));
+        const float sp = fmaf(hw_log2(1.0f + e), 0.693147180559945309f, relu_bits(s_raw));
         S += sp;
         A = fmaf(sp, p * g.t, A);                  // HALF convention: sp * atan(t)
         J = fmaf(sp, g.c, J);

@@ -618,7 +618,26 @@ template <int KT>
 __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvSegs<KT> &sg, float S, Rot &R, float &ldj) {
     S = pair_sum(S);
     const float invS = hw_rcp(S);
-    float lo = 0.5f * kPi, hi = 1.5f * kPi, th = kPi;
+    float lo = 0.5f * kPi, hi = 1.5f * kPi, th;
+    {   // Starting point: the exact inverse of ONE Moebius map with the weighted mean centre m = sum wt_k u_k (the map with centre -m
+        // applied to the target point).  To first order in the centres the mixture IS that map, and the Newton iteration then needs
+        // 3.8 - 4.0 passes per wave on trained-like weights instead of 5.4 - 6.7 from theta = pi (tests/test_inverse_rootfinder.py).
+        float mr = 0.f, mv = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4 * KT; ++s) {
+            mr = fmaf(sg.sp[s], sg.ur[s], mr);
+            mv = fmaf(sg.sp[s], sg.uv[s], mv);
+        }
+        mr = pair_sum(mr) * invS;
+        mv = pair_sum(mv) * invS;
+        float st, ct;
+        sincos_small(c.target, st, ct);
+        const float a = -fmaf(mv, st, mr * ct);                     // (a, b) = (-m) conj(z_target)
+        const float b = fmaf(mr, st, -mv * ct);
+        float d = angle_0_2pi(-b, 1.0f - a);                        // 1 - a >= 0.3: the angle is in (-pi/2, pi/2), returned mod 2 pi
+        d = d > kPi ? d - kTwoPi : d;
+        th = fminf(fmaxf(fmaf(2.0f, d, c.target), lo + 1.0e-3f), hi - 1.0e-3f);
+    }
     bool done = false;
 #pragma unroll 1
     for (int it = 0; it < 16; ++it) {

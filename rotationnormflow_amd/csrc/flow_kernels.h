@@ -646,14 +646,38 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
         // per segment (so3_math.h mobius_angle): phi = th + 2 atan(-b / (1 - a)), c = (1 - |u|^2) / (b^2 + (1 - a)^2), (a, b) = u conj(z);
         // the constant parts are hoisted: sum sp phi = th S + 2 sum sp atan(.), sum sp c = sum q / (b^2 + (1 - a)^2)   (21 + 2 instead of 27 + 2)
         float acc = 0.f, der = 0.f;
+        // two segments per instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): no matrix instruction runs during the root finder,
+        // so the packed fp32 VALU forms pay here (-6.5 % on the whole inverse pass) -- beside MFMAs they are an anti-lever
+        {
+            f2 acc2 = {0.f, 0.f}, der2 = {0.f, 0.f};
+            const f2 sn2 = {sn, sn}, cs2 = {cs, cs};
 #pragma unroll
-        for (int s = 0; s < 4 * KT; ++s) {
-            const float a = fmaf(sg.uv[s], sn, sg.ur[s] * cs);
-            const float b = fmaf(sg.uv[s], cs, -sg.ur[s] * sn);
-            const float e1 = 1.0f - a;
-            acc = fmaf(sg.sp[s], atan_unit(-b * hw_rcp(e1)), acc);
-            der = fmaf(sg.q[s], hw_rcp(fmaf(b, b, e1 * e1)), der);
+            for (int s = 0; s < 4 * KT; s += 2) {
+                const f2 ur = {sg.ur[s], sg.ur[s + 1]}, uv = {sg.uv[s], sg.uv[s + 1]};
+                const f2 sp = {sg.sp[s], sg.sp[s + 1]}, q = {sg.q[s], sg.q[s + 1]};
+                const f2 a = __builtin_elementwise_fma(uv, sn2, ur * cs2);
+                const f2 b = __builtin_elementwise_fma(uv, cs2, -(ur * sn2));
+                const f2 e1 = 1.0f - a;
+                const f2 r1 = {hw_rcp(e1.x), hw_rcp(e1.y)};
+                const f2 t = -b * r1;
+                const f2 z = t * t;
+                f2 p = __builtin_elementwise_fma(f2{2.456724578e-03f, 2.456724578e-03f}, z, f2{-1.440135792e-02f, -1.440135792e-02f});
+                p = __builtin_elementwise_fma(p, z, f2{3.978122362e-02f, 3.978122362e-02f});
+                p = __builtin_elementwise_fma(p, z, f2{-7.234857378e-02f, -7.234857378e-02f});
+                p = __builtin_elementwise_fma(p, z, f2{1.049894609e-01f, 1.049894609e-01f});
+                p = __builtin_elementwise_fma(p, z, f2{-1.416122920e-01f, -1.416122920e-01f});
+                p = __builtin_elementwise_fma(p, z, f2{1.998590677e-01f, 1.998590677e-01f});
+                p = __builtin_elementwise_fma(p, z, f2{-3.333259703e-01f, -3.333259703e-01f});
+                p = __builtin_elementwise_fma(p, z, f2{9.999998864e-01f, 9.999998864e-01f});
+                acc2 = __builtin_elementwise_fma(sp, p * t, acc2);
+                const f2 den = __builtin_elementwise_fma(b, b, e1 * e1);
+                const f2 r2 = {hw_rcp(den.x), hw_rcp(den.y)};
+                der2 = __builtin_elementwise_fma(q, r2, der2);
+            }
+            acc = acc2.x + acc2.y;
+            der = der2.x + der2.y;
         }
+
         const float fx = fmaf(2.0f * pair_sum(acc), invS, th) - c.target;
         const float dfx = pair_sum(der) * invS;
         if (fx < 0.f) lo = th; else hi = th;

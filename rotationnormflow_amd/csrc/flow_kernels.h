@@ -622,14 +622,15 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
     {   // Starting point: the exact inverse of ONE Moebius map with the weighted mean centre m = sum wt_k u_k (the map with centre -m
         // applied to the target point).  To first order in the centres the mixture IS that map, and the Newton iteration then needs
         // 3.8 - 4.0 passes per wave on trained-like weights instead of 5.4 - 6.7 from theta = pi (tests/test_inverse_rootfinder.py).
-        float mr = 0.f, mv = 0.f;
+        f2 mr2 = {0.f, 0.f}, mv2 = {0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 4 * KT; ++s) {
-            mr = fmaf(sg.sp[s], sg.ur[s], mr);
-            mv = fmaf(sg.sp[s], sg.uv[s], mv);
+        for (int s = 0; s < 4 * KT; s += 2) {
+            const f2 sp = {sg.sp[s], sg.sp[s + 1]};
+            mr2 = __builtin_elementwise_fma(sp, f2{sg.ur[s], sg.ur[s + 1]}, mr2);
+            mv2 = __builtin_elementwise_fma(sp, f2{sg.uv[s], sg.uv[s + 1]}, mv2);
         }
-        mr = pair_sum(mr) * invS;
-        mv = pair_sum(mv) * invS;
+        const float mr = pair_sum(mr2.x + mr2.y) * invS;
+        const float mv = pair_sum(mv2.x + mv2.y) * invS;
         float st, ct;
         sincos_small(c.target, st, ct);
         const float a = -fmaf(mv, st, mr * ct);                     // (a, b) = (-m) conj(z_target)
@@ -696,13 +697,20 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
     const float mid = fmaf(n + 0.5f, cell, 0.5f * kPi);
     float sn, cs;
     sincos_small(mid, sn, cs);
-    float J = 0.f;
+    float J;
+    {
+        f2 J2 = {0.f, 0.f};
+        const f2 sn2 = {sn, sn}, cs2 = {cs, cs};
 #pragma unroll
-    for (int s = 0; s < 4 * KT; ++s) {
-        const float a = fmaf(sg.uv[s], sn, sg.ur[s] * cs);
-        const float b = fmaf(sg.uv[s], cs, -sg.ur[s] * sn);
-        const float e1 = 1.0f - a;
-        J = fmaf(sg.q[s], hw_rcp(fmaf(b, b, e1 * e1)), J);
+        for (int s = 0; s < 4 * KT; s += 2) {
+            const f2 ur = {sg.ur[s], sg.ur[s + 1]}, uv = {sg.uv[s], sg.uv[s + 1]}, q = {sg.q[s], sg.q[s + 1]};
+            const f2 a = __builtin_elementwise_fma(uv, sn2, ur * cs2);
+            const f2 b = __builtin_elementwise_fma(uv, cs2, -(ur * sn2));
+            const f2 e1 = 1.0f - a;
+            const f2 den = __builtin_elementwise_fma(b, b, e1 * e1);
+            J2 = __builtin_elementwise_fma(q, f2{hw_rcp(den.x), hw_rcp(den.y)}, J2);
+        }
+        J = J2.x + J2.y;
     }
     J = pair_sum(J);
     const v3f xx = c.f.v * sn + c.f.r * cs;

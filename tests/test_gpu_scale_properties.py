@@ -86,3 +86,45 @@ def test_conditional_chunking_is_invisible():
         lo = (1 << 18) - 1000
         b = fl.log_prob(R[lo:].contiguous(), F[lo:].contiguous())["logp"]
     assert torch.equal(a[lo:], b)
+
+
+STRUCTURES = {
+    "mobius_affine": dict(layers=3),
+    "no_first_affine": dict(layers=3, first_affine=0),
+    "last_affine": dict(layers=3, last_affine=1),
+    "mobius_only": dict(layers=4, rot="None"),
+    "affine_only": dict(layers=3, dist="noflow"),
+    "k16_freq": dict(layers=3, segments=16, frequent_permute=1),
+    "k8": dict(layers=2, segments=8),
+    "lu": dict(layers=2, lu=1),
+    "cond16_first": dict(layers=3, condition=1, feature_dim=16, rot="16UnTrans", frequent_permute=1, last_affine=1, first_affine=0),
+}
+
+
+@pytest.mark.parametrize("name", list(STRUCTURES))
+@pytest.mark.parametrize("direction", ["forward", "inverse"])
+def test_launch_shape_is_invisible(name, direction):
+    """The library picks 4-, 8- or 16-wave workgroups, chunks and staging by launch size; a rotation's result must not depend on it.
+    Rows are evaluated once in a launch just above each dispatch threshold and once in small pieces, for layer stacks that exercise
+    every staging corner (affine blocks staged in LDS or not, consecutive constant layers, one fc_last tile, conditional first layer);
+    a few hundred rows are also checked against the oracle."""
+    cfg = make_config(None, **STRUCTURES[name])
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=11, regime="trained")
+    fl = product_flow(cfg, w)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    F = cfg.feature_dim if cfg.condition else None
+    for n in (cus * 128 + 33, cus * 256 + 31):                               # just into the 8-wave and the 16-wave forward launches
+        R = torch.from_numpy(synth.uniform_rotations(n, seed=n % 97)).cuda()
+        feat = torch.from_numpy(synth.features(n, F, seed=5)).cuda() if F else None
+        run = (lambda r, f: fl(r, f)) if direction == "forward" else (lambda r, f: fl.inverse(r, f))
+        with torch.no_grad():
+            Rt, ldj = run(R, feat)
+            lo = n - 777
+            Rs, ls = run(R[lo:].contiguous(), None if feat is None else feat[lo:].contiguous())       # 777 rows: the 4-wave shape
+        assert torch.isfinite(ldj).all()
+        assert (ls - ldj[lo:]).abs().max().item() < 3e-6 and (Rs - Rt[lo:]).abs().max().item() < 3e-6
+    pick = slice(n - 256, n)
+    fn = orc.flow_forward if direction == "forward" else orc.flow_inverse
+    wR, wl = fn(cfg, w, R[pick].cpu().numpy(), None if feat is None else feat[pick].cpu().numpy(), torch.float64)
+    tol = 2e-4 if direction == "inverse" else 5e-5                           # inverse: one bisection cell is pi / 2^14
+    assert (ldj[pick].cpu().double() - wl).abs().mean().item() < tol

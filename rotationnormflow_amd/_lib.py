@@ -65,22 +65,27 @@ _SIGNATURES = {
 EXPORTS = tuple(_SIGNATURES)
 
 
+def load(path):
+    """Load one build of the library and bind every export (tools/ab_variants.py loads several builds side by side)."""
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: the MI355X HIP library has not been built and there is no CPU fallback. "
+            "Run `python -m rotationnormflow_amd.build` (needs hipcc).")
+    handle = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(handle, name)
+        fn.restype = res
+        fn.argtypes = args
+    if handle.rnf_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version mismatch; rebuild")
+    return handle
+
+
 def lib():
     """The loaded library (loads on first use)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"{LIB_PATH} is missing: the MI355X HIP library has not been built and there is no CPU fallback. "
-                "Run `python -m rotationnormflow_amd.build` (needs hipcc).")
-        handle = C.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(handle, name)
-            fn.restype = res
-            fn.argtypes = args
-        if handle.rnf_abi_version() != ABI_VERSION:
-            raise RuntimeError("librnf_hip.so ABI version mismatch; rebuild")
-        _lib = handle
+        _lib = load(LIB_PATH)
     return _lib
 
 

@@ -8,6 +8,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "layout.h"
 #include "so3_math.h"
 
@@ -99,6 +101,14 @@ struct GFrag {
         c[8] = b2.x; c[9] = b2.y; c[10] = b2.z; c[11] = b2.w;
         c[12] = b3.x; c[13] = b3.y; c[14] = b3.z; c[15] = b3.w;
         return c;
+    }
+};
+
+// LEAN instantiations (unconditional Moebius / constant-affine stacks): there is no feature projection at all
+struct NoG {
+    __device__ __forceinline__ constexpr explicit operator bool() const { return false; }
+    __device__ __forceinline__ f32x16 load(int, int, int) const {
+        return f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     }
 };
 
@@ -416,7 +426,8 @@ struct MobiusCtx {
     bool cyc;         // branch of mobiusflow.py:75 / :172
 };
 
-template <int DIR>
+// S7: the context carries the frame PRE-SCALED by 0.7 (so3_math.h seg_s7_stage); mobius_fwd_finish<true> undoes the scale
+template <int DIR, bool S7 = false>
 __device__ __forceinline__ void mobius_begin(const Rot &R, int perm_row, MobiusCtx &c) {
     const int p0 = perm_row % 3, p1 = (perm_row + 1) % 3;                        // flow/flow.py:13-15
     c.p0 = p0;
@@ -433,13 +444,17 @@ __device__ __forceinline__ void mobius_begin(const Rot &R, int perm_row, MobiusC
     if (DIR) {   // target angle of the given column (== pi by construction), wrapped and snapped (mobiusflow.py:157-167)
         c.target = fabsf(c.zth - kTwoPi) < 1e-4f ? 0.f : c.zth;
     }
+    if (S7) c.f = scale_frame(c.f, kSquash);
 }
 
 // HALF (split-precision kernels): A accumulates sp * atan(t), mobius_fwd_finish<true> adds the constant part (so3_math.h)
 template <bool HALF>
 __device__ __forceinline__ void segments4(const f32x16 &o, const MobiusCtx &c, float &S, float &A, float &J) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) segment_fwd_pi<HALF>(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, S, A, J);
+    for (int g = 0; g < 4; ++g) {
+        if constexpr (HALF) segment_fwd_s7(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, S, A, J);      // c.f is the 0.7-scaled frame
+        else segment_fwd_pi<false>(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, S, A, J);
+    }
 }
 
 // forward, all fc_last tiles resident (K <= 64): software pipelined BY HAND.  Tile tau+1's 32 dependent MFMAs (64
@@ -478,7 +493,7 @@ __device__ __forceinline__ void tile_pipe(const float *rec, int lane, int h, con
 // behind the last matrix instruction of k-step s into the same registers (one look-ahead, 8 registers instead of 32).
 template <int M>
 __device__ __forceinline__ void tile_step_h(const float *rec, int lane, f32x16 &nxt, h8 &ah, h8 &al, const ActFrag &in,
-                                            const f32x16 &cur, SegPi (&seg)[4], const MobiusCtx &c, float &S, float &A, float &J) {
+                                            const f32x16 &cur, SegS7 (&seg)[4], const MobiusCtx &c, float &S, float &A, float &J) {
     constexpr int ks = M / 3, term = M % 3;
     if constexpr (term == 0) nxt = RNF_MFMA_H(ah, in.hi[ks], nxt);
     else if constexpr (term == 1) nxt = RNF_MFMA_H(ah, in.lo[ks], nxt);
@@ -488,12 +503,12 @@ __device__ __forceinline__ void tile_step_h(const float *rec, int lane, f32x16 &
         al = lds_h8(rec, ((ks + 1) * 2 + 1) * 64 + lane);
     }
     constexpr int g = M / 3, st = M % 3;
-    seg_pi_stage<st>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, S, A, J);
+    seg_s7_stage<st>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, S, A, J);
     // NOTE: the slice's results are only consumed slots later, and sched_barrier orders the machine scheduler, not the IR passes: the
     // optimiser sinks this arithmetic past the fences into one VALU block behind the 12 matrix instructions.  Pinning each slice in
     // its slot (-DRNF_PIN_L) gives the interleaved stream the source suggests and measured 0.8 % SLOWER, so the shipped build does not.
 #ifdef RNF_PIN_L
-    if constexpr (st == 0) asm volatile("" : "+v"(seg[g].ur), "+v"(seg[g].uv));
+    if constexpr (st == 0) asm volatile("" : "+v"(seg[g].a), "+v"(seg[g].b), "+v"(seg[g].n2), "+v"(seg[g].D));
     else if constexpr (st == 1) asm volatile("" : "+v"(seg[g].t), "+v"(seg[g].c), "+v"(seg[g].p), "+v"(seg[g].z));
     else asm volatile("" : "+v"(S), "+v"(A), "+v"(J));
 #endif
@@ -506,12 +521,12 @@ __device__ __forceinline__ void tile_pipe_h(const float *rec, int lane, int h, c
     nxt = load_bias16(rec + MOB_LAST_TILE_BIAS + h * 16);
     h8 ah = lds_h8(rec, 0 * 64 + lane);
     h8 al = lds_h8(rec, 1 * 64 + lane);
-    SegPi seg[4];
+    SegS7 seg[4];
     __builtin_amdgcn_sched_barrier(0);
     tile_step_h<0>(rec, lane, nxt, ah, al, tt, cur, seg, c, S, A, J);
 }
 
-template <int PREC>
+template <int PREC, bool PINGPONG = false>
 __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int lane, int h, const typename Mlp<PREC>::Act &tt,
                                                  const MobiusCtx &c, float &S, float &A, float &J, Fair &fair) {
     const float *rec = lds + MOB_LAST;
@@ -532,6 +547,21 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int l
         // tile tau+1's 12 matrix instructions and tile tau's segment math in one loop body (tile_pipe_h).  (`cur = nxt` costs 8
         // v_mov_b64 per tile; the two-tiles-per-trip ping-pong of the fp32 path avoids them but spills 10 registers under the 128
         // budget of the 16-wave instantiation and measured 1 % slower.)
+        if constexpr (PINGPONG) {          // two tiles per trip, the accumulators change roles: no register copies
+            f32x16 bufA = Mlp<1>::last(rec, lane, h, tt), bufB;
+            int tau = 1;
+            for (; tau + 1 < KT; tau += 2) {
+                tile_pipe_h(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt, bufB, bufA, c, S, A, J);
+                tile_pipe_h(rec + (tau + 1) * MOB_LAST_TILE_FLOATS, lane, h, tt, bufA, bufB, c, S, A, J);
+            }
+            if (tau < KT) {
+                tile_pipe_h(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt, bufB, bufA, c, S, A, J);
+                segments4<true>(bufB, c, S, A, J);
+            } else {
+                segments4<true>(bufA, c, S, A, J);
+            }
+            return;
+        }
         f32x16 cur = Mlp<1>::last(rec, lane, h, tt);
         for (int tau = 1; tau < KT; ++tau) {
             f32x16 nxt;
@@ -570,7 +600,7 @@ __device__ __forceinline__ void mobius_fwd_finish(const MobiusCtx &c, float S, f
     float sn, cs;
     // HALF: theta' = pi + 2 A / S, and sin / cos of pi + d are -sin d, -cos d
     sincos_small(HALF ? 2.0f * A * invS : A * invS, sn, cs);
-    if (HALF) { sn = -sn; cs = -cs; }
+    if (HALF) { sn *= -kInvSquash; cs *= -kInvSquash; }                                   // the frame of the split-precision path is 0.7-scaled
     const v3f tx = c.f.v * sn + c.f.r * cs;
     const v3f tz = normalize3(c.cyc ? cross3(tx, c.y) : cross3(c.y, tx));               // mobiusflow.py:75-79
     set_col(R, c.p0, tx);
@@ -845,7 +875,9 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 #define RNF_STAMP_FLUSH
 #endif
 
-template <int DIR, int KT_INV, int NW, bool PIPE, int PREC, bool EXT = false>
+// LEAN: the stack holds Moebius and constant 4x4 affine layers only, nothing conditional, no saved states (BASELINE configs C1 / C2 / C3):
+// every other layer kind, the feature-projection reads and the kind dispatch are compiled out.
+template <int DIR, int KT_INV, int NW, bool PIPE, int PREC, bool EXT = false, bool LEAN = false>
 __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -925,7 +957,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             const int2 d = args.layers[layer_at(pos)];
             const int kind = d.x & 15, perm_row = (d.x >> 4) & 15, slot = ((d.x >> 8) & 255) - 1;
             const float *params = args.blob + d.y;
-            if (DIR == 0 && args.states && valid && h == 0) {       // saved for train_kernels.h (backward recomputes from here)
+            if (!LEAN && DIR == 0 && args.states && valid && h == 0) {       // saved for train_kernels.h (backward recomputes from here)
                 float *dst = args.states + ((size_t)pos * args.states_n + args.sample_base + sample_now()) * 9;
                 dst[0] = R.c0.x; dst[1] = R.c1.x; dst[2] = R.c2.x;
                 dst[3] = R.c0.y; dst[4] = R.c1.y; dst[5] = R.c2.y;
@@ -942,24 +974,29 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 RNF_STAMP(6)                                      // 6: unconditional affine layer
                 continue;
             }
-            if (kind == RNF_KIND_GS9) {                           // Uncondition9Trans: the inverse pass uses M^-1 (squeezetrans.py:259-261)
+            if (!LEAN && kind == RNF_KIND_GS9) {                  // Uncondition9Trans: the inverse pass uses M^-1 (squeezetrans.py:259-261)
                 gs9_apply(params + (DIR ? 9 : 0), R, ldj);
                 continue;
             }
-            if (kind == RNF_KIND_GS36) {                          // Uncondition36Trans (squeezetrans.py:355-361)
+            if (!LEAN && kind == RNF_KIND_GS36) {                 // Uncondition36Trans (squeezetrans.py:355-361)
                 gs36_apply(params + (DIR ? 36 : 0), R, ldj);
                 continue;
             }
 
             // ---- layers with a conditioner MLP ----
-            GFrag<EXT> gfrag{nullptr, EXT && args.g_div > 0};
-            if (slot >= 0) {
-                if (EXT && args.g_div > 0) {
-                    long long row = (args.sample_base + (valid ? sample_now() : 0)) / args.g_div;
-                    if (row >= args.g_rows) row = args.g_rows - 1;
-                    gfrag.p = args.G + ((size_t)slot * args.g_rows + row) * 64;
-                } else {
-                    gfrag.p = args.G + ((size_t)slot * args.g_groups + group) * G_FLOATS_PER_GROUP;
+            typedef typename std::conditional<LEAN, NoG, GFrag<EXT>>::type GF;
+            GF gfrag{};
+            if constexpr (!LEAN) {
+                gfrag.p = nullptr;
+                gfrag.rows = EXT && args.g_div > 0;
+                if (slot >= 0) {
+                    if (EXT && args.g_div > 0) {
+                        long long row = (args.sample_base + (valid ? sample_now() : 0)) / args.g_div;
+                        if (row >= args.g_rows) row = args.g_rows - 1;
+                        gfrag.p = args.G + ((size_t)slot * args.g_rows + row) * 64;
+                    } else {
+                        gfrag.p = args.G + ((size_t)slot * args.g_groups + group) * G_FLOATS_PER_GROUP;
+                    }
                 }
             }
             // where the NEXT image comes from (DMA mode): next MLP layer of this tile, else the first one of the next tile
@@ -979,8 +1016,8 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
 
             MobiusCtx ctx;
             typename Mlp<PREC>::Act tt;
-            if (kind == RNF_KIND_MOBIUS) {
-                mobius_begin<DIR>(R, perm_row, ctx);
+            if (LEAN || kind == RNF_KIND_MOBIUS) {
+                mobius_begin<DIR, DIR == 0 && PREC == 1>(R, perm_row, ctx);
                 Mlp<PREC>::head(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair);
             } else {
                 Mlp<PREC>::head(lds, lane, h, 0.f, 0.f, 0.f, gfrag, tt, fair);
@@ -1011,7 +1048,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 RNF_STAMP(4)                                      // 4: barrier B2 (+ DMA issue)
             };
             auto barrier2 = [&]() { b2_sync(); b2_issue(); };
-            if (kind == RNF_KIND_MOBIUS) {
+            if (LEAN || kind == RNF_KIND_MOBIUS) {
                 if constexpr (DIR != 0) {
                     InvSegs<KTI> sg;
                     float S = 0.f;
@@ -1025,7 +1062,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     b2_issue();
                 } else {
                     float S = 0.f, A = 0.f, J = 0.f;
-                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC>(lds, KT, lane, h, tt, ctx, S, A, J, fair);
+                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC, LEAN>(lds, KT, lane, h, tt, ctx, S, A, J, fair);
                     else mobius_fwd_tiles_restage<PREC>(lds, params, KT, lane, h, tt, ctx, S, A, J, tid, NT);
                     barrier2();
                     mobius_fwd_finish<PREC == 1>(ctx, S, A, J, R, ldj);

@@ -404,9 +404,29 @@ static bool staging_dma() {
     return mode == 1;
 }
 
+// RNF_LEAN=0 keeps unconditional Moebius / affine stacks on the general instantiation (measurement switch)
+static bool lean_allowed() {
+#ifdef RNF_NO_LEAN
+    return false;
+#endif
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = std::getenv("RNF_LEAN");
+        mode = (e && e[0] == '0') ? 0 : 1;
+    }
+    return mode == 1;
+}
+
 template <int DIR, int KT_INV, bool PIPE, int PREC, bool EXT = false>
-static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream, int nwk) {
+static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream, int nwk, bool lean = false) {
     if constexpr (DIR == 0 && PREC == 1 && PIPE && !EXT) {
+        if (nwk == NW_FWD_WIDE && lean) {        // lean instantiation: Moebius + constant-affine layers only (BASELINE C1 / C2 / C3)
+            auto kern = flow_stack_kernel<DIR, KT_INV, NW_FWD_WIDE, PIPE, PREC, false, true>;
+            HIP_TRY(allow_lds(kern, lds_bytes));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_FWD_WIDE * 64), lds_bytes, stream, a);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
         if (nwk == NW_FWD_WIDE) {
             auto kern = flow_stack_kernel<DIR, KT_INV, NW_FWD_WIDE, PIPE, PREC, EXT>;
             HIP_TRY(allow_lds(kern, lds_bytes));
@@ -459,6 +479,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     int min_tiles = 1;                       // fc_last tiles the largest non-Moebius record needs resident in LDS
     bool any_mlp = false, ext = false;       // ext: the flow contains a layer kind only the extended kernel instantiation carries
     int prec = -1;
+    bool lean = lean_allowed() && !o.states;   // Moebius + constant 4x4 affine layers only, nothing conditional, no saved states
     for (int l = 0; l < n_layers; ++l) {
         const int32_t *d = desc + (size_t)l * D_STRIDE;
         const int kind = d[D_KIND], perm = d[D_PERM], slot = d[D_SLOT];
@@ -468,6 +489,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         if ((kind == RNF_KIND_COND16 || kind_is_cond9(kind) || kind == RNF_KIND_COND36) && slot < 0)
             return fail("layer %d: a conditional affine layer needs a cond_slot", l);
         if (kind_is_cond9(kind) || kind == RNF_KIND_COND36) ext = true;
+        if ((kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16) || slot >= 0) lean = false;
         if (kind == RNF_KIND_COND36) min_tiles = 2;
         if (slot >= 0) {
             if (slot >= MAX_SLOTS) return fail("layer %d: cond_slot %d >= %d", l, slot, MAX_SLOTS);
@@ -612,7 +634,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
                         : launch_stack<DIR_, KT_, true, 0, true>(a, grid, lds_bytes, stream, nwk))                  \
                 : (prec ? launch_stack<DIR_, KT_, false, 1, true>(a, grid, lds_bytes, stream, nwk)                  \
                         : launch_stack<DIR_, KT_, false, 0, true>(a, grid, lds_bytes, stream, nwk))) :              \
-    (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1>(a, grid, lds_bytes, stream, nwk)                               \
+    (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1>(a, grid, lds_bytes, stream, nwk, lean && a.tab_off >= 0)       \
                   : launch_stack<DIR_, KT_, true, 0>(a, grid, lds_bytes, stream, nwk))                              \
           : (prec ? launch_stack<DIR_, KT_, false, 1>(a, grid, lds_bytes, stream, nwk)                              \
                   : launch_stack<DIR_, KT_, false, 0>(a, grid, lds_bytes, stream, nwk)))

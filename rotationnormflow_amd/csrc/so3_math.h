@@ -318,6 +318,55 @@ RNF_HD void seg_pi_stage(SegPi &g, float s_raw, float w0, float w1, float w2, co
     }
 }
 
+// ---- the forward segment WITHOUT the squash reciprocal (round 2) --------------------------------------------------------------
+// With a = 0.7 w.r, b = 0.7 w.v (the frame handed in is PRE-SCALED by 0.7: Frame7), n2 = a^2 + b^2 = (0.7 |w|)^2 and D = 1 + |w|
+// the squashed centre of flow/mobiusflow.py:72 is u = (a, b) / D, and everything the segment needs is a ratio in which D cancels:
+//     t = uv / (1 + ur)                       = b / (D + a)
+//     c = (1 - |u|^2) / (uv^2 + (1 + ur)^2)   = (D^2 - n2) / ((D + a)^2 + b^2)
+// so 0.7 / (1 + |w|) is never formed: 37 VALU instructions with 5 transcendentals (sqrt, 2 rcp, exp2, log2) instead of 44 with 6,
+// and D + a >= 1 + 0.3 |w| >= 1 is better conditioned than 1 + ur >= 0.3.  HALF convention (A accumulates sp * atan(t)).
+constexpr float kSquash = 0.7f;                         // flow/mobiusflow.py:72
+constexpr float kInvSquash = 1.0f / 0.7f;
+RNF_HD Frame scale_frame(const Frame &f, float k) { return Frame{f.r * k, f.v * k}; }
+
+struct SegS7 {
+    float a, b, n2, D, t, c, z, p;
+};
+template <int STAGE>
+RNF_HD void seg_s7_stage(SegS7 &g, float s_raw, float w0, float w1, float w2, const Frame &f7, float &S, float &A, float &J) {
+    if constexpr (STAGE == 0) {
+        g.a = fmaf(w2, f7.r.z, fmaf(w1, f7.r.y, w0 * f7.r.x));
+        g.b = fmaf(w2, f7.v.z, fmaf(w1, f7.v.y, w0 * f7.v.x));
+        g.n2 = fmaf(g.b, g.b, g.a * g.a);
+        g.D = fmaf(hw_sqrt(g.n2), kInvSquash, 1.0f);
+    } else if constexpr (STAGE == 1) {
+        const float e = g.D + g.a;
+        g.t = g.b * hw_rcp(e);
+        g.c = fmaf(g.D, g.D, -g.n2) * hw_rcp(fmaf(g.b, g.b, e * e));
+        g.z = g.t * g.t;
+        float p = fmaf(2.456724578e-03f, g.z, -1.440135792e-02f);
+        p = fmaf(p, g.z, 3.978122362e-02f);
+        p = fmaf(p, g.z, -7.234857378e-02f);
+        g.p = fmaf(p, g.z, 1.049894609e-01f);
+    } else {
+        float p = fmaf(g.p, g.z, -1.416122920e-01f);
+        p = fmaf(p, g.z, 1.998590677e-01f);
+        p = fmaf(p, g.z, -3.333259703e-01f);
+        p = fmaf(p, g.z, 9.999998864e-01f);
+        const float e = hw_exp2(-1.44269504088896341f * fabsf(s_raw));
+        const float sp = fmaf(hw_log2(1.0f + e), 0.693147180559945309f, relu_bits(s_raw));
+        S += sp;
+        A = fmaf(sp, p * g.t, A);
+        J = fmaf(sp, g.c, J);
+    }
+}
+RNF_HD void segment_fwd_s7(float s_raw, float w0, float w1, float w2, const Frame &f7, float &S, float &A, float &J) {
+    SegS7 g;
+    seg_s7_stage<0>(g, s_raw, w0, w1, w2, f7, S, A, J);
+    seg_s7_stage<1>(g, s_raw, w0, w1, w2, f7, S, A, J);
+    seg_s7_stage<2>(g, s_raw, w0, w1, w2, f7, S, A, J);
+}
+
 // pytorch3d.transforms.matrix_to_quaternion (published 0.7.5 rule; call site flow/squeezetrans.py:34):
 // four candidates from sqrt(max(0, 1 +- m00 +- m11 +- m22)), keep the one with the largest |q_i| (first on ties),
 // denominators floored at 0.1.  Real part first.

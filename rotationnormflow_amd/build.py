@@ -12,6 +12,18 @@ DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HER
     os.path.join(os.path.dirname(HERE), "include", "rnf_hip.h")]
 
 
+def source_hash() -> str:
+    """Hash of the kernel sources (csrc/*.h, *.hip, include/rnf_hip.h): recorded beside committed profiler summaries so that bench.py
+    only replays counters that were collected from the sources the running library was built from."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT

@@ -265,10 +265,15 @@ __device__ __forceinline__ void hidden_slot(const float *w_tile, int lane, ActFr
     if constexpr (term == 0) acc = RNF_MFMA_H(ah, f.hi[ks], acc);
     else if constexpr (term == 1) acc = RNF_MFMA_H(ah, f.lo[ks], acc);
     else acc = RNF_MFMA_H(al, f.hi[ks], acc);
+#ifdef RNF_EARLY_AH        // each operand is re-fetched right behind ITS last reader: ah one matrix instruction earlier than al
+    if constexpr (term == 1 && ks + 1 < 4) ah = lds_h8(w_tile, ((ks + 1) * 2 + 0) * 64 + lane);
+    if constexpr (term == 2 && ks + 1 < 4) al = lds_h8(w_tile, ((ks + 1) * 2 + 1) * 64 + lane);
+#else
     if constexpr (term == 2 && ks + 1 < 4) {
         ah = lds_h8(w_tile, ((ks + 1) * 2 + 0) * 64 + lane);
         al = lds_h8(w_tile, ((ks + 1) * 2 + 1) * 64 + lane);
     }
+#endif
     // which fragment this k-step group fills (-1: none) and from which half of `src`
     constexpr int dst = FILL == 1 ? (ks == 0 ? 2 : (ks == 1 ? 3 : -1)) : (FILL == 2 ? (ks == 1 ? 0 : (ks == 2 ? 1 : -1)) : -1);
     if constexpr (dst >= 0) {
@@ -498,10 +503,15 @@ __device__ __forceinline__ void tile_step_h(const float *rec, int lane, f32x16 &
     if constexpr (term == 0) nxt = RNF_MFMA_H(ah, in.hi[ks], nxt);
     else if constexpr (term == 1) nxt = RNF_MFMA_H(ah, in.lo[ks], nxt);
     else nxt = RNF_MFMA_H(al, in.hi[ks], nxt);
+#ifdef RNF_EARLY_AH
+    if constexpr (term == 1 && ks + 1 < 4) ah = lds_h8(rec, ((ks + 1) * 2 + 0) * 64 + lane);
+    if constexpr (term == 2 && ks + 1 < 4) al = lds_h8(rec, ((ks + 1) * 2 + 1) * 64 + lane);
+#else
     if constexpr (term == 2 && ks + 1 < 4) {          // operands of the next k-step: the matrix instruction has read its registers at
         ah = lds_h8(rec, ((ks + 1) * 2 + 0) * 64 + lane);     // issue, the slice below and the other waves cover the LDS latency
         al = lds_h8(rec, ((ks + 1) * 2 + 1) * 64 + lane);
     }
+#endif
     constexpr int g = M / 3, st = M % 3;
     seg_s7_stage<st>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, S, A, J);
     // NOTE: the slice's results are only consumed slots later, and sched_barrier orders the machine scheduler, not the IR passes: the
@@ -513,7 +523,7 @@ __device__ __forceinline__ void tile_step_h(const float *rec, int lane, f32x16 &
     else asm volatile("" : "+v"(S), "+v"(A), "+v"(J));
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (M + 1 < 12) tile_step_h<M + 1>(rec, lane, nxt, ah, al, in, cur, seg, c, S, A, J);
+    if constexpr (M + 1 < 12) tile_step_h<M + 1>(rec, lane, nxt, ah, al, in, cur, seg, c, S, A, J);   // (rec already holds the lane offset when lane == 0 is passed)
 }
 
 __device__ __forceinline__ void tile_pipe_h(const float *rec, int lane, int h, const ActFrag &tt, f32x16 &nxt, const f32x16 &cur,
@@ -524,6 +534,20 @@ __device__ __forceinline__ void tile_pipe_h(const float *rec, int lane, int h, c
     SegS7 seg[4];
     __builtin_amdgcn_sched_barrier(0);
     tile_step_h<0>(rec, lane, nxt, ah, al, tt, cur, seg, c, S, A, J);
+}
+// The same tile addressed through two per-lane offsets the optimiser cannot fold (woff: floats from `base` to this lane's operand slot of
+// the tile, boff: to its bias half): every LDS read of the tile then carries its position as an immediate offset.  With the tile position
+// folded into constants instead, tiles beyond 64 KiB (the fc_last part starts at 50 KiB) need a v_add per read group: the DS offset field
+// is 16 bits.
+__device__ __forceinline__ void tile_pipe_h_off(const float *base, int woff, int boff, const ActFrag &tt, f32x16 &nxt, const f32x16 &cur,
+                                                const MobiusCtx &c, float &S, float &A, float &J) {
+    nxt = load_bias16(base + boff);
+    const float *rec = base + woff;
+    h8 ah = lds_h8(rec, 0 * 64);
+    h8 al = lds_h8(rec, 1 * 64);
+    SegS7 seg[4];
+    __builtin_amdgcn_sched_barrier(0);
+    tile_step_h<0>(rec, 0, nxt, ah, al, tt, cur, seg, c, S, A, J);
 }
 
 template <int PREC, bool PINGPONG = false>
@@ -550,12 +574,17 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int l
         if constexpr (PINGPONG) {          // two tiles per trip, the accumulators change roles: no register copies
             f32x16 bufA = Mlp<1>::last(rec, lane, h, tt), bufB;
             int tau = 1;
+            int woff = MOB_LAST_TILE_FLOATS + 4 * lane, boff = MOB_LAST_TILE_FLOATS + MOB_LAST_TILE_BIAS + 16 * h;
             for (; tau + 1 < KT; tau += 2) {
-                tile_pipe_h(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt, bufB, bufA, c, S, A, J);
-                tile_pipe_h(rec + (tau + 1) * MOB_LAST_TILE_FLOATS, lane, h, tt, bufA, bufB, c, S, A, J);
+                asm volatile("" : "+v"(woff), "+v"(boff));
+                tile_pipe_h_off(rec, woff, boff, tt, bufB, bufA, c, S, A, J);
+                tile_pipe_h_off(rec, woff + MOB_LAST_TILE_FLOATS, boff + MOB_LAST_TILE_FLOATS, tt, bufA, bufB, c, S, A, J);
+                woff += 2 * MOB_LAST_TILE_FLOATS;
+                boff += 2 * MOB_LAST_TILE_FLOATS;
             }
             if (tau < KT) {
-                tile_pipe_h(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt, bufB, bufA, c, S, A, J);
+                asm volatile("" : "+v"(woff), "+v"(boff));
+                tile_pipe_h_off(rec, woff, boff, tt, bufB, bufA, c, S, A, J);
                 segments4<true>(bufB, c, S, A, J);
             } else {
                 segments4<true>(bufA, c, S, A, J);
@@ -966,7 +995,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
 
             if (kind == RNF_KIND_AFFINE16) {
                 if (PIPE && tab_parity >= 0) {                    // block staged in LDS together with the previous layer's fc_last image
-                    affine16_table_apply(lds + args.tab_off + AFF_TABLE_LDS_STRIDE * tab_parity, R, ldj);
+                    affine16_table_apply_pair(lds + args.tab_off + AFF_TABLE_LDS_STRIDE * tab_parity, h, R, ldj);
                     tab_parity = -1;
                 } else {                                          // scalar loads (one ~2 us round trip per layer: 104 floats do not fit the SGPRs at once)
                     affine16_table_apply(params + (DIR ? AFF_TABLE_INV : AFF_TABLE_FWD), R, ldj);

@@ -24,7 +24,7 @@
 // i.e. reference row (c == 0 ? k : K + 3k + c - 1)   (flow/mobiusflow.py:58-61).
 #pragma once
 #include <stdint.h>
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define RNF_LAYOUT_INLINE __host__ __device__ inline constexpr
 #else
 #define RNF_LAYOUT_INLINE inline constexpr
@@ -60,7 +60,7 @@ inline constexpr int64_t mobius_packed_floats(int K) { return MOB_HEAD_FLOATS + 
 
 // ---- unconditional 4x4 affine record ----
 // [0..15] M row-major, [16] log|det M|, [17..32] M^-1, [33] log|det M^-1|, [34] 1.0 if M is orthogonal (log-det exactly 0), [35] 0,
-// [36..139] forward block: the 10x10 table of M (so3_math.h affine16_table), log|det M|, the orthogonal flag, 0, 0;
+// [36..139] forward block: the 10x10 table of M in two halves of 52 floats (so3_math.h affine16_table: five rows, log|det M|, the orthogonal flag);
 // [140..243] the same block for M^-1 (the inverse pass).  The forward kernel stages one block in LDS next to the layer images.
 constexpr int AFF_TABLE_FWD = 36, AFF_TABLE_INV = 140, AFF_TABLE_FLOATS = 104;
 constexpr int AFF_FLOATS = 244;

@@ -422,11 +422,15 @@ RNF_HD void affine16_apply(const float (&M)[16], float logabsdet, Rot &R, float 
 //     [ |q'|^2 ; |q'|^2 R' (row-major) ] = T . [ 1 ; R (row-major) ]       with one 10x10 table T(M) built by the packer (in double),
 // 90 fma + 1 rcp + 9 mul + log instead of the 4-candidate square-root selection, matrix-vector product and re-expansion (~330 VALU).
 // Same result as affine16_apply up to fp32 rounding (the quaternion's sign and the candidate choice never mattered).
+// Storage: two halves of 52 floats -- half hh holds rows 5 hh .. 5 hh + 4 of the table (T[52 hh + 10 i' + k]) followed by log|det M| and
+// the orthogonal flag -- so that the two lanes of a pair can each evaluate five of the ten rows from 13 aligned float4 of their own
+// (affine16_table_apply_pair) and exchange the results.
+constexpr int AFF_HALF = 52;
+RNF_HD int aff_idx(int row, int k) { return AFF_HALF * (row / 5) + 10 * (row % 5) + k; }
 RNF_HD void affine16_table(const double *M /* 4x4 row-major */, float logabsdet, bool orthogonal, float *T /* AFF_TABLE_FLOATS */) {
 #pragma clang fp contract(off)
-    T[100] = logabsdet;
-    T[101] = orthogonal ? 1.0f : 0.0f;
-    T[102] = T[103] = 0.0f;
+    T[50] = T[AFF_HALF + 50] = logabsdet;
+    T[51] = T[AFF_HALF + 51] = orthogonal ? 1.0f : 0.0f;
     for (int k = 0; k < 10; ++k) {
         double in[10];
         for (int i = 0; i < 10; ++i) in[i] = (i == k) ? 1.0 : 0.0;
@@ -467,26 +471,48 @@ RNF_HD void affine16_table(const double *M /* 4x4 row-major */, float logabsdet,
         o[7] = 2.0 * (P[1][3] - P[0][2]);
         o[8] = 2.0 * (P[2][3] + P[0][1]);
         o[9] = P[0][0] - P[1][1] - P[2][2] + P[3][3];
-        for (int i = 0; i < 10; ++i) T[10 * i + k] = (float)o[i];
+        for (int i = 0; i < 10; ++i) T[aff_idx(i, k)] = (float)o[i];
     }
 }
 
+RNF_HD void affine16_finish(const float (&o)[10], float logabsdet, float orthogonal, Rot &R, float &ldj) {
+    const float inv = hw_rcp(o[0]);
+    R.c0.x = o[1] * inv; R.c1.x = o[2] * inv; R.c2.x = o[3] * inv;
+    R.c0.y = o[4] * inv; R.c1.y = o[5] * inv; R.c2.y = o[6] * inv;
+    R.c0.z = o[7] * inv; R.c1.z = o[8] * inv; R.c2.z = o[9] * inv;
+    if (orthogonal == 0.0f) ldj += fmaf(-2.0f * 0.693147180559945309f, hw_log2(o[0]), logabsdet);
+}
 RNF_HD void affine16_table_apply(const float *T, Rot &R, float &ldj) {
     const float r[9] = {R.c0.x, R.c1.x, R.c2.x, R.c0.y, R.c1.y, R.c2.y, R.c0.z, R.c1.z, R.c2.z};
     float o[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        float a = T[10 * i];
+        float a = T[aff_idx(i, 0)];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) a = fmaf(T[10 * i + 1 + k], r[k], a);
+        for (int k = 0; k < 9; ++k) a = fmaf(T[aff_idx(i, 1 + k)], r[k], a);
         o[i] = a;
     }
-    const float inv = hw_rcp(o[0]);
-    R.c0.x = o[1] * inv; R.c1.x = o[2] * inv; R.c2.x = o[3] * inv;
-    R.c0.y = o[4] * inv; R.c1.y = o[5] * inv; R.c2.y = o[6] * inv;
-    R.c0.z = o[7] * inv; R.c1.z = o[8] * inv; R.c2.z = o[9] * inv;
-    if (T[101] == 0.0f) ldj += fmaf(-2.0f * 0.693147180559945309f, hw_log2(o[0]), T[100]);
+    affine16_finish(o, T[50], T[51], R, ldj);
 }
+#if defined(__HIPCC__)
+// The same layer with the ten rows split over the two lanes (j, j + 32) that hold one rotation: lane half h evaluates rows 5h .. 5h + 4
+// (45 FMAs instead of 90) and one v_permlane32_swap per row hands both halves to both lanes (v, v -> {row of half 0, row of half 1}).
+__device__ __forceinline__ void affine16_table_apply_pair(const float *T, int h, Rot &R, float &ldj) {
+    const float r[9] = {R.c0.x, R.c1.x, R.c2.x, R.c0.y, R.c1.y, R.c2.y, R.c0.z, R.c1.z, R.c2.z};
+    const float *Th = T + AFF_HALF * h;
+    float o[10];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        float a = Th[10 * i];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a = fmaf(Th[10 * i + 1 + k], r[k], a);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+        o[i] = __uint_as_float(sw[0]);
+        o[5 + i] = __uint_as_float(sw[1]);
+    }
+    affine16_finish(o, Th[50], Th[51], R, ldj);
+}
+#endif
 
 // ---- 3x3 / 6x6 ablation layers: Gram-Schmidt of two transformed columns, log-det from three tangent directions ----------------
 // (calculate_9 / calculate_36, flow/squeezetrans.py:176-231, 293-331).  a0, a1: the two columns; da0[k], da1[k]: their derivatives

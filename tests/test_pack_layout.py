@@ -104,13 +104,15 @@ def test_affine16_record():
     from oracle import flow_oracle as orc
     R = synth.uniform_rotations(64, seed=4).astype(np.float64)
     for off, mat in ((36, M.astype(np.float64)), (140, np.linalg.inv(M.astype(np.float64)))):
-        T = rec[off:off + 100].reshape(10, 10).astype(np.float64)
+        # two halves of 52 floats: five rows of the table, log|det|, the orthogonal flag (so3_math.h affine16_table)
+        halves = rec[off:off + 104].reshape(2, 52)
+        T = halves[:, :50].reshape(10, 10).astype(np.float64)
         out = np.concatenate([np.ones((64, 1)), R.reshape(64, 9)], axis=1) @ T.T
         q = orc.matrix_to_quaternion(torch.from_numpy(R)).numpy() @ mat.T
         want = orc.quaternion_to_matrix(torch.from_numpy(q)).numpy()
         assert np.abs(out[:, 0] - (q * q).sum(1)).max() < 1e-6
         assert np.abs(out[:, 1:] / out[:, :1] - want.reshape(64, 9)).max() < 1e-6
-        assert rec[off + 100] == rec[16 if off == 36 else 33] and np.abs(rec[off + 101:off + 104]).max() == 0.0
+        assert (halves[:, 50] == rec[16 if off == 36 else 33]).all() and (halves[:, 51] == 0.0).all()
 
 
 @pytest.mark.parametrize("K", [8, 64])

@@ -4,6 +4,9 @@ the benchmark launches, not the parity spot check), plus the HBM traffic per lau
 MI355X_MICROARCH.md (FETCH_SIZE counts 64 B per 128-B request: x2; both counters are in KiB).
 
     python tools/pmc_summary.py <out.csv> <out.json> <kernel substring> <rocprofv3 output dir> [more dirs ...]
+
+The JSON records the hash of the kernel sources (rotationnormflow_amd.build.source_hash) and the rotations per launch
+(RNF_PMC_ROTATIONS, default 2^20): bench.py replays a committed summary only when both match the running build / batch.
 """
 import csv
 import glob
@@ -11,6 +14,8 @@ import json
 import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
@@ -40,7 +45,9 @@ def main():
             vals = [v for g, v in rows[name] if g == gmax]
             summary[name] = sum(vals) / len(vals)
             fh.write(f"{name},{summary[name]:.1f},{len(vals)},{gmax}\n")
-    out = {"kernel": next(iter(meta.values()))[4] if meta else None, "counters": summary}
+    from rotationnormflow_amd.build import source_hash
+    out = {"kernel": next(iter(meta.values()))[4] if meta else None, "counters": summary, "csrc_sha": source_hash(),
+           "rotations_per_launch": int(os.environ.get("RNF_PMC_ROTATIONS", 1 << 20))}
     if meta:
         g, wg, vgpr, lds, _ = next(iter(meta.values()))
         out.update(workgroup_size=wg, vgpr_count=vgpr, lds_block_size=lds)

@@ -68,7 +68,7 @@ static void pack_w64(float *img, int n_ot, RowFn row_of /* (ot, i) -> const floa
 // split-precision image of the same rows: [ot][s (4)][hi, lo][lane] 8 x fp16, element j of lane (i, h) of k-step
 // s = 2t + s' is W[row][32t + 16s' + 8(j>>2) + 4h + (j&3)] as hi = fp16(w), lo = fp16(w - hi) (unscaled, flow_kernels.h; the feature
 // projection images keep lo scaled by 2^12, layout.h)
-static bool g_half_overflow = false;
+static thread_local bool g_half_overflow = false;     // per calling thread: ctypes releases the GIL and two flows may be packed at once
 template <typename RowFn>
 static void pack_w64_h(float *img, int n_ot, RowFn row_of) {
     _Float16 *out = reinterpret_cast<_Float16 *>(img);

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define RNF_ABI_VERSION 3
+#define RNF_ABI_VERSION 4
 
 /* width of the conditioner MLP's hidden layers: flow/condition.py:9 (Nh=64, never overridden by any caller) */
 #define RNF_HIDDEN 64
@@ -34,8 +34,15 @@ extern "C" {
  *   desc[i][3] cond_slot     index of this layer among the layers that consume the feature vector, or -1
  *   desc[i][4] feat_offset   offset in the blob of the layer's packed feature-projection weights, or -1
  *   desc[i][5] precision     RNF_PREC_* the layer's weight image was packed with (same for every MLP layer)
+ *   desc[i][6] fallback param_offset   } RNF_PREC_F16X2 flows only: offsets in the SAME blob of the layer's records packed with
+ *   desc[i][7] fallback feat_offset    } RNF_PREC_FP32 (or -1).  When every MLP layer has them, each rnf_flow_forward / _inverse /
+ *                            _log_prob call is GUARDED: a sample that ends non-finite (an fp16 operand left the fp16 range, |x| >= 65504;
+ *                            flow/condition.py:24-30 has no such limit) sets a device flag and the exact-fp32 kernels, launched right
+ *                            behind on the same stream, redo the chunk -- they return at once when the flag is clear.  No host
+ *                            synchronisation; int32 word 1 of the last 8 bytes of the first 32 KiB of the workspace is 1 after a call in
+ *                            which the re-run happened.
  */
-#define RNF_DESC_STRIDE 6
+#define RNF_DESC_STRIDE 8
 #define RNF_LAYER_MOBIUS 1        /* flow/mobiusflow.py:27-183  MobiusFlow                                  */
 #define RNF_LAYER_AFFINE16 2      /* flow/squeezetrans.py:161-174 Uncondition16Trans (any constant 4x4 M)   */
 #define RNF_LAYER_AFFINE16_COND 3 /* flow/squeezetrans.py:41-55  Condition16Trans (M = I + MLP(feature))    */

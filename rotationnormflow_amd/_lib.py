@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librnf_hip.so")
 
 _lib = None
-ABI_VERSION = 3
+ABI_VERSION = 4
 PREC_FP32, PREC_F16X2 = 0, 1
 
 c_f32p = C.c_void_p      # device or host float*, passed as integer addresses

@@ -46,7 +46,7 @@ class TrainPlan:
         rec_sizes = []
         for i, (layer, (kind, k, f)) in enumerate(zip(layers, shapes)):
             flagged = kind | (ORTHOGONAL_FLAG if getattr(layer, "_rnf_orthogonal", False) else 0)
-            self.desc[i] = (kind, perm_rows[i], rec_off, -1, -1, self.prec)
+            self.desc[i] = (kind, perm_rows[i], rec_off, -1, -1, self.prec, -1, -1)     # no fp32 fallback images in training
             self.pack_desc[i] = (flagged, plain_off, rec_off, -1)
             self.train_desc[i] = (flagged, perm_rows[i], plain_off)
             if kind == runtime.KIND_MOBIUS:

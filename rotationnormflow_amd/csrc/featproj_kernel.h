@@ -23,6 +23,7 @@ struct FeatProjArgs {
     int F;
     int n_slots;
     int row_mode;            // 1: the "samples" are shared feature rows; G holds a 64-float record per (slot, row), see flow_kernels.h GFrag
+    const int *only_if;      // != nullptr: run only when *only_if != 0 (exact-fp32 re-run of a guarded split-precision call)
     int feat_off[MAX_SLOTS]; // blob offset (floats) of each slot's featproj record
 };
 
@@ -58,6 +59,7 @@ struct GOut {
 template <int NW, int PREC>
 __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (args.only_if && __hip_atomic_load(args.only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     constexpr int NT = NW * 64;

@@ -45,6 +45,11 @@ struct FlowArgs {
     int n_layers;
     int KT;                   // fc_last tiles = segments / 8
     int tab_off;              // >= 0 (DMA staging): float offset in LDS of two AFF_TABLE_LDS_STRIDE-float buffers for constant-affine blocks
+    // Range guard of the split-precision kernels (an fp16 operand beyond 65504 turns into inf and the sample's log-det into NaN):
+    //   guard_mode 1: set guard[0] when a sample ends with a non-finite log-det or rotation;
+    //   guard_mode 2 (the exact-fp32 instantiation launched right behind): run only if guard[0] != 0, and note the re-run in guard[1].
+    int *guard;
+    int guard_mode;
     // per layer: x = kind | perm_row << 4 | (cond_slot + 1) << 8 | (position of the next MLP layer + 1) << 16 ; y = param offset (floats)
     int2 layers[MAX_LAYERS];
 };
@@ -332,7 +337,7 @@ struct Mlp<0> {
     // g: this wave's feature-projection fragments for the layer (global memory), or nullptr for an unconditional layer
     template <class GF>
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
-                                                const GF &g, Act &out, Fair &) {
+                                                const GF &g, Act &out, Fair &, bool &) {
         f32x16 cinit[2];
         if (g) {
             cinit[0] = g.load(0, lane, h);
@@ -359,9 +364,13 @@ struct Mlp<1> {
         c = RNF_MFMA(a.x, bA, c);
         return RNF_MFMA(a.y, bB, c);
     }
+    // `bad`: set when a hidden layer comes out NaN.  An operand beyond the fp16 range splits into (inf, -inf) and turns EVERY output of
+    // the next layer into NaN (each output row meets each input); the integer ReLU of split_pair would then launder a NaN with the sign
+    // bit set into 0, so one accumulator register per hidden layer is tested before it is split (1 VALU each).  An overflow of the last
+    // activation needs no test: the fc_last outputs, the segment sums and finally the log-det are NaN (flow_stack_kernel's guard).
     template <class GF>
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
-                                                const GF &g, Act &out, Fair &fair) {
+                                                const GF &g, Act &out, Fair &fair, bool &bad) {
         const float bA = h ? y1 : y0;
         const float bB = h ? 1.0f : y2;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -372,6 +381,7 @@ struct Mlp<1> {
             f32x16 x0[2];
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) x0[ot] = first_tile(lds, ot, lane, bA, bB, g ? g.load(ot, lane, h) : zero);
+            if (g) bad |= x0[0][0] != x0[0][0];              // a feature beyond the fp16 range: the whole projection row is NaN
             split_act<true>(x0, f);
         }
         auto w = [&](int L, int ot) { return lds + MOB_HID + (L * 2 + ot) * (8 * 64 * 4); };
@@ -379,17 +389,20 @@ struct Mlp<1> {
         // layer 0: tile 0 bare (its input is complete), tile 1 carries the split of tile 0
         f32x16 a0 = bias(0, 0), a1 = bias(0, 1);
         hidden_tile<0>(w(0, 0), lane, f, a0, a0, m1);
+        bad |= a0[0] != a0[0];
         hidden_tile<2>(w(0, 1), lane, f, a1, a0, m1);
         fair.tick();
         // layer 1: tile 0 carries the split of layer 0's tile 1, tile 1 the split of its own tile 0
         f32x16 b0 = bias(1, 0), b1 = bias(1, 1);
         hidden_tile<1>(w(1, 0), lane, f, b0, a1, m1);
+        bad |= b0[0] != b0[0];
         hidden_tile<2>(w(1, 1), lane, f, b1, b0, m1);
         fair.tick();
         // layer 2, then the residual x0 + h3 (flow/condition.py:29) tile by tile: tile 0's residual + split ride behind tile 1's MFMAs
         a0 = bias(2, 0);
         a1 = bias(2, 1);
         hidden_tile<1>(w(2, 0), lane, f, a0, b1, m1);
+        bad |= a0[0] != a0[0];
         a0 = first_tile(lds, 0, lane, bA, bB, a0);
         if (g) {
             const f32x16 gg = g.load(0, lane, h);
@@ -909,6 +922,10 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 template <int DIR, int KT_INV, int NW, bool PIPE, int PREC, bool EXT = false, bool LEAN = false>
 __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (args.guard_mode == 2) {                                      // fp32 re-run of a split-precision call: only when its guard fired
+        if (__hip_atomic_load(args.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+        if (blockIdx.x == 0 && threadIdx.x == 0) args.guard[1] = 1;
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -980,6 +997,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             R.c2 = v3f{src[2], src[5], src[8]};
         }
         float ldj = 0.f;
+        bool bad = false;                                         // split-precision kernels: a hidden layer came out NaN (Mlp<1>::head)
         RNF_STAMP(7)                                              // 7: tile prologue / epilogue
 
         for (int pos = 0; pos < n_layers; ++pos) {
@@ -1047,9 +1065,9 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             typename Mlp<PREC>::Act tt;
             if (LEAN || kind == RNF_KIND_MOBIUS) {
                 mobius_begin<DIR, DIR == 0 && PREC == 1>(R, perm_row, ctx);
-                Mlp<PREC>::head(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair);
+                Mlp<PREC>::head(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair, bad);
             } else {
-                Mlp<PREC>::head(lds, lane, h, 0.f, 0.f, 0.f, gfrag, tt, fair);
+                Mlp<PREC>::head(lds, lane, h, 0.f, 0.f, 0.f, gfrag, tt, fair, bad);
             }
             RNF_STAMP(1)                                          // 1: frame + hidden layers (H part)
             if (PIPE) {       // B1: every wave is past the H part and this layer's L part has landed
@@ -1111,6 +1129,10 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             RNF_STAMP(5)                                          // 5: layer finish (bisection for the inverse)
         }
 
+        if (PREC == 1 && args.guard_mode == 1 && valid) {            // see FlowArgs::guard
+            const float chk = ldj + ((R.c0.x + R.c0.y + R.c0.z) + (R.c1.x + R.c1.y + R.c1.z) + (R.c2.x + R.c2.y + R.c2.z));
+            if (bad || !(fabsf(chk) <= 3.0e38f)) atomicOr(args.guard, 1);
+        }
         // epilogue: outputs + fused base density + NLL partial (utils/fisher.py:217-232, agent.py:55-65)
         double lp_d = 0.0;
         if (valid && h == 0) {
@@ -1160,9 +1182,12 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     RNF_STAMP_FLUSH
 }
 
-// fixed-order final reduction of the block partials -> out[0] += sum, out[1] += count
-__global__ void nll_finalize_kernel(const double *partials, int nparts, double count, double *out, int accumulate) {
+// fixed-order final reduction of the block partials -> out[0] += sum, out[1] += count.  guard != nullptr and guard[0] != 0: the call was
+// re-run on the exact-fp32 kernels, whose partials are the ones to add.
+__global__ void nll_finalize_kernel(const double *partials, int nparts, double count, double *out, int accumulate,
+                                    const double *partials_fb = nullptr, int nparts_fb = 0, const int *guard = nullptr) {
     __shared__ double red[256];
+    if (guard && guard[0]) { partials = partials_fb; nparts = nparts_fb; }
     double s = 0.0;
     for (int i = threadIdx.x; i < nparts; i += 256) s += partials[i];
     red[threadIdx.x] = s;

@@ -99,7 +99,9 @@ RNF_LAYOUT_INLINE bool kind_has_mlp(int kind) { return kind == RNF_KIND_MOBIUS |
 RNF_LAYOUT_INLINE int kind_last_tiles(int kind, int KT) { return kind == RNF_KIND_MOBIUS ? KT : (kind == RNF_KIND_COND36 ? 2 : 1); }
 
 // layer descriptor columns (include/rnf_hip.h)
-constexpr int D_KIND = 0, D_PERM = 1, D_PARAM = 2, D_SLOT = 3, D_FEAT = 4, D_PREC = 5, D_STRIDE = 6;   // D_PREC: RNF_PREC_* of include/rnf_hip.h
+constexpr int D_KIND = 0, D_PERM = 1, D_PARAM = 2, D_SLOT = 3, D_FEAT = 4, D_PREC = 5;   // D_PREC: RNF_PREC_* of include/rnf_hip.h
+// fallback records (exact fp32 images of the same layers) for flows packed in split precision: offsets in the same blob, or -1
+constexpr int D_PARAM_FB = 6, D_FEAT_FB = 7, D_STRIDE = 8;
 
 inline constexpr int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

@@ -347,7 +347,10 @@ constexpr int NW_FWD_WIDE = 16;                         // same kernel, 4 waves 
 #endif
 constexpr int NW_FP = RNF_NW_FP;                        // waves per workgroup of the feature projection (workgroups per CU: 8 / NW_FP)
 constexpr long long CHUNK_SAMPLES = 1LL << 18;          // samples per launch when a feature projection scratch is needed
+// head of the workspace: [0, 2048) block partials of the primary launch, [2048, 4095) partials of the exact-fp32 re-run, double 4095 =
+// two int32: {guard of the current chunk, sticky "a re-run happened in this call"} (flow_kernels.h FlowArgs::guard)
 constexpr size_t PARTIALS_BYTES = 4096 * sizeof(double);
+constexpr int PARTIALS_FB_AT = 2048, GUARD_AT = 4095;
 
 static int device_cus() {
     static int cus = 0;
@@ -400,6 +403,16 @@ static bool staging_dma() {
     if (mode < 0) {
         const char *e = std::getenv("RNF_STAGING");
         mode = (e && std::strcmp(e, "sync") == 0) ? 0 : 1;
+    }
+    return mode == 1;
+}
+
+// RNF_GUARD=0: no range guard / fp32 re-run behind split-precision calls (measurement switch)
+static bool guard_allowed() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = std::getenv("RNF_GUARD");
+        mode = (e && e[0] == '0') ? 0 : 1;
     }
     return mode == 1;
 }
@@ -475,6 +488,10 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     std::memset(&a, 0, sizeof(a));
     FeatProjArgs fp;
     std::memset(&fp, 0, sizeof(fp));
+    // exact-fp32 images of the same layers in the same blob (desc columns D_PARAM_FB / D_FEAT_FB): a split-precision call is guarded and
+    // re-run on them, on the device, when a sample comes out non-finite (an fp16 operand overflowed)
+    bool have_fb = !o.states;
+    std::vector<int> fbp(n_layers, -1), fbf(MAX_SLOTS, -1), fp_primary(MAX_SLOTS, -1);
     int n_slots = 0;
     int min_tiles = 1;                       // fc_last tiles the largest non-Moebius record needs resident in LDS
     bool any_mlp = false, ext = false;       // ext: the flow contains a layer kind only the extended kernel instantiation carries
@@ -495,10 +512,14 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             if (slot >= MAX_SLOTS) return fail("layer %d: cond_slot %d >= %d", l, slot, MAX_SLOTS);
             if (d[D_FEAT] < 0 || d[D_FEAT] % 4) return fail("layer %d: feat offset %d invalid", l, d[D_FEAT]);
             fp.feat_off[slot] = d[D_FEAT];
+            fp_primary[slot] = d[D_FEAT];
             if (slot + 1 > n_slots) n_slots = slot + 1;
         }
         if (kind_has_mlp(kind)) {
             any_mlp = true;
+            if (d[D_PARAM_FB] < 0 || d[D_PARAM_FB] % 4 || (slot >= 0 && (d[D_FEAT_FB] < 0 || d[D_FEAT_FB] % 4))) have_fb = false;
+            fbp[l] = d[D_PARAM_FB];
+            if (slot >= 0) fbf[slot] = d[D_FEAT_FB];
             const int p = d[D_PREC];
             if (p != RNF_PREC_FP32 && p != RNF_PREC_F16X2) return fail("layer %d: unknown precision %d", l, p);
             if (prec >= 0 && p != prec) return fail("layer %d: all MLP layers of a flow must be packed with the same precision", l);
@@ -579,6 +600,16 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         lds_bytes += sizeof(float) * 2 * AFF_TABLE_LDS_STRIDE;
     }
     const int fair_off = a.fair_off;
+    // guarded split-precision call: every chunk is followed by the exact-fp32 kernels, which return at once unless the chunk's guard fired
+    const bool guarded = prec == 1 && any_mlp && have_fb && ws && ws_bytes >= PARTIALS_BYTES && guard_allowed();
+    int *guard = guarded ? reinterpret_cast<int *>(reinterpret_cast<double *>(ws) + GUARD_AT) : nullptr;
+    FlowArgs afb;
+    if (guarded) {
+        HIP_TRY(hipMemsetAsync(guard, 0, 2 * sizeof(int), stream));
+        afb = a;
+        for (int l = 0; l < n_layers; ++l)
+            if (kind_has_mlp(afb.layers[l].x & 15)) afb.layers[l].y = fbp[l];
+    }
     bool first = true;
     for (long long base = 0; base < n; base += chunk_cap) {
         const long long cn = (n - base) < chunk_cap ? (n - base) : chunk_cap;
@@ -590,11 +621,16 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         a.fair_off = (wide || narrow) ? -1 : fair_off;                       // the governor pairs two waves per SIMD
         const long long ntiles = (cn + nwk * 32 - 1) / (nwk * 32);
         const long long ntiles_fp = (cn + NW_FP * 32 - 1) / (NW_FP * 32);
-        const long long groups = (ntiles * nwk > ntiles_fp * NW_FP) ? ntiles * nwk : ntiles_fp * NW_FP;
+        const long long ntiles_fb = (cn + NW * 32 - 1) / (NW * 32);               // the exact-fp32 re-run uses NW-wave workgroups
+        long long groups = (ntiles * nwk > ntiles_fp * NW_FP) ? ntiles * nwk : ntiles_fp * NW_FP;
+        if (guarded && ntiles_fb * NW > groups) groups = ntiles_fb * NW;
+        if (guarded && base > 0) HIP_TRY(hipMemsetAsync(guard, 0, sizeof(int), stream));   // per-chunk guard; guard[1] stays
         int grid = (int)(ntiles < cus ? ntiles : cus);
         const int cus_fp = cus * (8 / NW_FP);
         const int grid_fp = (int)(ntiles_fp < cus_fp ? ntiles_fp : cus_fp);
-        if (n_slots && (!shared || base == 0)) {          // shared rows: ONE projection of the feature rows, before the first chunk
+        // feature projection of this chunk (shared rows: ONE projection of the feature rows, before the first chunk); `fb`: the
+        // exact-fp32 projection of a guarded call, which runs only if the guard fired (every chunk, also with shared rows)
+        auto project = [&](bool fb) -> int {
             const long long pn = shared ? feat_rows : cn;
             const long long pt = (pn + NW_FP * 32 - 1) / (NW_FP * 32);
             const int grid_p = shared ? (int)(pt < cus_fp ? pt : cus_fp) : grid_fp;
@@ -606,9 +642,12 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             fp.F = F;
             fp.n_slots = n_slots;
             fp.row_mode = shared ? 1 : 0;
+            fp.only_if = fb ? guard : nullptr;
+            if (fb) for (int sl = 0; sl < n_slots; ++sl) fp.feat_off[sl] = fbf[sl];
+            const int pprec = fb ? 0 : prec;
             const int kchunk = F < FP_KCHUNK ? F : FP_KCHUNK;
-            size_t fl = sizeof(float) * (prec ? (size_t)2 * (FP_KCHUNK / 16) * 512 : (size_t)kchunk / 8 * 256);   // f16x2: two DMA buffers
-            if (prec) {
+            size_t fl = sizeof(float) * (pprec ? (size_t)2 * (FP_KCHUNK / 16) * 512 : (size_t)kchunk / 8 * 256);   // f16x2: two DMA buffers
+            if (pprec) {
                 auto kern = featproj_kernel<NW_FP, 1>;
                 HIP_TRY(allow_lds(kern, fl));
                 hipLaunchKernelGGL(kern, dim3(grid_p), dim3(NW_FP * 64), fl, stream, fp);
@@ -618,6 +657,10 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
                 hipLaunchKernelGGL(kern, dim3(grid_p), dim3(NW_FP * 64), fl, stream, fp);
             }
             HIP_TRY(hipGetLastError());
+            return 0;
+        };
+        if (n_slots && (!shared || base == 0)) {
+            if (int rc = project(false)) return rc;
         }
         a.rot_in = rot + base * 9;
         a.G = G;
@@ -628,6 +671,8 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         a.n = cn;
         a.sample_base = base;
         a.g_groups = groups;
+        a.guard = guard;
+        a.guard_mode = guarded ? 1 : 0;
         int rc;
 #define RNF_LAUNCH(DIR_, KT_)                                                                                   \
     ext ? (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1, true>(a, grid, lds_bytes, stream, nwk)                   \
@@ -643,10 +688,37 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         else if (KT == 2) rc = RNF_LAUNCH(1, 2);
         else if (KT == 4) rc = RNF_LAUNCH(1, 4);
         else rc = RNF_LAUNCH(1, 8);
-#undef RNF_LAUNCH
         if (rc) return rc;
+        int grid_fb = 0;
+        if (guarded) {                                   // the same chunk on the exact-fp32 kernels, skipped on the device unless the guard fired
+            if (n_slots) {
+                if (int rc2 = project(true)) return rc2;
+                for (int sl = 0; sl < n_slots; ++sl) fp.feat_off[sl] = fp_primary[sl];
+            }
+            FlowArgs b = afb;
+            b.rot_in = a.rot_in; b.G = a.G; b.rot_out = a.rot_out; b.ldj_out = a.ldj_out; b.logp_out = a.logp_out;
+            b.partials = a.partials ? partials + PARTIALS_FB_AT : nullptr;
+            b.n = cn; b.sample_base = base; b.g_groups = groups; b.guard = guard; b.guard_mode = 2; b.fair_off = -1;
+            grid_fb = (int)(ntiles_fb < cus ? ntiles_fb : cus);
+            const int grid_keep = grid;
+            {
+                FlowArgs &a = b;                          // RNF_LAUNCH names `a`, `grid`, `prec`, `nwk`
+                const int grid = grid_fb, prec = 0, nwk = NW;
+                const bool lean = false;
+                (void)lean;
+                if (o.dir == 0) rc = RNF_LAUNCH(0, 0);
+                else if (KT == 1) rc = RNF_LAUNCH(1, 1);
+                else if (KT == 2) rc = RNF_LAUNCH(1, 2);
+                else if (KT == 4) rc = RNF_LAUNCH(1, 4);
+                else rc = RNF_LAUNCH(1, 8);
+            }
+            (void)grid_keep;
+            if (rc) return rc;
+        }
+#undef RNF_LAUNCH
         if (o.sum_out) {
-            hipLaunchKernelGGL(nll_finalize_kernel, dim3(1), dim3(256), 0, stream, (const double *)partials, grid, (double)cn, o.sum_out, first ? 0 : 1);
+            hipLaunchKernelGGL(nll_finalize_kernel, dim3(1), dim3(256), 0, stream, (const double *)partials, grid, (double)cn, o.sum_out, first ? 0 : 1,
+                               (const double *)(partials + PARTIALS_FB_AT), grid_fb, (const int *)guard);
             HIP_TRY(hipGetLastError());
         }
         first = false;
@@ -963,7 +1035,8 @@ __global__ __launch_bounds__(NWc * 64) void conditioner_kernel(const float *y, l
         __syncthreads();
         typename Mlp<PREC>::Act tt;
         Fair nofair{lds, wave, -1, 0};
-        Mlp<PREC>::head(lds, lane, h, y0, y1, y2, GFrag<false>{nullptr, false}, tt, nofair);
+        bool bad = false;
+        Mlp<PREC>::head(lds, lane, h, y0, y1, y2, GFrag<false>{nullptr, false}, tt, nofair, bad);
         for (int tau = 0; tau < KT; ++tau) {
             __syncthreads();
             stage_floats(lds + MOB_LAST, layer + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS, MOB_LAST_TILE_FLOATS, tid, NWc * 64);

@@ -14,7 +14,7 @@ from . import _lib
 
 KIND_MOBIUS, KIND_AFFINE16, KIND_COND16, KIND_GS9, KIND_GS36 = 1, 2, 3, 4, 5
 KIND_COND9_GS, KIND_COND9_SMITH, KIND_COND9_POLAR_L, KIND_COND9_POLAR_R, KIND_COND36 = 6, 7, 8, 9, 10
-DESC_STRIDE = 6
+DESC_STRIDE = 8            # include/rnf_hip.h RNF_DESC_STRIDE: kind, perm_row, param, cond_slot, feat, precision, fallback param, fallback feat
 
 # Arithmetic of the conditioner GEMMs (include/rnf_hip.h RNF_PREC_*): "f16x2" = split-precision fp16 MFMA (22-bit
 # operands, fp32 accumulate; default), "fp32" = exact fp32 MFMA.  Environment override: RNF_PRECISION=fp32|f16x2.
@@ -105,12 +105,41 @@ def pack_layers(layers, perm_rows, device, precision=None) -> PackedFlow:
     L = _lib.lib()
     _prefetched.map = _prefetch_parameters(layers)
     try:
-        return _pack_layers(layers, perm_rows, device, precision, prec, L)
+        blob, desc, slot, feat_dim, segments = _pack_layers(layers, perm_rows, prec, L)
+        if precision == "f16x2" and _guard_fallback:
+            # the same layers once more as exact-fp32 images behind the split-precision ones: the library re-runs a call on them, on the
+            # device, when a sample comes out non-finite (an fp16 operand overflowed; include/rnf_hip.h desc columns 6, 7)
+            blob32, desc32, _, _, _ = _pack_layers(layers, perm_rows, _lib.PREC_FP32, L)
+            base = blob.size
+            mlp = np.array([kind_has_mlp(int(k)) for k in desc[:, 0]])
+            desc[mlp, 6] = base + desc32[mlp, 2]
+            has_feat = desc32[:, 4] >= 0
+            desc[has_feat, 7] = base + desc32[has_feat, 4]
+            blob = np.concatenate([blob, blob32])
     finally:
         _prefetched.map = {}
+    return PackedFlow(torch.from_numpy(blob).to(device), np.ascontiguousarray(desc), slot, feat_dim, pad8(feat_dim), segments, precision)
 
 
-def _pack_layers(layers, perm_rows, device, precision, prec, L) -> PackedFlow:
+_guard_fallback = os.environ.get("RNF_GUARD", "1") != "0"
+
+
+def kind_has_mlp(kind: int) -> bool:
+    return kind in (KIND_MOBIUS, KIND_COND16, KIND_COND9_GS, KIND_COND9_SMITH, KIND_COND9_POLAR_L, KIND_COND9_POLAR_R, KIND_COND36)
+
+
+def fallback_fired(device) -> bool:
+    """True when the last guarded split-precision call on this (device, current stream) was re-run on the exact-fp32 kernels.
+    Synchronises (diagnostics / tests only)."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    with _ws_lock:
+        ws = _workspaces.get(key)
+    if ws is None:
+        return False
+    return bool(ws[4095 * 8 + 4: 4095 * 8 + 8].view(torch.int32).item())
+
+
+def _pack_layers(layers, perm_rows, prec, L):
     records, feat_records = [], []
     desc = np.zeros((len(layers), DESC_STRIDE), dtype=np.int32)
     feat_dim = 0
@@ -128,6 +157,8 @@ def _pack_layers(layers, perm_rows, device, precision, prec, L) -> PackedFlow:
         desc[i, 3] = -1
         desc[i, 4] = -1
         desc[i, 5] = prec
+        desc[i, 6] = -1
+        desc[i, 7] = -1
         if feat_rec is not None:
             if feat_dim and fdim != feat_dim:
                 raise ValueError("all conditional layers of one flow must share feature_dim")
@@ -144,14 +175,13 @@ def _pack_layers(layers, perm_rows, device, precision, prec, L) -> PackedFlow:
         if rec is not None:
             desc[i, 4] = off
             off += (rec.size + 3) // 4 * 4
-    blob = np.zeros(max(off, 4), dtype=np.float32)
+    blob = np.zeros(max((off + 3) // 4 * 4, 4), dtype=np.float32)
     for i, rec in enumerate(records):
         blob[desc[i, 2]: desc[i, 2] + rec.size] = rec
     for i, rec in enumerate(feat_records):
         if rec is not None:
             blob[desc[i, 4]: desc[i, 4] + rec.size] = rec
-    return PackedFlow(torch.from_numpy(blob).to(device), np.ascontiguousarray(desc), slot, feat_dim, pad8(feat_dim), segments,
-                      precision)
+    return blob, desc, slot, feat_dim, segments
 
 
 def _check_pack(L, rc):

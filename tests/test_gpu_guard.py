@@ -1,0 +1,91 @@
+"""GPU: the range guard of the split-precision kernels.  An activation (or feature) beyond the fp16 range turns a sample's log-det into
+NaN inside the f16x2 kernels; the call is then re-run, on the device and without a host synchronisation, on the exact-fp32 kernels
+(include/rnf_hip.h desc columns 6 / 7; flow/condition.py:24-30 knows no such range limit)."""
+import numpy as np
+import pytest
+import torch
+
+import rotationnormflow_amd as rnf
+from oracle import flow_oracle as orc
+from rotationnormflow_amd import make_config, runtime, synth
+from rotationnormflow_amd.utils.fisher import MatrixFisherN
+from tests.gpu_helpers import product_flow
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights(cfg, seed, blow_up):
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=seed, regime="trained")
+    if blow_up:                       # weights stay far inside the fp16 range, the hidden activations of every Moebius layer do not
+        for k in w:
+            if k.endswith("conditioner.fc_first.weight") or k.endswith("conditioner.fc_first.bias"):
+                w[k] = w[k] * np.float32(40.0)
+            if k.endswith("conditioner.layers.1.weight"):
+                w[k] = w[k] * np.float32(2000.0)
+            if k.endswith("conditioner.layers.3.weight") or k.endswith("conditioner.layers.5.weight"):
+                w[k] = w[k] * np.float32(1.0e-2)
+    return w
+
+
+@pytest.mark.parametrize("direction", ["forward", "inverse"])
+def test_activation_overflow_falls_back_to_fp32(direction):
+    cfg = make_config(layers=3, segments=16)
+    w = _weights(cfg, 5, True)
+    assert max(float(np.abs(v).max()) for v in w.values()) < 6.0e4
+    fl = product_flow(cfg, w)
+    R = torch.from_numpy(synth.uniform_rotations(3000, seed=11)).cuda()
+    assert rnf.get_precision() == "f16x2"
+    with torch.no_grad():
+        Rt, ldj = fl(R) if direction == "forward" else fl.inverse(R)
+    assert fl._packed(R.device).precision == "f16x2"            # the weights themselves packed fine
+    assert runtime.fallback_fired(R.device)
+    assert torch.isfinite(ldj).all() and torch.isfinite(Rt).all()
+    # the re-run IS the exact-fp32 path: bit-identical to a call that asks for it
+    rnf.set_precision("fp32")
+    try:
+        with torch.no_grad():
+            Rt32, ldj32 = fl(R) if direction == "forward" else fl.inverse(R)
+    finally:
+        rnf.set_precision("f16x2")
+    assert torch.equal(ldj, ldj32) and torch.equal(Rt, Rt32)
+    # and it follows the oracle (fp64)
+    fn = orc.flow_forward if direction == "forward" else orc.flow_inverse
+    Rw, lw = fn(cfg, w, R.cpu().numpy(), None, dtype=torch.float64)
+    err = np.abs(ldj.cpu().double().numpy() - lw.numpy())
+    assert np.median(err) < 1e-4 and np.quantile(err, 0.99) < 2e-2, (np.median(err), err.max())
+
+
+def test_no_fallback_in_range_and_fused_sum_uses_the_rerun():
+    cfg = make_config(layers=3, segments=16)
+    base = MatrixFisherN(torch.from_numpy(synth.fisher_A("diag531")))
+    R = torch.from_numpy(synth.uniform_rotations(2500, seed=12)).cuda()
+    fl = product_flow(cfg, _weights(cfg, 6, False))
+    with torch.no_grad():
+        res = fl.log_prob(R, base=base)
+    assert not runtime.fallback_fired(R.device)
+    assert abs(float(res["sum"][0]) - float(res["logp"].double().sum())) < 1e-6 * abs(float(res["sum"][0]))
+    fl = product_flow(cfg, _weights(cfg, 6, True))
+    with torch.no_grad():
+        res = fl.log_prob(R, base=base)
+    assert runtime.fallback_fired(R.device)
+    assert torch.isfinite(res["logp"]).all()
+    assert abs(float(res["sum"][0]) - float(res["logp"].double().sum())) < 1e-6 * abs(float(res["sum"][0]))
+    assert float(res["sum"][1]) == 2500.0
+
+
+def test_feature_overflow_falls_back_to_fp32():
+    cfg = make_config(layers=2, segments=16, condition=1, feature_dim=24, rot="16UnTrans", frequent_permute=1, last_affine=1, first_affine=0)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=8, regime="trained")
+    fl = product_flow(cfg, w)
+    n = 1500
+    R = torch.from_numpy(synth.uniform_rotations(n, seed=13)).cuda()
+    feat = synth.features(n, 24, seed=14)
+    feat[7, 3] = 1.0e5                                          # one feature entry outside the fp16 range
+    fd = torch.from_numpy(feat).cuda()
+    with torch.no_grad():
+        Rt, ldj = fl(R, fd)
+    assert runtime.fallback_fired(R.device)
+    assert torch.isfinite(ldj).all() and torch.isfinite(Rt).all()
+    _, lw = orc.flow_forward(cfg, w, R.cpu().numpy(), feat, dtype=torch.float64)
+    err = np.abs(ldj.cpu().double().numpy() - lw.numpy())
+    assert np.quantile(err, 0.99) < 1e-3, err.max()

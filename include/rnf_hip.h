@@ -69,7 +69,9 @@ int rnf_abi_version(void);
 const char *rnf_last_error(void);
 
 /* ---- parameter packing (host side, pure CPU; called once per parameter version) ------------------------------
- * Sizes are in floats.  `segments` (K) must be a positive multiple of 8.  `feature_dim` (F) is the number of
+ * Sizes are in floats.  `segments` (K) is any positive count (flow/mobiusflow.py:7-14 takes any): records hold ceil(K / 8) fc_last tiles,
+ * the last one zero padded, and the kernels give the pad segments weight 0.  rnf_flow_inverse keeps a layer's segment parameters in
+ * registers and supports K <= 128; the training entry points need K % 8 == 0, K <= 64.  `feature_dim` (F) is the number of
  * feature inputs of the layer's MLP (0 for an unconditional Moebius layer).
  */
 int64_t rnf_mobius_packed_floats(int32_t segments);

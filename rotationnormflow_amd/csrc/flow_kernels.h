@@ -43,7 +43,8 @@ struct FlowArgs {
     float *states;            // training forward: [n_layers][states_n][9] rotation at the input of every layer, else nullptr
     long long states_n;       // rotations in the whole call (chunks write at sample_base)
     int n_layers;
-    int KT;                   // fc_last tiles = segments / 8
+    int KT;                   // fc_last tiles = ceil(segments / 8)
+    int K;                    // segments of the Moebius layers (pad segments of the last tile are masked when K % 8 != 0)
     int tab_off;              // >= 0 (DMA staging): float offset in LDS of two AFF_TABLE_LDS_STRIDE-float buffers for constant-affine blocks
     // Range guard of the split-precision kernels (an fp16 operand beyond 65504 turns into inf and the sample's log-det into NaN):
     //   guard_mode 1: set guard[0] when a sample ends with a non-finite log-det or rotation;
@@ -475,6 +476,33 @@ __device__ __forceinline__ void segments4(const f32x16 &o, const MobiusCtx &c, f
     }
 }
 
+// The last fc_last tile of a layer whose segment count K is not a multiple of 8: the packer pads the tile with zero rows, and the pad
+// segments (k = 8 tau + 2 g + h >= K) must carry weight 0 -- softplus(0) = ln 2 is not 0 -- so their contribution is masked out AFTER the
+// activation.  nv = number of real segments among this lane's four (g < nv).
+template <bool HALF>
+__device__ __forceinline__ void segments4_tail(const f32x16 &o, const MobiusCtx &c, float &S, float &A, float &J, int nv) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float s1 = 0.f, a1 = 0.f, j1 = 0.f;
+        if constexpr (HALF) segment_fwd_s7(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, s1, a1, j1);
+        else segment_fwd_pi<false>(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, s1, a1, j1);
+        const bool real = g < nv;
+        S += real ? s1 : 0.f;
+        A += real ? a1 : 0.f;
+        J += real ? j1 : 0.f;
+    }
+}
+// real segments among the four of lane-half h in the LAST tile of a K-segment layer (4 when K % 8 == 0)
+__device__ __forceinline__ int tail_segments(int K, int h) {
+    const int rem = K - 8 * ((K + 7) / 8 - 1) - h;          // segments k = base + 2 g + h, g = 0..3, real while 2 g + h < K - base
+    return min(4, max(0, (rem + 1) / 2));
+}
+template <bool HALF>
+__device__ __forceinline__ void segments4_last(const f32x16 &o, const MobiusCtx &c, float &S, float &A, float &J, int K, int h) {
+    if (K & 7) segments4_tail<HALF>(o, c, S, A, J, tail_segments(K, h));     // wave-uniform branch
+    else segments4<HALF>(o, c, S, A, J);
+}
+
 // forward, all fc_last tiles resident (K <= 64): software pipelined BY HAND.  Tile tau+1's 32 dependent MFMAs (64
 // cycles each on the matrix pipe) are interleaved one-for-one with 32 slices (4 segments x 8 stages, ~10 VALU issue
 // slots each, so3_math.h seg_stage) of tile tau's segment math, every MFMA + slice pair fenced with sched_barrier(0).  Left to
@@ -564,7 +592,7 @@ __device__ __forceinline__ void tile_pipe_h_off(const float *base, int woff, int
 }
 
 template <int PREC, bool PINGPONG = false>
-__device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int lane, int h, const typename Mlp<PREC>::Act &tt,
+__device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int K, int lane, int h, const typename Mlp<PREC>::Act &tt,
                                                  const MobiusCtx &c, float &S, float &A, float &J, Fair &fair) {
     const float *rec = lds + MOB_LAST;
     if constexpr (PREC == 0) {
@@ -576,9 +604,9 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int l
         }
         if (tau < KT) {
             tile_pipe(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt.t, bufB, bufA, c, S, A, J);
-            segments4<false>(bufB, c, S, A, J);
+            segments4_last<false>(bufB, c, S, A, J, K, h);
         } else {
-            segments4<false>(bufA, c, S, A, J);
+            segments4_last<false>(bufA, c, S, A, J, K, h);
         }
     } else {
         // tile tau+1's 12 matrix instructions and tile tau's segment math in one loop body (tile_pipe_h).  (`cur = nxt` costs 8
@@ -598,9 +626,9 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int l
             if (tau < KT) {
                 asm volatile("" : "+v"(woff), "+v"(boff));
                 tile_pipe_h_off(rec, woff, boff, tt, bufB, bufA, c, S, A, J);
-                segments4<true>(bufB, c, S, A, J);
+                segments4_last<true>(bufB, c, S, A, J, K, h);
             } else {
-                segments4<true>(bufA, c, S, A, J);
+                segments4_last<true>(bufA, c, S, A, J, K, h);
             }
             return;
         }
@@ -611,13 +639,13 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int l
             cur = nxt;
             fair.tick();
         }
-        segments4<true>(cur, c, S, A, J);
+        segments4_last<true>(cur, c, S, A, J, K, h);
     }
 }
 
 // forward, K > 64: fc_last tiles restaged synchronously 8 at a time (staging mode SYNC only)
 template <int PREC>
-__device__ __forceinline__ void mobius_fwd_tiles_restage(float *lds, const float *layer_params, int KT, int lane, int h,
+__device__ __forceinline__ void mobius_fwd_tiles_restage(float *lds, const float *layer_params, int KT, int K, int lane, int h,
                                                          const typename Mlp<PREC>::Act &tt, const MobiusCtx &c, float &S,
                                                          float &A, float &J, int tid, int nthreads) {
     for (int tau = 0; tau < KT; ++tau) {
@@ -629,7 +657,8 @@ __device__ __forceinline__ void mobius_fwd_tiles_restage(float *lds, const float
             __syncthreads();
         }
         f32x16 o = Mlp<PREC>::last(lds + MOB_LAST + (tau % MOB_MAX_TILES_IN_LDS) * MOB_LAST_TILE_FLOATS, lane, h, tt);
-        segments4<PREC == 1>(o, c, S, A, J);
+        if (tau + 1 == KT) segments4_last<PREC == 1>(o, c, S, A, J, K, h);
+        else segments4<PREC == 1>(o, c, S, A, J);
     }
 }
 
@@ -657,19 +686,35 @@ struct InvSegs {
     float q[4 * KT];          // sp * (1 - |u|^2): the theta-independent numerator of the segment's derivative term
 };
 
+// kt: tiles this layer really has (<= KT, the instantiation's capacity), K: its real segment count; slots beyond them get weight 0.
+// KT > MOB_MAX_TILES_IN_LDS (K > 64, synchronous staging only): the second half of the fc_last image is staged in the middle.
 template <int KT, int PREC>
-__device__ __forceinline__ void mobius_inv_tiles(const float *lds, int lane, int h, const typename Mlp<PREC>::Act &tt,
-                                                 const MobiusCtx &c, InvSegs<KT> &sg, float &S) {
-    static_assert(KT <= MOB_MAX_TILES_IN_LDS, "inverse keeps all fc_last tiles in LDS");
+__device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_params, int kt, int K, int lane, int h, const typename Mlp<PREC>::Act &tt,
+                                                 const MobiusCtx &c, InvSegs<KT> &sg, float &S, int tid, int nthreads) {
 #pragma unroll
     for (int tau = 0; tau < KT; ++tau) {
-        f32x16 o = Mlp<PREC>::last(lds + MOB_LAST + tau * MOB_LAST_TILE_FLOATS, lane, h, tt);
+        if (tau < kt) {                                         // wave uniform
+            if constexpr (KT > MOB_MAX_TILES_IN_LDS) {
+                if (tau == MOB_MAX_TILES_IN_LDS) {
+                    __syncthreads();
+                    stage_floats(lds + MOB_LAST, layer_params + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS,
+                                 min(MOB_MAX_TILES_IN_LDS, kt - tau) * MOB_LAST_TILE_FLOATS, tid, nthreads);
+                    __syncthreads();
+                }
+            }
+            f32x16 o = Mlp<PREC>::last(lds + MOB_LAST + (tau % MOB_MAX_TILES_IN_LDS) * MOB_LAST_TILE_FLOATS, lane, h, tt);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, sg.ur[4 * tau + g], sg.uv[4 * tau + g]);
-            sg.sp[4 * tau + g] = PREC == 1 ? softplus_lean(o[4 * g]) : softplus(o[4 * g]);
-            sg.q[4 * tau + g] = sg.sp[4 * tau + g] * (1.0f - fmaf(sg.uv[4 * tau + g], sg.uv[4 * tau + g], sg.ur[4 * tau + g] * sg.ur[4 * tau + g]));
-            S += sg.sp[4 * tau + g];
+            for (int g = 0; g < 4; ++g) {
+                squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, sg.ur[4 * tau + g], sg.uv[4 * tau + g]);
+                float sp = PREC == 1 ? softplus_lean(o[4 * g]) : softplus(o[4 * g]);
+                if (8 * tau + 2 * g + h >= K) sp = 0.f;          // pad segment of a K % 8 != 0 layer: weight 0 AFTER the activation
+                sg.sp[4 * tau + g] = sp;
+                sg.q[4 * tau + g] = sp * (1.0f - fmaf(sg.uv[4 * tau + g], sg.uv[4 * tau + g], sg.ur[4 * tau + g] * sg.ur[4 * tau + g]));
+                S += sp;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sg.sp[4 * tau + g] = sg.ur[4 * tau + g] = sg.uv[4 * tau + g] = sg.q[4 * tau + g] = 0.f;
         }
         // keep the tiles in order: letting the scheduler hoist all 8 tiles' MFMAs (8 x 16 accumulators) on top of the
         // 96 live segment registers spills; the inverse is VALU-bound in the bisection anyway
@@ -934,7 +979,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     constexpr int TILE = NW * TILE_SAMPLES;
     constexpr int KTI = KT_INV > 0 ? KT_INV : 1;
     const long long ntiles = (args.n + TILE - 1) / TILE;
-    const int KT = DIR ? KT_INV : args.KT;
+    const int KT = args.KT;                                          // DIR = 1: <= KT_INV, the capacity of this instantiation
     const int n_layers = args.n_layers;
     double dsum = 0.0;                                               // wave-uniform running sum of log p (kept in scalar registers)
     Fair fair{lds, wave, args.fair_off, 0};
@@ -1099,7 +1144,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 if constexpr (DIR != 0) {
                     InvSegs<KTI> sg;
                     float S = 0.f;
-                    mobius_inv_tiles<KTI, PREC>(lds, lane, h, tt, ctx, sg, S);
+                    mobius_inv_tiles<KTI, PREC>(lds, params, KT, args.K, lane, h, tt, ctx, sg, S, tid, NT);
                     // the barrier right behind the tiles (the root finder does not touch LDS, and its pass count differs from wave to wave:
                     // a barrier behind it was 19 % of the wave time), the DMA request of the next fc_last image behind the root finder:
                     // in front of it the DMA address arithmetic would sit on top of the 96 live segment registers (36 spills at K = 64);
@@ -1109,8 +1154,8 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     b2_issue();
                 } else {
                     float S = 0.f, A = 0.f, J = 0.f;
-                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC, LEAN>(lds, KT, lane, h, tt, ctx, S, A, J, fair);
-                    else mobius_fwd_tiles_restage<PREC>(lds, params, KT, lane, h, tt, ctx, S, A, J, tid, NT);
+                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC, LEAN>(lds, KT, args.K, lane, h, tt, ctx, S, A, J, fair);
+                    else mobius_fwd_tiles_restage<PREC>(lds, params, KT, args.K, lane, h, tt, ctx, S, A, J, tid, NT);
                     barrier2();
                     mobius_fwd_finish<PREC == 1>(ctx, S, A, J, R, ldj);
                 }

@@ -56,7 +56,7 @@ constexpr int MOB_LAST_TILE_FLOATS = 8 * 64 * 4 + 32;     // 2080
 constexpr int MOB_LAST_TILE_BIAS = 8 * 64 * 4;            // bias offset inside a tile record
 constexpr int MOB_MAX_TILES_IN_LDS = 8;                   // fc_last tiles resident at once (K = 64 -> all of them)
 
-inline constexpr int64_t mobius_packed_floats(int K) { return MOB_HEAD_FLOATS + (int64_t)(K / 8) * MOB_LAST_TILE_FLOATS; }
+inline constexpr int64_t mobius_packed_floats(int K) { return MOB_HEAD_FLOATS + (int64_t)((K + 7) / 8) * MOB_LAST_TILE_FLOATS; }   // last tile zero padded
 
 // ---- unconditional 4x4 affine record ----
 // [0..15] M row-major, [16] log|det M|, [17..32] M^-1, [33] log|det M^-1|, [34] 1.0 if M is orthogonal (log-det exactly 0), [35] 0,

@@ -165,13 +165,13 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
     hw[1] = hb[0] + 64; hb[1] = hw[1] + 4096;
     hw[2] = hb[1] + 64; hb[2] = hw[2] + 4096;
     const float *WL = hb[2] + 64, *bL = WL + (size_t)NO * 64;
-    const int n_tiles = mob ? K / 8 : 1;
+    const int n_tiles = mob ? (K + 7) / 8 : 1;
     const int rec_floats = MOB_HEAD_FLOATS + n_tiles * MOB_LAST_TILE_FLOATS;
     // reference row of packed fc_last row `row` of tile tau (layout.h): Moebius: segment k = 8 tau + 2g + h, component c;
     // Condition16Trans: M[2g + h][c], rows >= 16 are zero padding
     auto src_row = [&](int tau, int row) {
         const int g = row >> 3, h = (row >> 2) & 1, c = row & 3;
-        if (mob) { const int k = 8 * tau + 2 * g + h; return c == 0 ? k : K + 3 * k + (c - 1); }
+        if (mob) { const int k = 8 * tau + 2 * g + h; return k >= K ? -1 : (c == 0 ? k : K + 3 * k + (c - 1)); }
         return row >= 16 ? -1 : 4 * (2 * g + h) + c;
     };
     for (int idx = tid; idx < rec_floats; idx += nth) {

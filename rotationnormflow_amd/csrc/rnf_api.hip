@@ -47,7 +47,7 @@ extern "C" const char *rnf_last_error(void) { return g_err; }
 // ------------------------------------------------------------------------------------------------------------
 // packing (pure host code)
 // ------------------------------------------------------------------------------------------------------------
-extern "C" int64_t rnf_mobius_packed_floats(int32_t K) { return (K > 0 && K % 8 == 0) ? mobius_packed_floats(K) : -1; }
+extern "C" int64_t rnf_mobius_packed_floats(int32_t K) { return K > 0 ? mobius_packed_floats(K) : -1; }
 extern "C" int64_t rnf_affine16_packed_floats(void) { return AFF_FLOATS; }
 extern "C" int64_t rnf_cond16_packed_floats(void) { return COND16_FLOATS; }
 extern "C" int64_t rnf_featproj_packed_floats(int32_t F) { return (F >= 0 && F % 8 == 0) ? featproj_packed_floats(F) : -1; }
@@ -146,7 +146,7 @@ extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b,
                                const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
                                const float *fc_last_w, const float *fc_last_b, int32_t K, int32_t F, int32_t prec,
                                float *out, float *out_feat) {
-    if (K <= 0 || K % 8) return fail("rnf_pack_mobius: segments=%d must be a positive multiple of 8", K);
+    if (K <= 0) return fail("rnf_pack_mobius: segments=%d must be positive", K);
     if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2) return fail("rnf_pack_mobius: unknown precision %d", prec);
     g_half_overflow = false;
     if (F < 0 || F % 8) return fail("rnf_pack_mobius: feature_dim=%d must be a multiple of 8 (pad on the host)", F);
@@ -163,16 +163,18 @@ extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b,
     const float *hb[3] = {l1_b, l3_b, l5_b};
     pack_hidden(out, hw, hb, prec);
     // fc_last: packed row P = 32*tau + 8g + 4h + c  <->  segment k = 8*tau + 2g + h, component c
+    // (K % 8 != 0: the last tile is padded with zero rows for segments k >= K; the kernels give those segments weight 0)
     auto src_row = [&](int tau, int row) {
         const int g = row >> 3, h = (row >> 2) & 1, c = row & 3;
         const int k = 8 * tau + 2 * g + h;
+        if (k >= K) return -1;
         return c == 0 ? k : K + 3 * k + (c - 1);
     };
-    for (int tau = 0; tau < K / 8; ++tau) {
+    for (int tau = 0; tau < (K + 7) / 8; ++tau) {
         float *rec = out + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS;
-        auto row_of = [&](int, int i) { return fc_last_w + (size_t)src_row(tau, i) * 64; };
+        auto row_of = [&](int, int i) { const int r = src_row(tau, i); return r < 0 ? (const float *)nullptr : fc_last_w + (size_t)r * 64; };
         if (prec) pack_w64_h(rec, 1, row_of); else pack_w64(rec, 1, row_of);
-        pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) { return fc_last_b[src_row(tau, row)]; });
+        pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) { const int r = src_row(tau, row); return r < 0 ? 0.f : fc_last_b[r]; });
     }
     if (F) { if (prec) pack_featproj_h(out_feat, fc_first_w, ni, 3, F, fc_first_b); else pack_featproj(out_feat, fc_first_w, ni, 3, F, fc_first_b); }
     if (prec && g_half_overflow) return fail("rnf_pack_mobius: a weight is outside the fp16 range; use RNF_PREC_FP32") + 1;
@@ -345,6 +347,7 @@ constexpr int NW_FWD_WIDE = 16;                         // same kernel, 4 waves 
 #ifndef RNF_NW_FP
 #define RNF_NW_FP 8
 #endif
+constexpr int NW_INV_BIG = 4;                           // inverse with 64 < K <= 128: one wave per SIMD
 constexpr int NW_FP = RNF_NW_FP;                        // waves per workgroup of the feature projection (workgroups per CU: 8 / NW_FP)
 constexpr long long CHUNK_SAMPLES = 1LL << 18;          // samples per launch when a feature projection scratch is needed
 // head of the workspace: [0, 2048) block partials of the primary launch, [2048, 4095) partials of the exact-fp32 re-run, double 4095 =
@@ -409,6 +412,9 @@ static bool staging_dma() {
 
 // RNF_GUARD=0: no range guard / fp32 re-run behind split-precision calls (measurement switch)
 static bool guard_allowed() {
+#ifdef RNF_NO_GUARD
+    return false;
+#endif
     static int mode = -1;
     if (mode < 0) {
         const char *e = std::getenv("RNF_GUARD");
@@ -464,6 +470,16 @@ static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream
     return 0;
 }
 
+// inverse with 64 < K <= 128 (flow_kernels.h mobius_inv_tiles: 16 tiles of segment parameters in registers, synchronous staging)
+template <int PREC>
+static int launch_big_inverse(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream) {
+    auto kern = flow_stack_kernel<1, 16, NW_INV_BIG, false, PREC, false>;
+    HIP_TRY(allow_lds(kern, lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_INV_BIG * 64), lds_bytes, stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 struct RunOpts {
     int dir;                  // 0 forward, 1 inverse
     const float *fisher_A, *fisher_c;
@@ -480,7 +496,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     if (n < 0) return fail("n=%lld is negative", (long long)n);
     if (n_layers <= 0 || n_layers > MAX_LAYERS) return fail("n_layers=%d outside [1,%d]", n_layers, MAX_LAYERS);
-    if (K <= 0 || K % 8) return fail("segments=%d must be a positive multiple of 8", K);
+    if (K <= 0) return fail("segments=%d must be positive", K);
     if (!blob || !desc || (n > 0 && !rot)) return fail("null rotation / blob / desc pointer");
     if (o.fisher_A && (o.fisher_B <= 0 || n % o.fisher_B)) return fail("n=%lld not divisible by fisher rows B=%lld (utils/fisher.py:226)", (long long)n, (long long)o.fisher_B);
 
@@ -552,9 +568,14 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     if (ws_bytes < ws_need && (n_slots > 0 || o.sum_out)) return fail("workspace of %zu bytes is smaller than the %zu needed", ws_bytes, ws_need);
     if ((n_slots > 0 || o.sum_out) && !ws) return fail("workspace pointer is null");
 
-    const int KT = K / 8;
-    if (o.dir == 1 && any_mlp && !(KT == 1 || KT == 2 || KT == 4 || KT == 8))
-        return fail("inverse pass supports segments in {8,16,32,64}; got %d", K);
+    const int KT = (K + 7) / 8;
+    // inverse: the segment parameters of a layer stay in registers through the root finder; instantiations hold 1, 2, 4, 8 tiles
+    // (8-wave workgroups) or 16 (K <= 128: 4-wave workgroups with the whole register file, fc_last staged in two halves)
+    const int kt_inv = KT <= 1 ? 1 : (KT <= 2 ? 2 : (KT <= 4 ? 4 : (KT <= 8 ? 8 : 16)));
+    if (o.dir == 1 && any_mlp && KT > 16)
+        return fail("inverse pass supports segments <= 128; got %d", K);
+    if (o.dir == 1 && any_mlp && KT > 8 && (ext || o.feature_div > 0))
+        return fail("inverse pass with segments > 64 is not built for conditional 3x3 / 6x6 layers or shared feature rows; got %d", K);
 
     double *partials = reinterpret_cast<double *>(ws);
     float *G = n_slots ? reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + PARTIALS_BYTES) : nullptr;
@@ -586,6 +607,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
 #endif
     a.n_layers = n_layers;
     a.KT = KT;
+    a.K = K;
     a.states = o.states;
     a.states_n = n;
     a.fisher_A = o.fisher_A;
@@ -617,13 +639,15 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         // no longer fit the CUs in one round
         const bool wide = o.dir == 0 && prec == 1 && pipe && !ext && wide_allowed() && cn > (long long)cus * NW_FWD_H * 32;
         const bool narrow = o.dir == 0 && prec == 1 && pipe && !ext && wide_allowed() && cn <= (long long)cus * NW_FWD_NARROW * 32;
-        const int nwk = wide ? NW_FWD_WIDE : (narrow ? NW_FWD_NARROW : ((o.dir == 0 && prec == 1) ? NW_FWD_H : NW));
+        const bool big_inv = o.dir == 1 && any_mlp && KT > 8;                  // 4-wave instantiation (512 registers per lane)
+        const int nwk = big_inv ? NW_INV_BIG : (wide ? NW_FWD_WIDE : (narrow ? NW_FWD_NARROW : ((o.dir == 0 && prec == 1) ? NW_FWD_H : NW)));
         a.fair_off = (wide || narrow) ? -1 : fair_off;                       // the governor pairs two waves per SIMD
         const long long ntiles = (cn + nwk * 32 - 1) / (nwk * 32);
         const long long ntiles_fp = (cn + NW_FP * 32 - 1) / (NW_FP * 32);
-        const long long ntiles_fb = (cn + NW * 32 - 1) / (NW * 32);               // the exact-fp32 re-run uses NW-wave workgroups
+        const int nw_fb = (o.dir == 1 && any_mlp && KT > 8) ? NW_INV_BIG : NW;
+        const long long ntiles_fb = (cn + nw_fb * 32 - 1) / (nw_fb * 32);         // the exact-fp32 re-run uses NW-wave workgroups
         long long groups = (ntiles * nwk > ntiles_fp * NW_FP) ? ntiles * nwk : ntiles_fp * NW_FP;
-        if (guarded && ntiles_fb * NW > groups) groups = ntiles_fb * NW;
+        if (guarded && ntiles_fb * nw_fb > groups) groups = ntiles_fb * nw_fb;
         if (guarded && base > 0) HIP_TRY(hipMemsetAsync(guard, 0, sizeof(int), stream));   // per-chunk guard; guard[1] stays
         int grid = (int)(ntiles < cus ? ntiles : cus);
         const int cus_fp = cus * (8 / NW_FP);
@@ -684,10 +708,11 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
           : (prec ? launch_stack<DIR_, KT_, false, 1>(a, grid, lds_bytes, stream, nwk)                              \
                   : launch_stack<DIR_, KT_, false, 0>(a, grid, lds_bytes, stream, nwk)))
         if (o.dir == 0) rc = RNF_LAUNCH(0, 0);
-        else if (KT == 1) rc = RNF_LAUNCH(1, 1);
-        else if (KT == 2) rc = RNF_LAUNCH(1, 2);
-        else if (KT == 4) rc = RNF_LAUNCH(1, 4);
-        else rc = RNF_LAUNCH(1, 8);
+        else if (kt_inv == 1) rc = RNF_LAUNCH(1, 1);
+        else if (kt_inv == 2) rc = RNF_LAUNCH(1, 2);
+        else if (kt_inv == 4) rc = RNF_LAUNCH(1, 4);
+        else if (kt_inv == 8) rc = RNF_LAUNCH(1, 8);
+        else rc = prec ? launch_big_inverse<1>(a, grid, lds_bytes, stream) : launch_big_inverse<0>(a, grid, lds_bytes, stream);
         if (rc) return rc;
         int grid_fb = 0;
         if (guarded) {                                   // the same chunk on the exact-fp32 kernels, skipped on the device unless the guard fired
@@ -707,10 +732,11 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
                 const bool lean = false;
                 (void)lean;
                 if (o.dir == 0) rc = RNF_LAUNCH(0, 0);
-                else if (KT == 1) rc = RNF_LAUNCH(1, 1);
-                else if (KT == 2) rc = RNF_LAUNCH(1, 2);
-                else if (KT == 4) rc = RNF_LAUNCH(1, 4);
-                else rc = RNF_LAUNCH(1, 8);
+                else if (kt_inv == 1) rc = RNF_LAUNCH(1, 1);
+                else if (kt_inv == 2) rc = RNF_LAUNCH(1, 2);
+                else if (kt_inv == 4) rc = RNF_LAUNCH(1, 4);
+                else if (kt_inv == 8) rc = RNF_LAUNCH(1, 8);
+                else rc = launch_big_inverse<0>(a, grid, lds_bytes, stream);
             }
             (void)grid_keep;
             if (rc) return rc;
@@ -1049,7 +1075,7 @@ __global__ __launch_bounds__(NWc * 64) void conditioner_kernel(const float *y, l
                     for (int c = 0; c < 4; ++c) {
                         const int k = 8 * tau + 2 * g + h;
                         const int row = c == 0 ? k : K + 3 * k + (c - 1);
-                        out[sample * 4 * K + row] = o[4 * g + c];
+                        if (k < K) out[sample * 4 * K + row] = o[4 * g + c];          // (k >= K: pad rows of the last tile)
                     }
             }
         }
@@ -1058,7 +1084,7 @@ __global__ __launch_bounds__(NWc * 64) void conditioner_kernel(const float *y, l
 
 extern "C" int rnf_conditioner_forward(const float *y, int64_t n, const float *layer, int32_t K, int32_t prec, float *out,
                                        void *stream) {
-    if (K <= 0 || K % 8) return fail("segments=%d must be a positive multiple of 8", K);
+    if (K <= 0) return fail("segments=%d must be positive", K);
     if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2) return fail("unknown precision %d", prec);
     if (!y || !layer || !out) return fail("rnf_conditioner_forward: null pointer");
     if (n == 0) return 0;
@@ -1068,11 +1094,11 @@ extern "C" int rnf_conditioner_forward(const float *y, int64_t n, const float *l
     if (prec) {
         auto kern = conditioner_kernel<NW, 1>;
         HIP_TRY(allow_lds(kern, lds_bytes));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, reinterpret_cast<hipStream_t>(stream), y, (long long)n, layer, K / 8, K, out);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, reinterpret_cast<hipStream_t>(stream), y, (long long)n, layer, (K + 7) / 8, K, out);
     } else {
         auto kern = conditioner_kernel<NW, 0>;
         HIP_TRY(allow_lds(kern, lds_bytes));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, reinterpret_cast<hipStream_t>(stream), y, (long long)n, layer, K / 8, K, out);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, reinterpret_cast<hipStream_t>(stream), y, (long long)n, layer, (K + 7) / 8, K, out);
     }
     HIP_TRY(hipGetLastError());
     return 0;

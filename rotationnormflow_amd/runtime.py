@@ -195,8 +195,8 @@ def pack_mobius(L, cond, K, feature_dim, prec=_lib.PREC_FP32):
     """cond: ConditionalTransform(3+F, 4K).  -> (layer record, feature-projection record | None)"""
     F = feature_dim
     Fp = pad8(F)
-    if K <= 0 or K % 8:
-        raise NotImplementedError(f"segments={K}: the HIP kernels need a positive multiple of 8")
+    if K <= 0:
+        raise ValueError(f"segments={K} must be positive")
     rec = np.empty(L.rnf_mobius_packed_floats(K), dtype=np.float32)
     frec = np.empty(L.rnf_featproj_packed_floats(Fp), dtype=np.float32) if F else None
     arrs = [_pad_cols(_np32(cond.fc_first.weight), 3, F, Fp), _np32(cond.fc_first.bias)]

@@ -31,6 +31,11 @@ CASES = {
     "k16_freqperm":    dict(cfg=dict(layers=5, segments=16, frequent_permute=1), n=1024, regime="trained", wseed=11, rseed=55, direction="forward", fisher=None),
     "k8_nofirst":      dict(cfg=dict(layers=7, segments=8, first_affine=0), n=1024, regime="trained", wseed=12, rseed=56, direction="forward", fisher=None),
     "k128_inv":        dict(cfg=dict(layers=3, segments=128), n=512, regime="trained", wseed=13, rseed=57, direction="inverse", fisher=None),
+    # segment counts that are not multiples of 8 (flow/mobiusflow.py:7-14 takes any `segments`): the kernels pad the last fc_last tile
+    "k20_fwd":         dict(cfg=dict(layers=4, segments=20), n=1024, regime="trained", wseed=31, rseed=91, direction="forward", fisher=None),
+    "k20_inv":         dict(cfg=dict(layers=4, segments=20), n=512, regime="trained", wseed=31, rseed=92, direction="inverse", fisher=None),
+    "k75_cond_inv":    dict(cfg=dict(layers=2, segments=75, condition=1, feature_dim=24, rot="None", frequent_permute=1, last_affine=0, first_affine=0),
+                            n=512, regime="trained", wseed=32, rseed=93, direction="inverse", fisher=None),
     # unconditional LU parameterisation of the 4x4 affine, and the SVD-rotation layer (registry rows a15 / a18)
     "lu16_uncond":     dict(cfg=dict(layers=3, rot="16Trans", lu=1), n=1024, regime="trained", wseed=15, rseed=59, direction="forward", fisher=None),
     "lu16_uncond_inv": dict(cfg=dict(layers=3, rot="16Trans", lu=1), n=512, regime="trained", wseed=15, rseed=60, direction="inverse", fisher=None),

@@ -83,13 +83,15 @@ def conditioner_from_record(rec, y, K):
     rec = np.asarray(rec, np.float64)
     tt = mlp_head(rec, y)
     out = np.zeros((32, 4 * K))
-    for tau in range(K // 8):
+    for tau in range((K + 7) // 8):                  # K % 8 != 0: the last tile is zero padded, its pad rows must come out 0
         o = last_tile(rec, tau, tt)
         for g in range(4):
             for c in range(4):
                 k = 8 * tau + 2 * g + H
+                real = k < K
+                assert np.abs(o[4 * g + c][~real]).max(initial=0.0) == 0.0
                 row = np.where(c == 0, k, K + 3 * k + (c - 1))
-                out[J, row] = o[4 * g + c]          # each (sample, row) is written by exactly one lane
+                out[J[real], row[real]] = o[4 * g + c][real]          # each (sample, row) is written by exactly one lane
     return out
 
 
@@ -170,13 +172,15 @@ def conditioner_from_record_h(rec32, y, K):
             act = split_act(hcur)
     act = split_act([x0[t] + hcur[t] for t in range(2)])
     out = np.zeros((32, 4 * K))
-    for tau in range(K // 8):
+    for tau in range((K + 7) // 8):
         off = MOB_HEAD + tau * TILE_FLOATS
         o = gemm_tile64_h(rec32, off, act, bias16(rec, off + TILE_BIAS))
         for g in range(4):
             for c in range(4):
                 k = 8 * tau + 2 * g + H
-                out[J, np.where(c == 0, k, K + 3 * k + (c - 1))] = o[4 * g + c]
+                real = k < K
+                row = np.where(c == 0, k, K + 3 * k + (c - 1))
+                out[J[real], row[real]] = o[4 * g + c][real]
     return out
 
 

@@ -30,7 +30,7 @@ def precision(request):
     runtime.set_precision(old)
 
 FORWARD = [n for n, s in CASES.items() if s["direction"] == "forward"]
-INVERSE = [n for n, s in CASES.items() if s["direction"] == "inverse" and s["cfg"].get("segments", 64) <= 64]
+INVERSE = [n for n, s in CASES.items() if s["direction"] == "inverse"]          # incl. K = 128 (two staged halves) and K % 8 != 0
 
 
 def test_native_library_is_loaded():
@@ -89,12 +89,16 @@ def test_inverse_matches_reference_golden(name):
     # bulk: as close to the fp64 truth as the reference's own fp32 run
     assert err.mean() <= 3 * noise.mean() + 1e-5
     assert rerr.mean() <= 3 * rnoise.mean() + 1e-5
-    # tail: a sample whose root sits within rounding error of a bisection-cell boundary lands one cell (pi/2^14) away
-    # in EITHER implementation (the reference's fp32 and fp64 runs disagree on such samples too); allow a few percent
-    assert np.mean(err > 3 * np.quantile(noise, 0.99) + 2e-5) <= 0.03
-    assert np.mean(rerr > 3 * np.quantile(rnoise, 0.99) + 2e-5) <= 0.03
-    assert err.max() <= 3 * noise.max() + 2e-3
-    assert rerr.max() <= 3 * rnoise.max() + 2e-3
+    # tail: a sample whose root sits within rounding error of a boundary of the bisection grid lands one cell (pi / 2^14 = 1.9e-4 rad)
+    # away in EITHER implementation -- the reference's own fp32 and fp64 runs disagree on such samples too (tools/inverse_stats.py,
+    # profiles/r2/inverse_stats.jsonl: 0.6 - 1.2 cells for 2 - 8 layer stacks, the reference's fp32 run 0.7 - 2.2) and in a deep stack
+    # the shifts of several layers add up (42 layers: 6.6 cells here, 8.5 in the reference's fp32 run).  So: never more than 1.25 cells
+    # beyond the reference's own spread, no more samples off by half a cell than the reference has (+0.5 %), and the log-det within
+    # 6 cells' worth (|d ldj / d theta| stays below ~6 on these weights) of it.
+    cell = np.pi / 2 ** 14
+    assert rerr.max() <= 1.25 * cell + rnoise.max()
+    assert err.max() <= 6 * cell + noise.max()
+    assert np.mean(rerr > 0.5 * cell) <= max(0.01, np.mean(rnoise > 0.5 * cell)) + 0.005
 
 
 @pytest.mark.parametrize("name", ["c2_default", "c2_trained"])

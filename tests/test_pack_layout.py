@@ -23,11 +23,11 @@ def _oracle_mlp(m, x):
     return orc.conditioner(torch.as_tensor(x, dtype=torch.float64), p, "c").numpy()
 
 
-@pytest.mark.parametrize("K", [8, 64, 128])
+@pytest.mark.parametrize("K", [8, 64, 128, 10, 20])
 def test_unconditional_mobius_record_matches_oracle(K):
     m = _filled_mlp(3, 4 * K, seed=K)
     rec, frec = runtime.pack_mobius(_lib.lib(), m, K, 0)
-    assert frec is None and rec.size == 12736 + (K // 8) * 2080
+    assert frec is None and rec.size == 12736 + ((K + 7) // 8) * 2080          # K % 8 != 0: last tile zero padded
     y = synth.uniform_rotations(32, seed=3)[:, :, 1]
     got = emu.conditioner_from_record(rec, y, K)
     want = _oracle_mlp(m, y)
@@ -115,12 +115,12 @@ def test_affine16_record():
         assert (halves[:, 50] == rec[16 if off == 36 else 33]).all() and (halves[:, 51] == 0.0).all()
 
 
-@pytest.mark.parametrize("K", [8, 64])
+@pytest.mark.parametrize("K", [8, 64, 20])
 def test_split_precision_record_matches_oracle(K):
     """f16x2 image + the fp16 MFMA lane maps + hi/lo operand split reproduce the fp64 conditioner to ~2^-22."""
     m = _filled_mlp(3, 4 * K, seed=40 + K)
     rec, _ = runtime.pack_mobius(_lib.lib(), m, K, 0, _lib.PREC_F16X2)
-    assert rec.size == 12736 + (K // 8) * 2080
+    assert rec.size == 12736 + ((K + 7) // 8) * 2080
     y = synth.uniform_rotations(32, seed=3)[:, :, 1]
     got = emu.conditioner_from_record_h(rec, y, K)
     want = _oracle_mlp(m, y)
@@ -142,7 +142,8 @@ def test_split_precision_refuses_weights_outside_fp16_range():
 
 def test_pack_rejects_bad_sizes():
     m = _filled_mlp(3, 40, seed=1)
-    with pytest.raises(NotImplementedError):
-        runtime.pack_mobius(_lib.lib(), m, 10, 0)
+    with pytest.raises(ValueError):
+        runtime.pack_mobius(_lib.lib(), m, 0, 0)
     L = _lib.lib()
-    assert L.rnf_mobius_packed_floats(10) == -1 and L.rnf_featproj_packed_floats(12) == -1
+    assert L.rnf_mobius_packed_floats(0) == -1 and L.rnf_featproj_packed_floats(12) == -1
+    assert L.rnf_mobius_packed_floats(10) == 12736 + 2 * 2080

@@ -128,3 +128,81 @@ def test_launch_shape_is_invisible(name, direction):
     wR, wl = fn(cfg, w, R[pick].cpu().numpy(), None if feat is None else feat[pick].cpu().numpy(), torch.float64)
     tol = 2e-4 if direction == "inverse" else 5e-5                           # inverse: one bisection cell is pi / 2^14
     assert (ldj[pick].cpu().double() - wl).abs().mean().item() < tol
+
+
+def test_c4_full_size_independence_chunks_and_oracle():
+    """BASELINE configs[3] at its full size: SYMSOL-I structure (Condition16Trans + 24 Moebius (3+256 inputs) + 23 Uncondition16Trans),
+    2^20 rotations with their own 256-d feature rows.  Four workspace chunks of 2^18: rows must not depend on the chunk, the position in
+    the batch or the launch shape they travel in; the fp64 sum is the sum of the rows; 256 rows are checked against the oracle (fp64)."""
+    cfg = make_config("C4")
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=2024, regime="trained")
+    fl = product_flow(cfg, w)
+    n = 1 << 20
+    R = torch.from_numpy(synth.uniform_rotations(n, seed=42)).cuda()
+    F = torch.from_numpy(synth.features(n, 256, seed=43)).cuda()
+    with torch.no_grad():
+        full = fl.log_prob(R, F)
+        again = fl.log_prob(R, F)
+    lp = full["logp"]
+    assert torch.isfinite(lp).all()
+    assert torch.equal(lp, again["logp"]) and torch.equal(full["sum"], again["sum"])
+    s = full["sum"].cpu().numpy()
+    assert s[1] == n and abs(s[0] - lp.double().sum().item()) < 1e-9 * abs(s[0])
+    # a window that straddles the second chunk boundary, evaluated on its own (other chunk offsets, other tiles)
+    lo, hi = (1 << 19) - 70_001, (1 << 19) + 50_003
+    with torch.no_grad():
+        win = fl.log_prob(R[lo:hi].contiguous(), F[lo:hi].contiguous())["logp"]
+    assert torch.equal(win, lp[lo:hi])
+    # scattered rows in a small launch (8-wave instantiation): same arithmetic, not necessarily the same instruction order
+    idx = torch.randperm(n, generator=torch.Generator().manual_seed(3))[:30_011].cuda()
+    with torch.no_grad():
+        sub = fl.log_prob(R[idx].contiguous(), F[idx].contiguous())["logp"]
+    assert (sub - lp[idx]).abs().max().item() < 3e-6
+    pick = idx[:256]
+    want, _ = orc.log_prob(cfg, w, R[pick].cpu().numpy(), F[pick].cpu().numpy(), None, torch.float64)
+    got = lp[pick].cpu().double()
+    assert abs(float(got.mean()) - float(want.mean())) < 1e-5
+    assert float((got - want).abs().max()) < 2e-4
+
+
+def test_c5_full_size_sample_inverse_roundtrip_and_oracle():
+    """BASELINE configs[4] at its full size: 2^20 base samples from MatrixFisherN(diag(5,3,1)) drawn on the device, pushed through the
+    inverse of the 42-layer Moebius-only conditional flow (F = 512 precomputed features), eval.py:327-347.  Property checks: finite
+    rotations, forward(inverse(z)) == z up to the bisection cells of 42 layers, the forward log-det is minus the inverse one; 256 rows
+    against the oracle's 15-step bisection (fp64)."""
+    cfg = make_config("C5")
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=2024, regime="trained")
+    fl = product_flow(cfg, w)
+    n = 1 << 20
+    base = MatrixFisherN(torch.from_numpy(synth.fisher_A("diag531")).cuda())
+    torch.manual_seed(7)
+    z = base._sample(n).reshape(-1, 3, 3)
+    F = torch.from_numpy(synth.features(n, 512, seed=44)).cuda()
+    with torch.no_grad():
+        x, ldj_inv = fl.inverse(z, F)
+    assert torch.isfinite(x).all() and torch.isfinite(ldj_inv).all()
+    assert (torch.linalg.det(x[:4096]) - 1).abs().max().item() < 1e-4
+    with torch.no_grad():
+        back, ldj_fwd = fl(x, F)
+    rt = (back - z).abs().reshape(n, -1).max(1).values                     # 42 layers of pi / 2^14 cells, amplified by the later layers:
+    assert rt.max().item() < 5e-2                                          # gated below against the reference's own round trip
+    # rows do not depend on the chunk or position they travel in
+    lo, hi = (1 << 18) - 5_001, (1 << 18) + 7_003
+    with torch.no_grad():
+        xs, ls = fl.inverse(z[lo:hi].contiguous(), F[lo:hi].contiguous())
+    assert torch.equal(xs, x[lo:hi]) and torch.equal(ls, ldj_inv[lo:hi])
+    # oracle spot check (the reference's batch-global 15-step bisection, fp64)
+    pick = torch.arange(0, n, n // 256)[:256].cuda()
+    wR, wl = orc.flow_inverse(cfg, w, z[pick].cpu().numpy(), F[pick].cpu().numpy(), dtype=torch.float64)
+    rerr = (x[pick].cpu().double() - wR).abs().reshape(256, -1).max(1).values
+    lerr = (ldj_inv[pick].cpu().double() - wl).abs()
+    cell = np.pi / 2 ** 14
+    assert rerr.median().item() < 0.5 * cell and rerr.max().item() < 12 * cell     # (the reference's own fp32 run: 8.5 cells at 42 layers)
+    assert lerr.median().item() < 1e-4 and lerr.max().item() < 2e-2
+    # round trip: no worse than what the reference's algorithm achieves on the same rows (its bisection leaves half a cell per layer too)
+    bR, bl = orc.flow_forward(cfg, w, wR.numpy(), F[pick].cpu().numpy(), dtype=torch.float64)
+    rt_ref = (bR - z[pick].cpu().double()).abs().reshape(256, -1).max(1).values
+    assert rt[pick].mean().item() <= 1.5 * rt_ref.mean().item() + 1e-5
+    assert rt.mean().item() <= 2.0 * rt_ref.mean().item() + 1e-5
+    ld_ref = (bl + wl).abs().mean().item()
+    assert (ldj_fwd + ldj_inv).abs().mean().item() <= 2.0 * ld_ref + 1e-5

@@ -268,6 +268,27 @@ def _bisect(target, r, v, sw, w):
     return mid
 
 
+class _BinFind(torch.autograd.Function):
+    """BinFind (mobiusflow.py:186-273) with its custom backward: the implicit-function gradient of the root of
+    _forward_theta(theta; r, v, weights, w) = y, evaluated at the bisection's returned midpoint --
+    d theta / dy = 1 / F_theta and d theta / dp = -F_p / F_theta for p in (r, v, weights, w), zero where F_theta == 0 (:262-272)."""
+
+    @staticmethod
+    def forward(ctx, y, r, v, sw, w):
+        theta = _bisect(y.detach(), r.detach(), v.detach(), sw.detach(), w.detach())
+        ctx.save_for_backward(theta, r.detach(), v.detach(), sw.detach(), w.detach())
+        return theta.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        theta, r, v, sw, w = (t.clone().requires_grad_(True) for t in ctx.saved_tensors)
+        with torch.enable_grad():
+            gt, gr, gv, gsw, gw = torch.autograd.grad(_theta_map(theta, r, v, sw, w), (theta, r, v, sw, w), torch.ones_like(g))
+        ok = gt != 0
+        inv = torch.where(ok, 1 / gt, torch.zeros_like(gt))
+        return inv * g, -gr * inv * g, -gv * inv * g, -gsw * inv * g, -gw * inv[..., None] * g[..., None]
+
+
 def mobius_inverse(R, perm, feature, p, prefix, K):
     """mobiusflow.py:127-183."""
     tx = R[..., perm[0]]
@@ -279,7 +300,7 @@ def mobius_inverse(R, perm, feature, p, prefix, K):
     tt = torch.atan2((tx * v).sum(-1), (tx * r).sum(-1)).reshape(-1, 1)
     tt = torch.where(tt >= 0, tt, tt + TWO_PI)
     tt = torch.where((tt - TWO_PI).abs() < 1e-4, torch.zeros_like(tt), tt)
-    theta = _bisect(tt, r, v, sw, w)
+    theta = _BinFind.apply(tt, r, v, sw, w) if torch.is_grad_enabled() else _bisect(tt, r, v, sw, w)
     x = r * torch.cos(theta) + v * torch.sin(theta)
     _, ldj = _mobius_core(x, r, v, sw, w)
     return _assemble(x, ty, perm), -ldj
@@ -515,8 +536,9 @@ def flow_forward(cfg, params, R, feature=None, dtype=torch.float32, grad=False):
     return R, ldj
 
 
-def flow_inverse(cfg, params, R, feature=None, dtype=torch.float32):
-    """Flow.inverse (flow.py:74-92): returns (R [N,3,3], ldj_of_inverse_map [N])."""
+def flow_inverse(cfg, params, R, feature=None, dtype=torch.float32, grad=False):
+    """Flow.inverse (flow.py:74-92): returns (R [N,3,3], ldj_of_inverse_map [N]).  grad=True keeps the autograd graph (through
+    BinFind's custom backward): the oracle for gradients through the inverse pass."""
     p = _as_params(params, dtype)
     R = torch.as_tensor(R).to(dtype)
     feature = None if (feature is None or not cfg.condition) else torch.as_tensor(feature).to(dtype)
@@ -524,7 +546,7 @@ def flow_inverse(cfg, params, R, feature=None, dtype=torch.float32):
     K = cfg.segments
     ldj = torch.zeros(R.shape[0], dtype=dtype)
     count = len(kinds) if cfg.frequent_permute else cfg.layers  # flow.py:78-79
-    with torch.no_grad():
+    with torch.set_grad_enabled(grad):
         for i in reversed(range(len(kinds))):
             kind = kinds[i]
             if kind == "mobius" or cfg.frequent_permute:        # flow.py:85-86 (decrement BEFORE use)

@@ -74,3 +74,13 @@ CASES = {
     "embed_cond":      dict(cfg=dict(layers=3, condition=1, feature_dim=24, embedding=1, embedding_dim=8, rot="16UnTrans", last_affine=1), n=512,
                             regime="default", wseed=14, rseed=58, direction="forward", fisher=None),
 }
+
+
+# Gradients through Flow.inverse (BinFind.backward, flow/mobiusflow.py:247-273): the reference's own autograd in fp64, loss =
+# sum(a * ldj) + sum(B * R_out) with seeded a [n], B [n,3,3] (tests/golden/make_golden.py run_inverse_grad_case).
+GRAD_CASES = {
+    "invgrad_uncond":      dict(cfg=dict(layers=3, segments=16), n=192, regime="trained", wseed=41, rseed=141),
+    "invgrad_mobius_only": dict(cfg=dict(layers=3, segments=8, rot="None", first_affine=0), n=160, regime="trained", wseed=42, rseed=142),
+    "invgrad_cond":        dict(cfg=dict(layers=2, segments=16, condition=1, feature_dim=24, rot="16UnTrans", frequent_permute=1,
+                                         last_affine=1, first_affine=0), n=160, regime="trained", wseed=43, rseed=143),
+}

@@ -96,11 +96,48 @@ def run_case(name, spec):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+def grad_case_loss_weights(n, seed):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal(n), rng.standard_normal((n, 3, 3))
+
+
+def run_inverse_grad_case(name, spec):
+    """Gradients of loss = sum(a * ldj) + sum(B * R_out) through the reference's Flow.inverse (BinFind.backward), fp64."""
+    cfg = make_config(**spec["cfg"])
+    n = spec["n"]
+    dtype = torch.float64
+    fl = build_reference_flow(cfg, dtype).train()
+    sd = fl.state_dict()
+    weights = synth.fill_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed=spec["wseed"], regime=spec["regime"])
+    fl.load_state_dict({k: torch.from_numpy(v).to(dtype) for k, v in weights.items()})
+    R = torch.from_numpy(synth.uniform_rotations(n, seed=spec["rseed"])).to(dtype).requires_grad_(True)
+    feat = None
+    if cfg.condition:
+        feat = torch.from_numpy(synth.features(n, fl.feature_dim, seed=spec["rseed"] + 1000)).to(dtype).requires_grad_(True)
+    a, B = grad_case_loss_weights(n, spec["rseed"] + 7)
+    Rt, ldj = fl.inverse(R, feat)
+    loss = (torch.from_numpy(a) * ldj).sum() + (torch.from_numpy(B) * Rt).sum()
+    loss.backward()
+    out = {"loss": np.float64(loss.item()), "g_rot": R.grad.numpy().copy(), "rot_out": Rt.detach().numpy().copy(), "ldj": ldj.detach().numpy().copy()}
+    if feat is not None:
+        out["g_feat"] = feat.grad.numpy().copy()
+    for k, prm in fl.named_parameters():
+        out["g:" + k] = prm.grad.numpy().copy() if prm.grad is not None else np.zeros(tuple(prm.shape))
+    torch.set_default_dtype(torch.float32)
+    gmax = max(float(np.abs(v).max()) for k, v in out.items() if k.startswith("g:"))
+    print(f"{name:22s} n={n} params={sum(1 for k in out if k.startswith('g:'))} loss={out['loss']:.6f} max|grad|={gmax:.3e}")
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
 def main():
+    from tests.golden.cases import GRAD_CASES
     torch.manual_seed(0)
     names = [n for n in sys.argv[1:] if n in CASES] or ([] if len(sys.argv) > 1 else list(CASES))
     for name in names:
         run_case(name, CASES[name])
+    gnames = [n for n in sys.argv[1:] if n in GRAD_CASES] or ([] if len(sys.argv) > 1 else list(GRAD_CASES))
+    for name in gnames:
+        run_inverse_grad_case(name, GRAD_CASES[name])
 
 
 if __name__ == "__main__":

@@ -185,6 +185,22 @@ int rnf_flow_backward(const float *states_dev, const float *feature_dev, int64_t
                       const float *g_rotation_out_dev, const float *g_ldj_dev, float *grads_dev, float *g_rotation_in_dev,
                       float *g_feature_dev, float *layer_scratch_dev, void *stream);
 
+/* Gradients THROUGH Flow.inverse (flow/flow.py:74-92; MobiusFlow.inverse with BinFind.backward's implicit-function gradient of the
+ * root, flow/mobiusflow.py:247-273; the affine layers apply M^-1, flow/squeezetrans.py:51-55,171-174).
+ * rnf_flow_inverse_train is rnf_flow_inverse that also saves the rotation entering every ITERATION position of the inverse pass
+ * (position 0 = the last flow layer): states_dev float[n_layers][n][9].  rnf_flow_inverse_backward is the reverse sweep:
+ * train_desc lists the layers in that iteration order, rotation_out_dev is the output of the inverse pass (each Moebius layer reads its
+ * root back from its own output, no second root search); everything else as in rnf_flow_backward.  g_rotation_in_dev is the gradient
+ * w.r.t. the rotations GIVEN to Flow.inverse. */
+int rnf_flow_inverse_train(const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim,
+                           const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments,
+                           float *rotation_out_dev, float *ldj_out_dev, float *states_dev, void *workspace_dev,
+                           size_t workspace_bytes, void *stream);
+int rnf_flow_inverse_backward(const float *states_dev, const float *rotation_out_dev, const float *feature_dev, int64_t n,
+                              int32_t feature_dim, const float *plain_dev, const int32_t *train_desc, int32_t n_layers, int32_t segments,
+                              const float *g_rotation_out_dev, const float *g_ldj_dev, float *grads_dev, float *g_rotation_in_dev,
+                              float *g_feature_dev, float *layer_scratch_dev, void *stream);
+
 /* Shared feature rows: feature_dev holds n / feature_div rows and row r conditions rotations [r * feature_div, (r + 1) * feature_div)
  * -- the pose-estimation pattern of Agent.eval_acc (agent.py:238-263), where the reference materialises feature.repeat(number_queries).
  * The feature projection runs once per row; workspace from rnf_workspace_bytes_shared.  n must be a multiple of feature_div. */

@@ -72,6 +72,7 @@ class TrainPlan:
         self.plain_floats = plain_off
         self.blob_floats = max(rec_off, 4)
         self.desc = np.ascontiguousarray(self.desc)
+        self.train_desc_inverse = np.ascontiguousarray(self.train_desc[::-1])    # rnf_flow_inverse_backward: iteration order of the inverse pass
         # packer status word: checked one call later through pinned memory, so that no step waits for the device
         self.flags = torch.zeros(1, dtype=torch.int32, device=device)
         self.flags_host = torch.zeros(1, dtype=torch.int32).pin_memory() if torch.cuda.is_available() else torch.zeros(1, dtype=torch.int32)
@@ -203,8 +204,91 @@ class _FlowForwardFn(torch.autograd.Function):
         return (None, None, g_rotation, g_feature, *outs)
 
 
-def flow_forward(module, layers, perm_rows, rotation, feature):
-    """Differentiable (rotation', ldj) for a stack of layers; called by runtime.run_flow when a gradient is required."""
+class _FlowInverseFn(torch.autograd.Function):
+    """Differentiable ``Flow.inverse`` (flow/flow.py:74-92): the inverse stack kernel saves the rotation entering every iteration
+    position; the backward sweep is the same kernel as for the forward direction, walking the layers in the order the inverse pass
+    visited them, with MobiusFlow.inverse differentiated by BinFind.backward's implicit-function rule (flow/mobiusflow.py:247-273)."""
+
+    @staticmethod
+    def forward(ctx, plan, grad_sync, rotation, feature, *tensors):
+        rot, feat = runtime._check_inputs(rotation, feature, plan)
+        n = rot.shape[0]
+        dev = rot.device
+        L = _lib.lib()
+        out_rot = torch.empty_like(rot)
+        out_ldj = torch.empty(n, dtype=torch.float32, device=dev)
+        states = torch.empty((plan.n_layers, n, 9), dtype=torch.float32, device=dev)
+        f32 = torch.float32
+        plain = torch.cat([t.reshape(-1) if (t.is_cuda and t.dtype is f32) else t.to(device=dev, dtype=f32).reshape(-1)
+                           for t in tensors]) if tensors else torch.zeros(0, device=dev)
+        if plain.numel() != plan.plain_floats:
+            raise RuntimeError(f"plain parameter blob has {plain.numel()} floats, layer table expects {plan.plain_floats}")
+        if n:
+            ws = runtime.workspace(dev, L.rnf_workspace_bytes(n, plan.n_cond))
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                blob = plan.pack(plain, stream)
+                _lib.check(L.rnf_flow_inverse_train(rot.data_ptr(), feat.data_ptr() if feat is not None else None, n,
+                                                    plan.feat_padded, blob.data_ptr(), plan.desc.ctypes.data,
+                                                    plan.n_layers, plan.segments, out_rot.data_ptr(), out_ldj.data_ptr(),
+                                                    states.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+        feat_plain = None
+        if plan.n_cond:
+            feat_plain = feature.reshape(n, plan.feat_dim).to(device=dev, dtype=torch.float32).contiguous()
+        ctx.plan = plan
+        ctx.grad_sync = grad_sync
+        ctx.rot_shape = rotation.shape
+        ctx.feat_shape = feature.shape if feature is not None else None
+        ctx.shapes = [(t.shape, t.device, t.dtype) for t in tensors]
+        ctx.sizes = [t.numel() for t in tensors]
+        ctx.save_for_backward(states, out_rot, feat_plain, plain)
+        return out_rot.reshape(rotation.shape), out_ldj
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_rot, g_ldj):
+        states, out_rot, feat_plain, plain = ctx.saved_tensors
+        plan = ctx.plan
+        n = states.shape[1]
+        dev = states.device
+        L = _lib.lib()
+        want_w = any(ctx.needs_input_grad[4:])
+        grads = torch.zeros_like(plain) if want_w else None
+        g_rot_in = torch.zeros((n, 9), dtype=torch.float32, device=dev)
+        want_gfeat = feat_plain is not None and ctx.needs_input_grad[3]
+        g_feat = torch.zeros_like(feat_plain) if want_gfeat else None
+        scratch = torch.zeros(max(plan.n_layers, 1), dtype=torch.float32, device=dev)
+        if n:
+            g_rot_c = g_rot.reshape(n, 9).to(torch.float32).contiguous() if g_rot is not None else None
+            g_ldj_c = (g_ldj.to(torch.float32).contiguous() if g_ldj is not None
+                       else torch.zeros(n, dtype=torch.float32, device=dev))
+            ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                _lib.check(L.rnf_flow_inverse_backward(states.data_ptr(), out_rot.data_ptr(), ptr(feat_plain), n, plan.feat_dim,
+                                                       plain.data_ptr(), plan.train_desc_inverse.ctypes.data, plan.n_layers, plan.segments,
+                                                       ptr(g_rot_c), g_ldj_c.data_ptr(), ptr(grads), g_rot_in.data_ptr(), ptr(g_feat),
+                                                       scratch.data_ptr(), stream))
+        needs = ctx.needs_input_grad
+        if want_w:
+            runtime.note_training_step()
+            if ctx.grad_sync is not None:
+                ctx.grad_sync(grads)
+        pieces = torch.split(grads, ctx.sizes) if (ctx.sizes and want_w) else ()
+        outs = []
+        for i, (shape, device, dtype) in enumerate(ctx.shapes):
+            g = None
+            if want_w and needs[4 + i]:
+                g = pieces[i].view(shape)
+                if device != dev or dtype is not torch.float32:
+                    g = g.to(device=device, dtype=dtype)
+            outs.append(g)
+        g_rotation = g_rot_in.reshape(ctx.rot_shape) if ctx.needs_input_grad[2] else None
+        g_feature = g_feat.reshape(ctx.feat_shape) if want_gfeat else None
+        return (None, None, g_rotation, g_feature, *outs)
+
+
+def _plan_for(module, layers, perm_rows, rotation):
     if not rotation.is_cuda:
         raise RuntimeError("rotationnormflow_amd runs on the GPU only (HIP kernels, no CPU fallback): got a CPU tensor")
     for layer in layers:
@@ -215,4 +299,17 @@ def flow_forward(module, layers, perm_rows, rotation, feature):
     if cached is None or cached[0] != key:
         cached = (key, TrainPlan(layers, perm_rows, rotation.device, runtime.get_precision()))
         module._rnf_train_plan = cached
-    return _FlowForwardFn.apply(cached[1], getattr(module, "_rnf_grad_sync", None), rotation, feature, *train_tensors(layers))
+    return cached[1]
+
+
+def flow_inverse(module, layers, perm_rows, rotation, feature):
+    """Differentiable Flow.inverse: (rotation, ldj of the inverse map) with gradients w.r.t. parameters, the given rotations and the
+    features (flow/mobiusflow.py:247-273 BinFind.backward for the Moebius layers)."""
+    plan = _plan_for(module, layers, perm_rows, rotation)
+    return _FlowInverseFn.apply(plan, getattr(module, "_rnf_grad_sync", None), rotation, feature, *train_tensors(layers))
+
+
+def flow_forward(module, layers, perm_rows, rotation, feature):
+    """Differentiable (rotation', ldj) for a stack of layers; called by runtime.run_flow when a gradient is required."""
+    plan = _plan_for(module, layers, perm_rows, rotation)
+    return _FlowForwardFn.apply(plan, getattr(module, "_rnf_grad_sync", None), rotation, feature, *train_tensors(layers))

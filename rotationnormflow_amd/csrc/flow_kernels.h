@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             const int2 d = args.layers[layer_at(pos)];
             const int kind = d.x & 15, perm_row = (d.x >> 4) & 15, slot = ((d.x >> 8) & 255) - 1;
             const float *params = args.blob + d.y;
-            if (!LEAN && DIR == 0 && args.states && valid && h == 0) {       // saved for train_kernels.h (backward recomputes from here)
+            if (!LEAN && args.states && valid && h == 0) {       // saved for train_kernels.h (the backward sweep recomputes from here), both directions
                 float *dst = args.states + ((size_t)pos * args.states_n + args.sample_base + sample_now()) * 9;
                 dst[0] = R.c0.x; dst[1] = R.c1.x; dst[2] = R.c2.x;
                 dst[3] = R.c0.y; dst[4] = R.c1.y; dst[5] = R.c2.y;

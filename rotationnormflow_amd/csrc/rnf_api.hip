@@ -825,9 +825,26 @@ extern "C" size_t rnf_plain_layer_floats(int32_t kind, int32_t segments, int32_t
     return 64 * ni + 64 + 3 * (4096 + 64) + no * 64 + no;
 }
 
+static int run_backward(const float *states, const float *rot_final, int dir, const float *feat, int64_t n, int32_t F, const float *plain,
+                        const int32_t *tdesc, int32_t n_layers, int32_t K, const float *g_rot_out, const float *g_ldj, float *grads,
+                        float *g_rot_in, float *g_feature, float *g_ldj_sum, void *stream_v);
+
 extern "C" int rnf_flow_backward(const float *states, const float *feat, int64_t n, int32_t F, const float *plain, const int32_t *tdesc,
                                  int32_t n_layers, int32_t K, const float *g_rot_out, const float *g_ldj, float *grads,
                                  float *g_rot_in, float *g_feature, float *g_ldj_sum, void *stream_v) {
+    return run_backward(states, nullptr, 0, feat, n, F, plain, tdesc, n_layers, K, g_rot_out, g_ldj, grads, g_rot_in, g_feature, g_ldj_sum, stream_v);
+}
+
+extern "C" int rnf_flow_inverse_backward(const float *states, const float *rot_out, const float *feat, int64_t n, int32_t F, const float *plain,
+                                         const int32_t *tdesc, int32_t n_layers, int32_t K, const float *g_rot_out, const float *g_ldj,
+                                         float *grads, float *g_rot_in, float *g_feature, float *g_ldj_sum, void *stream_v) {
+    if (n > 0 && !rot_out) return fail("rnf_flow_inverse_backward: the output rotations of the inverse pass are needed (they carry the roots)");
+    return run_backward(states, rot_out, 1, feat, n, F, plain, tdesc, n_layers, K, g_rot_out, g_ldj, grads, g_rot_in, g_feature, g_ldj_sum, stream_v);
+}
+
+static int run_backward(const float *states, const float *rot_final, int dir, const float *feat, int64_t n, int32_t F, const float *plain,
+                        const int32_t *tdesc, int32_t n_layers, int32_t K, const float *g_rot_out, const float *g_ldj, float *grads,
+                        float *g_rot_in, float *g_feature, float *g_ldj_sum, void *stream_v) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     if (n < 0) return fail("n=%lld is negative", (long long)n);
     if (n_layers < 0 || n_layers > TR_MAX_LAYERS) return fail("n_layers=%d outside [0,%d] (training path)", n_layers, TR_MAX_LAYERS);
@@ -851,6 +868,7 @@ extern "C" int rnf_flow_backward(const float *states, const float *feat, int64_t
     a.states = states; a.feature = F ? feat : nullptr; a.plain = plain; a.grads = grads; a.g_rot_out = g_rot_out; a.g_ldj = g_ldj;
     a.g_rot_in = g_rot_in; a.g_feature = F ? g_feature : nullptr; a.g_ldj_sum = g_ldj_sum;
     a.n = n; a.n_layers = n_layers; a.K = K; a.F = F;
+    a.dir = dir; a.rot_final = rot_final;
 #ifdef RNF_STAMPS
     {   // diagnostic build: RNF_TRAIN_STAMPS_PTR=<device address of 10 zeroed uint64> (tools/phase_stamps_train.py)
         const char *sp = std::getenv("RNF_TRAIN_STAMPS_PTR");
@@ -877,6 +895,17 @@ extern "C" int rnf_flow_backward(const float *states, const float *feat, int64_t
         HIP_TRY(hipGetLastError());
     }
     return 0;
+}
+
+// Flow.inverse that also saves the rotation entering every iteration position of the inverse pass (position 0 = the last flow layer)
+extern "C" int rnf_flow_inverse_train(const float *rot, const float *feat, int64_t n, int32_t F, const float *blob, const int32_t *desc,
+                                      int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, float *states, void *ws, size_t ws_bytes,
+                                      void *stream) {
+    if (!states && n > 0) return fail("rnf_flow_inverse_train: states pointer is null");
+    if (!rot_out && n > 0) return fail("rnf_flow_inverse_train: rotation_out is needed by rnf_flow_inverse_backward");
+    RunOpts o{1, nullptr, nullptr, 0, nullptr, nullptr};
+    o.states = states;
+    return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
 }
 
 extern "C" int rnf_flow_inverse(const float *rot, const float *feat, int64_t n, int32_t F, const float *blob,

@@ -188,6 +188,167 @@ RNF_HD void mobius_segments_backward(const MobiusSaved &sv, const CondRow &cond,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// MobiusFlow.inverse backward (flow/mobiusflow.py:127-183 with BinFind.backward, :247-273).
+//
+// Forward of the inverse layer, per sample: frame (r, v) from the GIVEN column tx and the conditioning column ty; theta = the root of
+//     F(theta) = sum_k sp_k phi_k(theta; u_k) / S = T           (T = angle of tx in its own frame == pi, a constant)
+// on the bisection grid; x = r cos(theta) + v sin(theta); ldj = -log(J / S), J = sum_k sp_k c_k(theta; u_k); third column from x and ty.
+// BinFind.backward is the implicit-function gradient of the root AT THE RETURNED ITERATE:  d theta = -(sum_p F_p dp) / F_theta with
+// F_theta = sum_k sp_k c_k / S = J / S  (d phi_k / d theta = c_k), so with
+//     g_theta = g_x . (v cos - r sin)  +  g_J * sum_k sp_k dc_k/dtheta          (the second term: ldj is evaluated at theta too)
+// the root contributes the adjoint  g_F = -g_theta * S / J  to F = A / S (A = sum_k sp_k phi_k), and every segment gets
+//     g_sp_k = g_S + g_A phi_k + g_J c_k,   g_phi_k = g_A sp_k,   g_c_k = g_J sp_k
+// exactly as in the forward layer -- only the values of (g_S, g_A, g_J) and the evaluation point (cos, sin, theta) instead of
+// (-1, 0, pi) differ.  The layer's output state gives theta back without a second root search: x = column p0 of the layer output.
+// ---------------------------------------------------------------------------------------------------------------------
+struct MobiusInvSaved {
+    MobiusSaved b;            // frame of (tx, ty): b.x = tx, b.y = ty, b.f, b.inv_x, b.inv_cr, b.cyc, b.p0..p2
+    float cs, sn, theta;      // evaluation point: x = r cs + v sn
+    float S, A, J, Cth;       // sums at theta: sp, sp phi, sp c, sp dc/dtheta
+    v3f x, zu;                // restored column and un-normalised third column
+    float inv_zu;
+};
+
+RNF_HD void mobius_inv_frame(const Rot &Rin, int perm_row, const Rot &Rout, MobiusInvSaved &sv) {
+    mobius_frame(Rin, perm_row, sv.b);
+    sv.x = get_col(Rout, sv.b.p0);
+    const float c0 = dot3(sv.x, sv.b.f.r), s0 = dot3(sv.x, sv.b.f.v);
+    const float inv = 1.0f / sqrtf(fmaf(s0, s0, c0 * c0));
+    sv.cs = c0 * inv;
+    sv.sn = s0 * inv;
+    sv.theta = angle_0_2pi(s0, c0);
+    sv.zu = sv.b.cyc ? cross3(sv.x, sv.b.y) : cross3(sv.b.y, sv.x);
+    sv.inv_zu = 1.0f / sqrtf(dot3(sv.zu, sv.zu));
+}
+
+// one segment at a general point of the circle: phi, c and dc/dtheta
+RNF_HD void mobius_segment_at(float ur, float uv, float cs, float sn, float theta, float &phi, float &c, float &dc) {
+    const float a = fmaf(uv, sn, ur * cs), b = fmaf(uv, cs, -ur * sn);
+    const float e1 = 1.0f - a;
+    phi = fmaf(2.0f, atan_unit(-b * hw_rcp(e1)), theta);
+    const float inv_d2 = hw_rcp(fmaf(b, b, e1 * e1));
+    c = (1.0f - fmaf(uv, uv, ur * ur)) * inv_d2;
+    dc = 2.0f * b * c * inv_d2;                           // d(d2)/dtheta = -2 b
+}
+
+template <class CondRow>
+RNF_HD void mobius_inv_segments_sums(const MobiusInvSaved &sv, const CondRow &cond, int K, int k0, int k1, float &S, float &A, float &J, float &Cth) {
+    for (int k = k0; k < k1; ++k) {
+        float ur, uv, phi, c, dc;
+        squash_center(cond.get(K + 3 * k), cond.get(K + 3 * k + 1), cond.get(K + 3 * k + 2), sv.b.f, ur, uv);
+        mobius_segment_at(ur, uv, sv.cs, sv.sn, sv.theta, phi, c, dc);
+        const float sp = softplus(cond.get(k));
+        S += sp; A = fmaf(sp, phi, A); J = fmaf(sp, c, J); Cth = fmaf(sp, dc, Cth);
+    }
+}
+
+RNF_HD void mobius_inv_backward_head(MobiusInvSaved &sv, float S, float A, float J, float Cth, const Rot &gRout, float g_ldj, MobiusGrad &mg) {
+    sv.S = S; sv.A = A; sv.J = J; sv.Cth = Cth;
+    const v3f z3 = sv.zu * sv.inv_zu;
+    v3f g_x = get_col(gRout, sv.b.p0);
+    mg.g_y = get_col(gRout, sv.b.p1);
+    const v3f g_zu = normalize_bwd(z3, sv.inv_zu, get_col(gRout, sv.b.p2));
+    if (sv.b.cyc) {          // zu = x x ty
+        g_x = g_x + cross3(sv.b.y, g_zu);
+        mg.g_y = mg.g_y + cross3(g_zu, sv.x);
+    } else {                 // zu = ty x x
+        mg.g_y = mg.g_y + cross3(sv.x, g_zu);
+        g_x = g_x + cross3(g_zu, sv.b.y);
+    }
+    // x = r cos(theta) + v sin(theta)
+    mg.g_r = g_x * sv.cs;
+    mg.g_v = g_x * sv.sn;
+    // ldj = -(log J - log S)
+    mg.g_J = -g_ldj / J;
+    const float g_theta = dot3(g_x, sv.b.f.v * sv.cs - sv.b.f.r * sv.sn) + mg.g_J * Cth;
+    // root of A / S = T:  adjoint of F is -g_theta / F_theta, F_theta = J / S
+    const float invS = 1.0f / S;
+    const float g_F = -g_theta * S / J;
+    mg.g_A = g_F * invS;
+    mg.g_S = -g_F * A * invS * invS + g_ldj * invS;
+}
+
+// segments [k0, k1) of a layer evaluated at (cs, sn, theta): conditioner-output gradients and the frame-vector contributions
+template <class CondRow, class GradRow>
+RNF_HD void mobius_segments_backward_range_at(const Frame &f, float cs, float sn, float theta, const CondRow &cond, int K, int k0, int k1,
+                                              const MobiusGrad &mg, const GradRow &g_cond, v3f &g_r, v3f &g_v) {
+    for (int k = k0; k < k1; ++k) {
+        const float s_raw = cond.get(k);
+        const float w0 = cond.get(K + 3 * k), w1 = cond.get(K + 3 * k + 1), w2 = cond.get(K + 3 * k + 2);
+        const float wr = fmaf(w2, f.r.z, fmaf(w1, f.r.y, w0 * f.r.x));
+        const float wv = fmaf(w2, f.v.z, fmaf(w1, f.v.y, w0 * f.v.x));
+        const float n = hw_sqrt(fmaf(wv, wv, wr * wr));
+        const float inv1n = hw_rcp(1.0f + n);
+        const float sc = 0.7f * inv1n;
+        const float ur = wr * sc, uv = wv * sc;
+        const float a = fmaf(uv, sn, ur * cs), b = fmaf(uv, cs, -ur * sn);
+        const float e1 = 1.0f - a;
+        const float inv_e1 = hw_rcp(e1);
+        const float t = -b * inv_e1;
+        const float phi = fmaf(2.0f, atan_unit(t), theta);
+        const float u2 = fmaf(uv, uv, ur * ur), d2 = fmaf(b, b, e1 * e1);
+        const float inv_d2 = hw_rcp(d2);
+        const float c = (1.0f - u2) * inv_d2;
+        const float sp = softplus(s_raw);
+        const float g_sp = mg.g_S + mg.g_A * phi + mg.g_J * c;
+        const float g_phi = mg.g_A * sp, g_c = mg.g_J * sp;
+        g_cond.put(k, g_sp * hw_rcp(1.0f + hw_exp2(-1.44269504088896341f * s_raw)));
+        // phi = theta + 2 atan(t), t = -b / e1, e1 = 1 - a
+        const float g_t = g_phi * 2.0f * hw_rcp(fmaf(t, t, 1.0f));
+        float g_b = -g_t * inv_e1, g_e1 = -g_t * t * inv_e1;
+        // c = (1 - u2) / d2, d2 = b^2 + e1^2
+        const float g_u2 = -g_c * inv_d2, g_d2 = -g_c * c * inv_d2;
+        g_b += 2.0f * b * g_d2;
+        g_e1 += 2.0f * e1 * g_d2;
+        const float g_a = -g_e1;
+        // (a, b) = u conj(z)
+        const float g_ur = fmaf(g_a, cs, -g_b * sn) + 2.0f * ur * g_u2;
+        const float g_uv = fmaf(g_a, sn, g_b * cs) + 2.0f * uv * g_u2;
+        const float g_sc = g_ur * wr + g_uv * wv;
+        float g_wr = g_ur * sc, g_wv = g_uv * sc;
+        const float g_n = -g_sc * sc * inv1n;
+        if (n > 0.f) { const float gn = g_n * hw_rcp(n); g_wr = fmaf(gn, wr, g_wr); g_wv = fmaf(gn, wv, g_wv); }
+        g_cond.put(K + 3 * k, g_wr * f.r.x + g_wv * f.v.x);
+        g_cond.put(K + 3 * k + 1, g_wr * f.r.y + g_wv * f.v.y);
+        g_cond.put(K + 3 * k + 2, g_wr * f.r.z + g_wv * f.v.z);
+        g_r = g_r + v3f{w0, w1, w2} * g_wr;
+        g_v = g_v + v3f{w0, w1, w2} * g_wv;
+    }
+}
+
+// whole layer (host test entry): dL/d(cond) and dL/dRin (excluding the conditioner-input path of ty) from dL/dRout, dL/dldj
+template <class CondRow, class GradRow>
+RNF_HD void mobius_inverse_backward(const Rot &Rin, int perm_row, const Rot &Rout, const CondRow &cond, int K, const Rot &gRout, float g_ldj,
+                                    const GradRow &g_cond, Rot &gRin) {
+    MobiusInvSaved sv;
+    mobius_inv_frame(Rin, perm_row, Rout, sv);
+    float S = 0.f, A = 0.f, J = 0.f, Cth = 0.f;
+    mobius_inv_segments_sums(sv, cond, K, 0, K, S, A, J, Cth);
+    MobiusGrad mg;
+    mobius_inv_backward_head(sv, S, A, J, Cth, gRout, g_ldj, mg);
+    mobius_segments_backward_range_at(sv.b.f, sv.cs, sv.sn, sv.theta, cond, K, 0, K, mg, g_cond, mg.g_r, mg.g_v);
+    mobius_backward_tail(sv.b, mg, gRin);
+}
+
+// M^-1 enters the inverse pass of the affine layers (flow/squeezetrans.py:51-55,171-174: torch.linalg.inv): dL/dM = -M^-T (dL/dM^-1) M^-T
+template <int N>
+RNF_HD void inverse_matrix_grad(const float *Minv, const float *gMinv, float *gM) {
+    float t[N * N];
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {           // t = Minv^T gMinv
+            float a = 0.f;
+            for (int l = 0; l < N; ++l) a += Minv[l * N + i] * gMinv[l * N + j];
+            t[i * N + j] = a;
+        }
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {           // gM = -t Minv^T
+            float a = 0.f;
+            for (int l = 0; l < N; ++l) a += t[i * N + l] * Minv[j * N + l];
+            gM[i * N + j] = -a;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // calculate_16 (flow/squeezetrans.py:33-38) backward.  Forward: q = quat(R) (candidate `best`), t = M q, l2 = |t|^2,
 // R' = rot(t) with two_s = 2 / l2, ldj = log|det M| - 2 log l2.
 // ---------------------------------------------------------------------------------------------------------------------

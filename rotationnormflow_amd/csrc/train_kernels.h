@@ -42,6 +42,11 @@ struct TrainArgs {
     float *g_ldj_sum;         // [n_layers] sum over the batch of dL/dldj (for the log|det M| term), zeroed by the caller
     long long n;
     int n_layers, K, F;
+    // dir = 1: backward of Flow.inverse (flow/flow.py:74-92; MobiusFlow.inverse with BinFind.backward, flow/mobiusflow.py:247-273).  The
+    // layer table is then in ITERATION order of the inverse pass (last flow layer first), states[p] is the rotation entering iteration
+    // position p and rot_final [n][9] the output of the whole pass: a Moebius layer reads its root theta back from its own output.
+    int dir;
+    const float *rot_final;
     unsigned long long *stamps;   // diagnostic builds only (RNF_STAMPS): per-phase cycle sums of wave 0, else nullptr
     // per layer: x = kind | perm_row << 4 | orthogonal << 8, y = plain offset
     int2 layers[TR_MAX_LAYERS];
@@ -278,6 +283,20 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                 float M[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) M[i] = P[i];
+                const bool orth = (d.x >> 8) & 1;         // UnconditionRot: ldj = 0 (flow/rottrans.py:21)
+                float Mp[16];                             // the parameter matrix; the inverse pass applies M^-1 (squeezetrans.py:171-174), or
+                if (args.dir) {                           // M^T for the orthogonal UnconditionRot (rottrans.py:26-28)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) Mp[i] = M[i];
+                    if (orth) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) M[4 * i + jj] = Mp[4 * jj + i];
+                    } else {
+                        inv4(Mp, M);
+                    }
+                }
                 Rot Rout, gRin;
                 AffineSaved sv;
                 float l;
@@ -285,8 +304,20 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                 float gM[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) gM[i] = 0.f;
-                const bool orth = (d.x >> 8) & 1;         // UnconditionRot: ldj = 0 (flow/rottrans.py:21)
                 affine16_backward(M, sv, gR, g_ldj, orth, gM, gRin);
+                if (args.dir) {                           // dL/dM from dL/d(applied matrix)
+                    float gA[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) gA[i] = gM[i];
+                    if (orth) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) gM[4 * i + jj] = gA[4 * jj + i];
+                    } else {
+                        inverse_matrix_grad<4>(M, gA, gM);
+                    }
+                }
                 if (wave == 0 && want_w) {                // batch sums through LDS: lane 4v + q adds 16 rotations of entry v
 #pragma unroll
                     for (int i = 0; i < 16; ++i) GA.at(i, lane) = valid ? gM[i] : 0.f;
@@ -296,8 +327,8 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                     for (int i = 0; i < 16; ++i) tot += GA.at(v, 16 * q + i);
                     tot = quad_sum(tot);
                     if (q == 0) atomicAdd(Gp + v, tot);
-                    const float gl = wave_sum(valid && !orth ? g_ldj : 0.f);
-                    if (lane == 0) atomicAdd(args.g_ldj_sum + pos, gl);
+                    const float gl = wave_sum(valid && !orth ? g_ldj : 0.f);      // log|det M^-1| = -log|det M| on the inverse pass
+                    if (lane == 0) atomicAdd(args.g_ldj_sum + pos, args.dir ? -gl : gl);
                 }
                 gR = gRin;
                 RNF_TSTAMP(8)
@@ -308,7 +339,16 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
 #pragma unroll
                 for (int i = 0; i < 9; ++i) { M[i] = P[i]; gM[i] = 0.f; }
                 Rot gRin;
-                gs9_backward(M, Rin, gR, g_ldj, gM, gRin);
+                if (args.dir) {                           // the inverse pass applies M^-1 (squeezetrans.py:259-261)
+                    float Mi[9], gMi[9];
+                    inv3(M, Mi);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) gMi[i] = 0.f;
+                    gs9_backward(Mi, Rin, gR, g_ldj, gMi, gRin);
+                    inverse_matrix_grad<3>(Mi, gMi, gM);
+                } else {
+                    gs9_backward(M, Rin, gR, g_ldj, gM, gRin);
+                }
                 if (wave == 0 && want_w) {
 #pragma unroll
                     for (int i = 0; i < 9; ++i) GA.at(i, lane) = valid ? gM[i] : 0.f;
@@ -438,7 +478,48 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
             RNF_TSTAMP(2)
             // ================= layer math: forward sums + backward; dL/dC overwrites C =================
             Rot gRin;
-            if (mob) {
+            if (mob && args.dir) {
+                // ---- MobiusFlow.inverse: the root theta comes back from the layer's own output (column p0 of the next state) ----
+                Rot Rout;
+                Rout.c0 = v3f{1.f, 0.f, 0.f}; Rout.c1 = v3f{0.f, 1.f, 0.f}; Rout.c2 = v3f{0.f, 0.f, 1.f};
+                if (valid) {
+                    const float *s = pos + 1 < args.n_layers ? args.states + ((size_t)(pos + 1) * args.n + sample) * 9 : args.rot_final + sample * 9;
+                    Rout.c0 = v3f{s[0], s[3], s[6]}; Rout.c1 = v3f{s[1], s[4], s[7]}; Rout.c2 = v3f{s[2], s[5], s[8]};
+                } else {
+                    Rout = Rin;                             // padding lanes: x = tx, i.e. theta = pi; finite everywhere, gradients exactly 0
+                }
+                MobiusInvSaved sv;
+                mobius_inv_frame(Rin, perm_row, Rout, sv);
+                const LaneRow crow{Cm, lane};
+                const int k0 = wave * K / TR_WAVES, k1 = (wave + 1) * K / TR_WAVES;
+                float S = 0.f, A = 0.f, J = 0.f, Cth = 0.f;
+                mobius_inv_segments_sums(sv, crow, K, k0, k1, S, A, J, Cth);
+                red[(wave * 4 + 0) * 64 + lane] = S;
+                red[(wave * 4 + 1) * 64 + lane] = A;
+                red[(wave * 4 + 2) * 64 + lane] = J;
+                red[(wave * 4 + 3) * 64 + lane] = Cth;
+                lds_barrier();
+                S = A = J = Cth = 0.f;
+#pragma unroll
+                for (int w = 0; w < TR_WAVES; ++w) {
+                    S += red[(w * 4 + 0) * 64 + lane]; A += red[(w * 4 + 1) * 64 + lane];
+                    J += red[(w * 4 + 2) * 64 + lane]; Cth += red[(w * 4 + 3) * 64 + lane];
+                }
+                MobiusGrad mg;
+                mobius_inv_backward_head(sv, S, A, J, Cth, gR, g_ldj, mg);
+                v3f pr = v3f{0.f, 0.f, 0.f}, pv = pr;
+                mobius_segments_backward_range_at(sv.b.f, sv.cs, sv.sn, sv.theta, crow, K, k0, k1, mg, crow, pr, pv);
+                float *red2 = red + TR_WAVES * 4 * 64;
+                red2[(wave * 6 + 0) * 64 + lane] = pr.x; red2[(wave * 6 + 1) * 64 + lane] = pr.y; red2[(wave * 6 + 2) * 64 + lane] = pr.z;
+                red2[(wave * 6 + 3) * 64 + lane] = pv.x; red2[(wave * 6 + 4) * 64 + lane] = pv.y; red2[(wave * 6 + 5) * 64 + lane] = pv.z;
+                lds_barrier();
+#pragma unroll
+                for (int w = 0; w < TR_WAVES; ++w) {
+                    mg.g_r = mg.g_r + v3f{red2[(w * 6 + 0) * 64 + lane], red2[(w * 6 + 1) * 64 + lane], red2[(w * 6 + 2) * 64 + lane]};
+                    mg.g_v = mg.g_v + v3f{red2[(w * 6 + 3) * 64 + lane], red2[(w * 6 + 4) * 64 + lane], red2[(w * 6 + 5) * 64 + lane]};
+                }
+                mobius_backward_tail(sv.b, mg, gRin);
+            } else if (mob) {
                 MobiusSaved sv;
                 mobius_frame(Rin, perm_row, sv);
                 const LaneRow crow{Cm, lane};
@@ -478,14 +559,24 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                 Rot Rout;
                 AffineSaved sv;
                 float l;
-                affine16_forward_saved(M, 0.f, Rin, Rout, l, sv);
-                affine16_backward(M, sv, gR, g_ldj, false, gM, gRin);
+                if (args.dir) {                         // inverse pass: the layer applies M^-1 (squeezetrans.py:51-55), log|det M^-1| = -log|det M|
+                    float gMi[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) gMi[i] = 0.f;
+                    affine16_forward_saved(Mi, 0.f, Rin, Rout, l, sv);
+                    affine16_backward(Mi, sv, gR, g_ldj, false, gMi, gRin);
+                    inverse_matrix_grad<4>(Mi, gMi, gM);
+                } else {
+                    affine16_forward_saved(M, 0.f, Rin, Rout, l, sv);
+                    affine16_backward(M, sv, gR, g_ldj, false, gM, gRin);
+                }
+                const float gl = args.dir ? -g_ldj : g_ldj;
                 lds_barrier();                          // every wave has read C
                 if (wave == 0) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) Cm.at(4 * i + jj, lane) = gM[4 * i + jj] + g_ldj * Mi[4 * jj + i];
+                        for (int jj = 0; jj < 4; ++jj) Cm.at(4 * i + jj, lane) = gM[4 * i + jj] + gl * Mi[4 * jj + i];
                 }
                 lds_barrier();
             }

@@ -95,7 +95,8 @@ class Flow(nn.Module):
     def inverse(self, rotation, feature=None, draw=False, feature_repeat=None):
         if not self.condition:
             feature = None
-        return runtime.run_flow(self, self._packed(rotation.device), rotation, feature, inverse=True, feature_repeat=feature_repeat)
+        return runtime.run_flow(self, lambda: self._packed(rotation.device), rotation, feature, inverse=True,
+                                train_layers=list(self.layers), train_rows=self._inverse_rows(), feature_repeat=feature_repeat)
 
     # ---- fused density evaluation (agent.py:54-65,217-229 + utils/fisher.py:217-232) -------------------------
     def log_prob(self, rotation, feature=None, base=None, return_rotation=False, feature_repeat=None):

@@ -332,7 +332,7 @@ def _needs_grad(rotation, feature, module) -> bool:
 def _refuse_autograd(rotation, feature, module, what):
     if _needs_grad(rotation, feature, module):
         raise NotImplementedError(
-            f"rotationnormflow_amd: {what} has no backward kernel (only Flow.forward is differentiable); call it under "
+            f"rotationnormflow_amd: {what} has no backward kernel (Flow.forward and Flow.inverse are differentiable); call it under "
             "torch.no_grad() -- there is deliberately no PyTorch fallback path")
 
 
@@ -344,11 +344,11 @@ def run_flow(module, packed, rotation, feature, inverse=False, train_layers=None
     ``feature_repeat`` = Q: ``feature`` has N / Q rows and row r conditions rotations [r Q, (r + 1) Q) (pose estimation, agent.py:238-263;
     evaluation only) -- the feature projection then runs once per row instead of once per rotation."""
     if _needs_grad(rotation, feature, module):
-        if inverse:
-            _refuse_autograd(rotation, feature, module, "Flow.inverse")
         if feature_repeat:
             _refuse_autograd(rotation, feature, module, "a flow call with shared feature rows (feature_repeat)")
         from . import autograd
+        if inverse:                                        # BinFind.backward (flow/mobiusflow.py:247-273) and friends
+            return autograd.flow_inverse(module, train_layers, train_rows, rotation, feature)
         return autograd.flow_forward(module, train_layers, train_rows, rotation, feature)
     if callable(packed):
         packed = packed()

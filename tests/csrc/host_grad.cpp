@@ -28,6 +28,17 @@ void hg_mobius(const float *Rin, int perm_row, const float *cond, int K, const f
         store_rot(gi, gRin + 9 * i);
     }
 }
+// backward of MobiusFlow.inverse given the layer's input, its output (which carries the root theta) and the conditioner output
+void hg_mobius_inverse(const float *Rin, int perm_row, const float *Rout, const float *cond, int K, const float *gRout, const float *g_ldj, int n,
+                       float *g_cond, float *gRin) {
+    for (int i = 0; i < n; ++i) {
+        Rot gi;
+        mobius_inverse_backward(load_rot(Rin + 9 * i), perm_row, load_rot(Rout + 9 * i), StridedRow{const_cast<float *>(cond) + (size_t)4 * K * i, 1}, K,
+                                load_rot(gRout + 9 * i), g_ldj[i], StridedRow{g_cond + (size_t)4 * K * i, 1}, gi);
+        store_rot(gi, gRin + 9 * i);
+    }
+}
+void hg_inverse_matrix_grad4(const float *Minv, const float *gMinv, float *gM) { inverse_matrix_grad<4>(Minv, gMinv, gM); }
 void hg_affine(const float *M, float logabsdet, const float *Rin, const float *gRout, const float *g_ldj, int n, float *Rout, float *ldj,
                float *gM, float *gRin) {
     float m[16], gm[16];

@@ -105,13 +105,82 @@ def test_gradients_match_oracle_autograd(name):
         assert np.abs(gf - want_gf).max() / max(np.abs(want_gf).max(), 1e-3) < REL
 
 
-def test_inverse_stays_undifferentiable():
-    cfg, w, R, feat, gR, gl = _make("uncond_k16")
+INVERSE_CASES = ["uncond_k16", "cond_k32", "cond_first_affine", "mobius_only", "lu", "rot", "gs9", "svdl9"]
+
+
+@pytest.mark.parametrize("name", INVERSE_CASES)
+def test_inverse_gradients_match_oracle_autograd(name):
+    """Gradients THROUGH Flow.inverse (rnf_flow_inverse_train + rnf_flow_inverse_backward): BinFind.backward's implicit-function rule
+    for the Moebius layers (flow/mobiusflow.py:247-273), M^-1 for the affine layers, against fp64 autograd of the oracle (whose BinFind
+    Function is pinned to the reference's own backward, tests/test_oracle_golden.py)."""
+    cfg, w, R, feat, gR, gl = _make(name)
+    p = {k: torch.from_numpy(v).double().requires_grad_(v.dtype.kind == "f" and not k.split(".")[-1] in
+                                                          ("w_p", "u_mask", "l_mask", "s_sign", "l_eye")) for k, v in w.items()}
+    Rt = torch.from_numpy(R).double().requires_grad_(True)
+    ft = None if feat is None else torch.from_numpy(feat).double().requires_grad_(True)
+    Ro_w, ldj_w = orc.flow_inverse(cfg, p, Rt, ft, dtype=torch.float64, grad=True)
+    (Ro_w * torch.from_numpy(gR).double()).sum().add((ldj_w * torch.from_numpy(gl).double()).sum()).backward()
     fl = product_flow(cfg, w).train()
-    with pytest.raises(NotImplementedError):
-        fl.inverse(torch.from_numpy(R).cuda())                 # BinFind.backward (flow/mobiusflow.py:16-24) is not built
-    with torch.no_grad():
-        fl.inverse(torch.from_numpy(R).cuda())
+    Rd = torch.from_numpy(R).cuda().requires_grad_(True)
+    fd = None if feat is None else torch.from_numpy(feat).cuda().requires_grad_(True)
+    Ro, ldj = fl.inverse(Rd, fd)
+    assert Ro.requires_grad and ldj.requires_grad
+    # the forward values agree up to the bisection grid (one cell = pi / 2^14)
+    assert np.abs(Ro.detach().cpu().numpy() - Ro_w.detach().numpy()).max() < 4e-4
+    ((Ro * torch.from_numpy(gR).cuda()).sum() + (ldj * torch.from_numpy(gl).cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    # the gradient is evaluated at the returned grid point in both implementations; a sample whose root sits on a cell boundary may
+    # differ by one cell between them (a change of ~1e-4 relative in its contribution), hence 5e-4 instead of the forward path's 2e-4
+    rel = 5e-4
+    checked = 0
+    for k, prm in fl.named_parameters():
+        if p[k].grad is None:
+            continue
+        g_want = p[k].grad.numpy()
+        assert prm.grad is not None, k
+        err = np.abs(prm.grad.cpu().numpy().astype(np.float64) - g_want).max() / max(np.abs(g_want).max(), 1e-3)
+        assert err < rel, (k, err)
+        checked += 1
+    assert checked > 0
+    tg, tw = tangent(R.astype(np.float64), Rd.grad.cpu().numpy().astype(np.float64)), tangent(R.astype(np.float64), Rt.grad.numpy())
+    assert np.abs(tg - tw).max() / max(np.abs(tw).max(), 1e-3) < rel
+    if feat is not None:
+        assert np.abs(fd.grad.cpu().numpy().astype(np.float64) - ft.grad.numpy()).max() / max(np.abs(ft.grad.numpy()).max(), 1e-3) < rel
+
+
+@pytest.mark.parametrize("name", ["invgrad_uncond", "invgrad_mobius_only", "invgrad_cond"])
+def test_inverse_gradients_match_the_reference_binfind_backward(name):
+    """The same through the C ABI against gradients the REAL reference produced (tests/golden/invgrad_*.npz, fp64)."""
+    import os
+
+    from rotationnormflow_amd.configs import make_config
+    from tests.golden.cases import GRAD_CASES
+    from tests.helpers import GOLDEN
+    spec = GRAD_CASES[name]
+    cfg = make_config(**spec["cfg"])
+    fx = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n = spec["n"]
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=spec["wseed"], regime=spec["regime"])
+    R = synth.uniform_rotations(n, seed=spec["rseed"])
+    feat = synth.features(n, orc.feature_dim_of(cfg), seed=spec["rseed"] + 1000) if cfg.condition else None
+    rng = np.random.default_rng(spec["rseed"] + 7)
+    a, B = rng.standard_normal(n), rng.standard_normal((n, 3, 3))
+    fl = product_flow(cfg, w).train()
+    Rd = torch.from_numpy(R).cuda().requires_grad_(True)
+    fd = None if feat is None else torch.from_numpy(feat).cuda().requires_grad_(True)
+    Ro, ldj = fl.inverse(Rd, fd)
+    loss = (torch.from_numpy(a).float().cuda() * ldj).sum() + (torch.from_numpy(B).float().cuda() * Ro).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(fx["loss"])) < 2e-3 * max(1.0, abs(float(fx["loss"])))
+    for k, prm in fl.named_parameters():
+        want = fx["g:" + k]
+        err = np.abs(prm.grad.cpu().numpy().astype(np.float64) - want).max() / max(np.abs(want).max(), 1e-3)
+        assert err < 5e-4, (k, err)
+    tg, tw = tangent(R.astype(np.float64), Rd.grad.cpu().numpy().astype(np.float64)), tangent(R.astype(np.float64), fx["g_rot"])
+    assert np.abs(tg - tw).max() / max(np.abs(tw).max(), 1e-3) < 5e-4
+    if feat is not None:
+        assert np.abs(fd.grad.cpu().numpy().astype(np.float64) - fx["g_feat"]).max() / max(np.abs(fx["g_feat"]).max(), 1e-3) < 5e-4
 
 
 def test_adam_steps_follow_the_oracle():
@@ -156,13 +225,14 @@ def test_device_packer_matches_host_packer(name, precision):
     layers, rows = list(fl.layers), fl._forward_rows()
     host = runtime.pack_layers(layers, rows, "cuda", precision)
     plan = autograd.TrainPlan(layers, rows, torch.device("cuda"), precision)
-    assert np.array_equal(plan.desc, host.desc)
+    assert np.array_equal(plan.desc[:, :6], host.desc[:, :6])        # (columns 6, 7: the host packer's fp32 fallback images, not built in training)
     with torch.no_grad():
         plain = torch.cat([t.detach().to("cuda", torch.float32).reshape(-1) for t in autograd.train_tensors(layers)])
     blob = plan.pack(plain, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     got, want = blob.cpu().numpy(), host.blob.cpu().numpy()
-    assert got.shape == want.shape
+    assert got.size <= want.size
+    want = want[:got.size]                                           # the split-precision images come first, the fallback images behind
     for i, layer in enumerate(layers):
         off = plan.desc[i, 2]
         if layer._rnf_kind == runtime.KIND_AFFINE16:

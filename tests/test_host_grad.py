@@ -125,3 +125,61 @@ def test_gram_schmidt_3x3_backward(hg):
     assert np.abs(gM.reshape(3, 3) - gMw.numpy()).max() / np.abs(gMw.numpy()).max() < 2e-5
     tg, tw = tangent(R.astype(np.float64), gRin.astype(np.float64)), tangent(R.astype(np.float64), gRw.numpy())
     assert np.abs(tg - tw).max() / np.abs(tw).max() < 2e-5
+
+
+def mobius_inverse_given_cond(R, perm, cond, K):
+    """oracle.mobius_inverse with the conditioner output supplied (differentiable torch, fp64; BinFind's custom backward)."""
+    tx, ty = R[..., perm[0]], R[..., perm[1]]
+    sw, w = torch.split(cond, [K, 3 * K], dim=1)
+    w = w.reshape(-1, K, 3)
+    proj = torch.eye(3, dtype=R.dtype)[None] - torch.einsum("ni,nj->nij", ty, ty)
+    w = torch.einsum("nij,nkj->nki", proj, w)
+    sw = torch.nn.functional.softplus(sw)
+    sw = sw / sw.sum(-1, keepdim=True)
+    w = 0.7 / (1 + torch.norm(w, dim=-1, keepdim=True)) * w
+    r = orc._unit(-tx)
+    v = orc._unit(orc._cross(ty, r))
+    tt = torch.atan2((tx * v).sum(-1), (tx * r).sum(-1)).reshape(-1, 1)
+    tt = torch.where(tt >= 0, tt, tt + orc.TWO_PI)
+    theta = orc._BinFind.apply(tt, r, v, sw, w)
+    x = r * torch.cos(theta) + v * torch.sin(theta)
+    _, ldj = orc._mobius_core(x, r, v, sw, w)
+    cz = orc._unit(orc._cross(x, ty) if (perm[1] - perm[0]) in (1, -2) else orc._cross(ty, x))
+    cols = [None, None, None]
+    cols[perm[0]], cols[perm[1]], cols[perm[2]] = x, ty, cz
+    return torch.stack(cols, dim=-1), -ldj
+
+
+@pytest.mark.parametrize("perm_row", [0, 1, 2])
+def test_mobius_inverse_backward_is_the_implicit_gradient_of_binfind(hg, perm_row):
+    """so3_grad.h mobius_inverse_backward (in-plane formulation, theta read back from the layer output) against the oracle's BinFind
+    autograd Function (flow/mobiusflow.py:247-273, pinned to the reference's own backward in tests/test_oracle_golden.py)."""
+    n, K = 384, 32
+    rng = np.random.default_rng(30 + perm_row)
+    R = synth.uniform_rotations(n, seed=50 + perm_row)
+    cond = f32(rng.standard_normal((n, 4 * K)) * 2.0)
+    gR = f32(rng.standard_normal((n, 3, 3)))
+    gl = f32(rng.standard_normal(n))
+    Rt = torch.from_numpy(R).double().requires_grad_(True)
+    ct = torch.from_numpy(cond).double().requires_grad_(True)
+    Rw, lw = mobius_inverse_given_cond(Rt, orc.PERMUTE_ROWS[perm_row], ct, K)
+    loss = (Rw * torch.from_numpy(gR).double()).sum() + (lw * torch.from_numpy(gl).double()).sum()
+    gRw, gcw = torch.autograd.grad(loss, (Rt, ct))
+    Rout = f32(Rw.detach().numpy())                   # the layer output as the inverse pass stores it (fp32)
+    gc, gRin = np.empty_like(cond), np.empty_like(R)
+    hg.hg_mobius_inverse(ptr(R), perm_row, ptr(Rout), ptr(cond), K, ptr(gR), ptr(gl), n, ptr(gc), ptr(gRin))
+    scale = max(1.0, float(gcw.abs().max()))
+    assert np.abs(gc - gcw.numpy()).max() < 3e-4 * scale
+    tw, tg = tangent(R.astype(np.float64), gRw.numpy()), tangent(R.astype(np.float64), gRin.astype(np.float64))
+    assert np.abs(tg - tw).max() < 3e-4 * max(1.0, np.abs(tw).max())
+
+
+def test_inverse_matrix_gradient(hg):
+    rng = np.random.default_rng(9)
+    M = np.eye(4) + 0.3 * rng.standard_normal((4, 4))
+    G = rng.standard_normal((4, 4))
+    Mt = torch.from_numpy(M).requires_grad_(True)
+    (torch.linalg.inv(Mt) * torch.from_numpy(G)).sum().backward()
+    got = np.empty(16, np.float32)
+    hg.hg_inverse_matrix_grad4(ptr(f32(np.linalg.inv(M))), ptr(f32(G)), ptr(got))
+    assert np.abs(got.reshape(4, 4) - Mt.grad.numpy()).max() < 1e-5 * max(1.0, float(Mt.grad.abs().max()))

@@ -289,6 +289,7 @@ class _FlowInverseFn(torch.autograd.Function):
 
 
 def _plan_for(module, layers, perm_rows, rotation):
+    """(``rotation`` only supplies the device.)"""
     if not rotation.is_cuda:
         raise RuntimeError("rotationnormflow_amd runs on the GPU only (HIP kernels, no CPU fallback): got a CPU tensor")
     for layer in layers:

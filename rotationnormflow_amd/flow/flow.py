@@ -70,7 +70,39 @@ class Flow(nn.Module):
             rows[i] = count % 6
         return rows
 
+    def invalidate(self):
+        """Drop every packed copy of the parameters.  Call it after editing parameters in a way ``Tensor._version`` does not record --
+        ``p.data.copy_()`` / ``p.data.add_()``, EMA weight swaps, a fused / foreach optimizer stepped outside this module's backward --
+        while the module is in eval mode.  (In training mode, and for nn.DataParallel replicas, every call re-packs on the device from
+        the live parameters, so nothing can go stale there.)"""
+        self._cache.invalidate()
+        self.__dict__.pop("_rnf_train_plan", None)
+
+    def _device_packed(self, device):
+        """Kernel blob built on the device from the live parameters (rnf_pack_flow_device, one 18 us launch): used when the host cache
+        cannot be trusted or would thrash -- training mode (optimizers may write through .data) and nn.DataParallel replicas (fresh
+        parameter tensors on every forward, agent.py:22).  None when a layer has no device-packing support (ragged K, 3x3 / 6x6 kinds)."""
+        from .. import autograd
+        layers = list(self.layers)
+        try:
+            plan = autograd._plan_for(self, layers, self._forward_rows(), torch.empty(0, device=device))
+            tensors = autograd.train_tensors(layers)
+        except NotImplementedError:
+            return None
+        with torch.no_grad():
+            f32 = torch.float32
+            plain = torch.cat([t.reshape(-1) if (t.is_cuda and t.dtype is f32) else t.to(device=device, dtype=f32).reshape(-1)
+                               for t in tensors]) if tensors else torch.zeros(0, device=device)
+            with torch.cuda.device(device):
+                blob = plan.pack(plain, torch.cuda.current_stream(device).cuda_stream)
+        return runtime.PackedFlow(blob, plan.desc, plan.n_cond, plan.feat_dim, plan.feat_padded, plan.segments, plan.precision)
+
     def _packed(self, device):
+        if (self.training or getattr(self, "_is_replica", False)) and torch.device(device).type == "cuda":
+            packed = self._device_packed(torch.device(device))
+            if packed is not None:
+                return packed
+
         def build():
             rows = self._forward_rows()
             inv = self._inverse_rows()

@@ -32,6 +32,8 @@ class UnconditionRot(nn.Module, _SingleLayer):
     def _rnf_shape(self):
         return (self._rnf_kind, 0, 0)
 
+    _rnf_host_preprocess = True       # the training tensors go through a host SVD: a device->host copy per iteration, no stream capture
+
     def _rnf_train_tensors(self):
         U, S, V = torch.svd(self.rot.cpu().float())      # differentiable; the 4x4 SVD stays on the host (see _rnf_pack)
         return [U.transpose(-1, -2) @ V]
@@ -108,6 +110,8 @@ class _ConstantRotationLayer(nn.Module, _SingleLayer):
 
     def _rnf_shape(self):
         return (self._rnf_kind, 0, 0)
+
+    _rnf_host_preprocess = True       # polar factor / Gram-Schmidt + quaternion on the host: a device->host copy per training iteration
 
     def _rnf_train_tensors(self):
         return [self._quat_matrix()]

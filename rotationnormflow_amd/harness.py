@@ -68,6 +68,12 @@ def save_reference_checkpoint(path, flow: Flow, optimizer, epoch: int, minibatch
     }, path)
 
 
+def host_preprocess_layers(flow) -> list:
+    """Names of the layer classes of ``flow`` whose training tensors go through host-side linear algebra (rot='16Rot' / '16UnRot',
+    '9TransLSVD' / '9TransRSVD' / '9TransRSmith'): such flows cannot be captured into a HIP graph."""
+    return sorted({type(l).__name__ for l in flow.layers if getattr(l, "_rnf_host_preprocess", False)})
+
+
 class GraphedTrainStep:
     """One training iteration (agent.py:75-92: forward, loss, zero_grad, backward, optimizer step) captured ONCE as a HIP graph and
     replayed: the iteration is launch-bound on the host (264 parameter tensors go through autograd and the optimizer one by one), the
@@ -81,6 +87,11 @@ class GraphedTrainStep:
 
     def __init__(self, flow: Flow, optimizer, rotation_shape, feature_shape=None, base=None, warmup: int = 3, device="cuda"):
         from . import runtime
+        blockers = host_preprocess_layers(flow)
+        if blockers:
+            raise RuntimeError(f"GraphedTrainStep: {', '.join(blockers)} build their training tensors on the host (a 4x4 / 3x3 SVD or "
+                               "Gram-Schmidt per iteration: a device->host copy, illegal during stream capture); train this flow eagerly "
+                               "(train_uncondition(..., graph=False))")
         self._runtime = runtime
         self.flow, self.optimizer, self.base = flow, optimizer, base
         self.rotation = torch.eye(3, device=device).expand(*rotation_shape).contiguous()
@@ -150,6 +161,10 @@ def train_uncondition(flow: Flow, train_rotations: torch.Tensor, iterations: int
         from .dist import data_parallel_training, shard_bounds
         data_parallel_training(flow)
         graph = False
+    if graph and host_preprocess_layers(flow):
+        log(f"train_uncondition: {', '.join(host_preprocess_layers(flow))} need host-side linear algebra every iteration; training eagerly "
+            "(no HIP graph)")
+        graph = False
     opt = torch.optim.Adam(flow.parameters(), lr=lr, fused=True, capturable=graph)   # one launch instead of a dozen foreach kernels
     batch_size = min(batch_size, n)
     gstep = GraphedTrainStep(flow, opt, (batch_size, 3, 3), base=base, device=device) if graph else None
@@ -216,10 +231,6 @@ def main(argv=None):
         return
     flow = build_flow_from_checkpoint(config, args.ckpt)
     print(mean_log_likelihood(flow, load_raw_rotations(args.data), batch_size=args.batch_size))
-
-
-if __name__ == "__main__":
-    main()
 
 
 def estimate_rotations(flow: Flow, feature: torch.Tensor, queries: torch.Tensor = None, base=None, number_queries: int = 500):
@@ -309,3 +320,7 @@ def pose_accuracy(flow: Flow, feature, gt_rotation, queries=None, base=None, num
     est, _ = estimate_rotations(flow, feature, queries=queries, base=base, number_queries=number_queries)
     err_deg = torch.rad2deg(min_geodesic_distance(est, gt_rotation))
     return dict(err_deg=err_deg, est_rotation=est, acc={t: float((err_deg <= t).float().mean()) for t in thresholds_deg})
+
+
+if __name__ == "__main__":
+    main()

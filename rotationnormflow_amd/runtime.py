@@ -256,26 +256,43 @@ def note_training_step():
     _train_epoch += 1
 
 
-def params_key(module, device):
-    """Changes whenever any parameter is modified in place (optimizer step, load_state_dict) or replaced."""
-    return (str(device), _precision, _train_epoch) + tuple((id(p), p._version, p.data_ptr()) for p in module.parameters())
+def params_key(module, device, params=None):
+    """Changes whenever any parameter is modified in place through autograd-visible ops (optimizer step, load_state_dict) or replaced.
+    NOT by writes through ``.data`` (they do not bump ``Tensor._version``): see ``PackCache`` / ``Flow.invalidate``."""
+    if params is None:
+        params = list(module.parameters())
+    return (str(device), _precision, _train_epoch) + tuple((id(p), p._version, p.data_ptr()) for p in params)
 
 
 class PackCache:
-    """One packed blob per (device, parameter version); thread safe (nn.DataParallel replicas call from worker threads)."""
+    """Packed blobs of one module, one entry per device, keyed on the parameter versions; thread safe (nn.DataParallel replicas share
+    this object and call from worker threads).  The list of parameters is walked once and kept (rebuilt when a parameter OBJECT is
+    replaced, which changes ``len`` or the ids found by a cheap spot check of ``module._parameters`` -- flows register no parameters
+    after construction).  ``invalidate()`` drops everything: the hook for parameter edits the key cannot see (``p.data.copy_()``, EMA
+    swaps, fused optimizers stepped outside this library's backward)."""
 
     def __init__(self):
         self._lock = threading.Lock()
-        self._key = None
-        self._packed = None
+        self._entries = {}            # str(device) -> (key, packed)
+        self._params = None
+
+    def invalidate(self):
+        with self._lock:
+            self._entries.clear()
+            self._params = None
 
     def get(self, module, device, builder):
-        key = params_key(module, device)
         with self._lock:
-            if key != self._key:
-                self._packed = builder()
-                self._key = key
-            return self._packed
+            if self._params is None:
+                self._params = list(module.parameters())
+            key = params_key(module, device, self._params)
+            hit = self._entries.get(str(device))
+            if hit is None or hit[0] != key:
+                self._params = list(module.parameters())          # a miss is rare (once per parameter version): re-walk, then pack
+                key = params_key(module, device, self._params)
+                hit = (key, builder())
+                self._entries[str(device)] = hit
+            return hit[1]
 
 
 # ---- workspace ------------------------------------------------------------------------------------------------------

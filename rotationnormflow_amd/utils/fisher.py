@@ -58,6 +58,34 @@ class _FisherLogProb(torch.autograd.Function):
         return g_rot.reshape(ctx.in_shape).to(ctx.in_dtype), None, None
 
 
+# fail flags of earlier _sample calls (a proposal loop that exhausted its 4096 attempts leaves the identity rotation in that slot): read
+# back through pinned memory and checked when their copy has landed -- at the next _sample call or by sampler_failures() -- so that
+# sampling never waits for the device
+_pending_flags = []
+
+
+def _check_sampler_flag(wait: bool = False):
+    keep = []
+    bad = False
+    for ev, host, flag in _pending_flags:
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            bad = bad or bool(int(host[0]))
+        else:
+            keep.append((ev, host, flag))
+    _pending_flags[:] = keep
+    if bad:
+        raise RuntimeError("MatrixFisherN._sample: a rejection loop exhausted its 4096 proposals in an earlier call (utils/fisher.py:117-207 "
+                           "oversamples 8x and retries; here the slot was left at the identity rotation) -- the parameter matrix is far outside "
+                           "the range the ACG envelope covers")
+
+
+def sampler_failures(wait: bool = True):
+    """Raise if any earlier ``MatrixFisherN._sample`` call reported an exhausted rejection loop (waits for outstanding calls by default)."""
+    _check_sampler_flag(wait)
+
+
 class MatrixFisherN(torch.nn.Module):
     """MatrixFisherN(A [B,3,3], norm_type=1).  ``_log_prob(R [N,3,3])`` broadcasts row b over N/B consecutive samples."""
 
@@ -130,11 +158,18 @@ class MatrixFisherN(torch.nn.Module):
         U32, V32, lam32 = (t.to(dev, torch.float32).contiguous() for t in (U, V, lam))
         B = A.shape[0]
         out = torch.empty(B, num_samples, 3, 3, dtype=torch.float32, device=dev)
+        _check_sampler_flag()                                # a failure of an EARLIER call surfaces here, without a device wait now
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().rnf_fisher_sample(U32.data_ptr(), V32.data_ptr(), lam32.data_ptr(), B, num_samples, seed,
                                                     out.data_ptr(), flag.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+            if not torch.cuda.is_current_stream_capturing():
+                host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                host.copy_(flag, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                _pending_flags.append((ev, host, flag))
         if context == 9:
             return out
         if context == 4:

@@ -1,0 +1,91 @@
+"""GPU: freshness of the packed parameters.  The eval-mode cache is keyed on Tensor._version (which ``.data`` writes do not bump:
+``Flow.invalidate()`` is the documented hook); in training mode and for nn.DataParallel replicas (agent.py:22) every call packs on the
+device from the live parameters."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import flow_oracle as orc
+from rotationnormflow_amd import make_config, synth
+from tests.gpu_helpers import product_flow
+
+pytestmark = pytest.mark.gpu
+
+
+def _flow(seed=3, **kw):
+    cfg = make_config(**{**dict(layers=3, segments=16), **kw})
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=seed, regime="trained")
+    return cfg, w, product_flow(cfg, w)
+
+
+def test_data_writes_need_invalidate_in_eval_mode_and_nothing_in_training_mode():
+    cfg, w, fl = _flow()
+    R = torch.from_numpy(synth.uniform_rotations(700, seed=5)).cuda()
+    with torch.no_grad():
+        before = fl(R)[1].clone()
+        p = fl.layers[0].conditioner.fc_last.weight
+        v0 = p._version
+        p.data.mul_(1.5)                                        # invisible to Tensor._version
+        assert p._version == v0
+        stale = fl(R)[1]
+        assert torch.equal(stale, before)                       # documented limitation of the version-keyed cache ...
+        fl.invalidate()                                         # ... and its hook
+        fresh = fl(R)[1]
+        assert (fresh - before).abs().max().item() > 1e-3
+        w2 = {k: v.detach().cpu().numpy() for k, v in fl.state_dict().items()}
+        want = orc.flow_forward(cfg, w2, R.cpu().numpy(), None, dtype=torch.float64)[1].numpy()
+        assert np.abs(fresh.cpu().double().numpy() - want).max() < 1e-4
+        # visible edits need nothing
+        p.mul_(0.5)
+        again = fl(R)[1]
+        assert (again - fresh).abs().max().item() > 1e-3
+        # training mode: packs on the device from the live parameters at every call
+        fl.train()
+        a = fl(R)[1].clone()
+        p.data.mul_(2.0)
+        b = fl(R)[1]
+        assert (a - b).abs().max().item() > 1e-3
+        w3 = {k: v.detach().cpu().numpy() for k, v in fl.state_dict().items()}
+        want = orc.flow_forward(cfg, w3, R.cpu().numpy(), None, dtype=torch.float64)[1].numpy()
+        assert np.abs(b.cpu().double().numpy() - want).max() < 1e-4
+
+
+def test_data_parallel_replicas_forward_and_backward():
+    """nn.DataParallel re-creates the replicas (fresh parameter tensors) on every forward and calls them from worker threads
+    (agent.py:22, eval.py:158-160).  Two replicas on the one GPU of the box."""
+    cfg, w, fl = _flow(seed=4)
+    R = torch.from_numpy(synth.uniform_rotations(512, seed=6)).cuda()
+    with torch.no_grad():
+        want_R, want_l = fl(R)
+    replicas = torch.nn.parallel.replicate(fl.train(), [0, 0])
+    assert all(getattr(r, "_is_replica", False) for r in replicas)
+    halves = [R[:256].clone().requires_grad_(True), R[256:].clone().requires_grad_(True)]
+    outs = torch.nn.parallel.parallel_apply(replicas, [(h,) for h in halves], devices=[0, 0])        # worker threads
+    got_l = torch.cat([o[1] for o in outs])
+    assert (got_l.detach() - want_l).abs().max().item() < 3e-6
+    (-got_l).mean().backward()                                  # replica gradients flow back to the master parameters
+    g = fl.layers[0].conditioner.fc_last.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0
+    # against the single-module gradient
+    fl.zero_grad()
+    Rg = R.clone()
+    (-fl(Rg)[1]).mean().backward()
+    g1 = fl.layers[0].conditioner.fc_last.weight.grad
+    assert (g - g1).abs().max().item() < 2e-4 * max(1.0, g1.abs().max().item())
+    # the wrapper itself
+    dp = torch.nn.DataParallel(fl.eval(), device_ids=[0])
+    with torch.no_grad():
+        assert torch.equal(dp(R)[1], want_l)
+
+
+def test_flows_with_host_side_linear_algebra_refuse_graph_capture():
+    from rotationnormflow_amd import harness
+    cfg, w, fl = _flow(seed=5, rot="16Rot", layers=2)
+    assert harness.host_preprocess_layers(fl) == ["UnconditionRot"]
+    opt = torch.optim.Adam(fl.parameters(), lr=1e-4, capturable=True)
+    with pytest.raises(RuntimeError, match="host"):
+        harness.GraphedTrainStep(fl.cuda().train(), opt, (64, 3, 3))
+    logs = []
+    data = torch.from_numpy(synth.uniform_rotations(256, seed=7))
+    hist, _ = harness.train_uncondition(fl, data, iterations=2, batch_size=64, log=logs.append)     # falls back to eager by itself
+    assert len(hist) >= 1 and any("eagerly" in str(m) for m in logs)

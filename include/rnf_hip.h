@@ -54,6 +54,14 @@ extern "C" {
 #define RNF_LAYER_COND9_POLAR_L 8 /* flow/rottrans.py:108-121     Condition9RotL                               */
 #define RNF_LAYER_COND9_POLAR_R 9 /* flow/rottrans.py:138-151     Condition9RotR                               */
 #define RNF_LAYER_COND36 10       /* flow/squeezetrans.py:334-347 Condition36Trans (record from rnf_pack_cond36) */
+/* layers whose per-sample matrix the CALLER builds and hands in (rnf_flow_*_side; desc param_offset = slot in the side buffer, no blob
+ * record): the reference forms these matrices with batched torch ops that are not a per-sample function -- ConditionRot's U^T V of a
+ * batched SVD (flow/rottrans.py:37-66; depends on the SVD routine's sign conventions) and ConditionLU's torch.diag over the BATCH
+ * dimension (flow/squeezetrans.py:121-131) -- so the host side reproduces them with the same torch calls on outputs of
+ * rnf_cond_mlp_forward and the kernels apply the result: */
+#define RNF_LAYER_SIDE16 11       /* flow/squeezetrans.py:134-144 Condition16TransLU: calculate_16 with the given 4x4 (log|det|) */
+#define RNF_LAYER_SIDE16_ROT 12   /* flow/rottrans.py:37-66     ConditionRot: the given orthogonal 4x4 on the quaternion, log-det 0 */
+#define RNF_LAYER_SIDE9 13        /* flow/squeezetrans.py:264-277 Condition9TransLU: calculate_9 with the given 3x3 (first 9 of 16 floats) */
 
 /* ---- arithmetic of the conditioner GEMMs --------------------------------------------------------------------
  * RNF_PREC_FP32  : exact fp32 (v_mfma_f32_32x32x2_f32; bit-for-bit an fp32 fma chain).
@@ -143,6 +151,24 @@ int rnf_flow_inverse(const float *rotation_dev, const float *feature_dev, int64_
                      const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments,
                      float *rotation_out_dev, float *ldj_out_dev, void *workspace_dev, size_t workspace_bytes,
                      void *stream);
+
+/* The same three calls for flows that contain RNF_LAYER_SIDE* layers: side_dev float[n_side_layers][n][16] (row-major matrices; 3x3 ones
+ * in the first 9 floats). */
+int rnf_flow_forward_side(const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim, const float *side_dev,
+                          const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments,
+                          float *rotation_out_dev, float *ldj_out_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+int rnf_flow_inverse_side(const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim, const float *side_dev,
+                          const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments,
+                          float *rotation_out_dev, float *ldj_out_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+int rnf_flow_log_prob_side(const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim, const float *side_dev,
+                           const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments, const float *fisher_A_dev,
+                           const float *fisher_c_dev, int64_t fisher_B, float *rotation_out_dev, float *ldj_out_dev, float *logp_out_dev,
+                           double *sum_out_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* ConditionalTransform(feature_dim, <= 16 outputs)(feature) alone (flow/condition.py:24-30): records packed by rnf_pack_cond16 at
+ * layer_offset / feat_offset (floats) of blob_dev; out_dev float[n][16], output o in column o.  Workspace: rnf_workspace_bytes(n, 1). */
+int rnf_cond_mlp_forward(const float *feature_dev, int64_t n, int32_t feature_dim, const float *blob_dev, int32_t layer_offset,
+                         int32_t feat_offset, int32_t precision, float *out_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* ---- training (agent.py:75-92: loss = mean(-ldj), loss.backward(), Adam step) ----------------------------------------
  *

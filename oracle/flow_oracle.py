@@ -36,16 +36,16 @@ def _affine_kind(cfg, first_layer_condition=False):
     unconditional LU parameterisation ('lu16') and the unconditional SVD rotation ('rot16')."""
     rot, lu = cfg.rot, bool(getattr(cfg, "lu", 0))
     if first_layer_condition and rot == "16UnTrans":           # affineflow.py:7-11
-        if lu:
-            raise NotImplementedError("oracle does not restate Condition16TransLU")
-        return "cond16"
+        return "clu16" if lu else "cond16"
     if first_layer_condition and rot == "16UnRot":             # affineflow.py:12-13
-        raise NotImplementedError("oracle does not restate ConditionRot")
+        return "crot16"
     if cfg.condition:
         if rot == "16Trans":                                    # affineflow.py:16-20
-            if lu:
-                raise NotImplementedError("oracle does not restate Condition16TransLU")
-            return "cond16"
+            return "clu16" if lu else "cond16"
+        if rot == "16Rot":                                      # affineflow.py:41-42
+            return "crot16"
+        if rot == "9TransLSmith" and lu:                        # affineflow.py:34-36
+            return "clu9"
         if rot == "16UnTrans":                                  # affineflow.py:21-25
             return "lu16" if lu else "uncond16"
         if rot == "16UnRot":                                    # affineflow.py:43-44
@@ -133,6 +133,15 @@ def state_shapes(cfg):
             mlp(f"layers.{i}.net", fd, 9)
         elif kind == "cgs36":                                   # squeezetrans.py:337
             mlp(f"layers.{i}.net", fd, 36)
+        elif kind == "crot16":                                  # ConditionRot, rottrans.py:40
+            mlp(f"layers.{i}.net", fd, 16)
+        elif kind in ("clu16", "clu9"):                         # ConditionLU(C, F), squeezetrans.py:94-119
+            C = 4 if kind == "clu16" else 3
+            for name, shp in (("w_p", (C, C)), ("u_mask", (C, C)), ("l_mask", (C, C)), ("s_sign", (C,)), ("l_eye", (C, C))):
+                shapes[f"layers.{i}.net.{name}"] = shp
+            mlp(f"layers.{i}.net.w_l_net", fd, C * C)
+            mlp(f"layers.{i}.net.w_u_net", fd, C * C)
+            mlp(f"layers.{i}.net.w_s_net", fd, C)
         elif kind == "lu16":                                    # UnconditionLU(4), squeezetrans.py:76-83
             for name, shp in (("w_p", (4, 4)), ("u_mask", (4, 4)), ("l_mask", (4, 4)), ("s_sign", (4,)), ("l_eye", (4, 4)),
                               ("w_l", (4, 4)), ("w_s", (4,)), ("w_u", (4, 4))):
@@ -473,6 +482,25 @@ def cond36_matrix(feature, p, prefix):
     return conditioner(feature, p, prefix).reshape(-1, 6, 6) + torch.eye(6, dtype=feature.dtype)[None]
 
 
+def cond_lu_matrix(feature, p, prefix, C):
+    """ConditionLU.forward (squeezetrans.py:121-131).  NOTE torch.diag of the 2-D [N, C] tensor s_sign * exp(w_s_net(feature)) takes the
+    diagonal ACROSS THE BATCH (entry i of sample i, i < C), and the resulting C-vector is broadcast onto every row of every sample's
+    upper factor: the layer's output for one sample depends on the first C samples of the batch it travels in.  Restated as written."""
+    wl = conditioner(feature, p, f"{prefix}.w_l_net").reshape(-1, C, C)
+    wu = conditioner(feature, p, f"{prefix}.w_u_net").reshape(-1, C, C)
+    ws = conditioner(feature, p, f"{prefix}.w_s_net")
+    return torch.einsum("ab,nbc,ncd->nad", p[f"{prefix}.w_p"], wl * p[f"{prefix}.l_mask"] + p[f"{prefix}.l_eye"],
+                        wu * p[f"{prefix}.u_mask"] + torch.diag(p[f"{prefix}.s_sign"] * torch.exp(ws)))
+
+
+def cond_rot16_matrix(feature, p, prefix, inverse=False):
+    """ConditionRot (rottrans.py:42-46, 55-59): U^T V of the batched SVD of I + reshape(net(feature), 4, 4); transposed for the inverse."""
+    mat = conditioner(feature, p, prefix).reshape(-1, 4, 4) + torch.eye(4, dtype=feature.dtype)[None]
+    U, S, V = torch.svd(mat)
+    rot = U.transpose(-1, -2) @ V
+    return rot.transpose(-1, -2) if inverse else rot
+
+
 def cond16_matrix(feature, p, prefix):
     """Condition16Trans (squeezetrans.py:47-48)."""
     return conditioner(feature, p, prefix).reshape(-1, 4, 4) + torch.eye(4, dtype=feature.dtype)[None]
@@ -518,6 +546,12 @@ def flow_forward(cfg, params, R, feature=None, dtype=torch.float32, grad=False):
                 R, l = svdr9(p[f"layers.{i}.mat"], R)                                   # rottrans.py:129-131
             elif kind == "smithr9":
                 R, l = smithr9(p[f"layers.{i}.mat"], R)                                 # rottrans.py:159-161
+            elif kind == "clu16":
+                R, l = affine16(cond_lu_matrix(feature, p, f"layers.{i}.net", 4), R)    # squeezetrans.py:139-140
+            elif kind == "clu9":
+                R, l = gs9(cond_lu_matrix(feature, p, f"layers.{i}.net", 3) + torch.eye(3, dtype=R.dtype)[None], R)   # squeezetrans.py:269-271
+            elif kind == "crot16":
+                R, l = rot16_apply(cond_rot16_matrix(feature, p, f"layers.{i}.net"), R)  # rottrans.py:42-53
             elif kind == "cgs9":
                 R, l = gs9(cond9_matrix(feature, p, f"layers.{i}.net"), R)              # squeezetrans.py:239-242
             elif kind == "cgs36":
@@ -572,6 +606,12 @@ def flow_inverse(cfg, params, R, feature=None, dtype=torch.float32, grad=False):
                 R, l = svdr9(p[f"layers.{i}.mat"].transpose(-1, -2), R)                 # rottrans.py:133-135
             elif kind == "smithr9":
                 R, l = smithr9(p[f"layers.{i}.mat"], R, inverse=True)                   # rottrans.py:163-165
+            elif kind == "clu16":
+                R, l = affine16(torch.linalg.inv(cond_lu_matrix(feature, p, f"layers.{i}.net", 4)), R)                  # squeezetrans.py:142-144
+            elif kind == "clu9":
+                R, l = gs9(torch.linalg.inv(cond_lu_matrix(feature, p, f"layers.{i}.net", 3) + torch.eye(3, dtype=R.dtype)[None]), R)   # :273-277
+            elif kind == "crot16":
+                R, l = rot16_apply(cond_rot16_matrix(feature, p, f"layers.{i}.net", inverse=True), R)                  # rottrans.py:55-66
             elif kind == "cgs9":
                 R, l = gs9(torch.linalg.inv(cond9_matrix(feature, p, f"layers.{i}.net")), R)        # squeezetrans.py:244-247
             elif kind == "cgs36":

@@ -37,6 +37,15 @@ _SIGNATURES = {
                                    c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnf_flow_inverse": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
                                    c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnf_flow_forward_side": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_f32p, c_i32p, C.c_int32, C.c_int32,
+                                        c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnf_flow_inverse_side": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_f32p, c_i32p, C.c_int32, C.c_int32,
+                                        c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnf_flow_log_prob_side": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_f32p, c_i32p, C.c_int32, C.c_int32,
+                                         c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p,
+                                         C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnf_cond_mlp_forward": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnf_pack_flow_device": (C.c_int, [c_f32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_i32p, C.c_void_p]),
     "rnf_plain_layer_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rnf_flow_forward_train": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,

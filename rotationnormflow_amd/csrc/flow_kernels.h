@@ -51,6 +51,8 @@ struct FlowArgs {
     //   guard_mode 2 (the exact-fp32 instantiation launched right behind): run only if guard[0] != 0, and note the re-run in guard[1].
     int *guard;
     int guard_mode;
+    const float *side;        // per-sample matrices of the RNF_KIND_SIDE* layers: [side slot][side_n][16] floats, or nullptr
+    long long side_n;         // rotations in the whole call (chunks index at sample_base)
     // per layer: x = kind | perm_row << 4 | (cond_slot + 1) << 8 | (position of the next MLP layer + 1) << 16 ; y = param offset (floats)
     int2 layers[MAX_LAYERS];
 };
@@ -1064,6 +1066,36 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     affine16_table_apply(params + (DIR ? AFF_TABLE_INV : AFF_TABLE_FWD), R, ldj);
                 }
                 RNF_STAMP(6)                                      // 6: unconditional affine layer
+                continue;
+            }
+            if (EXT && kind_is_side(kind)) {                      // the caller built this layer's matrix per sample (param offset = side slot)
+                const float *m = args.side + ((size_t)d.y * args.side_n + args.sample_base + (valid ? sample_now() : 0)) * 16;
+                if (kind == RNF_KIND_SIDE9) {                     // calculate_9 with a per-sample M (flow/squeezetrans.py:264-277)
+                    float M9[9];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) M9[i] = m[i];
+                    if (DIR) { float Mi[9]; inv3(M9, Mi); gs9_apply(Mi, R, ldj); }
+                    else gs9_apply(M9, R, ldj);
+                } else {
+                    float M[16], Mi[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) M[i] = m[i];
+                    if (kind == RNF_KIND_SIDE16_ROT) {            // ConditionRot (flow/rottrans.py:37-66): orthogonal, log-det 0, inverse = transpose
+                        if (DIR) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) Mi[4 * i + jj] = M[4 * jj + i];
+                            affine16_apply(Mi, 0.f, R, ldj, true);
+                        } else {
+                            affine16_apply(M, 0.f, R, ldj, true);
+                        }
+                    } else {                                      // Condition16TransLU (flow/squeezetrans.py:134-144)
+                        const float det = inv4(M, Mi);
+                        if (DIR) affine16_apply(Mi, -logf(fabsf(det)), R, ldj);
+                        else affine16_apply(M, logf(fabsf(det)), R, ldj);
+                    }
+                }
                 continue;
             }
             if (!LEAN && kind == RNF_KIND_GS9) {                  // Uncondition9Trans: the inverse pass uses M^-1 (squeezetrans.py:259-261)

@@ -92,7 +92,12 @@ constexpr int RNF_KIND_MOBIUS = 1, RNF_KIND_AFFINE16 = 2, RNF_KIND_COND16 = 3, R
 constexpr int RNF_KIND_COND9_GS = 6, RNF_KIND_COND9_SMITH = 7, RNF_KIND_COND9_POLAR_L = 8, RNF_KIND_COND9_POLAR_R = 9, RNF_KIND_COND9_LAST = 9;
 // Condition36Trans: M = I + reshape(MLP(feature), 6, 6) per sample; TWO fc_last tiles (packed row P of tile 0 is output P, rows 0..3 of
 // tile 1 are outputs 32..35)
-constexpr int RNF_KIND_COND36 = 10, RNF_KIND_LAST = 10;
+constexpr int RNF_KIND_COND36 = 10;
+// per-sample matrices handed in by the caller (side buffer [slot][n][16], slot = desc cond_slot... see include/rnf_hip.h): the layers whose
+// matrix the reference builds with batched torch ops the kernels do not restate (ConditionRot: SVD; ConditionLU: its batch-coupled
+// torch.diag) -- 4x4 on the quaternion with log-det, 4x4 orthogonal (log-det 0), 3x3 Gram-Schmidt with the tangent log-det
+constexpr int RNF_KIND_SIDE16 = 11, RNF_KIND_SIDE16_ROT = 12, RNF_KIND_SIDE9 = 13, RNF_KIND_LAST = 13;
+RNF_LAYOUT_INLINE bool kind_is_side(int kind) { return kind >= RNF_KIND_SIDE16 && kind <= RNF_KIND_SIDE9; }
 RNF_LAYOUT_INLINE bool kind_is_cond9(int kind) { return kind >= RNF_KIND_COND9_GS && kind <= RNF_KIND_COND9_LAST; }
 RNF_LAYOUT_INLINE bool kind_has_mlp(int kind) { return kind == RNF_KIND_MOBIUS || kind == RNF_KIND_COND16 || kind_is_cond9(kind) || kind == RNF_KIND_COND36; }
 // fc_last tiles of one layer record (KT = segments / 8 for a Moebius layer)

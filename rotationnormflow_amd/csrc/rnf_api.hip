@@ -20,7 +20,8 @@
 using namespace rnf;
 
 static_assert(RNF_LAYER_MOBIUS == RNF_KIND_MOBIUS && RNF_LAYER_AFFINE16 == RNF_KIND_AFFINE16 &&
-                  RNF_LAYER_AFFINE16_COND == RNF_KIND_COND16 && RNF_DESC_STRIDE == D_STRIDE && RNF_HIDDEN == HID,
+                  RNF_LAYER_AFFINE16_COND == RNF_KIND_COND16 && RNF_DESC_STRIDE == D_STRIDE && RNF_HIDDEN == HID &&
+                  RNF_LAYER_SIDE16 == RNF_KIND_SIDE16 && RNF_LAYER_SIDE16_ROT == RNF_KIND_SIDE16_ROT && RNF_LAYER_SIDE9 == RNF_KIND_SIDE9,
               "include/rnf_hip.h and csrc/layout.h disagree");
 
 // ------------------------------------------------------------------------------------------------------------
@@ -488,6 +489,7 @@ struct RunOpts {
     double *sum_out;
     float *states = nullptr;  // training forward: per-layer input rotations [n_layers][n][9]
     int64_t feature_div = 0;  // > 0: feature row r serves rotations [r * feature_div, (r + 1) * feature_div)
+    const float *side = nullptr;   // per-sample matrices of RNF_LAYER_SIDE* layers: [side slot][n][16]
 };
 
 static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, const float *blob, const int32_t *desc,
@@ -518,10 +520,12 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         const int kind = d[D_KIND], perm = d[D_PERM], slot = d[D_SLOT];
         if (kind < RNF_KIND_MOBIUS || kind > RNF_KIND_LAST) return fail("layer %d: unknown kind %d", l, kind);
         if (perm < 0 || perm > 5) return fail("layer %d: perm_row %d outside [0,5]", l, perm);
-        if (d[D_PARAM] < 0 || d[D_PARAM] % 4) return fail("layer %d: param offset %d must be a non-negative multiple of 4", l, d[D_PARAM]);
+        if (d[D_PARAM] < 0 || (d[D_PARAM] % 4 && !kind_is_side(kind))) return fail("layer %d: param offset %d must be a non-negative multiple of 4", l, d[D_PARAM]);
         if ((kind == RNF_KIND_COND16 || kind_is_cond9(kind) || kind == RNF_KIND_COND36) && slot < 0)
             return fail("layer %d: a conditional affine layer needs a cond_slot", l);
-        if (kind_is_cond9(kind) || kind == RNF_KIND_COND36) ext = true;
+        if (kind_is_cond9(kind) || kind == RNF_KIND_COND36 || kind_is_side(kind)) ext = true;
+        if (kind_is_side(kind) && !o.side) return fail("layer %d takes per-sample matrices: call the rnf_flow_*_side entry points with a side buffer", l);
+        if (kind_is_side(kind) && o.states) return fail("layer %d: per-sample matrix layers have no training path", l);
         if ((kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16) || slot >= 0) lean = false;
         if (kind == RNF_KIND_COND36) min_tiles = 2;
         if (slot >= 0) {
@@ -608,6 +612,8 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     a.n_layers = n_layers;
     a.KT = KT;
     a.K = K;
+    a.side = o.side;
+    a.side_n = n;
     a.states = o.states;
     a.states_n = n;
     a.fisher_A = o.fisher_A;
@@ -781,6 +787,107 @@ extern "C" int rnf_flow_inverse_shared(const float *rot, const float *feat, int6
 // ------------------------------------------------------------------------------------------------------------
 // training: forward that saves per-layer states, and the reverse sweep (train_kernels.h)
 // ------------------------------------------------------------------------------------------------------------
+// per-sample matrix layers (RNF_LAYER_SIDE16 / SIDE16_ROT / SIDE9): side_dev float[n_side_layers][n][16], desc param_offset = slot
+extern "C" int rnf_flow_forward_side(const float *rot, const float *feat, int64_t n, int32_t F, const float *side, const float *blob,
+                                     const int32_t *desc, int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, void *ws,
+                                     size_t ws_bytes, void *stream) {
+    RunOpts o{0, nullptr, nullptr, 0, nullptr, nullptr};
+    o.side = side;
+    return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
+}
+extern "C" int rnf_flow_inverse_side(const float *rot, const float *feat, int64_t n, int32_t F, const float *side, const float *blob,
+                                     const int32_t *desc, int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, void *ws,
+                                     size_t ws_bytes, void *stream) {
+    RunOpts o{1, nullptr, nullptr, 0, nullptr, nullptr};
+    o.side = side;
+    return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
+}
+extern "C" int rnf_flow_log_prob_side(const float *rot, const float *feat, int64_t n, int32_t F, const float *side, const float *blob,
+                                      const int32_t *desc, int32_t n_layers, int32_t K, const float *fisher_A, const float *fisher_c,
+                                      int64_t fisher_B, float *rot_out, float *ldj_out, float *logp_out, double *sum_out, void *ws,
+                                      size_t ws_bytes, void *stream) {
+    if ((fisher_A == nullptr) != (fisher_c == nullptr)) return fail("fisher_A and fisher_c must both be given or both be null");
+    RunOpts o{0, fisher_A, fisher_c, fisher_B, logp_out, sum_out};
+    o.side = side;
+    return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
+}
+
+// ConditionalTransform(F, <= 16 outputs)(feature) alone (flow/condition.py:24-30): the nets of ConditionRot (flow/rottrans.py:40) and
+// ConditionLU (flow/squeezetrans.py:117-119), whose outputs the reference post-processes with batched torch ops.  Records from
+// rnf_pack_cond16 (rows beyond the net's outputs zero); out [n][16], output o of the net in column o.
+template <int NWc, int PREC>
+__global__ __launch_bounds__(NWc * 64) void cond_mlp_kernel(const float *G, long long g_groups, long long n, const float *layer, float *out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const long long ntiles = (n + NWc * 32 - 1) / (NWc * 32);
+    stage_floats(lds, layer, MOB_HEAD_FLOATS + MOB_LAST_TILE_FLOATS, tid, NWc * 64);
+    __syncthreads();
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long group = tile * NWc + wave;
+        const long long sample = group * 32 + j;
+        typename Mlp<PREC>::Act tt;
+        Fair nofair{lds, wave, -1, 0};
+        bool bad = false;
+        GFrag<false> g{G + (size_t)group * G_FLOATS_PER_GROUP, false};
+        Mlp<PREC>::head(lds, lane, h, 0.f, 0.f, 0.f, g, tt, nofair, bad);
+        const f32x16 o = Mlp<PREC>::last(lds + MOB_LAST, lane, h, tt);
+        if (sample < n) {
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq) {              // packed row 8g + 4h + c  <->  output 4 (2g + h) + c (rnf_pack_cond16)
+                float4 v = make_float4(o[4 * gq], o[4 * gq + 1], o[4 * gq + 2], o[4 * gq + 3]);
+                if (bad) v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+                reinterpret_cast<float4 *>(out + sample * 16)[2 * gq + h] = v;
+            }
+        }
+    }
+}
+
+extern "C" int rnf_cond_mlp_forward(const float *feat, int64_t n, int32_t F, const float *blob, int32_t layer_off, int32_t feat_off,
+                                    int32_t prec, float *out, void *ws, size_t ws_bytes, void *stream_v) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    if (n < 0) return fail("n=%lld is negative", (long long)n);
+    if (F <= 0 || F % 8) return fail("feature_dim=%d must be a positive multiple of 8 (pad on the host)", F);
+    if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2) return fail("unknown precision %d", prec);
+    if (layer_off < 0 || layer_off % 4 || feat_off < 0 || feat_off % 4) return fail("record offsets must be non-negative multiples of 4");
+    if (n == 0) return 0;
+    if (!feat || !blob || !out || !ws) return fail("rnf_cond_mlp_forward: null pointer");
+    if (ws_bytes < rnf_workspace_bytes(n, 1)) return fail("workspace of %zu bytes is smaller than the %zu needed", ws_bytes, rnf_workspace_bytes(n, 1));
+    float *G = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + PARTIALS_BYTES);
+    const int cus = device_cus();
+    const size_t lds_bytes = sizeof(float) * (MOB_HEAD_FLOATS + MOB_LAST_TILE_FLOATS);
+    for (long long base = 0; base < n; base += CHUNK_SAMPLES) {
+        const long long cn = (n - base) < CHUNK_SAMPLES ? (n - base) : CHUNK_SAMPLES;
+        const long long ntiles = (cn + NW * 32 - 1) / (NW * 32), ntiles_fp = (cn + NW_FP * 32 - 1) / (NW_FP * 32);
+        const long long groups = (ntiles * NW > ntiles_fp * NW_FP) ? ntiles * NW : ntiles_fp * NW_FP;
+        FeatProjArgs fp;
+        std::memset(&fp, 0, sizeof(fp));
+        fp.feat = feat + base * F; fp.blob = blob; fp.G = G; fp.n = cn; fp.g_groups = groups; fp.F = F; fp.n_slots = 1; fp.row_mode = 0;
+        fp.feat_off[0] = feat_off;
+        const int cus_fp = cus * (8 / NW_FP);
+        const int grid_fp = (int)(ntiles_fp < cus_fp ? ntiles_fp : cus_fp);
+        const int kchunk = F < FP_KCHUNK ? F : FP_KCHUNK;
+        const size_t fl = sizeof(float) * (prec ? (size_t)2 * (FP_KCHUNK / 16) * 512 : (size_t)kchunk / 8 * 256);
+        const int grid = (int)(ntiles < cus ? ntiles : cus);
+        if (prec) {
+            auto kp = featproj_kernel<NW_FP, 1>;
+            HIP_TRY(allow_lds(kp, fl));
+            hipLaunchKernelGGL(kp, dim3(grid_fp), dim3(NW_FP * 64), fl, stream, fp);
+            auto kern = cond_mlp_kernel<NW, 1>;
+            HIP_TRY(allow_lds(kern, lds_bytes));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, (const float *)G, groups, cn, blob + layer_off, out + base * 16);
+        } else {
+            auto kp = featproj_kernel<NW_FP, 0>;
+            HIP_TRY(allow_lds(kp, fl));
+            hipLaunchKernelGGL(kp, dim3(grid_fp), dim3(NW_FP * 64), fl, stream, fp);
+            auto kern = cond_mlp_kernel<NW, 0>;
+            HIP_TRY(allow_lds(kern, lds_bytes));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, (const float *)G, groups, cn, blob + layer_off, out + base * 16);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
 extern "C" int rnf_flow_forward_train(const float *rot, const float *feat, int64_t n, int32_t F, const float *blob, const int32_t *desc,
                                       int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, float *states, void *ws,
                                       size_t ws_bytes, void *stream) {

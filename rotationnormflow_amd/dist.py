@@ -31,6 +31,11 @@ def all_reduce_nll(sum_count: torch.Tensor) -> torch.Tensor:
 def sharded_mean_nll(evaluate, rotation, feature=None, rank: int = 0, world: int = 1):
     """evaluate(rotation_shard, feature_shard) -> float64 [2] {sum log p, count} on the shard's device.
     Every rank passes the SAME global batch (or only its own rows are touched); returns (mean NLL, {sum, count})."""
+    coupled = getattr(evaluate, "batch_coupled", None)
+    if world > 1 and coupled:
+        raise NotImplementedError(f"{', '.join(coupled)}: the reference builds these layers' matrices from the first rows of the batch "
+                                  "(torch.diag over the batch dimension, flow/squeezetrans.py:127), so a sharded evaluation would not "
+                                  "reproduce the single-batch result; evaluate the whole batch on one rank")
     lo, hi = shard_bounds(rotation.shape[0], rank, world)
     part = evaluate(rotation[lo:hi], None if feature is None else feature[lo:hi])
     tot = all_reduce_nll(part.clone())
@@ -39,10 +44,13 @@ def sharded_mean_nll(evaluate, rotation, feature=None, rank: int = 0, world: int
 
 def flow_evaluator(flow, base=None):
     """evaluate() for sharded_mean_nll built on the fused HIP density evaluation (Flow.log_prob)."""
+    coupled = sorted({type(m).__name__ for m in flow.modules() if getattr(m, "_rnf_batch_coupled", False)})
+
     def evaluate(rot, feat):
         if rot.shape[0] == 0:
             return torch.zeros(2, dtype=torch.float64, device=rot.device)
         return flow.log_prob(rot, feat, base=base)["sum"]
+    evaluate.batch_coupled = coupled
     return evaluate
 
 

@@ -6,7 +6,6 @@ import torch.nn as nn
 
 from .. import runtime
 from .mobiusflow import _SingleLayer
-from .squeezetrans import _not_built
 
 
 class UnconditionRot(nn.Module, _SingleLayer):
@@ -153,7 +152,8 @@ class Uncondition9RotRSmith(_ConstantRotationLayer):
         return torch.stack([m0, m1, torch.linalg.cross(m0, m1)], dim=-1)
 
 
-from .squeezetrans import _Conditional9  # noqa: E402
+from .squeezetrans import _Conditional9, _SideLayer  # noqa: E402
+from .condition import ConditionalTransform  # noqa: E402
 
 
 class Condition9RotL(_Conditional9):
@@ -171,4 +171,25 @@ class Condition9RotRSmith(_Conditional9):
     _rnf_kind = runtime.KIND_COND9_SMITH
 
 
-ConditionRot = _not_built("ConditionRot", "flow/rottrans.py:26-53")
+class ConditionRot(_SideLayer):
+    """flow/rottrans.py:37-66: rot = U^T V of the batched SVD of I + reshape(net(feature), 4, 4), applied to the quaternion; log-det 0;
+    the inverse pass applies its transpose.  U^T V (not the polar factor U V^T) depends on the sign conventions of the SVD routine, so
+    the layer is defined by the routine: the SVD here is the SAME ``torch.svd`` call as the reference's, on the host in fp32 (LAPACK), as
+    UnconditionRot does for its one matrix -- the conventions of the reference's CPU run.  net(feature) itself runs on the GPU."""
+    _rnf_kind = runtime.KIND_SIDE16_ROT
+    _rnf_host_preprocess = True
+
+    def __init__(self, feature_dim):
+        super().__init__()
+        self.feature_dim = feature_dim
+        self.net = ConditionalTransform(feature_dim, 16)
+        self._cache = runtime.PackCache()
+        self._net = None
+
+    def _rnf_side(self, feature):
+        if self._net is None:
+            self._net = runtime.SideNet(self.net, self.feature_dim, 16)
+        with torch.no_grad():
+            mat = self._net(feature).reshape(-1, 4, 4) + torch.eye(4, device=feature.device)
+            U, S, V = torch.svd(mat.cpu())
+            return (U.transpose(-1, -2) @ V).reshape(-1, 16).to(feature.device)

@@ -1,6 +1,7 @@
 """Mirror of the reference's flow/squeezetrans.py: the 4x4 quaternion-affine family (constant, LU-parameterised, feature-conditioned)
 and the unconditional 3x3 / 6x6 Gram-Schmidt ablation layers.  The remaining conditional variants are declared for the registry and
 fail loudly at construction."""
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -235,17 +236,95 @@ class Condition9Trans(_Conditional9):
     _rnf_kind = runtime.KIND_COND9_GS
 
 
-def _not_built(name, where):
-    class _Unbuilt(nn.Module):
-        def __init__(self, *a, **k):
-            super().__init__()
-            raise NotImplementedError(
-                f"{name} ({where}) has no HIP kernel yet and rotationnormflow_amd has no PyTorch fallback; "
-                "built affine layers: the Uncondition* family and Condition16Trans")
-    _Unbuilt.__name__ = _Unbuilt.__qualname__ = name
-    return _Unbuilt
+class _SideLayer(nn.Module, _SingleLayer):
+    """Layers whose per-sample matrix is formed with the reference's own batched torch ops on outputs of the HIP conditioner
+    (runtime.SideNet) and handed to the stack kernel in a side buffer (include/rnf_hip.h RNF_LAYER_SIDE*)."""
+
+    def _rnf_pack(self, L, prec=0):
+        return np.zeros(4, dtype=np.float32), None, 0, 0
+
+    def _rnf_shape(self):
+        return (self._rnf_kind, 0, self.feature_dim)
+
+    def forward(self, rotation, permute=None, feature=None):
+        return self._single(rotation, permute, feature, inverse=False)
+
+    def inverse(self, rotation, permute=None, feature=None):
+        return self._single(rotation, permute, feature, inverse=True)
 
 
-# declared so that the registry (flow/affineflow.py:5-73) resolves every name; constructing them fails loudly
-Condition16TransLU = _not_built("Condition16TransLU", "flow/squeezetrans.py:130-143")
-Condition9TransLU = _not_built("Condition9TransLU", "flow/squeezetrans.py:278-291")
+class ConditionLU(nn.Module):
+    """flow/squeezetrans.py:94-131: P (L * l_mask + I) (U * u_mask + diag) with L, U and the diagonal predicted from the feature by three
+    ConditionalTransforms.  Buffer / parameter names are the checkpoint contract.  ``forward`` keeps the reference's expression verbatim,
+    including ``torch.diag`` of the 2-D [N, C] tensor: that call takes the diagonal ACROSS THE BATCH (entry i of sample i, i < C) and the
+    C-vector is then broadcast onto every row of every sample's upper factor -- the weight of one sample depends on the first C samples
+    of the batch it travels in (and a batch of fewer than C rows fails to broadcast, as in the reference).  The three MLPs run on the GPU
+    through the HIP conditioner (runtime.SideNet)."""
+
+    _rnf_batch_coupled = True
+
+    def __init__(self, in_channel, feature_dim):
+        super().__init__()
+        import scipy.linalg as la
+        self.in_channel = in_channel
+        weight = np.random.randn(in_channel, in_channel)
+        q, _ = la.qr(weight)
+        w_p, w_l, w_u = la.lu(q.astype(np.float32))
+        w_s = np.diag(w_u)
+        u_mask = np.triu(np.ones_like(w_u), 1)
+        self.register_buffer("w_p", torch.from_numpy(w_p))
+        self.register_buffer("u_mask", torch.from_numpy(u_mask))
+        self.register_buffer("l_mask", torch.from_numpy(u_mask.T.copy()))
+        self.register_buffer("s_sign", torch.sign(torch.from_numpy(np.copy(w_s))))
+        self.register_buffer("l_eye", torch.eye(in_channel))
+        self.w_l_net = ConditionalTransform(feature_dim, in_channel * in_channel)
+        self.w_u_net = ConditionalTransform(feature_dim, in_channel * in_channel)
+        self.w_s_net = ConditionalTransform(feature_dim, in_channel)
+        self._nets = None
+        self._feature_dim = feature_dim
+
+    def forward(self, feature):
+        if not feature.is_cuda:
+            raise RuntimeError("rotationnormflow_amd runs on the GPU only (HIP kernels, no CPU fallback): got a CPU tensor")
+        if self._nets is None:
+            C = self.in_channel
+            self._nets = (runtime.SideNet(self.w_l_net, self._feature_dim, C * C), runtime.SideNet(self.w_u_net, self._feature_dim, C * C),
+                          runtime.SideNet(self.w_s_net, self._feature_dim, C))
+        C = self.in_channel
+        wl, wu, ws = (net(feature) for net in self._nets)
+        return torch.einsum("ab,nbc,ncd->nad", self.w_p,
+                            wl.reshape(-1, C, C) * self.l_mask + self.l_eye,
+                            (wu.reshape(-1, C, C) * self.u_mask) + torch.diag(self.s_sign * torch.exp(ws)))
+
+
+class Condition16TransLU(_SideLayer):
+    """calculate_16 with the per-sample ConditionLU(4) matrix; the inverse pass inverts it per sample (flow/squeezetrans.py:134-144)."""
+    _rnf_kind = runtime.KIND_SIDE16
+    _rnf_batch_coupled = True
+
+    def __init__(self, feature_dim):
+        super().__init__()
+        self.feature_dim = feature_dim
+        self.net = ConditionLU(4, feature_dim)
+        self._cache = runtime.PackCache()
+
+    def _rnf_side(self, feature):
+        with torch.no_grad():
+            return self.net(feature).reshape(-1, 16)
+
+
+class Condition9TransLU(_SideLayer):
+    """calculate_9 with I + the per-sample ConditionLU(3) matrix (flow/squeezetrans.py:264-277; note the + I, which the unconditional
+    Uncondition9TransLU does not have)."""
+    _rnf_kind = runtime.KIND_SIDE9
+    _rnf_batch_coupled = True
+
+    def __init__(self, feature_dim):
+        super().__init__()
+        self.feature_dim = feature_dim
+        self.net = ConditionLU(3, feature_dim)
+        self._cache = runtime.PackCache()
+
+    def _rnf_side(self, feature):
+        with torch.no_grad():
+            return (self.net(feature).reshape(-1, 3, 3) + torch.eye(3, device=feature.device)).reshape(-1, 9)

@@ -14,6 +14,10 @@ from . import _lib
 
 KIND_MOBIUS, KIND_AFFINE16, KIND_COND16, KIND_GS9, KIND_GS36 = 1, 2, 3, 4, 5
 KIND_COND9_GS, KIND_COND9_SMITH, KIND_COND9_POLAR_L, KIND_COND9_POLAR_R, KIND_COND36 = 6, 7, 8, 9, 10
+# layers whose per-sample matrix is built on the host side with the reference's own batched torch ops and handed to the kernels in a side
+# buffer (include/rnf_hip.h RNF_LAYER_SIDE*): Condition16TransLU, ConditionRot, Condition9TransLU
+KIND_SIDE16, KIND_SIDE16_ROT, KIND_SIDE9 = 11, 12, 13
+SIDE_KINDS = (KIND_SIDE16, KIND_SIDE16_ROT, KIND_SIDE9)
 DESC_STRIDE = 8            # include/rnf_hip.h RNF_DESC_STRIDE: kind, perm_row, param, cond_slot, feat, precision, fallback param, fallback feat
 
 # Arithmetic of the conditioner GEMMs (include/rnf_hip.h RNF_PREC_*): "f16x2" = split-precision fp16 MFMA (22-bit
@@ -87,6 +91,7 @@ class PackedFlow:
         self.feat_dim = feat_dim
         self.feat_padded = feat_padded
         self.segments = segments
+        self.side_layers = []                 # layer modules with _rnf_side(feature) -> [n, 16], in side-slot order
 
 
 class HalfRangeError(RuntimeError):
@@ -118,7 +123,16 @@ def pack_layers(layers, perm_rows, device, precision=None) -> PackedFlow:
             blob = np.concatenate([blob, blob32])
     finally:
         _prefetched.map = {}
-    return PackedFlow(torch.from_numpy(blob).to(device), np.ascontiguousarray(desc), slot, feat_dim, pad8(feat_dim), segments, precision)
+    packed = PackedFlow(torch.from_numpy(blob).to(device), np.ascontiguousarray(desc), slot, feat_dim, pad8(feat_dim), segments, precision)
+    for i, layer in enumerate(layers):
+        if layer._rnf_kind in SIDE_KINDS:
+            packed.desc[i, 2] = len(packed.side_layers)          # param offset column = slot in the side buffer
+            packed.desc[i, 6] = -1
+            packed.side_layers.append(layer)
+            if not feat_dim:
+                packed.feat_dim = layer.feature_dim              # a flow whose only conditional layers are side layers
+                packed.feat_padded = pad8(layer.feature_dim)
+    return packed
 
 
 _guard_fallback = os.environ.get("RNF_GUARD", "1") != "0"
@@ -242,6 +256,71 @@ def pack_rot16(L, rot_mat):
     m = _np32(rot_mat).reshape(16)
     _lib.check(L.rnf_pack_rot16(m.ctypes.data, rec.ctypes.data))
     return rec
+
+
+# ---- per-sample matrix layers ("side" layers) ---------------------------------------------------------------------------------------
+class SideNet:
+    """Evaluates one ConditionalTransform(F, <= 16 outputs) on the GPU through rnf_cond_mlp_forward (record = rnf_pack_cond16 with the
+    unused fc_last rows zero), with its own version-keyed packed copy."""
+
+    def __init__(self, net, feature_dim, n_out):
+        self.net, self.feature_dim, self.n_out = net, feature_dim, n_out
+        self.cache = PackCache()
+
+    def _pack(self, device):
+        L = _lib.lib()
+        prec_name = _precision
+        for name in ([prec_name, "fp32"] if prec_name != "fp32" else ["fp32"]):
+            try:
+                rec, frec = pack_cond16(L, _Padded16(self.net, self.n_out), self.feature_dim, _PRECISIONS[name])
+                break
+            except HalfRangeError:
+                continue
+        blob = np.concatenate([rec, np.zeros((-rec.size) % 4, np.float32), frec])
+        return (torch.from_numpy(blob).to(device), (rec.size + 3) // 4 * 4, _PRECISIONS[name])
+
+    def __call__(self, feature):
+        """feature [n, F] (cuda, fp32) -> [n, n_out]"""
+        dev = feature.device
+        blob, feat_off, prec = self.cache.get(self.net, dev, lambda: self._pack(dev))
+        L = _lib.lib()
+        n = feature.shape[0]
+        Fp = pad8(self.feature_dim)
+        f = feature.to(torch.float32)
+        if Fp != self.feature_dim:
+            f = torch.nn.functional.pad(f, (0, Fp - self.feature_dim))
+        f = f.contiguous()
+        out = torch.empty((n, 16), dtype=torch.float32, device=dev)
+        if n:
+            ws = workspace(dev, L.rnf_workspace_bytes(n, 1))
+            with torch.cuda.device(dev):
+                _lib.check(L.rnf_cond_mlp_forward(f.data_ptr(), n, Fp, blob.data_ptr(), 0, feat_off, prec, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  torch.cuda.current_stream(dev).cuda_stream))
+        return out[:, : self.n_out]
+
+
+class _Padded16:
+    """View of a ConditionalTransform whose fc_last has fewer than 16 rows as one with 16 (zero rows appended): what rnf_pack_cond16 packs."""
+
+    def __init__(self, net, n_out):
+        self.fc_first, self.layers = net.fc_first, net.layers
+        w, b = net.fc_last.weight.detach(), net.fc_last.bias.detach()
+        self.fc_last = type("L", (), {})()
+        self.fc_last.weight = torch.cat([w, w.new_zeros(16 - n_out, w.shape[1])]) if n_out < 16 else w
+        self.fc_last.bias = torch.cat([b, b.new_zeros(16 - n_out)]) if n_out < 16 else b
+
+
+def build_side_buffer(packed, feature, n, device, inverse):
+    """[n_side_layers, n, 16] per-sample matrices of the flow's side layers for THIS batch (the matrices of ConditionLU depend on the
+    first rows of the batch: flow/squeezetrans.py:127)."""
+    if feature is None:
+        raise AssertionError("The input feature is needed in this module")
+    feat = feature.reshape(n, -1).to(device=device, dtype=torch.float32)
+    side = torch.zeros((len(packed.side_layers), n, 16), dtype=torch.float32, device=device)
+    for slot, layer in enumerate(packed.side_layers):
+        m = layer._rnf_side(feat)                                # [n, 16] or [n, 9]
+        side[slot, :, : m.shape[1]] = m
+    return side
 
 
 # ---- parameter-version keyed cache -------------------------------------------------------------------------------
@@ -370,6 +449,8 @@ def run_flow(module, packed, rotation, feature, inverse=False, train_layers=None
     if callable(packed):
         packed = packed()
     shared = bool(feature_repeat) and packed.n_cond > 0
+    if packed.side_layers and feature_repeat:
+        raise NotImplementedError("feature_repeat is not built for flows with ConditionRot / ConditionLU layers: pass repeated feature rows")
     rot, feat = _check_inputs(rotation, feature, packed, feature_repeat if shared else None)
     n = rot.shape[0]
     L = _lib.lib()
@@ -385,6 +466,13 @@ def run_flow(module, packed, rotation, feature, inverse=False, train_layers=None
             _lib.check(fn(rot.data_ptr(), feat.data_ptr(), n, packed.feat_padded, feature_repeat, packed.blob.data_ptr(),
                           packed.desc.ctypes.data, packed.n_layers, packed.segments, out_rot.data_ptr(), out_ldj.data_ptr(),
                           ws.data_ptr(), ws.numel(), stream))
+        elif packed.side_layers:
+            side = build_side_buffer(packed, feature, n, rot.device, inverse)
+            ws = workspace(rot.device, L.rnf_workspace_bytes(n, max(packed.n_cond, 1)))
+            fn = L.rnf_flow_inverse_side if inverse else L.rnf_flow_forward_side
+            _lib.check(fn(rot.data_ptr(), feat.data_ptr() if feat is not None else None, n, packed.feat_padded, side.data_ptr(),
+                          packed.blob.data_ptr(), packed.desc.ctypes.data, packed.n_layers, packed.segments,
+                          out_rot.data_ptr(), out_ldj.data_ptr(), ws.data_ptr(), ws.numel(), stream))
         else:
             ws = workspace(rot.device, L.rnf_workspace_bytes(n, packed.n_cond))
             fn = L.rnf_flow_inverse if inverse else L.rnf_flow_forward
@@ -423,6 +511,13 @@ def run_log_prob(module, packed: PackedFlow, rotation, feature, fisher_A=None, f
                                                   packed.desc.ctypes.data, packed.n_layers, packed.segments,
                                                   ptr(fisher_A), ptr(fisher_c), B, ptr(out_rot), ptr(out_ldj), ptr(out_lp),
                                                   out_sum.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+        elif packed.side_layers:
+            side = build_side_buffer(packed, feature, n, dev, False)
+            ws = workspace(dev, L.rnf_workspace_bytes(n, max(packed.n_cond, 1)))
+            _lib.check(L.rnf_flow_log_prob_side(rot.data_ptr(), ptr(feat), n, packed.feat_padded, side.data_ptr(), packed.blob.data_ptr(),
+                                                packed.desc.ctypes.data, packed.n_layers, packed.segments,
+                                                ptr(fisher_A), ptr(fisher_c), B, ptr(out_rot), ptr(out_ldj), ptr(out_lp),
+                                                out_sum.data_ptr(), ws.data_ptr(), ws.numel(), stream))
         else:
             ws = workspace(dev, L.rnf_workspace_bytes(n, packed.n_cond))
             _lib.check(L.rnf_flow_log_prob(rot.data_ptr(), ptr(feat), n, packed.feat_padded, packed.blob.data_ptr(),

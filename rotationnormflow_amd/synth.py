@@ -62,6 +62,13 @@ def fill_state_dict(shapes: dict, seed: int = 0, regime: str = "default") -> dic
         z = rng.standard_normal(shape).astype(np.float32)
         if key.endswith(".mat") or key.endswith(".rot"):   # Uncondition16Trans.mat / UnconditionRot.rot [1,4,4]; 3x3 / 6x6 ablations
             val = np.eye(shape[-1], dtype=np.float32).reshape((1,) * (len(shape) - 2) + (shape[-1], shape[-1])) + np.float32(sigma) * z
+        elif key.endswith(".net.w_p") or key.endswith(".net.u_mask") or key.endswith(".net.l_mask") or key.endswith(".net.l_eye") \
+                or key.endswith(".net.s_sign"):             # ConditionLU buffers (flow/squeezetrans.py:110-114): same fixed structure
+            d = shape[-1]
+            name = key.rsplit(".", 1)[1]
+            val = {"w_p": np.eye(d, dtype=np.float32)[[1, 0] + list(range(2, d))], "u_mask": np.triu(np.ones((d, d), dtype=np.float32), 1),
+                   "l_mask": np.triu(np.ones((d, d), dtype=np.float32), 1).T, "l_eye": np.eye(d, dtype=np.float32),
+                   "s_sign": np.array([1, -1, 1, 1], dtype=np.float32)[:d]}[name]
         elif key.endswith(".mat.w_p"):                   # UnconditionLU buffers: fixed, valid structure (the draw is discarded)
             d = shape[-1]
             val = np.eye(d, dtype=np.float32)[[1, 0] + list(range(2, d))]
@@ -82,7 +89,7 @@ def fill_state_dict(shapes: dict, seed: int = 0, regime: str = "default") -> dic
             val = z / np.float32(np.sqrt(fan_in))
             if "conditioner.fc_last" in key:
                 val = val * np.float32(gain)
-            elif "net.fc_last" in key:                 # Condition16Trans: keep I + net(f) well conditioned
+            elif "net.fc_last" in key:                 # Condition16Trans / ConditionLU nets: keep the per-sample matrix well conditioned
                 val = val * np.float32(0.2)
         elif key.endswith(".bias"):
             val = np.float32(0.1) * z

@@ -75,6 +75,20 @@ CASES = {
                             regime="default", wseed=14, rseed=58, direction="forward", fisher=None),
 }
 
+# the conditional LU / SVD-rotation registry rows (flow/squeezetrans.py:94-144,264-277; flow/rottrans.py:37-66): per-sample matrices
+# built by the reference with batched torch ops (batch-coupled torch.diag; U^T V of a batched SVD)
+CASES.update({
+    "clu16_cond":      dict(cfg=dict(layers=2, segments=16, condition=1, feature_dim=24, rot="16Trans", lu=1), n=512, regime="trained", wseed=51, rseed=151, direction="forward", fisher=None),
+    "clu16_cond_inv":  dict(cfg=dict(layers=2, segments=16, condition=1, feature_dim=24, rot="16Trans", lu=1), n=512, regime="trained", wseed=51, rseed=152, direction="inverse", fisher=None),
+    "clu16_first":     dict(cfg=dict(layers=2, segments=16, condition=1, feature_dim=24, rot="16UnTrans", lu=1, last_affine=1, first_affine=0, frequent_permute=1),
+                            n=512, regime="trained", wseed=52, rseed=153, direction="forward", fisher=None),
+    "clu9_cond":       dict(cfg=dict(layers=2, segments=16, condition=1, feature_dim=24, rot="9TransLSmith", lu=1), n=512, regime="trained", wseed=53, rseed=154, direction="forward", fisher=None),
+    "clu9_cond_inv":   dict(cfg=dict(layers=2, segments=16, condition=1, feature_dim=24, rot="9TransLSmith", lu=1), n=512, regime="trained", wseed=53, rseed=155, direction="inverse", fisher=None),
+    "crot16_cond":     dict(cfg=dict(layers=2, segments=16, condition=1, feature_dim=24, rot="16Rot"), n=512, regime="trained", wseed=54, rseed=156, direction="forward", fisher=None),
+    "crot16_cond_inv": dict(cfg=dict(layers=2, segments=16, condition=1, feature_dim=24, rot="16Rot"), n=512, regime="trained", wseed=54, rseed=157, direction="inverse", fisher=None),
+    "crot16_first":    dict(cfg=dict(layers=2, segments=16, condition=1, feature_dim=24, rot="16UnRot", last_affine=1, first_affine=0), n=512, regime="trained", wseed=55, rseed=158, direction="forward", fisher=None),
+})
+
 
 # Gradients through Flow.inverse (BinFind.backward, flow/mobiusflow.py:247-273): the reference's own autograd in fp64, loss =
 # sum(a * ldj) + sum(B * R_out) with seeded a [n], B [n,3,3] (tests/golden/make_golden.py run_inverse_grad_case).

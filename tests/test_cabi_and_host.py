@@ -101,14 +101,17 @@ def test_registry_table():
                      ("9TransLSmith", squeezetrans.Condition9Trans), ("9TransRSmith", rottrans.Condition9RotRSmith),
                      ("36Trans", squeezetrans.Condition36Trans)):
         assert isinstance(affineflow.get_affine(mk(rot=rot, condition=1), 8), cls)
-    for kw in (dict(rot="9TransLSmith", lu=1), dict(rot="16Rot")):
-        with pytest.raises(NotImplementedError):                          # declared, not built: loud, no fallback
-            affineflow.get_affine(mk(condition=1, **kw), 8)
+    # the conditional LU / SVD-rotation rows (built in round 2 as per-sample "side" matrices)
+    assert isinstance(affineflow.get_affine(mk(rot="9TransLSmith", lu=1, condition=1), 8), squeezetrans.Condition9TransLU)
+    assert isinstance(affineflow.get_affine(mk(rot="16Rot", condition=1), 8), rottrans.ConditionRot)
     assert isinstance(affineflow.get_affine(mk(rot="9TransLSmith", lu=1), 0), squeezetrans.Uncondition9TransLU)
-    with pytest.raises(NotImplementedError):
-        affineflow.get_affine(mk(rot="16Trans", lu=1, condition=1), 8)   # Condition16TransLU (batch-coupled in the reference)
-    with pytest.raises(NotImplementedError):
-        affineflow.get_affine(mk(rot="16UnRot", condition=1), 8, first_layer_condition=True)    # ConditionRot
+    assert isinstance(affineflow.get_affine(mk(rot="16Trans", lu=1, condition=1), 8), squeezetrans.Condition16TransLU)
+    assert isinstance(affineflow.get_affine(mk(rot="16UnTrans", lu=1, condition=1), 8, first_layer_condition=True), squeezetrans.Condition16TransLU)
+    assert isinstance(affineflow.get_affine(mk(rot="16UnRot", condition=1), 8, first_layer_condition=True), rottrans.ConditionRot)
+    lu = squeezetrans.Condition16TransLU(8)
+    assert all(k.startswith("net.") for k in lu.state_dict()) and len(lu.state_dict()) == 5 + 3 * 10
+    assert {"net.w_p", "net.u_mask", "net.l_mask", "net.s_sign", "net.l_eye", "net.w_l_net.fc_first.weight", "net.w_u_net.fc_last.bias",
+            "net.w_s_net.layers.3.weight"} <= set(lu.state_dict())            # flow/squeezetrans.py:110-119 names
 
 
 def test_rot_none_with_last_affine_is_a_type_error():

@@ -190,6 +190,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    if os.environ.get("RNF_BENCH_HANG_DUMP"):                 # diagnostics: dump every thread's stack and exit after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["RNF_BENCH_HANG_DUMP"]), exit=True)
 
     import numpy as np
     import torch
@@ -223,7 +226,7 @@ def main():
     cfg, weights, fl = build_flow(device, wl["preset"])
     n = 1 << args.batch_log2
     A = synth.fisher_A("diag531")
-    base = MatrixFisherN(torch.from_numpy(A)).to(device) if wl["fisher"] else None
+    base = MatrixFisherN(torch.from_numpy(A).to(device)) if wl["fisher"] else None
     feat_dim = fl.feature_dim if cfg.condition else 0
     # rank r evaluates its own shard of the global batch (seeded per rank): no data-path collective
     R = torch.from_numpy(synth.uniform_rotations(n, seed=synth.RD_SEED + rank)).to(device)

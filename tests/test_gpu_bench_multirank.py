@@ -17,10 +17,10 @@ def test_two_ranks_one_json_line():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, RNF_BENCH_SHARED_GPU="1")
+    env = dict(os.environ, RNF_BENCH_SHARED_GPU="1", RNF_BENCH_HANG_DUMP="150")     # a hung rank dumps its stacks and exits
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch-log2", "15"]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -29,3 +29,49 @@ def test_two_ranks_one_json_line():
     assert rec["config"]["global_batch"] == 2 * (1 << 15)
     assert rec["value"] > 0 and 10.0 < rec["mean_nll"] < 18.0          # 2 x 2^15 uniform rotations under MF(diag(5,3,1)) after the flow
     assert "cpu_baseline" not in rec                                   # rank-0-at-N=1 only
+
+
+def test_self_launch_from_gpus_flag():
+    """`python bench.py --gpus 2` with no torchrun around it: the script starts its two ranks itself (child torch.distributed.run, before
+    the parent touches the GPU) and relays the one JSON line; here both ranks share the one GPU of the box over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["RNF_BENCH_SHARED_GPU"] = "1"
+    env["RNF_BENCH_HANG_DUMP"] = "150"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch-log2", "15",
+                          "--no-secondary"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["backend"] == "gloo"
+    assert rec["config"]["global_batch"] == 2 * (1 << 15)
+
+
+def test_more_gpus_than_the_box_has_fails_loudly():
+    import torch
+    have = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RNF_BENCH_SHARED_GPU")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 1), "--steps", "1", "--warmup", "0"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "GPU(s) are visible" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    # a rank count that contradicts the launcher is refused too
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1"], env=env2, cwd=ROOT, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
+
+
+def test_single_gpu_line_carries_both_arithmetics_and_every_config_runs():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch-log2", "16", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["roofline"]["bound"] == "valu" and "frac" in rec["roofline"] and rec["secondary"]["roofline"]["bound"] == "mfma"
+    assert rec["secondary"]["value"] > 0 and abs(rec["secondary"]["mean_nll"] - rec["mean_nll"]) < 1e-4
+    for cfg in ("C1", "C4", "C5", "C5u"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "1", "--warmup", "1", "--batch-log2", "14",
+                              "--no-cpu-baseline", "--no-secondary"], cwd=ROOT, capture_output=True, text=True, timeout=400)
+        assert out.returncode == 0, (cfg, out.stderr[-2000:])
+        rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+        assert rec["value"] > 0 and rec["config"]["workload"].startswith(cfg)

@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     out_csv, out_json, needle = sys.argv[1:4]
-    rows = defaultdict(list)          # counter -> [(grid, value)]
+    rows = defaultdict(list)          # counter -> [(grid, kernel name, value)]
     meta = {}
     for d in sys.argv[4:]:
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -35,16 +35,24 @@ def main():
                     info[r["Dispatch_Id"]] = (int(r["Grid_Size"]), int(r["Workgroup_Size"]), int(r["VGPR_Count"]), int(r["LDS_Block_Size"]),
                                               r["Kernel_Name"])
             for (disp, name), v in per_dispatch.items():
-                rows[name].append((info[disp][0], v))
-                meta[name] = info[disp]
+                rows[name].append((info[disp][0], info[disp][4], v))
+                meta[info[disp][4]] = info[disp]
+    # the instantiation that did the work: largest grid, and among equal grids the largest counter total (the range guard enqueues an
+    # early-exit launch of the exact-fp32 instantiation behind every split-precision launch; it must not dilute the means)
     with open(out_csv, "w") as fh:
-        fh.write("counter,mean_per_dispatch,dispatches,grid_size\n")
+        fh.write("counter,mean_per_dispatch,dispatches,grid_size,kernel\n")
         summary = {}
+        chosen = None
         for name in sorted(rows):
-            gmax = max(g for g, _ in rows[name])
-            vals = [v for g, v in rows[name] if g == gmax]
+            totals = defaultdict(float)
+            for g, k, v in rows[name]:
+                totals[(g, k)] += v
+            g, k = max(totals, key=lambda t: (t[0], totals[t]))
+            chosen = chosen or k
+            vals = [v for gg, kk, v in rows[name] if (gg, kk) == (g, k)]
             summary[name] = sum(vals) / len(vals)
-            fh.write(f"{name},{summary[name]:.1f},{len(vals)},{gmax}\n")
+            fh.write(f"{name},{summary[name]:.1f},{len(vals)},{g},\"{k}\"\n")
+    meta = {chosen: meta[chosen]} if chosen else {}
     from rotationnormflow_amd.build import source_hash
     out = {"kernel": next(iter(meta.values()))[4] if meta else None, "counters": summary, "csrc_sha": source_hash(),
            "rotations_per_launch": int(os.environ.get("RNF_PMC_ROTATIONS", 1 << 20))}

@@ -31,7 +31,9 @@ python3 tools/parity_stats.py > $OUT/parity_stats.jsonl 2>/dev/null
 python3 tools/inverse_stats.py > $OUT/inverse_stats.jsonl 2>/dev/null
 python3 tools/host_overhead.py > $OUT/host_overhead.jsonl 2>/dev/null
 python3 tools/bench_train.py > $OUT/train.json 2>/dev/null
+python3 tools/bench_train.py --graph > $OUT/train_graph.json 2>/dev/null
+python3 tools/bench_train.py --graph --config C4 --batch 128 > $OUT/train_graph_c4.json 2>/dev/null
 find $OUT -name "*.csv" -size +1M -delete
 find $OUT -name "*.db" -delete
-rm -rf $OUT/pmc[0-9] $OUT/pmc[0-9][0-9] $OUT/stats
+rm -rf $OUT/stats
 ls $OUT

@@ -269,8 +269,24 @@ int rnf_min_geodesic(const float *est_dev, const float *gt_dev, int64_t n, int32
  * values, :93-97 norm_type = 1): log p(R) = tr(A^T R) - c.  A_dev float[B][9], c_out_dev float[B]; fp64 inside. */
 int rnf_fisher_log_const(const float *A_dev, int64_t B, float *c_out_dev, void *stream);
 
+/* The same for either closed-form normaliser approximation of matrix_fisher_norm_N (utils/fisher.py:79-97):
+ *   norm_type 1 (default): 1/sqrt(8 pi (s0+s1)(s1+s2)(s0+s2));
+ *   norm_type 0: (1 + Q/6 + s0 s1 s2/6)/exp(s0+s1+s2), where the reference's `(S**2).sum()` has no `dim`: Q runs over ALL B matrices of
+ *   the call (batch-coupled, reproduced as is).  Types 2 (Monte-Carlo over pytorch3d random rotations) and 3 (scipy ODE; indexes rows
+ *   of the [B,3] tensor) are refused.  scratch_dev: rnf_fisher_scratch_bytes(B) bytes of device memory (16 suffice here). */
+size_t rnf_fisher_scratch_bytes(int64_t B);
+int rnf_fisher_log_const_nt(const float *A_dev, int64_t B, int32_t norm_type, void *scratch_dev, size_t scratch_bytes,
+                            float *c_out_dev, void *stream);
+
+/* Gradient of MatrixFisherN._log_prob w.r.t. A (agent.py:57-65 keeps a network-predicted A in the autograd graph; the reference
+ * differentiates torch.svd, utils/fisher.py:67-76,217-232):  g_A[b] = sum_i g_logp[i] R_i - (sum_i g_logp[i]) dc/dA_b over the n/B
+ * samples of row b, dc/dA = U' diag(dc/ds) V'^T on the proper SVD (csrc/fisher_math.h), plus the batch coupling of norm_type 0.
+ * rotation_dev float[n][9], g_A_dev float[B][9] (overwritten), scratch_dev: rnf_fisher_scratch_bytes(B) bytes.  fp64 accumulation. */
+int rnf_fisher_log_prob_backward_param(const float *g_logp_dev, const float *rotation_dev, int64_t n, const float *A_dev, int64_t B,
+                                   int32_t norm_type, void *scratch_dev, size_t scratch_bytes, float *g_A_dev, void *stream);
+
 /* Gradient of rnf_fisher_log_prob w.r.t. the rotations (training with a matrix-Fisher base, agent.py:58-64):
- * g_rotation[i] = g_logp[i] * A[i / (n/B)].  (The gradient w.r.t. A needs the derivative of the normaliser and is not built.) */
+ * g_rotation[i] = g_logp[i] * A[i / (n/B)]. */
 int rnf_fisher_log_prob_backward(const float *g_logp_dev, int64_t n, const float *A_dev, int64_t B, float *g_rotation_dev,
                                  void *stream);
 

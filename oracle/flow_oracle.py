@@ -634,18 +634,29 @@ def flow_inverse(cfg, params, R, feature=None, dtype=torch.float32, grad=False):
 def proper_singular_values(A):
     """proper_svd_N (fisher.py:67-76): singular values with the last one sign-flipped by det(U)det(V)."""
     U, S, Vh = torch.linalg.svd(A)
-    S = S.clone()
-    S[:, 2] = S[:, 2] * torch.det(U) * torch.det(Vh)
-    return S
+    return torch.stack([S[:, 0], S[:, 1], S[:, 2] * torch.det(U) * torch.det(Vh)], dim=-1)   # out of place: differentiable w.r.t. A
 
 
-def fisher_log_prob(R, A, dtype=torch.float32):
-    """MatrixFisherN(A)._log_prob(R) with the default norm_type=1 (fisher.py:93-97,217-232).
-    A [B,3,3] broadcasts over N/B consecutive samples (fisher.py:226)."""
+def fisher_norm(S, norm_type=1):
+    """matrix_fisher_norm_N (fisher.py:79-115) on the proper singular values S [B,3].  norm_type 0 follows the reference to the
+    letter: ``(S**2).sum()`` has no ``dim`` (fisher.py:91), so the quadratic term is summed over the WHOLE batch of matrices.
+    Types 2 (Monte-Carlo over pytorch3d random rotations) and 3 (an ODE on S[0], S[1], S[2], which index ROWS of the [B,3] tensor
+    and fail for B < 3) are not restated."""
+    if norm_type == 0:
+        norm = 1.0 + 1.0 / 6.0 * (S ** 2).sum() + 1.0 / 6.0 * S[:, 0] * S[:, 1] * S[:, 2]
+        return norm / torch.sum(S, dim=-1).exp()
+    if norm_type == 1:
+        return 1.0 / torch.sqrt(8 * math.pi * (S[:, 0] + S[:, 1]) * (S[:, 2] + S[:, 1]) * (S[:, 0] + S[:, 2]))
+    raise NotImplementedError(f"norm_type={norm_type}")
+
+
+def fisher_log_prob(R, A, dtype=torch.float32, norm_type=1):
+    """MatrixFisherN(A, norm_type)._log_prob(R) (fisher.py:79-97,217-232).  A [B,3,3] broadcasts over N/B consecutive samples
+    (fisher.py:226).  Built from differentiable torch ops: autograd of this function w.r.t. A is the checker of the d/dA kernel."""
     A = torch.as_tensor(A).to(dtype)
     R = torch.as_tensor(R).to(dtype).reshape(A.shape[0], -1, 3, 3)
     S = proper_singular_values(A)
-    norm = 1.0 / torch.sqrt(8 * math.pi * (S[:, 0] + S[:, 1]) * (S[:, 2] + S[:, 1]) * (S[:, 0] + S[:, 2]))
+    norm = fisher_norm(S, norm_type)
     tr = (R * A.reshape(-1, 1, 3, 3)).sum(-1).sum(-1)
     return ((tr - S.sum(-1).reshape(-1, 1)) - norm.log().reshape(-1, 1)).reshape(-1)
 

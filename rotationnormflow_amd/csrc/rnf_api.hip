@@ -15,6 +15,7 @@
 #include "train_kernels.h"
 #include "pack_device.h"
 #include "sampler_kernel.h"
+#include "fisher_math.h"
 #include "layout.h"
 
 using namespace rnf;
@@ -1093,53 +1094,137 @@ extern "C" int rnf_min_geodesic(const float *est, const float *gt, int64_t n, in
     return 0;
 }
 
-// log-constants of MatrixFisherN(A) (utils/fisher.py:67-76,93-97): c = s0 + s1 + s2 + log norm with the PROPER singular values of A
-// (the smallest one carries the sign of det A) and norm = 1 / sqrt(8 pi (s0+s1)(s1+s2)(s0+s2)).  One thread per matrix, fp64:
-// eigenvalues of A^T A by cyclic Jacobi (robust for repeated singular values), so that a per-sample A coming out of a network never
-// goes through a host SVD and a device->host sync.
-__global__ void fisher_log_const_kernel(const float *A, long long B, float *c_out) {
+// log-constants of MatrixFisherN(A, norm_type) (utils/fisher.py:67-76,79-97): c = s0 + s1 + s2 + log norm with the PROPER singular values
+// of A (fisher_math.h).  One thread per matrix, fp64, so that a per-sample A coming out of a network never goes through a host SVD and a
+// device->host sync.  scratch (doubles): [0] = Q = sum_b |A_b|_F^2 (norm_type 0 is batch-coupled through it), [1] = W, [2 + 10 b ..] =
+// per-row gradient accumulators of the backward pass.
+__global__ void fisher_frobenius_kernel(const float *A, long long B, double *q) {
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < B * 9; i += (long long)gridDim.x * blockDim.x) acc += (double)A[i] * (double)A[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(q, acc);
+}
+
+__global__ void fisher_log_const_kernel(const float *A, long long B, int norm_type, const double *q, float *c_out) {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    double a[3][3], m[3][3];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a[i][j] = A[b * 9 + 3 * i + j];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) m[i][j] = a[0][i] * a[0][j] + a[1][i] * a[1][j] + a[2][i] * a[2][j];
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        const double off = fabs(m[0][1]) + fabs(m[0][2]) + fabs(m[1][2]);
-        if (off <= 1e-300 || off <= 1e-18 * (fabs(m[0][0]) + fabs(m[1][1]) + fabs(m[2][2]))) break;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                if (m[p][q] == 0.0) continue;
-                const double theta = (m[q][q] - m[p][p]) / (2.0 * m[p][q]);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
-                for (int k = 0; k < 3; ++k) {               // M <- M J
-                    const double mkp = m[k][p], mkq = m[k][q];
-                    m[k][p] = cs * mkp - sn * mkq;
-                    m[k][q] = sn * mkp + cs * mkq;
-                }
-                for (int k = 0; k < 3; ++k) {               // M <- J^T M
-                    const double mpk = m[p][k], mqk = m[q][k];
-                    m[p][k] = cs * mpk - sn * mqk;
-                    m[q][k] = sn * mpk + cs * mqk;
-                }
-            }
+    double a[9];
+    for (int k = 0; k < 9; ++k) a[k] = A[b * 9 + k];
+    c_out[b] = (float)fisher_log_const(a, norm_type, norm_type == 0 ? q[0] : 0.0, nullptr);
+}
+
+static int fisher_const_launch(const float *A, int64_t B, int32_t norm_type, double *scratch, float *c_out, hipStream_t st) {
+    if (norm_type == 0) {
+        HIP_TRY(hipMemsetAsync(scratch, 0, 2 * sizeof(double), st));
+        long long blocks = (B * 9 + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(fisher_frobenius_kernel, dim3((int)blocks), dim3(256), 0, st, A, (long long)B, scratch);
     }
-    double s0 = sqrt(fmax(m[0][0], 0.0)), s1 = sqrt(fmax(m[1][1], 0.0)), s2 = sqrt(fmax(m[2][2], 0.0)), t;
-    if (s0 < s1) { t = s0; s0 = s1; s1 = t; }
-    if (s1 < s2) { t = s1; s1 = s2; s2 = t; }
-    if (s0 < s1) { t = s0; s0 = s1; s1 = t; }
-    const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
-                       a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
-    if (det < 0.0) s2 = -s2;
-    const double norm = 1.0 / sqrt(8.0 * 3.14159265358979323846 * (s0 + s1) * (s2 + s1) * (s0 + s2));
-    c_out[b] = (float)(s0 + s1 + s2 + log(norm));
+    if (c_out) hipLaunchKernelGGL(fisher_log_const_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, A, (long long)B, norm_type, scratch, c_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 extern "C" int rnf_fisher_log_const(const float *A, int64_t B, float *c_out, void *stream) {
     if (!A || !c_out) return fail("rnf_fisher_log_const: null pointer");
     if (B <= 0) return fail("rnf_fisher_log_const: B=%lld", (long long)B);
-    hipLaunchKernelGGL(fisher_log_const_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), A, (long long)B, c_out);
+    return fisher_const_launch(A, B, 1, nullptr, c_out, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t rnf_fisher_scratch_bytes(int64_t B) { return (size_t)(2 + 10 * (B > 0 ? B : 0)) * sizeof(double); }
+
+extern "C" int rnf_fisher_log_const_nt(const float *A, int64_t B, int32_t norm_type, void *scratch, size_t scratch_bytes, float *c_out, void *stream) {
+    if (!A || !c_out) return fail("rnf_fisher_log_const_nt: null pointer");
+    if (B <= 0) return fail("rnf_fisher_log_const_nt: B=%lld", (long long)B);
+    if (norm_type != 0 && norm_type != 1)
+        return fail("rnf_fisher_log_const_nt: norm_type=%d -- only the closed-form approximations 0 and 1 are built (utils/fisher.py:88-97)", (int)norm_type);
+    if (norm_type == 0 && (!scratch || scratch_bytes < 2 * sizeof(double))) return fail("rnf_fisher_log_const_nt: norm_type 0 needs 16 bytes of scratch");
+    return fisher_const_launch(A, B, norm_type, static_cast<double *>(scratch), c_out, reinterpret_cast<hipStream_t>(stream));
+}
+
+// d log p / dA (agent.py:57-65 keeps a predicted A in the graph):  g_A[b] = sum_{i in row b} g_i R_i  -  (sum_{i in row b} g_i) dc_b/dA_b
+// (+ the batch coupling of norm_type 0 through Q).  Pass 1 accumulates T_b = sum g_i R_i and G_b = sum g_i in fp64: 256 consecutive
+// samples per block step; a step inside one row reduces in the block and issues 10 atomics, a step that spans rows lets every sample
+// add to its own row.
+__global__ void fisher_grad_accum_kernel(const float *g, const float *rot, long long n, long long div, double *acc) {
+    __shared__ double red[4][10];
+    for (long long base = (long long)blockIdx.x * 256; base < n; base += (long long)gridDim.x * 256) {
+        const long long i = base + threadIdx.x;
+        const long long last = base + 255 < n ? base + 255 : n - 1;
+        const bool one_row = base / div == last / div;                   // block uniform
+        double v[10];
+        const float gi = i < n ? g[i] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[k] = i < n ? (double)gi * (double)rot[i * 9 + k] : 0.0;
+        v[9] = gi;
+        if (one_row) {
+#pragma unroll
+            for (int k = 0; k < 10; ++k)
+                for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+            if ((threadIdx.x & 63) == 0)
+                for (int k = 0; k < 10; ++k) red[threadIdx.x >> 6][k] = v[k];
+            __syncthreads();
+            if (threadIdx.x < 10) atomicAdd(acc + 10 * (base / div) + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+            __syncthreads();
+        } else if (i < n) {
+            double *dst = acc + 10 * (i / div);
+#pragma unroll
+            for (int k = 0; k < 10; ++k) atomicAdd(dst + k, v[k]);
+        }
+    }
+}
+
+// norm_type 0: W = sum_b G_b / D_b, D_b = 1 + Q/6 + det(A_b)/6  (the weight of dQ/dA_b' = 2 A_b' in every row's gradient)
+__global__ void fisher_grad_w_kernel(const float *A, long long B, double *scratch) {
+    double w = 0.0;
+    for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (long long)gridDim.x * blockDim.x) {
+        double a[9];
+        for (int k = 0; k < 9; ++k) a[k] = A[b * 9 + k];
+        w += scratch[2 + 10 * b + 9] / (1.0 + scratch[0] / 6.0 + det3d(a) / 6.0);
+    }
+    for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(scratch + 1, w);
+}
+
+__global__ void fisher_grad_final_kernel(const float *A, long long B, int norm_type, const double *scratch, float *g_A) {
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double a[9], dc[9];
+    for (int k = 0; k < 9; ++k) a[k] = A[b * 9 + k];
+    fisher_log_const(a, norm_type, norm_type == 0 ? scratch[0] : 0.0, dc);
+    const double *acc = scratch + 2 + 10 * b;
+    for (int k = 0; k < 9; ++k) {
+        double v = acc[k] - acc[9] * dc[k];
+        if (norm_type == 0) v -= scratch[1] * a[k] / 3.0;
+        g_A[b * 9 + k] = (float)v;
+    }
+}
+
+extern "C" int rnf_fisher_log_prob_backward_param(const float *g_logp, const float *rot, int64_t n, const float *A, int64_t B, int32_t norm_type,
+                                              void *scratch, size_t scratch_bytes, float *g_A, void *stream) {
+    if (!g_logp || !rot || !A || !g_A || !scratch) return fail("rnf_fisher_log_prob_backward_param: null pointer");
+    if (B <= 0 || n % B) return fail("n=%lld not divisible by fisher rows B=%lld (utils/fisher.py:226)", (long long)n, (long long)B);
+    if (norm_type != 0 && norm_type != 1) return fail("rnf_fisher_log_prob_backward_param: norm_type=%d is not built", (int)norm_type);
+    if (scratch_bytes < rnf_fisher_scratch_bytes(B)) return fail("rnf_fisher_log_prob_backward_param: scratch of %zu bytes, need %zu", scratch_bytes, rnf_fisher_scratch_bytes(B));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    double *sc = static_cast<double *>(scratch);
+    HIP_TRY(hipMemsetAsync(sc, 0, rnf_fisher_scratch_bytes(B), st));
+    if (norm_type == 0) {
+        long long blocks = (B * 9 + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(fisher_frobenius_kernel, dim3((int)blocks), dim3(256), 0, st, A, (long long)B, sc);
+    }
+    if (n > 0) {
+        long long blocks = (n + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(fisher_grad_accum_kernel, dim3((int)blocks), dim3(256), 0, st, g_logp, rot, (long long)n, (long long)(n / B), sc + 2);
+    }
+    if (norm_type == 0) {
+        long long blocks = (B + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(fisher_grad_w_kernel, dim3((int)blocks), dim3(256), 0, st, A, (long long)B, sc);
+    }
+    hipLaunchKernelGGL(fisher_grad_final_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, A, (long long)B, norm_type, sc, g_A);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -1,7 +1,8 @@
 """Mirror of the reference's utils/fisher.py: ``MatrixFisherN`` (log-density on the GPU through rnf_fisher_log_prob).
 
-log p(R) = tr(A^T R) - (s0+s1+s2) - log norm, norm = 1/sqrt(8 pi (s0+s1)(s1+s2)(s0+s2))   (utils/fisher.py:93-97,217-232)
-with s the *proper* singular values of A (last one sign-flipped by det(U) det(V), utils/fisher.py:67-76).
+log p(R) = tr(A^T R) - (s0+s1+s2) - log norm, norm = 1/sqrt(8 pi (s0+s1)(s1+s2)(s0+s2))   (utils/fisher.py:93-97,217-232; norm_type 1)
+with s the *proper* singular values of A (last one sign-flipped by det(U) det(V), utils/fisher.py:67-76); norm_type 0 is the
+small-s approximation of utils/fisher.py:88-91.  Differentiable w.r.t. the rotations and w.r.t. A.
 """
 import math
 
@@ -29,33 +30,53 @@ def quaternion_to_matrix(q):
     return m.reshape(q.shape[:-1] + (3, 3))
 
 
+def _norm_from_singular_values(S, norm_type):
+    """matrix_fisher_norm_N (utils/fisher.py:79-97) for the two closed-form approximations; type 0 keeps the reference's batch-global
+    ``(S**2).sum()``."""
+    if norm_type == 0:
+        return (1.0 + (S ** 2).sum() / 6.0 + S[:, 0] * S[:, 1] * S[:, 2] / 6.0) / S.sum(-1).exp()
+    return 1.0 / torch.sqrt(8 * math.pi * (S[:, 0] + S[:, 1]) * (S[:, 2] + S[:, 1]) * (S[:, 0] + S[:, 2]))
+
+
 class _FisherLogProb(torch.autograd.Function):
-    """log p(R) = tr(A^T R) - c through rnf_fisher_log_prob; d/dR = A through rnf_fisher_log_prob_backward (training with a
-    matrix-Fisher base differentiates it w.r.t. the flow's output rotation, agent.py:58-64)."""
+    """log p(R) = tr(A^T R) - c through rnf_fisher_log_prob; d/dR = g A through rnf_fisher_log_prob_backward (training with a
+    matrix-Fisher base differentiates it w.r.t. the flow's output rotation, agent.py:58-64); d/dA -- needed when A is predicted by a
+    network and kept in the graph, agent.py:57-65 -- through rnf_fisher_log_prob_backward_param (derivative of the normaliser included)."""
 
     @staticmethod
-    def forward(ctx, inputs, A, c):
+    def forward(ctx, inputs, A_param, A, c, norm_type):
         R = inputs.reshape(-1, 3, 3).to(torch.float32).contiguous()
         n, B = R.shape[0], A.shape[0]
         out = torch.empty(n, dtype=torch.float32, device=R.device)
         with torch.cuda.device(R.device):
             _lib.check(_lib.lib().rnf_fisher_log_prob(R.data_ptr(), n, A.data_ptr(), c.data_ptr(), B, out.data_ptr(),
                                                       torch.cuda.current_stream(R.device).cuda_stream))
-        ctx.save_for_backward(A)
-        ctx.in_shape, ctx.in_dtype = inputs.shape, inputs.dtype
+        ctx.save_for_backward(A, R)
+        ctx.in_shape, ctx.in_dtype, ctx.norm_type = inputs.shape, inputs.dtype, norm_type
+        ctx.A_shape, ctx.A_dtype, ctx.A_device = A_param.shape, A_param.dtype, A_param.device
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
-        (A,) = ctx.saved_tensors
+        A, R = ctx.saved_tensors
         g = g.to(torch.float32).contiguous()
-        n = g.shape[0]
-        g_rot = torch.empty((n, 3, 3), dtype=torch.float32, device=g.device)
+        n, B = g.shape[0], A.shape[0]
+        L = _lib.lib()
+        g_rot = g_A = None
         with torch.cuda.device(g.device):
-            _lib.check(_lib.lib().rnf_fisher_log_prob_backward(g.data_ptr(), n, A.data_ptr(), A.shape[0], g_rot.data_ptr(),
-                                                               torch.cuda.current_stream(g.device).cuda_stream))
-        return g_rot.reshape(ctx.in_shape).to(ctx.in_dtype), None, None
+            stream = torch.cuda.current_stream(g.device).cuda_stream
+            if ctx.needs_input_grad[0]:
+                g_rot = torch.empty((n, 3, 3), dtype=torch.float32, device=g.device)
+                _lib.check(L.rnf_fisher_log_prob_backward(g.data_ptr(), n, A.data_ptr(), B, g_rot.data_ptr(), stream))
+                g_rot = g_rot.reshape(ctx.in_shape).to(ctx.in_dtype)
+            if ctx.needs_input_grad[1]:
+                g_A = torch.empty((B, 3, 3), dtype=torch.float32, device=g.device)
+                scratch = torch.empty(int(L.rnf_fisher_scratch_bytes(B)) // 8, dtype=torch.float64, device=g.device)
+                _lib.check(L.rnf_fisher_log_prob_backward_param(g.data_ptr(), R.data_ptr(), n, A.data_ptr(), B, ctx.norm_type, scratch.data_ptr(),
+                                                            scratch.numel() * 8, g_A.data_ptr(), stream))
+                g_A = g_A.reshape(ctx.A_shape).to(device=ctx.A_device, dtype=ctx.A_dtype)
+        return g_rot, g_A, None, None, None
 
 
 # fail flags of earlier _sample calls (a proposal loop that exhausted its 4096 attempts leaves the identity rotation in that slot): read
@@ -91,20 +112,25 @@ class MatrixFisherN(torch.nn.Module):
 
     def __init__(self, A, norm_type=1, approx_num=None):
         super().__init__()
-        if norm_type != 1:
-            raise NotImplementedError("only the default normaliser approximation norm_type=1 is built (utils/fisher.py:93-97)")
+        if norm_type not in (0, 1):
+            raise NotImplementedError("normaliser approximations 0 and 1 (closed forms, utils/fisher.py:88-97) are built; type 2 is a Monte-Carlo "
+                                      "estimate over pytorch3d's random_rotations and type 3 indexes rows of the [N,3] singular values "
+                                      "(utils/fisher.py:98-113)")
+        self.norm_type = int(norm_type)
         self.A = A.reshape(-1, 3, 3)
         if self.A.is_cuda:
             # per-sample A from a network (agent.py:57-60): constants on the device, no host SVD and no device->host sync
             A32 = self.A.detach().to(torch.float32).contiguous()
+            L = _lib.lib()
             self._c = torch.empty(A32.shape[0], dtype=torch.float32, device=A32.device)
+            scratch = torch.empty(2, dtype=torch.float64, device=A32.device)
             with torch.cuda.device(A32.device):
-                _lib.check(_lib.lib().rnf_fisher_log_const(A32.data_ptr(), A32.shape[0], self._c.data_ptr(),
-                                                           torch.cuda.current_stream(A32.device).cuda_stream))
+                _lib.check(L.rnf_fisher_log_const_nt(A32.data_ptr(), A32.shape[0], self.norm_type, scratch.data_ptr(), 16, self._c.data_ptr(),
+                                                     torch.cuda.current_stream(A32.device).cuda_stream))
             self._norm = None
         else:
             S = proper_singular_values(self.A)
-            norm = 1.0 / torch.sqrt(8 * math.pi * (S[:, 0] + S[:, 1]) * (S[:, 2] + S[:, 1]) * (S[:, 0] + S[:, 2]))
+            norm = _norm_from_singular_values(S, self.norm_type)
             self._norm = norm.to(dtype=self.A.dtype)
             self._c = (S.sum(-1) + norm.log()).to(torch.float32)      # log p = tr(A^T R) - c
 
@@ -113,8 +139,7 @@ class MatrixFisherN(torch.nn.Module):
         """The reference's ``self.norm`` (utils/fisher.py:215); computed lazily when A lives on the GPU (needs the singular values)."""
         if self._norm is None:
             S = proper_singular_values(self.A)
-            self._norm = (1.0 / torch.sqrt(8 * math.pi * (S[:, 0] + S[:, 1]) * (S[:, 2] + S[:, 1]) * (S[:, 0] + S[:, 2]))).to(
-                device=self.A.device, dtype=self.A.dtype)
+            self._norm = _norm_from_singular_values(S, self.norm_type).to(device=self.A.device, dtype=self.A.dtype)
         return self._norm
 
     def log_const(self):
@@ -123,9 +148,6 @@ class MatrixFisherN(torch.nn.Module):
     def _log_prob(self, inputs, context=9):
         if not inputs.is_cuda:
             raise RuntimeError("rotationnormflow_amd runs on the GPU only (no CPU fallback)")
-        if torch.is_grad_enabled() and self.A.requires_grad:
-            raise NotImplementedError("rotationnormflow_amd: the gradient of the matrix-Fisher density w.r.t. A (it needs the derivative of "
-                                      "the normaliser) is not built; detach A (the reference trains the flow on a frozen A, agent.py:58-60)")
         if inputs.shape[-1] == 4:
             if torch.is_grad_enabled() and inputs.requires_grad:
                 raise NotImplementedError("rotationnormflow_amd: quaternion inputs are not differentiable here; pass rotation matrices")
@@ -133,7 +155,7 @@ class MatrixFisherN(torch.nn.Module):
         dev = inputs.device
         A = self.A.detach().to(device=dev, dtype=torch.float32).contiguous()
         c = self._c.to(dev).contiguous()
-        return _FisherLogProb.apply(inputs, A, c)
+        return _FisherLogProb.apply(inputs, self.A, A, c, self.norm_type)
 
     def log_prob(self, inputs, context=None):
         return self._log_prob(inputs)

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE: csrc/so3_grad.h compiled for the HOST so the reverse-mode formulas of the training path can be
 // checked on a CPU against torch autograd of the oracle (tests/test_host_grad.py).  Not part of librnf_hip.so.
 #include "../../rotationnormflow_amd/csrc/so3_grad.h"
+#include "../../rotationnormflow_amd/csrc/fisher_math.h"
 
 using namespace rnf;
 
@@ -69,5 +70,12 @@ void hg_gs9(const float *M, const float *Rin, const float *gRout, const float *g
         store_rot(gi, gRin + 9 * i);
     }
     for (int k = 0; k < 9; ++k) gM[k] = gm[k];
+}
+// matrix-Fisher log-constant and its derivative for fixed Q (fisher_math.h); proper SVD factors for inspection
+void hg_fisher_const(const double *A, int B, int norm_type, double Q, double *c, double *dc, double *U, double *S, double *V) {
+    for (int b = 0; b < B; ++b) {
+        c[b] = fisher_log_const(A + 9 * b, norm_type, Q, dc + 9 * b);
+        proper_svd3(A + 9 * b, U + 9 * b, S + 3 * b, V + 9 * b);
+    }
 }
 }

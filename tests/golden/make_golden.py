@@ -158,3 +158,33 @@ def run_fisher_sampler_case():
 
 if __name__ == "__main__" and (len(sys.argv) == 1 or "fisher_sampler" in sys.argv):
     run_fisher_sampler_case()
+
+
+def run_fisher_grad_case():
+    """The reference's own autograd through MatrixFisherN(A, norm_type)._log_prob w.r.t. A (agent.py:57-65 keeps a predicted A in the
+    graph) and w.r.t. the rotations, for the two normaliser approximations that are closed forms (norm_type 0 and 1), fp32 and fp64.
+    Six matrices (one with det < 0, one small) x 5 rotations each; the loss is a fixed random weighting of the log-densities."""
+    rng = np.random.RandomState(77)
+    A = np.concatenate([synth.fisher_A("diag531"), synth.fisher_A("tilted"), rng.randn(4, 3, 3)], axis=0)
+    A[3] *= 0.2
+    if np.linalg.det(A[4]) > 0:
+        A[4, :, 0] *= -1.0
+    R = synth.uniform_rotations(A.shape[0] * 5, seed=78).astype(np.float64)
+    g = rng.randn(R.shape[0])
+    out = dict(A=A, R=R, g=g)
+    for nt in (0, 1):
+        for dtype, tag in ((torch.float64, "64"), (torch.float32, "32")):
+            At = torch.from_numpy(A).to(dtype).requires_grad_(True)
+            Rt = torch.from_numpy(R).to(dtype).requires_grad_(True)
+            dist = ref_fisher_mod.MatrixFisherN(At, norm_type=nt)
+            lp = dist._log_prob(Rt)
+            (lp * torch.from_numpy(g).to(dtype)).sum().backward()
+            out[f"logp_t{nt}_{tag}"] = lp.detach().numpy().copy()
+            out[f"gA_t{nt}_{tag}"] = At.grad.numpy().copy()
+            out[f"gR_t{nt}_{tag}"] = Rt.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "fisher_grad.npz"), **out)
+    print("fisher_grad: ", {k: tuple(v.shape) for k, v in out.items() if k.startswith("gA")})
+
+
+if __name__ == "__main__" and (len(sys.argv) == 1 or "fisher_grad" in sys.argv):
+    run_fisher_grad_case()

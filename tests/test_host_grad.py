@@ -16,7 +16,7 @@ from rotationnormflow_amd import synth
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "host_grad.cpp")
 OUT = os.path.join(HERE, "csrc", "_host_grad.so")
-HDRS = [os.path.join(os.path.dirname(HERE), "rotationnormflow_amd", "csrc", f) for f in ("so3_grad.h", "so3_math.h")]
+HDRS = [os.path.join(os.path.dirname(HERE), "rotationnormflow_amd", "csrc", f) for f in ("so3_grad.h", "so3_math.h", "fisher_math.h")]
 
 
 @pytest.fixture(scope="module")
@@ -183,3 +183,42 @@ def test_inverse_matrix_gradient(hg):
     got = np.empty(16, np.float32)
     hg.hg_inverse_matrix_grad4(ptr(f32(np.linalg.inv(M))), ptr(f32(G)), ptr(got))
     assert np.abs(got.reshape(4, 4) - Mt.grad.numpy()).max() < 1e-5 * max(1.0, float(Mt.grad.abs().max()))
+
+
+@pytest.mark.parametrize("norm_type", [0, 1])
+def test_fisher_log_const_and_its_derivative(hg, norm_type):
+    """csrc/fisher_math.h against the reference-generated fixture (tests/golden/fisher_grad.npz: the reference's own autograd through
+    torch.svd) and against autograd of the oracle on extra matrices, including a repeated singular value (where torch's svd backward is
+    singular but the derivative of the symmetric function is not: checked against the closed form there)."""
+    d = np.load(os.path.join(HERE, "golden", "fisher_grad.npz"))
+    A = np.ascontiguousarray(d["A"], np.float64)
+    B = A.shape[0]
+    Q = float((A ** 2).sum())
+    c, dc = np.zeros(B), np.zeros((B, 3, 3))
+    U, S, V = np.zeros((B, 3, 3)), np.zeros((B, 3)), np.zeros((B, 3, 3))
+    hg.hg_fisher_const(ptr(A), B, norm_type, C.c_double(Q), ptr(c), ptr(dc), ptr(U), ptr(S), ptr(V))
+    # proper SVD: rotations, reconstruction, ordering
+    assert np.allclose(np.linalg.det(U), 1.0, atol=1e-12) and np.allclose(np.linalg.det(V), 1.0, atol=1e-12)
+    assert np.abs(np.einsum("bik,bk,bjk->bij", U, S, V) - A).max() < 1e-12
+    assert (S[:, 0] >= S[:, 1]).all() and (S[:, 1] >= np.abs(S[:, 2])).all() and (np.sign(S[:, 2]) == np.sign(np.linalg.det(A))).all()
+    # log-density and the full gradient (sum over samples + coupling through Q) as the kernels assemble them
+    R = d["R"].reshape(B, -1, 3, 3)
+    g = d["g"].reshape(B, -1)
+    logp = (R * A[:, None]).sum((-1, -2)) - c[:, None]
+    assert np.abs(logp.reshape(-1) - d[f"logp_t{norm_type}_64"]).max() < 1e-12
+    G = g.sum(1)
+    gA = np.einsum("bm,bmij->bij", g, R) - G[:, None, None] * dc
+    if norm_type == 0:
+        D = 1.0 + Q / 6.0 + np.linalg.det(A) / 6.0
+        gA -= (G / D).sum() * A / 3.0
+    assert np.abs(gA - d[f"gA_t{norm_type}_64"]).max() < 1e-11
+    if norm_type == 1:                                      # repeated singular values: A = s I and A = diag(2, 2, 1)
+        A2 = np.ascontiguousarray(np.stack([1.5 * np.eye(3), np.diag([2.0, 2.0, 1.0])]), np.float64)
+        c2, dc2 = np.zeros(2), np.zeros((2, 3, 3))
+        hg.hg_fisher_const(ptr(A2), 2, 1, C.c_double(0.0), ptr(c2), ptr(dc2), ptr(np.zeros((2, 3, 3))), ptr(np.zeros((2, 3))), ptr(np.zeros((2, 3, 3))))
+        for b, s in enumerate(([1.5, 1.5, 1.5], [2.0, 2.0, 1.0])):
+            s = np.array(s)
+            f = np.array([1 - 0.5 * (1 / (s[0] + s[1]) + 1 / (s[0] + s[2])), 1 - 0.5 * (1 / (s[0] + s[1]) + 1 / (s[1] + s[2])),
+                          1 - 0.5 * (1 / (s[1] + s[2]) + 1 / (s[0] + s[2]))])
+            assert np.abs(dc2[b] - np.diag(f)).max() < 1e-12
+            assert abs(c2[b] - (s.sum() - 0.5 * np.log(8 * np.pi * (s[0] + s[1]) * (s[1] + s[2]) * (s[0] + s[2])))) < 1e-12

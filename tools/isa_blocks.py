@@ -19,6 +19,8 @@ def main():
     for i in range(start + 1, len(lines)):
         l = lines[i]
         s = l.strip()
+        if s.startswith(".Lfunc_end") or s.startswith(".section"):      # end of the function (early s_endpgm exits are not)
+            break
         if s.startswith(".LBB") or re.match(r"^; %bb\.\d+", s):
             blocks.append(cur)
             cur = dict(name=s.split()[0] if s.startswith(".LBB") else s.split()[1], line=i, valu=0, trans=0, mfma=0, ds=0, vmem=0, salu=0, mov=0, cnd=0, bar=0, perm=0)
@@ -46,8 +48,6 @@ def main():
             cur["bar"] += 1
         elif op.startswith("s_"):
             cur["salu"] += 1
-        if op == "s_endpgm":
-            break
     blocks.append(cur)
     tot = {k: sum(b[k] for b in blocks) for k in ("valu", "trans", "mfma", "ds", "vmem", "salu", "mov", "cnd")}
     print("total", tot)

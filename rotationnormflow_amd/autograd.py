@@ -51,8 +51,8 @@ class TrainPlan:
             self.train_desc[i] = (flagged, perm_rows[i], plain_off)
             if kind == runtime.KIND_MOBIUS:
                 size = L.rnf_mobius_packed_floats(self.segments)
-            elif kind == runtime.KIND_COND16:
-                size = L.rnf_cond16_packed_floats()
+            elif kind == runtime.KIND_COND16 or kind in runtime.COND9_KINDS:
+                size = L.rnf_cond16_packed_floats()                # Condition9*: the same record with a 9-row fc_last
             elif kind == runtime.KIND_GS9:
                 size = L.rnf_gs_packed_floats(3)
             else:

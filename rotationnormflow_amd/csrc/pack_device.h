@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
         return;
     }
     const bool mob = kind == RNF_KIND_MOBIUS;
-    const int yo = mob ? 3 : 0, ni = yo + F, NO = mob ? 4 * K : 16;
+    const int yo = mob ? 3 : 0, ni = yo + F, NO = mob ? 4 * K : (kind_is_cond9(kind) ? 9 : 16);
     const float *W0 = P, *b0 = W0 + 64 * ni;
     const float *hw[3], *hb[3];
     hw[0] = b0 + 64; hb[0] = hw[0] + 4096;
@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
     auto src_row = [&](int tau, int row) {
         const int g = row >> 3, h = (row >> 2) & 1, c = row & 3;
         if (mob) { const int k = 8 * tau + 2 * g + h; return k >= K ? -1 : (c == 0 ? k : K + 3 * k + (c - 1)); }
-        return row >= 16 ? -1 : 4 * (2 * g + h) + c;
+        const int o = 4 * (2 * g + h) + c;                                // Condition9*: output i sits where output i of the 4x4 sits
+        return (row >= 16 || o >= NO) ? -1 : o;
     };
     for (int idx = tid; idx < rec_floats; idx += nth) {
         float v;

@@ -7,6 +7,7 @@
 // Checked on the CPU against torch autograd of the oracle (tests/test_host_grad.py).
 #pragma once
 #include "so3_math.h"
+#include "layout.h"
 
 namespace rnf {
 
@@ -468,6 +469,92 @@ RNF_HD void gs9_backward(const float (&M)[9], const Rot &R, const Rot &gRout, fl
     }
     auto mt = [&](v3f g) { return v3f{M[0] * g.x + M[3] * g.y + M[6] * g.z, M[1] * g.x + M[4] * g.y + M[7] * g.z, M[2] * g.x + M[5] * g.y + M[8] * g.z}; };
     gRin.c0 = mt(g_x0); gRin.c1 = mt(g_x1); gRin.c2 = mt(g_x2);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Conditional 3x3 rotation layers (flow/rottrans.py:68-91,108-181): per-sample M = I + reshape(net(feature), 3, 3).
+//   Condition9RotL:      R' = Q R      Condition9RotR: R' = R Q,      Q = U V^T of svd(M R) R^T = the orthogonal polar factor of M
+//                        (R is orthogonal), inverse pass: M^T, i.e. Q^T;  ldj = 0
+//   Condition9RotRSmith: R' = R N,     N = Gram-Schmidt of the COLUMNS of M, inverse pass: R N^T;  ldj = 0
+// The reference differentiates torch.svd; here the polar factor is differentiated directly: M = Q S (S symmetric positive definite),
+// dQ = Q Omega with Omega skew and Omega S + S Omega = Q^T dM - dM^T Q, hence for G = Q^T (dL/dQ):
+//     dL/dM = Q hat(z),   (tr(S) I - S) z = vee(G - G^T)          (hat(z) S + S hat(z) = hat((tr(S) I - S) z) for symmetric S)
+// Q given by its rows (polar3 of so3_math.h), gQ row-major.
+// ---------------------------------------------------------------------------------------------------------------------
+RNF_HD void polar3_backward(const float (&M)[9], v3f p0, v3f p1, v3f p2, const float (&gQ)[9], float (&gM)[9]) {
+    const float Q[9] = {p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, p2.x, p2.y, p2.z};
+    float S[9], G[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            S[3 * i + j] = Q[i] * M[j] + Q[3 + i] * M[3 + j] + Q[6 + i] * M[6 + j];            // Q^T M
+            G[3 * i + j] = Q[i] * gQ[j] + Q[3 + i] * gQ[3 + j] + Q[6 + i] * gQ[6 + j];          // Q^T gQ
+        }
+    const float tr = S[0] + S[4] + S[8];
+    // symmetrise S (it is symmetric up to rounding) and build T = tr(S) I - S
+    const float s01 = 0.5f * (S[1] + S[3]), s02 = 0.5f * (S[2] + S[6]), s12 = 0.5f * (S[5] + S[7]);
+    const float T[9] = {tr - S[0], -s01, -s02, -s01, tr - S[4], -s12, -s02, -s12, tr - S[8]};
+    float Ti[9];
+    inv3(T, Ti);
+    const v3f w = v3f{G[7] - G[5], G[2] - G[6], G[3] - G[1]};                                 // vee(G - G^T)
+    const v3f z = v3f{Ti[0] * w.x + Ti[1] * w.y + Ti[2] * w.z, Ti[3] * w.x + Ti[4] * w.y + Ti[5] * w.z, Ti[6] * w.x + Ti[7] * w.y + Ti[8] * w.z};
+    const float Z[9] = {0.f, -z.z, z.y, z.z, 0.f, -z.x, -z.y, z.x, 0.f};                       // hat(z)
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) gM[3 * i + j] = Q[3 * i] * Z[j] + Q[3 * i + 1] * Z[3 + j] + Q[3 * i + 2] * Z[6 + j];
+}
+
+// One conditional 3x3 layer: forward from the saved input (so that the caller need not keep the output) and the reverse step.
+// kind: RNF_KIND_COND9_*; inverse: the layer ran inside Flow.inverse.  gM is dL/d(net output) (the identity is a constant).
+RNF_HD void cond9_backward(int kind, bool inverse, const float (&M)[9], const Rot &Rin, const Rot &gRout, float g_ldj, float (&gM)[9], Rot &gRin) {
+    for (int i = 0; i < 9; ++i) gM[i] = 0.f;
+    if (kind == RNF_KIND_COND9_GS) {                       // Condition9Trans (squeezetrans.py:234-247): inverse pass applies M^-1
+        if (inverse) {
+            float Mi[9], gMi[9];
+            inv3(M, Mi);
+            for (int i = 0; i < 9; ++i) gMi[i] = 0.f;
+            gs9_backward(Mi, Rin, gRout, g_ldj, gMi, gRin);
+            inverse_matrix_grad<3>(Mi, gMi, gM);
+        } else {
+            gs9_backward(M, Rin, gRout, g_ldj, gM, gRin);
+        }
+        return;
+    }
+    const v3f rc[3] = {Rin.c0, Rin.c1, Rin.c2}, gc[3] = {gRout.c0, gRout.c1, gRout.c2};
+    auto rin = [&](int i, int j) { const v3f c = rc[j]; return i == 0 ? c.x : (i == 1 ? c.y : c.z); };      // R[i][j]
+    auto gout = [&](int i, int j) { const v3f c = gc[j]; return i == 0 ? c.x : (i == 1 ? c.y : c.z); };
+    float N[9], gN[9], gRi[9];                              // the rotation that multiplies R, and its gradient
+    const bool left = kind == RNF_KIND_COND9_POLAR_L;
+    v3f p0, p1, p2;
+    if (kind == RNF_KIND_COND9_SMITH) {
+        v3f q0, q1, q2;
+        smith3(M, q0, q1, q2);
+        const float Nf[9] = {q0.x, q1.x, q2.x, q0.y, q1.y, q2.y, q0.z, q1.z, q2.z};
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) N[3 * i + j] = inverse ? Nf[3 * j + i] : Nf[3 * i + j];
+    } else {
+        polar3(M, p0, p1, p2);
+        const float Qf[9] = {p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, p2.x, p2.y, p2.z};
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) N[3 * i + j] = inverse ? Qf[3 * j + i] : Qf[3 * i + j];
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float a = 0.f, b = 0.f;
+            for (int l = 0; l < 3; ++l) {
+                if (left) { a += gout(i, l) * rin(j, l); b += N[3 * l + i] * gout(l, j); }       // R' = N R: gN = gR' R^T, gR = N^T gR'
+                else      { a += rin(l, i) * gout(l, j); b += gout(i, l) * N[3 * j + l]; }       // R' = R N: gN = R^T gR', gR = gR' N^T
+            }
+            gN[3 * i + j] = a;
+            gRi[3 * i + j] = b;
+        }
+    gRin.c0 = v3f{gRi[0], gRi[3], gRi[6]}; gRin.c1 = v3f{gRi[1], gRi[4], gRi[7]}; gRin.c2 = v3f{gRi[2], gRi[5], gRi[8]};
+    float gF[9];                                            // gradient w.r.t. the un-transposed factor
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) gF[3 * i + j] = inverse ? gN[3 * j + i] : gN[3 * i + j];
+    if (kind == RNF_KIND_COND9_SMITH) {                     // N = Gram-Schmidt of M's columns = the rotation gs9 makes of M I
+        Rot I, gq, dump;
+        I.c0 = v3f{1.f, 0.f, 0.f}; I.c1 = v3f{0.f, 1.f, 0.f}; I.c2 = v3f{0.f, 0.f, 1.f};
+        gq.c0 = v3f{gF[0], gF[3], gF[6]}; gq.c1 = v3f{gF[1], gF[4], gF[7]}; gq.c2 = v3f{gF[2], gF[5], gF[8]};
+        gs9_backward(M, I, gq, 0.f, gM, dump);
+    } else {
+        polar3_backward(M, p0, p1, p2, gF, gM);
+    }
 }
 
 }  // namespace rnf

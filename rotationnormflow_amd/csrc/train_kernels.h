@@ -367,7 +367,7 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
             }
             // ---- layers with a conditioner MLP (Moebius: input y (+) feature, 4K outputs; Condition16Trans: feature, 16 outputs) ----
             const bool mob = kind == RNF_KIND_MOBIUS;
-            const int yo = mob ? 3 : 0, NI = yo + F, NO = mob ? 4 * K : 16;
+            const int yo = mob ? 3 : 0, NI = yo + F, NO = mob ? 4 * K : (kind_is_cond9(kind) ? 9 : 16);
             const float *W0 = P, *b0 = W0 + 64 * NI, *W1 = b0 + 64, *b1 = W1 + 4096, *W3 = b1 + 64, *b3 = W3 + 4096, *W5 = b3 + 64,
                         *b5 = W5 + 4096, *WL = b5 + 64, *bL = WL + (size_t)NO * 64;
             float *gW0 = Gp, *gb0 = gW0 + 64 * NI, *gW1 = gb0 + 64, *gb1 = gW1 + 4096, *gW3 = gb1 + 64, *gb3 = gW3 + 4096, *gW5 = gb3 + 64,
@@ -550,6 +550,18 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                     mg.g_v = mg.g_v + v3f{red2[(w * 6 + 3) * 64 + lane], red2[(w * 6 + 4) * 64 + lane], red2[(w * 6 + 5) * 64 + lane]};
                 }
                 mobius_backward_tail(sv, mg, gRin);
+            } else if (kind_is_cond9(kind)) {
+                // Condition9Trans / 9RotL / 9RotR / 9RotRSmith (squeezetrans.py:234-247, rottrans.py:108-181): M = I + reshape(net(f), 3, 3)
+                float M[9], gM[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) M[i] = Cm.at(i, lane) + ((i % 4) == 0 ? 1.f : 0.f);
+                cond9_backward(kind, args.dir != 0, M, Rin, gR, g_ldj, gM, gRin);
+                lds_barrier();                          // every wave has read C
+                if (wave == 0) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) Cm.at(i, lane) = gM[i];
+                }
+                lds_barrier();
             } else {
                 // Condition16Trans (flow/squeezetrans.py:41-50): M = I + reshape(net(f), 4, 4), ldj = log|det M| - 2 log|M q|^2
                 float M[16], Mi[16], gM[16];

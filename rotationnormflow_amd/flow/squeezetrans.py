@@ -217,6 +217,15 @@ class _Conditional9(nn.Module, _SingleLayer):
         rec, frec = runtime.pack_cond16(L, self.net, self.feature_dim, prec, n_out=self._rnf_outputs)
         return rec, frec, self.feature_dim, 0
 
+    def _rnf_shape(self):
+        return (self._rnf_kind, 0, self.feature_dim)
+
+    def _rnf_train_tensors(self):
+        if self._rnf_outputs != 9:
+            raise NotImplementedError(f"{type(self).__name__} has no backward kernel yet (training path)")
+        from ..autograd import mlp_train_tensors
+        return mlp_train_tensors(self.net)
+
     def forward(self, rotation, permute=None, feature=None):
         return self._single(rotation, permute, feature, inverse=False)
 

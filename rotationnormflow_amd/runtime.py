@@ -14,6 +14,7 @@ from . import _lib
 
 KIND_MOBIUS, KIND_AFFINE16, KIND_COND16, KIND_GS9, KIND_GS36 = 1, 2, 3, 4, 5
 KIND_COND9_GS, KIND_COND9_SMITH, KIND_COND9_POLAR_L, KIND_COND9_POLAR_R, KIND_COND36 = 6, 7, 8, 9, 10
+COND9_KINDS = (KIND_COND9_GS, KIND_COND9_SMITH, KIND_COND9_POLAR_L, KIND_COND9_POLAR_R)
 # layers whose per-sample matrix is built on the host side with the reference's own batched torch ops and handed to the kernels in a side
 # buffer (include/rnf_hip.h RNF_LAYER_SIDE*): Condition16TransLU, ConditionRot, Condition9TransLU
 KIND_SIDE16, KIND_SIDE16_ROT, KIND_SIDE9 = 11, 12, 13

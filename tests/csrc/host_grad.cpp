@@ -78,4 +78,15 @@ void hg_fisher_const(const double *A, int B, int norm_type, double Q, double *c,
         proper_svd3(A + 9 * b, U + 9 * b, S + 3 * b, V + 9 * b);
     }
 }
+// conditional 3x3 layers (so3_grad.h cond9_backward): per-sample M [n][9]; returns dL/dM and dL/dR_in
+void hg_cond9(int kind, int inverse, const float *M, const float *Rin, const float *gRout, const float *g_ldj, int n, float *gM, float *gRin) {
+    for (int i = 0; i < n; ++i) {
+        float m[9], gm[9];
+        for (int k = 0; k < 9; ++k) m[k] = M[9 * i + k];
+        Rot gi;
+        cond9_backward(kind, inverse != 0, m, load_rot(Rin + 9 * i), load_rot(gRout + 9 * i), g_ldj[i], gm, gi);
+        for (int k = 0; k < 9; ++k) gM[9 * i + k] = gm[k];
+        store_rot(gi, gRin + 9 * i);
+    }
+}
 }

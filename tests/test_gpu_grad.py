@@ -54,6 +54,11 @@ CASES = {
     # Gram-Schmidt 3x3 layers: closed-form log-det, analytic backward
     "gs9": (dict(layers=2, segments=16, rot="9TransLSmith"), 130, "trained"),
     "gs9lu": (dict(layers=2, segments=16, rot="9TransLSmith", lu=1), 90, "default"),
+    # conditional 3x3 layers (per-sample M = I + net(feature)): Gram-Schmidt, polar rotation left / right, Smith rotation
+    "cgs9": (dict(layers=2, segments=16, condition=1, feature_dim=24, rot="9TransLSmith"), 150, "trained"),
+    "csvdl9": (dict(layers=2, segments=16, condition=1, feature_dim=24, rot="9TransLSVD"), 130, "trained"),
+    "csvdr9": (dict(layers=2, segments=16, condition=1, feature_dim=40, rot="9TransRSVD", last_affine=1), 70, "trained"),
+    "csmithr9": (dict(layers=2, segments=16, condition=1, feature_dim=24, rot="9TransRSmith"), 100, "trained"),
 }
 
 
@@ -105,7 +110,7 @@ def test_gradients_match_oracle_autograd(name):
         assert np.abs(gf - want_gf).max() / max(np.abs(want_gf).max(), 1e-3) < REL
 
 
-INVERSE_CASES = ["uncond_k16", "cond_k32", "cond_first_affine", "mobius_only", "lu", "rot", "gs9", "svdl9"]
+INVERSE_CASES = ["uncond_k16", "cond_k32", "cond_first_affine", "mobius_only", "lu", "rot", "gs9", "svdl9", "cgs9", "csvdl9", "csvdr9", "csmithr9"]
 
 
 @pytest.mark.parametrize("name", INVERSE_CASES)
@@ -283,8 +288,12 @@ def test_training_loss_with_matrix_fisher_base():
         gw = want[k].numpy()
         err = np.abs(prm.grad.cpu().numpy() - gw).max() / max(np.abs(gw).max(), 1e-3)
         assert err < REL, (k, err)
-    with pytest.raises(NotImplementedError):
-        MatrixFisherN(torch.from_numpy(A).cuda().requires_grad_(True))._log_prob(Rt.detach())
+    # a parameter matrix that requires grad (a predicted A, agent.py:57-65) gets its gradient, normaliser included
+    A64 = torch.from_numpy(A).double().requires_grad_(True)
+    (-orc.fisher_log_prob(Ro.detach(), A64, dtype=torch.float64)).mean().backward()
+    Ag = torch.from_numpy(A).cuda().requires_grad_(True)
+    (-MatrixFisherN(Ag)._log_prob(Rt.detach())).mean().backward()
+    assert (Ag.grad.cpu().double() - A64.grad).abs().max() < 2e-5 * max(1.0, float(A64.grad.abs().max()))
 
 
 def test_harness_training_learns_and_checkpoints(tmp_path):

@@ -222,3 +222,33 @@ def test_fisher_log_const_and_its_derivative(hg, norm_type):
                           1 - 0.5 * (1 / (s[1] + s[2]) + 1 / (s[0] + s[2]))])
             assert np.abs(dc2[b] - np.diag(f)).max() < 1e-12
             assert abs(c2[b] - (s.sum() - 0.5 * np.log(8 * np.pi * (s[0] + s[1]) * (s[1] + s[2]) * (s[0] + s[2])))) < 1e-12
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("kind,name", [(6, "cgs9"), (7, "csmithr9"), (8, "csvdl9"), (9, "csvdr9")])
+def test_conditional_3x3_layers_backward(hg, kind, name, inverse):
+    """so3_grad.h cond9_backward (polar factor differentiated directly, Gram-Schmidt, M^-1 / M^T / N^T on the inverse pass) against torch
+    autograd of the oracle's layer functions, which differentiate torch.linalg.svd as the reference does (rottrans.py:68-91)."""
+    rng = np.random.RandomState(kind + 10 * inverse)
+    n = 40
+    R = synth.uniform_rotations(n, seed=kind).astype(np.float64)
+    M = np.eye(3)[None] + 0.2 * rng.randn(n, 3, 3)          # I + net output: well conditioned, like the layer in use
+    gR = rng.randn(n, 3, 3)
+    gl = rng.randn(n)
+    Mt = torch.from_numpy(M).requires_grad_(True)
+    Rt = torch.from_numpy(R).requires_grad_(True)
+    if name == "cgs9":
+        Ro, l = orc.gs9(torch.linalg.inv(Mt) if inverse else Mt, Rt)
+    elif name == "csmithr9":
+        Ro, l = orc.smithr9(Mt, Rt, inverse=inverse)
+    elif name == "csvdl9":
+        Ro, l = orc.svdl9(Mt.transpose(-1, -2) if inverse else Mt, Rt)
+    else:
+        Ro, l = orc.svdr9(Mt.transpose(-1, -2) if inverse else Mt, Rt)
+    ((Ro * torch.from_numpy(gR)).sum() + (l * torch.from_numpy(gl)).sum()).backward()
+    gM, gRin = np.zeros((n, 9), np.float32), np.zeros((n, 9), np.float32)
+    hg.hg_cond9(kind, int(inverse), ptr(f32(M)), ptr(f32(R)), ptr(f32(gR)), ptr(f32(gl)), n, ptr(gM), ptr(gRin))
+    want_M = Mt.grad.numpy().reshape(n, 9)
+    assert np.abs(gM - want_M).max() < 2e-4 * max(1.0, np.abs(want_M).max())
+    got_t, want_t = tangent(R, gRin.reshape(n, 3, 3).astype(np.float64)), tangent(R, Rt.grad.numpy())
+    assert np.abs(got_t - want_t).max() < 2e-4 * max(1.0, np.abs(want_t).max())

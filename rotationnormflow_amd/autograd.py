@@ -55,6 +55,10 @@ class TrainPlan:
                 size = L.rnf_cond16_packed_floats()                # Condition9*: the same record with a 9-row fc_last
             elif kind == runtime.KIND_GS9:
                 size = L.rnf_gs_packed_floats(3)
+            elif kind == runtime.KIND_GS36:
+                size = L.rnf_gs_packed_floats(6)
+            elif kind == runtime.KIND_COND36:
+                size = L.rnf_cond36_packed_floats()
             else:
                 size = L.rnf_affine16_packed_floats()
             rec_sizes.append(size)

@@ -157,21 +157,45 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
         out[18] = out[19] = 0.f;
         return;
     }
+    if (kind == RNF_KIND_GS36) {                                       // rnf_pack_gs(n = 6): [M | M^-1], Gauss-Jordan in double
+        if (tid != 0) return;
+        double a[6][12];
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) { a[i][j] = P[6 * i + j]; a[i][6 + j] = (i == j); }
+        bool ok = true;
+        for (int c = 0; c < 6 && ok; ++c) {
+            int pr = c;
+            for (int r = c + 1; r < 6; ++r) if (fabs(a[r][c]) > fabs(a[pr][c])) pr = r;
+            if (a[pr][c] == 0.0) { ok = false; break; }
+            if (pr != c) for (int j = 0; j < 12; ++j) { const double t = a[pr][j]; a[pr][j] = a[c][j]; a[c][j] = t; }
+            const double ip = 1.0 / a[c][c];
+            for (int j = 0; j < 12; ++j) a[c][j] *= ip;
+            for (int r = 0; r < 6; ++r) if (r != c) {
+                const double f = a[r][c];
+                for (int j = 0; j < 12; ++j) a[r][j] -= f * a[c][j];
+            }
+        }
+        if (!ok) atomicOr(args.flags, PK_FLAG_SINGULAR);
+        for (int i = 0; i < (int)GS36_FLOATS; ++i) out[i] = 0.f;
+        for (int i = 0; i < 36; ++i) { out[i] = P[i]; out[36 + i] = ok ? (float)a[i / 6][6 + i % 6] : __builtin_nanf(""); }
+        return;
+    }
     const bool mob = kind == RNF_KIND_MOBIUS;
-    const int yo = mob ? 3 : 0, ni = yo + F, NO = mob ? 4 * K : (kind_is_cond9(kind) ? 9 : 16);
+    const int yo = mob ? 3 : 0, ni = yo + F, NO = mob ? 4 * K : (kind_is_cond9(kind) ? 9 : (kind == RNF_KIND_COND36 ? 36 : 16));
     const float *W0 = P, *b0 = W0 + 64 * ni;
     const float *hw[3], *hb[3];
     hw[0] = b0 + 64; hb[0] = hw[0] + 4096;
     hw[1] = hb[0] + 64; hb[1] = hw[1] + 4096;
     hw[2] = hb[1] + 64; hb[2] = hw[2] + 4096;
     const float *WL = hb[2] + 64, *bL = WL + (size_t)NO * 64;
-    const int n_tiles = mob ? (K + 7) / 8 : 1;
+    const int n_tiles = mob ? (K + 7) / 8 : (kind == RNF_KIND_COND36 ? 2 : 1);
     const int rec_floats = MOB_HEAD_FLOATS + n_tiles * MOB_LAST_TILE_FLOATS;
     // reference row of packed fc_last row `row` of tile tau (layout.h): Moebius: segment k = 8 tau + 2g + h, component c;
     // Condition16Trans: M[2g + h][c], rows >= 16 are zero padding
     auto src_row = [&](int tau, int row) {
         const int g = row >> 3, h = (row >> 2) & 1, c = row & 3;
         if (mob) { const int k = 8 * tau + 2 * g + h; return k >= K ? -1 : (c == 0 ? k : K + 3 * k + (c - 1)); }
+        if (kind == RNF_KIND_COND36) return tau == 0 ? row : (row < 4 ? 32 + row : -1);   // packed row P of tile 0 = output P, tile 1: 32..35
         const int o = 4 * (2 * g + h) + c;                                // Condition9*: output i sits where output i of the 4x4 sits
         return (row >= 16 || o >= NO) ? -1 : o;
     };

@@ -915,10 +915,10 @@ extern "C" int rnf_pack_flow_device(const float *plain, const int32_t *pdesc, in
         const int32_t *d = pdesc + (size_t)l * 4;
         const int kind = d[0] & 15;
         if ((d[0] & ~(15 | 256)) || (kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16 && kind != RNF_KIND_COND16 && kind != RNF_KIND_GS9 &&
-                                     !kind_is_cond9(kind)))
+                                     kind != RNF_KIND_GS36 && kind != RNF_KIND_COND36 && !kind_is_cond9(kind)))
             return fail("layer %d: unknown kind %d", l, d[0]);
         if (d[1] < 0 || d[2] < 0 || d[2] % 4 || (d[3] >= 0 && d[3] % 4)) return fail("layer %d: bad offsets", l);
-        if ((kind == RNF_KIND_COND16 || kind_is_cond9(kind)) && F == 0) return fail("layer %d: a conditional affine layer needs a feature", l);
+        if ((kind == RNF_KIND_COND16 || kind == RNF_KIND_COND36 || kind_is_cond9(kind)) && F == 0) return fail("layer %d: a conditional affine layer needs a feature", l);
         if (kind_has_mlp(kind) && (F > 0) != (d[3] >= 0)) return fail("layer %d: feature record offset does not match feature_dim", l);
         a.layers[l] = PackLayer{d[0], d[1], d[2], d[3]};
     }
@@ -930,8 +930,9 @@ extern "C" int rnf_pack_flow_device(const float *plain, const int32_t *pdesc, in
 extern "C" size_t rnf_plain_layer_floats(int32_t kind, int32_t segments, int32_t feature_dim) {
     if (kind == RNF_KIND_AFFINE16) return 16;
     if (kind == RNF_KIND_GS9) return 12;
+    if (kind == RNF_KIND_GS36) return 36;
     const size_t ni = (kind == RNF_KIND_MOBIUS ? 3 : 0) + (size_t)feature_dim,
-                 no = kind == RNF_KIND_MOBIUS ? 4 * (size_t)segments : (kind_is_cond9(kind) ? 9 : 16);
+                 no = kind == RNF_KIND_MOBIUS ? 4 * (size_t)segments : (kind_is_cond9(kind) ? 9 : (kind == RNF_KIND_COND36 ? 36 : 16));
     return 64 * ni + 64 + 3 * (4096 + 64) + no * 64 + no;
 }
 
@@ -968,11 +969,11 @@ static int run_backward(const float *states, const float *rot_final, int dir, co
         const int32_t *d = tdesc + (size_t)l * 3;
         const int kind = d[0] & 15, orth = (d[0] >> 8) & 1;
         if ((d[0] & ~(15 | 256)) || (kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16 && kind != RNF_KIND_COND16 && kind != RNF_KIND_GS9 &&
-                                     !kind_is_cond9(kind)))
+                                     kind != RNF_KIND_GS36 && kind != RNF_KIND_COND36 && !kind_is_cond9(kind)))
             return fail("layer %d: kind %d has no backward kernel", l, d[0]);
         if (d[1] < 0 || d[1] > 5) return fail("layer %d: perm_row %d outside [0,5]", l, d[1]);
         if (kind_has_mlp(kind) && F > 0 && !feat) return fail("conditional layer %d but feature pointer is null", l);
-        if ((kind == RNF_KIND_COND16 || kind_is_cond9(kind)) && F == 0) return fail("layer %d: a conditional affine layer needs a feature", l);
+        if ((kind == RNF_KIND_COND16 || kind == RNF_KIND_COND36 || kind_is_cond9(kind)) && F == 0) return fail("layer %d: a conditional affine layer needs a feature", l);
         if (d[2] < 0) return fail("layer %d: negative plain offset", l);
         a.layers[l] = make_int2(kind | (d[1] << 4) | (orth << 8), d[2]);
     }

@@ -472,6 +472,90 @@ RNF_HD void gs9_backward(const float (&M)[9], const Rot &R, const Rot &gRout, fl
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// calculate_36 (flow/squeezetrans.py:293-331) backward.  Forward: (a0; a1) = M (r0; r1) with M [6][6] in 3x3 blocks M_bc, Gram-Schmidt
+// t0 = a0/|a0|, b1 = a1 - (t0.a1) t0, t1 = b1/|b1|, t2 = t0 x t1, R' = [t0 t1 t2].  The reference's log-determinant of the three tangent
+// images (directions G_k R pushed through normalise / project / normalise / cross) has the closed form
+//     ldj = log|u . (p x q)| - 2 log|a0| - log|b1|,
+//     p = r0 x (M00^T t2) + r1 x (M01^T t2),   q = r0 x (M00^T t1) + r1 x (M01^T t1),   u = r0 x (M10^T t2) + r1 x (M11^T t2)
+// (rows t2^T B0, t1^T B0, t2^T B1 of the angular-velocity Jacobian, B_b = -(M_b0 hat(r0) + M_b1 hat(r1)); equal to the forward-mode
+// restatement oracle.gs36 to 4e-15 in fp64, tests/test_host_grad.py).  This function differentiates that closed form by hand.
+// gM (36, accumulated into) and dL/dR (the third column of R does not enter calculate_36: its gradient is 0).
+// ---------------------------------------------------------------------------------------------------------------------
+RNF_HD v3f blk_mv(const float *M, int bi, int bj, v3f v) {           // M_{bi,bj} v
+    const float *m = M + 18 * bi + 3 * bj;
+    return v3f{m[0] * v.x + m[1] * v.y + m[2] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z, m[12] * v.x + m[13] * v.y + m[14] * v.z};
+}
+RNF_HD v3f blk_mtv(const float *M, int bi, int bj, v3f v) {          // M_{bi,bj}^T v
+    const float *m = M + 18 * bi + 3 * bj;
+    return v3f{m[0] * v.x + m[6] * v.y + m[12] * v.z, m[1] * v.x + m[7] * v.y + m[13] * v.z, m[2] * v.x + m[8] * v.y + m[14] * v.z};
+}
+RNF_HD void blk_outer_add(float *gM, int bi, int bj, v3f a, v3f b) {   // gM_{bi,bj} += a b^T
+    float *g = gM + 18 * bi + 3 * bj;
+    g[0] += a.x * b.x; g[1] += a.x * b.y; g[2] += a.x * b.z;
+    g[6] += a.y * b.x; g[7] += a.y * b.y; g[8] += a.y * b.z;
+    g[12] += a.z * b.x; g[13] += a.z * b.y; g[14] += a.z * b.z;
+}
+// closed-form forward (used by the host mirror test; the kernels' forward is so3_math.h gs36_apply)
+RNF_HD void gs36_closed_form(const float *M, const Rot &R, Rot &Rout, float &ldj) {
+    const v3f r0 = R.c0, r1 = R.c1;
+    const v3f a0 = blk_mv(M, 0, 0, r0) + blk_mv(M, 0, 1, r1), a1 = blk_mv(M, 1, 0, r0) + blk_mv(M, 1, 1, r1);
+    const float in0 = 1.0f / sqrtf(dot3(a0, a0));
+    const v3f t0 = a0 * in0;
+    const v3f b1 = a1 - t0 * dot3(t0, a1);
+    const float in1 = 1.0f / sqrtf(dot3(b1, b1));
+    const v3f t1 = b1 * in1, t2 = cross3(t0, t1);
+    const v3f p = cross3(r0, blk_mtv(M, 0, 0, t2)) + cross3(r1, blk_mtv(M, 0, 1, t2));
+    const v3f q = cross3(r0, blk_mtv(M, 0, 0, t1)) + cross3(r1, blk_mtv(M, 0, 1, t1));
+    const v3f u = cross3(r0, blk_mtv(M, 1, 0, t2)) + cross3(r1, blk_mtv(M, 1, 1, t2));
+    Rout.c0 = t0; Rout.c1 = t1; Rout.c2 = t2;
+    ldj = logf(fabsf(dot3(u, cross3(p, q)))) + 2.0f * logf(in0) + logf(in1);
+}
+RNF_HD void gs36_backward(const float *M, const Rot &R, const Rot &gRout, float g_ldj, float *gM, Rot &gRin) {
+    const v3f r0 = R.c0, r1 = R.c1;
+    const v3f a0 = blk_mv(M, 0, 0, r0) + blk_mv(M, 0, 1, r1), a1 = blk_mv(M, 1, 0, r0) + blk_mv(M, 1, 1, r1);
+    const float in0 = 1.0f / sqrtf(dot3(a0, a0));
+    const v3f t0 = a0 * in0;
+    const float d = dot3(t0, a1);
+    const v3f b1 = a1 - t0 * d;
+    const float in1 = 1.0f / sqrtf(dot3(b1, b1));
+    const v3f t1 = b1 * in1, t2 = cross3(t0, t1);
+    const v3f c00 = blk_mtv(M, 0, 0, t2), c01 = blk_mtv(M, 0, 1, t2), e00 = blk_mtv(M, 0, 0, t1), e01 = blk_mtv(M, 0, 1, t1),
+              f10 = blk_mtv(M, 1, 0, t2), f11 = blk_mtv(M, 1, 1, t2);
+    const v3f p = cross3(r0, c00) + cross3(r1, c01), q = cross3(r0, e00) + cross3(r1, e01), u = cross3(r0, f10) + cross3(r1, f11);
+    const v3f pq = cross3(p, q);
+    const float gD = g_ldj / dot3(u, pq);
+    const v3f g_u = pq * gD, g_p = cross3(q, u) * gD, g_q = cross3(u, p) * gD;
+    // x = r x c:  g_r += c x g_x,  g_c = g_x x r
+    v3f g_r0 = cross3(c00, g_p) + cross3(e00, g_q) + cross3(f10, g_u);
+    v3f g_r1 = cross3(c01, g_p) + cross3(e01, g_q) + cross3(f11, g_u);
+    const v3f g_c00 = cross3(g_p, r0), g_c01 = cross3(g_p, r1), g_e00 = cross3(g_q, r0), g_e01 = cross3(g_q, r1),
+              g_f10 = cross3(g_u, r0), g_f11 = cross3(g_u, r1);
+    // c = M_b^T t:  gM_b += t g_c^T,  g_t += M_b g_c
+    blk_outer_add(gM, 0, 0, t2, g_c00); blk_outer_add(gM, 0, 1, t2, g_c01);
+    blk_outer_add(gM, 0, 0, t1, g_e00); blk_outer_add(gM, 0, 1, t1, g_e01);
+    blk_outer_add(gM, 1, 0, t2, g_f10); blk_outer_add(gM, 1, 1, t2, g_f11);
+    v3f g_t2 = gRout.c2 + blk_mv(M, 0, 0, g_c00) + blk_mv(M, 0, 1, g_c01) + blk_mv(M, 1, 0, g_f10) + blk_mv(M, 1, 1, g_f11);
+    v3f g_t1 = gRout.c1 + blk_mv(M, 0, 0, g_e00) + blk_mv(M, 0, 1, g_e01);
+    v3f g_t0 = gRout.c0;
+    // t2 = t0 x t1
+    g_t0 = g_t0 + cross3(t1, g_t2);
+    g_t1 = g_t1 + cross3(g_t2, t0);
+    // t1 = b1 / |b1|;  - log|b1|
+    const v3f g_b1 = normalize_bwd(t1, in1, g_t1) - t1 * (g_ldj * in1);
+    // b1 = a1 - d t0, d = t0 . a1
+    const float g_d = -dot3(g_b1, t0);
+    g_t0 = g_t0 - g_b1 * d + a1 * g_d;
+    const v3f g_a1 = g_b1 + t0 * g_d;
+    // t0 = a0 / |a0|;  - 2 log|a0|
+    const v3f g_a0 = normalize_bwd(t0, in0, g_t0) - t0 * (2.0f * g_ldj * in0);
+    blk_outer_add(gM, 0, 0, g_a0, r0); blk_outer_add(gM, 0, 1, g_a0, r1);
+    blk_outer_add(gM, 1, 0, g_a1, r0); blk_outer_add(gM, 1, 1, g_a1, r1);
+    g_r0 = g_r0 + blk_mtv(M, 0, 0, g_a0) + blk_mtv(M, 1, 0, g_a1);
+    g_r1 = g_r1 + blk_mtv(M, 0, 1, g_a0) + blk_mtv(M, 1, 1, g_a1);
+    gRin.c0 = g_r0; gRin.c1 = g_r1; gRin.c2 = v3f{0.f, 0.f, 0.f};
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Conditional 3x3 rotation layers (flow/rottrans.py:68-91,108-181): per-sample M = I + reshape(net(feature), 3, 3).
 //   Condition9RotL:      R' = Q R      Condition9RotR: R' = R Q,      Q = U V^T of svd(M R) R^T = the orthogonal polar factor of M
 //                        (R is orthogonal), inverse pass: M^T, i.e. Q^T;  ldj = 0

@@ -365,9 +365,45 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                 RNF_TSTAMP(8)
                 continue;
             }
+            if (kind == RNF_KIND_GS36) {                  // Uncondition36Trans: M [36] in the plain blob (squeezetrans.py:350-361)
+                float M[36], gM[36];
+#pragma unroll
+                for (int i = 0; i < 36; ++i) { M[i] = P[i]; gM[i] = 0.f; }
+                Rot gRin;
+                if (args.dir) {                           // the inverse pass applies M^-1 (squeezetrans.py:359-361)
+                    float Mc[36], Mi[36], gMi[36];
+#pragma unroll
+                    for (int i = 0; i < 36; ++i) { Mc[i] = M[i]; gMi[i] = 0.f; }
+                    inv6(Mc, Mi);
+                    gs36_backward(Mi, Rin, gR, g_ldj, gMi, gRin);
+                    inverse_matrix_grad<6>(Mi, gMi, gM);
+                } else {
+                    gs36_backward(M, Rin, gR, g_ldj, gM, gRin);
+                }
+                if (want_w) {                             // batch sums through LDS, 16 entries per round (wave 0), three rounds
+#pragma unroll
+                    for (int base = 0; base < 48; base += 16) {
+                        lds_barrier();
+                        if (wave == 0) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) GA.at(i, lane) = (valid && base + i < 36) ? gM[base + i < 36 ? base + i : 35] : 0.f;
+                            const int v = lane >> 2, q = lane & 3;
+                            float tot = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) tot += GA.at(v, 16 * q + i);
+                            tot = quad_sum(tot);
+                            if (q == 0 && base + v < 36) atomicAdd(Gp + base + v, tot);
+                        }
+                    }
+                    lds_barrier();
+                }
+                gR = gRin;
+                RNF_TSTAMP(8)
+                continue;
+            }
             // ---- layers with a conditioner MLP (Moebius: input y (+) feature, 4K outputs; Condition16Trans: feature, 16 outputs) ----
             const bool mob = kind == RNF_KIND_MOBIUS;
-            const int yo = mob ? 3 : 0, NI = yo + F, NO = mob ? 4 * K : (kind_is_cond9(kind) ? 9 : 16);
+            const int yo = mob ? 3 : 0, NI = yo + F, NO = mob ? 4 * K : (kind_is_cond9(kind) ? 9 : (kind == RNF_KIND_COND36 ? 36 : 16));
             const float *W0 = P, *b0 = W0 + 64 * NI, *W1 = b0 + 64, *b1 = W1 + 4096, *W3 = b1 + 64, *b3 = W3 + 4096, *W5 = b3 + 64,
                         *b5 = W5 + 4096, *WL = b5 + 64, *bL = WL + (size_t)NO * 64;
             float *gW0 = Gp, *gb0 = gW0 + 64 * NI, *gW1 = gb0 + 64, *gb1 = gW1 + 4096, *gW3 = gb1 + 64, *gb3 = gW3 + 4096, *gW5 = gb3 + 64,
@@ -550,6 +586,27 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                     mg.g_v = mg.g_v + v3f{red2[(w * 6 + 3) * 64 + lane], red2[(w * 6 + 4) * 64 + lane], red2[(w * 6 + 5) * 64 + lane]};
                 }
                 mobius_backward_tail(sv, mg, gRin);
+            } else if (kind == RNF_KIND_COND36) {
+                // Condition36Trans (squeezetrans.py:334-347): M = I + reshape(net(f), 6, 6) per sample; the inverse pass applies M^-1
+                float M[36], gM[36];
+#pragma unroll
+                for (int i = 0; i < 36; ++i) { M[i] = Cm.at(i, lane) + ((i % 7) == 0 ? 1.f : 0.f); gM[i] = 0.f; }
+                if (args.dir) {
+                    float Mc[36], Mi[36], gMi[36];
+#pragma unroll
+                    for (int i = 0; i < 36; ++i) { Mc[i] = M[i]; gMi[i] = 0.f; }
+                    inv6(Mc, Mi);
+                    gs36_backward(Mi, Rin, gR, g_ldj, gMi, gRin);
+                    inverse_matrix_grad<6>(Mi, gMi, gM);
+                } else {
+                    gs36_backward(M, Rin, gR, g_ldj, gM, gRin);
+                }
+                lds_barrier();                          // every wave has read C
+                if (wave == 0) {
+#pragma unroll
+                    for (int i = 0; i < 36; ++i) Cm.at(i, lane) = gM[i];
+                }
+                lds_barrier();
             } else if (kind_is_cond9(kind)) {
                 // Condition9Trans / 9RotL / 9RotR / 9RotRSmith (squeezetrans.py:234-247, rottrans.py:108-181): M = I + reshape(net(f), 3, 3)
                 float M[9], gM[9];

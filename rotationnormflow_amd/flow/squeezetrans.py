@@ -140,10 +140,10 @@ class _GramSchmidtLayer(nn.Module, _SingleLayer):
         return (self._rnf_kind, 0, 0)
 
     def _train_tensors(self):
-        """3x3 only: the plain blob holds M [9] + 3 floats of padding (the log-det has a closed form, csrc/so3_math.h gs9_apply, whose
-        reverse mode is csrc/so3_grad.h gs9_backward); the 6x6 layer has no backward kernel."""
+        """The plain blob holds M: [9] + 3 floats of padding, or [36].  Both log-dets have closed forms (csrc/so3_math.h gs9_apply,
+        csrc/so3_grad.h gs36_closed_form) whose reverse modes are gs9_backward / gs36_backward."""
         m = self._matrix()
-        return [m.reshape(9), m.new_zeros(3)]
+        return [m.reshape(9), m.new_zeros(3)] if self._rnf_n == 3 else [m.reshape(36)]
 
     def forward(self, rotation, permute=None, feature=None):
         return self._single(rotation, permute, None, inverse=False)
@@ -200,6 +200,9 @@ class Uncondition36Trans(_GramSchmidtLayer):
     def _matrix(self):
         return self.mat
 
+    def _rnf_train_tensors(self):
+        return self._train_tensors()
+
 
 class _Conditional9(nn.Module, _SingleLayer):
     """Shared body of the conditional 3x3 ablation layers: M = I + reshape(MLP(feature), 3, 3) per sample; the per-sample map (Gram-Schmidt
@@ -221,8 +224,6 @@ class _Conditional9(nn.Module, _SingleLayer):
         return (self._rnf_kind, 0, self.feature_dim)
 
     def _rnf_train_tensors(self):
-        if self._rnf_outputs != 9:
-            raise NotImplementedError(f"{type(self).__name__} has no backward kernel yet (training path)")
         from ..autograd import mlp_train_tensors
         return mlp_train_tensors(self.net)
 

@@ -89,4 +89,29 @@ void hg_cond9(int kind, int inverse, const float *M, const float *Rin, const flo
         store_rot(gi, gRin + 9 * i);
     }
 }
+// calculate_36 (so3_grad.h gs36_backward + its closed-form forward): one M [36] for all samples (per_sample = 0) or M [n][36]
+void hg_gs36(const float *M, int per_sample, int inverse, const float *Rin, const float *gRout, const float *g_ldj, int n, float *Rout, float *ldj,
+             float *gM, float *gRin) {
+    for (int i = 0; i < n; ++i) {
+        float m[36], gm[36], mi[36], gmi[36];
+        for (int k = 0; k < 36; ++k) { m[k] = M[(per_sample ? 36 * i : 0) + k]; gm[k] = 0.f; gmi[k] = 0.f; }
+        Rot Ro, gi;
+        float l;
+        if (inverse) {
+            float tmp[36];
+            for (int k = 0; k < 36; ++k) tmp[k] = m[k];
+            inv6(tmp, mi);
+            gs36_closed_form(mi, load_rot(Rin + 9 * i), Ro, l);
+            gs36_backward(mi, load_rot(Rin + 9 * i), load_rot(gRout + 9 * i), g_ldj[i], gmi, gi);
+            inverse_matrix_grad<6>(mi, gmi, gm);
+        } else {
+            gs36_closed_form(m, load_rot(Rin + 9 * i), Ro, l);
+            gs36_backward(m, load_rot(Rin + 9 * i), load_rot(gRout + 9 * i), g_ldj[i], gm, gi);
+        }
+        store_rot(Ro, Rout + 9 * i);
+        ldj[i] = l;
+        for (int k = 0; k < 36; ++k) gM[(per_sample ? 36 * i : 0) + k] += gm[k];
+        store_rot(gi, gRin + 9 * i);
+    }
+}
 }

@@ -59,6 +59,9 @@ CASES = {
     "csvdl9": (dict(layers=2, segments=16, condition=1, feature_dim=24, rot="9TransLSVD"), 130, "trained"),
     "csvdr9": (dict(layers=2, segments=16, condition=1, feature_dim=40, rot="9TransRSVD", last_affine=1), 70, "trained"),
     "csmithr9": (dict(layers=2, segments=16, condition=1, feature_dim=24, rot="9TransRSmith"), 100, "trained"),
+    # 6x6 Gram-Schmidt layers (closed-form log-det of so3_grad.h, hand-written reverse mode): one shared M / per-sample M
+    "gs36": (dict(layers=2, segments=16, rot="36Trans"), 110, "trained"),
+    "cgs36": (dict(layers=2, segments=16, condition=1, feature_dim=24, rot="36Trans", last_affine=1), 90, "trained"),
 }
 
 
@@ -110,7 +113,7 @@ def test_gradients_match_oracle_autograd(name):
         assert np.abs(gf - want_gf).max() / max(np.abs(want_gf).max(), 1e-3) < REL
 
 
-INVERSE_CASES = ["uncond_k16", "cond_k32", "cond_first_affine", "mobius_only", "lu", "rot", "gs9", "svdl9", "cgs9", "csvdl9", "csvdr9", "csmithr9"]
+INVERSE_CASES = ["uncond_k16", "cond_k32", "cond_first_affine", "mobius_only", "lu", "rot", "gs9", "svdl9", "cgs9", "csvdl9", "csvdr9", "csmithr9", "gs36", "cgs36"]
 
 
 @pytest.mark.parametrize("name", INVERSE_CASES)
@@ -343,15 +346,18 @@ def test_gradient_blob_sync_hook_is_applied():
         assert torch.allclose(p.grad, 0.5 * a, rtol=1e-4, atol=1e-7)
 
 
-def test_gram_schmidt_layers_refuse_training():
-    cfg = orc.make_config(layers=2, segments=16, rot="36Trans")
+def test_side_layers_refuse_training():
+    """The batch-coupled / SVD-convention layers (Condition16TransLU, ConditionRot: DESIGN 3.7) are inference only: a gradient-requiring
+    call is loud, not a silent detach."""
+    cfg = orc.make_config(layers=2, segments=16, condition=1, feature_dim=24, lu=1)
     w = synth.fill_state_dict(orc.state_shapes(cfg), seed=3)
     fl = product_flow(cfg, w).train()
     R = torch.from_numpy(synth.uniform_rotations(32, seed=4)).cuda()
+    f = torch.from_numpy(synth.features(32, 24, seed=5)).cuda()
     with pytest.raises(NotImplementedError):
-        fl(R)                                                   # Uncondition36Trans has no backward kernel: loud, no silent detach
+        fl(R, f)
     with torch.no_grad():
-        fl(R)
+        fl(R, f)
 
 
 def test_graphed_train_step_follows_the_oracle():

@@ -252,3 +252,30 @@ def test_conditional_3x3_layers_backward(hg, kind, name, inverse):
     assert np.abs(gM - want_M).max() < 2e-4 * max(1.0, np.abs(want_M).max())
     got_t, want_t = tangent(R, gRin.reshape(n, 3, 3).astype(np.float64)), tangent(R, Rt.grad.numpy())
     assert np.abs(got_t - want_t).max() < 2e-4 * max(1.0, np.abs(want_t).max())
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("per_sample", [0, 1])
+def test_gram_schmidt_6x6_closed_form_and_backward(hg, per_sample, inverse):
+    """calculate_36 (squeezetrans.py:293-331): the closed-form log-det of so3_grad.h equals the oracle's forward-mode restatement, and its
+    hand-written reverse mode equals torch autograd of that restatement -- one shared M (Uncondition36Trans) and per-sample M
+    (Condition36Trans), forward and through M^-1 (the inverse pass)."""
+    rng = np.random.RandomState(11 + per_sample + 2 * inverse)
+    n = 48
+    R = synth.uniform_rotations(n, seed=12).astype(np.float64)
+    M = np.eye(6)[None] + 0.2 * rng.randn(n if per_sample else 1, 6, 6)
+    gR = rng.randn(n, 3, 3)
+    gl = rng.randn(n)
+    Mt = torch.from_numpy(M).requires_grad_(True)
+    Rt = torch.from_numpy(R).requires_grad_(True)
+    Ro, l = orc.gs36(torch.linalg.inv(Mt) if inverse else Mt, Rt)
+    ((Ro * torch.from_numpy(gR)).sum() + (l * torch.from_numpy(gl)).sum()).backward()
+    Rout, ldj = np.zeros((n, 9), np.float32), np.zeros(n, np.float32)
+    gM, gRin = np.zeros(M.shape, np.float32), np.zeros((n, 9), np.float32)
+    hg.hg_gs36(ptr(f32(M)), per_sample, int(inverse), ptr(f32(R)), ptr(f32(gR)), ptr(f32(gl)), n, ptr(Rout), ptr(ldj), ptr(gM), ptr(gRin))
+    assert np.abs(Rout.reshape(n, 3, 3) - Ro.detach().numpy()).max() < 5e-6
+    assert np.abs(ldj - l.detach().numpy()).max() < 2e-5
+    want_M = Mt.grad.numpy()
+    assert np.abs(gM - want_M).max() < 2e-4 * max(1.0, np.abs(want_M).max())
+    got_t, want_t = tangent(R, gRin.reshape(n, 3, 3).astype(np.float64)), tangent(R, Rt.grad.numpy())
+    assert np.abs(got_t - want_t).max() < 2e-4 * max(1.0, np.abs(want_t).max())

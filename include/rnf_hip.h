@@ -227,6 +227,28 @@ int rnf_flow_inverse_backward(const float *states_dev, const float *rotation_out
                               const float *g_rotation_out_dev, const float *g_ldj_dev, float *grads_dev, float *g_rotation_in_dev,
                               float *g_feature_dev, float *layer_scratch_dev, void *stream);
 
+/* Training flows that contain side layers (RNF_LAYER_SIDE16 / SIDE16_ROT / SIDE9: Condition16TransLU, ConditionRot, Condition9TransLU;
+ * flow/squeezetrans.py:134-144,264-277, flow/rottrans.py:37-66).  Their per-sample matrices are built by the caller with the reference's
+ * own tensor ops (the LU layers' torch.diag couples the batch; ConditionRot's U^T V follows torch.svd's conventions), so the gradient
+ * chain is split: rnf_flow_train_side (dir 0 = Flow.forward, 1 = Flow.inverse) is the pass that saves the layer inputs;
+ * rnf_flow_backward_side is the reverse sweep, which also writes dL/d(matrix) into side_grad_dev float[n_side][n][16] (same layout as
+ * side_dev) for the caller's autograd to carry through those ops; rnf_cond_mlp_backward is the backward of ONE conditioner network
+ * evaluated by rnf_cond_mlp_forward.  train_desc: the side layer's slot goes into bits 16..23 of the kind word, its plain offset is
+ * unused (rnf_plain_layer_floats = 0); pack_desc / desc as for any layer (an empty 4-float record). */
+int rnf_flow_train_side(int32_t dir, const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim,
+                        const float *side_dev, const float *blob_dev, const int32_t *desc, int32_t n_layers, int32_t segments,
+                        float *rotation_out_dev, float *ldj_out_dev, float *states_dev, void *workspace_dev, size_t workspace_bytes,
+                        void *stream);
+int rnf_flow_backward_side(int32_t dir, const float *states_dev, const float *rotation_out_dev, const float *feature_dev, int64_t n,
+                           int32_t feature_dim, const float *plain_dev, const int32_t *train_desc, int32_t n_layers, int32_t segments,
+                           const float *side_dev, float *side_grad_dev, const float *g_rotation_out_dev, const float *g_ldj_dev,
+                           float *grads_dev, float *g_rotation_in_dev, float *g_feature_dev, float *layer_scratch_dev, void *stream);
+/* plain_dev: the network's parameters in reference order (fc_first.weight [64][F], .bias, layers.{1,3,5}.weight / .bias, fc_last.weight
+ * [n_out][64], .bias; flow/condition.py:14-22); g_out_dev float[n][n_out]; grads_dev (same layout as plain_dev) and g_feature_dev [n][F]
+ * are ACCUMULATED into and may be NULL; scratch1_dev: one zeroed float.  n_out <= 64. */
+int rnf_cond_mlp_backward(const float *feature_dev, int64_t n, int32_t feature_dim, const float *plain_dev, int32_t n_out,
+                          const float *g_out_dev, float *grads_dev, float *g_feature_dev, float *scratch1_dev, void *stream);
+
 /* Shared feature rows: feature_dev holds n / feature_div rows and row r conditions rotations [r * feature_div, (r + 1) * feature_div)
  * -- the pose-estimation pattern of Agent.eval_acc (agent.py:238-263), where the reference materialises feature.repeat(number_queries).
  * The feature projection runs once per row; workspace from rnf_workspace_bytes_shared.  n must be a multiple of feature_div. */

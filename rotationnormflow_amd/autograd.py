@@ -43,12 +43,20 @@ class TrainPlan:
         self.train_desc = np.zeros((n, 3), dtype=np.int32)                   # rnf_flow_backward
         plain_off = rec_off = 0
         slot = 0
+        side_slot = 0
         rec_sizes = []
         for i, (layer, (kind, k, f)) in enumerate(zip(layers, shapes)):
             flagged = kind | (ORTHOGONAL_FLAG if getattr(layer, "_rnf_orthogonal", False) else 0)
             self.desc[i] = (kind, perm_rows[i], rec_off, -1, -1, self.prec, -1, -1)     # no fp32 fallback images in training
             self.pack_desc[i] = (flagged, plain_off, rec_off, -1)
             self.train_desc[i] = (flagged, perm_rows[i], plain_off)
+            if kind in runtime.SIDE_KINDS:                 # per-sample matrices from the caller: an empty record, no plain parameters;
+                self.desc[i, 2] = side_slot                # the kernels find the layer's slot in the side buffer here
+                self.train_desc[i, 0] = flagged | (side_slot << 16)
+                side_slot += 1
+                rec_sizes.append(4)
+                rec_off += 4
+                continue
             if kind == runtime.KIND_MOBIUS:
                 size = L.rnf_mobius_packed_floats(self.segments)
             elif kind == runtime.KIND_COND16 or kind in runtime.COND9_KINDS:
@@ -69,10 +77,11 @@ class TrainPlan:
                 slot += 1
         fsize = L.rnf_featproj_packed_floats(self.feat_padded) if self.feat_dim else 0
         for i, (kind, k, f) in enumerate(shapes):
-            if f:
+            if f and kind not in runtime.SIDE_KINDS:
                 self.desc[i, 4] = self.pack_desc[i, 3] = rec_off
                 rec_off += (fsize + 3) // 4 * 4
         self.n_cond = slot
+        self.n_side = side_slot
         self.plain_floats = plain_off
         self.blob_floats = max(rec_off, 4)
         self.desc = np.ascontiguousarray(self.desc)
@@ -100,6 +109,8 @@ class TrainPlan:
             self.check_flags()
         blob = torch.empty(self.blob_floats, dtype=torch.float32, device=plain.device)
         self.flags.zero_()
+        if plain.numel() == 0:                             # a stack of side layers only: nothing to read, but the pointer must be valid
+            plain = torch.zeros(4, dtype=torch.float32, device=blob.device)
         _lib.check(L.rnf_pack_flow_device(plain.data_ptr(), self.pack_desc.ctypes.data, self.n_layers, self.segments, self.feat_dim,
                                           self.prec, blob.data_ptr(), self.flags.data_ptr(), stream))
         if self.flags_event is None and not capturing:
@@ -128,9 +139,15 @@ def mlp_train_tensors(net):
     return ts + [net.fc_last.weight, net.fc_last.bias]
 
 
-class _FlowForwardFn(torch.autograd.Function):
+class _FlowFn(torch.autograd.Function):
+    """Differentiable ``Flow.forward`` (direction 0) and ``Flow.inverse`` (direction 1; flow/flow.py:53-92).  The stack kernel saves the
+    rotation entering every layer (iteration position); the backward is one launch of the reverse sweep, which for the inverse pass walks
+    the layers in the order that pass visited them, with MobiusFlow.inverse differentiated by BinFind.backward's implicit-function rule
+    (flow/mobiusflow.py:247-273).  ``side``: [n_side, n, 16] per-sample matrices of the side layers (built differentiably by the caller
+    from the HIP conditioner's outputs with the reference's own tensor ops) or None; its gradient comes back from the sweep."""
+
     @staticmethod
-    def forward(ctx, plan, grad_sync, rotation, feature, *tensors):
+    def forward(ctx, plan, grad_sync, direction, rotation, feature, side, *tensors):
         rot, feat = runtime._check_inputs(rotation, feature, plan)
         n = rot.shape[0]
         dev = rot.device
@@ -143,52 +160,78 @@ class _FlowForwardFn(torch.autograd.Function):
                            for t in tensors]) if tensors else torch.zeros(0, device=dev)
         if plain.numel() != plan.plain_floats:
             raise RuntimeError(f"plain parameter blob has {plain.numel()} floats, layer table expects {plan.plain_floats}")
+        side_c = None
+        if plan.n_side:
+            if side is None or tuple(side.shape) != (plan.n_side, n, 16):
+                raise RuntimeError("side-layer matrices are missing or mis-shaped")
+            side_c = side.to(device=dev, dtype=f32).contiguous()
         if n:
             ws = runtime.workspace(dev, L.rnf_workspace_bytes(n, plan.n_cond))
+            fptr = feat.data_ptr() if feat is not None else None
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream
                 blob = plan.pack(plain, stream)
-                _lib.check(L.rnf_flow_forward_train(rot.data_ptr(), feat.data_ptr() if feat is not None else None, n,
-                                                    plan.feat_padded, blob.data_ptr(), plan.desc.ctypes.data,
-                                                    plan.n_layers, plan.segments, out_rot.data_ptr(), out_ldj.data_ptr(),
-                                                    states.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+                if plan.n_side:
+                    _lib.check(L.rnf_flow_train_side(direction, rot.data_ptr(), fptr, n, plan.feat_padded, side_c.data_ptr(), blob.data_ptr(),
+                                                     plan.desc.ctypes.data, plan.n_layers, plan.segments, out_rot.data_ptr(),
+                                                     out_ldj.data_ptr(), states.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+                else:
+                    fn = L.rnf_flow_inverse_train if direction else L.rnf_flow_forward_train
+                    _lib.check(fn(rot.data_ptr(), fptr, n, plan.feat_padded, blob.data_ptr(), plan.desc.ctypes.data, plan.n_layers,
+                                  plan.segments, out_rot.data_ptr(), out_ldj.data_ptr(), states.data_ptr(), ws.data_ptr(), ws.numel(), stream))
         feat_plain = None
-        if plan.n_cond:
+        if plan.feat_dim and feature is not None:
             feat_plain = feature.reshape(n, plan.feat_dim).to(device=dev, dtype=torch.float32).contiguous()
         ctx.plan = plan
         ctx.grad_sync = grad_sync
+        ctx.direction = direction
         ctx.rot_shape = rotation.shape
         ctx.feat_shape = feature.shape if feature is not None else None
         ctx.shapes = [(t.shape, t.device, t.dtype) for t in tensors]
         ctx.sizes = [t.numel() for t in tensors]
-        ctx.save_for_backward(states, feat_plain, plain)
+        ctx.save_for_backward(states, out_rot if direction else None, feat_plain, plain, side_c)
         return out_rot.reshape(rotation.shape), out_ldj
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_rot, g_ldj):
-        states, feat_plain, plain = ctx.saved_tensors
+        states, out_rot, feat_plain, plain, side_c = ctx.saved_tensors
         plan = ctx.plan
         n = states.shape[1]
         dev = states.device
         L = _lib.lib()
-        want_w = any(ctx.needs_input_grad[4:])            # no parameter requires grad: input gradients only, weight products skipped
+        FIRST = 6                                         # index of the first parameter tensor among forward's arguments
+        want_w = any(ctx.needs_input_grad[FIRST:])        # no parameter requires grad: input gradients only, weight products skipped
         grads = torch.zeros_like(plain) if want_w else None
         g_rot_in = torch.zeros((n, 9), dtype=torch.float32, device=dev)
-        want_gfeat = feat_plain is not None and ctx.needs_input_grad[3]
+        want_gfeat = feat_plain is not None and plan.n_cond > 0 and ctx.needs_input_grad[4]
         g_feat = torch.zeros_like(feat_plain) if want_gfeat else None
+        g_side = torch.zeros_like(side_c) if side_c is not None else None
         scratch = torch.zeros(max(plan.n_layers, 1), dtype=torch.float32, device=dev)
         if n:
             g_rot_c = g_rot.reshape(n, 9).to(torch.float32).contiguous() if g_rot is not None else None
             g_ldj_c = (g_ldj.to(torch.float32).contiguous() if g_ldj is not None
                        else torch.zeros(n, dtype=torch.float32, device=dev))
             ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+            tdesc = plan.train_desc_inverse if ctx.direction else plan.train_desc
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream
-                _lib.check(L.rnf_flow_backward(states.data_ptr(), ptr(feat_plain), n, plan.feat_dim, plain.data_ptr(),
-                                               plan.train_desc.ctypes.data, plan.n_layers, plan.segments, ptr(g_rot_c),
-                                               g_ldj_c.data_ptr(), ptr(grads), g_rot_in.data_ptr(), ptr(g_feat),
-                                               scratch.data_ptr(), stream))
+                if plan.n_side:
+                    _lib.check(L.rnf_flow_backward_side(ctx.direction, states.data_ptr(), ptr(out_rot), ptr(feat_plain) if plan.n_cond else None, n,
+                                                        plan.feat_dim if plan.n_cond else 0, ptr(plain) if plain.numel() else None,
+                                                        tdesc.ctypes.data, plan.n_layers, plan.segments, side_c.data_ptr(), g_side.data_ptr(),
+                                                        ptr(g_rot_c), g_ldj_c.data_ptr(), ptr(grads), g_rot_in.data_ptr(), ptr(g_feat),
+                                                        scratch.data_ptr(), stream))
+                elif ctx.direction:
+                    _lib.check(L.rnf_flow_inverse_backward(states.data_ptr(), out_rot.data_ptr(), ptr(feat_plain), n, plan.feat_dim,
+                                                           plain.data_ptr(), tdesc.ctypes.data, plan.n_layers, plan.segments,
+                                                           ptr(g_rot_c), g_ldj_c.data_ptr(), ptr(grads), g_rot_in.data_ptr(), ptr(g_feat),
+                                                           scratch.data_ptr(), stream))
+                else:
+                    _lib.check(L.rnf_flow_backward(states.data_ptr(), ptr(feat_plain), n, plan.feat_dim, plain.data_ptr(),
+                                                   tdesc.ctypes.data, plan.n_layers, plan.segments, ptr(g_rot_c),
+                                                   g_ldj_c.data_ptr(), ptr(grads), g_rot_in.data_ptr(), ptr(g_feat),
+                                                   scratch.data_ptr(), stream))
         needs = ctx.needs_input_grad
         if want_w:
             runtime.note_training_step()                  # an optimizer step follows: host-packed blobs are stale from now on
@@ -198,98 +241,105 @@ class _FlowForwardFn(torch.autograd.Function):
         outs = []
         for i, (shape, device, dtype) in enumerate(ctx.shapes):
             g = None
-            if want_w and needs[4 + i]:
+            if want_w and needs[FIRST + i]:
                 g = pieces[i].view(shape)
                 if device != dev or dtype is not torch.float32:
                     g = g.to(device=device, dtype=dtype)
             outs.append(g)
-        g_rotation = g_rot_in.reshape(ctx.rot_shape) if ctx.needs_input_grad[2] else None
+        g_rotation = g_rot_in.reshape(ctx.rot_shape) if needs[3] else None
         g_feature = g_feat.reshape(ctx.feat_shape) if want_gfeat else None
-        return (None, None, g_rotation, g_feature, *outs)
+        return (None, None, None, g_rotation, g_feature, g_side if needs[5] else None, *outs)
 
 
-class _FlowInverseFn(torch.autograd.Function):
-    """Differentiable ``Flow.inverse`` (flow/flow.py:74-92): the inverse stack kernel saves the rotation entering every iteration
-    position; the backward sweep is the same kernel as for the forward direction, walking the layers in the order the inverse pass
-    visited them, with MobiusFlow.inverse differentiated by BinFind.backward's implicit-function rule (flow/mobiusflow.py:247-273)."""
+class _CondMLPFn(torch.autograd.Function):
+    """One ConditionalTransform(F -> n_out <= 16) on the GPU, differentiable: forward = device packer + rnf_cond_mlp_forward, backward =
+    rnf_cond_mlp_backward (the training backward kernel with the layer math replaced by dL/d(outputs)).  The networks of the side layers
+    (ConditionLU's three, ConditionRot's one) go through it when a gradient is required."""
 
     @staticmethod
-    def forward(ctx, plan, grad_sync, rotation, feature, *tensors):
-        rot, feat = runtime._check_inputs(rotation, feature, plan)
-        n = rot.shape[0]
-        dev = rot.device
+    def forward(ctx, feature, n_out, *tensors):
         L = _lib.lib()
-        out_rot = torch.empty_like(rot)
-        out_ldj = torch.empty(n, dtype=torch.float32, device=dev)
-        states = torch.empty((plan.n_layers, n, 9), dtype=torch.float32, device=dev)
+        dev = feature.device
         f32 = torch.float32
-        plain = torch.cat([t.reshape(-1) if (t.is_cuda and t.dtype is f32) else t.to(device=dev, dtype=f32).reshape(-1)
-                           for t in tensors]) if tensors else torch.zeros(0, device=dev)
-        if plain.numel() != plan.plain_floats:
-            raise RuntimeError(f"plain parameter blob has {plain.numel()} floats, layer table expects {plan.plain_floats}")
+        feat = feature.to(f32).contiguous()
+        n, F = feat.shape
+        ts = [t.to(device=dev, dtype=f32) for t in tensors]
+        plain = torch.cat([t.reshape(-1) for t in ts])
+        wl, bl = ts[-2], ts[-1]                                # pad fc_last to the 16 rows of a Condition16Trans record
+        plain16 = torch.cat([t.reshape(-1) for t in ts[:-2]] + [wl.reshape(-1), wl.new_zeros((16 - n_out) * 64), bl, bl.new_zeros(16 - n_out)])
+        Fp = runtime.pad8(F)
+        prec = runtime._PRECISIONS[runtime.get_precision()]
+        rec = (L.rnf_cond16_packed_floats() + 3) // 4 * 4
+        blob = torch.empty(rec + L.rnf_featproj_packed_floats(Fp), dtype=f32, device=dev)
+        pack_desc = np.array([[runtime.KIND_COND16, 0, 0, rec]], dtype=np.int32)
+        flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        out = torch.empty((n, 16), dtype=f32, device=dev)
+        fpad = torch.nn.functional.pad(feat, (0, Fp - F)) if Fp != F else feat
         if n:
-            ws = runtime.workspace(dev, L.rnf_workspace_bytes(n, plan.n_cond))
+            ws = runtime.workspace(dev, L.rnf_workspace_bytes(n, 1))
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream
-                blob = plan.pack(plain, stream)
-                _lib.check(L.rnf_flow_inverse_train(rot.data_ptr(), feat.data_ptr() if feat is not None else None, n,
-                                                    plan.feat_padded, blob.data_ptr(), plan.desc.ctypes.data,
-                                                    plan.n_layers, plan.segments, out_rot.data_ptr(), out_ldj.data_ptr(),
-                                                    states.data_ptr(), ws.data_ptr(), ws.numel(), stream))
-        feat_plain = None
-        if plan.n_cond:
-            feat_plain = feature.reshape(n, plan.feat_dim).to(device=dev, dtype=torch.float32).contiguous()
-        ctx.plan = plan
-        ctx.grad_sync = grad_sync
-        ctx.rot_shape = rotation.shape
-        ctx.feat_shape = feature.shape if feature is not None else None
+                _lib.check(L.rnf_pack_flow_device(plain16.data_ptr(), pack_desc.ctypes.data, 1, 8, F, prec, blob.data_ptr(), flags.data_ptr(), stream))
+                _lib.check(L.rnf_cond_mlp_forward(fpad.data_ptr(), n, Fp, blob.data_ptr(), 0, rec, prec, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  stream))
+        ctx.n_out = n_out
         ctx.shapes = [(t.shape, t.device, t.dtype) for t in tensors]
         ctx.sizes = [t.numel() for t in tensors]
-        ctx.save_for_backward(states, out_rot, feat_plain, plain)
-        return out_rot.reshape(rotation.shape), out_ldj
+        ctx.feat_meta = (feature.shape, feature.dtype)
+        ctx.save_for_backward(feat, plain)
+        return out[:, :n_out].contiguous()
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_rot, g_ldj):
-        states, out_rot, feat_plain, plain = ctx.saved_tensors
-        plan = ctx.plan
-        n = states.shape[1]
-        dev = states.device
+    def backward(ctx, g_out):
+        feat, plain = ctx.saved_tensors
         L = _lib.lib()
-        want_w = any(ctx.needs_input_grad[4:])
+        dev = feat.device
+        n, F = feat.shape
+        want_w = any(ctx.needs_input_grad[2:])
         grads = torch.zeros_like(plain) if want_w else None
-        g_rot_in = torch.zeros((n, 9), dtype=torch.float32, device=dev)
-        want_gfeat = feat_plain is not None and ctx.needs_input_grad[3]
-        g_feat = torch.zeros_like(feat_plain) if want_gfeat else None
-        scratch = torch.zeros(max(plan.n_layers, 1), dtype=torch.float32, device=dev)
+        g_feat = torch.zeros_like(feat) if ctx.needs_input_grad[0] else None
+        g = g_out.to(torch.float32).contiguous()
+        scratch = torch.zeros(1, dtype=torch.float32, device=dev)
         if n:
-            g_rot_c = g_rot.reshape(n, 9).to(torch.float32).contiguous() if g_rot is not None else None
-            g_ldj_c = (g_ldj.to(torch.float32).contiguous() if g_ldj is not None
-                       else torch.zeros(n, dtype=torch.float32, device=dev))
             ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
             with torch.cuda.device(dev):
-                stream = torch.cuda.current_stream(dev).cuda_stream
-                _lib.check(L.rnf_flow_inverse_backward(states.data_ptr(), out_rot.data_ptr(), ptr(feat_plain), n, plan.feat_dim,
-                                                       plain.data_ptr(), plan.train_desc_inverse.ctypes.data, plan.n_layers, plan.segments,
-                                                       ptr(g_rot_c), g_ldj_c.data_ptr(), ptr(grads), g_rot_in.data_ptr(), ptr(g_feat),
-                                                       scratch.data_ptr(), stream))
-        needs = ctx.needs_input_grad
+                _lib.check(L.rnf_cond_mlp_backward(feat.data_ptr(), n, F, plain.data_ptr(), ctx.n_out, g.data_ptr(), ptr(grads), ptr(g_feat),
+                                                   scratch.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
         if want_w:
             runtime.note_training_step()
-            if ctx.grad_sync is not None:
-                ctx.grad_sync(grads)
-        pieces = torch.split(grads, ctx.sizes) if (ctx.sizes and want_w) else ()
+        pieces = torch.split(grads, ctx.sizes) if want_w else ()
         outs = []
         for i, (shape, device, dtype) in enumerate(ctx.shapes):
-            g = None
-            if want_w and needs[4 + i]:
-                g = pieces[i].view(shape)
+            gi = None
+            if want_w and ctx.needs_input_grad[2 + i]:
+                gi = pieces[i].view(shape)
                 if device != dev or dtype is not torch.float32:
-                    g = g.to(device=device, dtype=dtype)
-            outs.append(g)
-        g_rotation = g_rot_in.reshape(ctx.rot_shape) if ctx.needs_input_grad[2] else None
-        g_feature = g_feat.reshape(ctx.feat_shape) if want_gfeat else None
-        return (None, None, g_rotation, g_feature, *outs)
+                    gi = gi.to(device=device, dtype=dtype)
+            outs.append(gi)
+        shape, dtype = ctx.feat_meta
+        return (g_feat.reshape(shape).to(dtype) if g_feat is not None else None, None, *outs)
+
+
+def cond_mlp(net, feature, n_out):
+    """Differentiable ConditionalTransform(feature) -> [n, n_out] through the HIP conditioner."""
+    return _CondMLPFn.apply(feature, n_out, *mlp_train_tensors(net))
+
+
+def _side_tensor(plan, layers, rotation, feature, inverse):
+    """[n_side, n, 16] matrices of the flow's side layers, built with autograd on (each layer's ``_rnf_side(feature, grad=True)``)."""
+    if not plan.n_side:
+        return None
+    if feature is None:
+        raise AssertionError("The input feature is needed in this module")
+    n = rotation.reshape(-1, 9).shape[0]
+    feat = feature.reshape(n, -1).to(device=rotation.device, dtype=torch.float32)
+    mats = []
+    for layer in layers:
+        if layer._rnf_shape()[0] in runtime.SIDE_KINDS:
+            m = layer._rnf_side(feat, grad=True)
+            mats.append(torch.nn.functional.pad(m, (0, 16 - m.shape[1])) if m.shape[1] < 16 else m)
+    return torch.stack(mats)
 
 
 def _plan_for(module, layers, perm_rows, rotation):
@@ -308,13 +358,14 @@ def _plan_for(module, layers, perm_rows, rotation):
 
 
 def flow_inverse(module, layers, perm_rows, rotation, feature):
-    """Differentiable Flow.inverse: (rotation, ldj of the inverse map) with gradients w.r.t. parameters, the given rotations and the
-    features (flow/mobiusflow.py:247-273 BinFind.backward for the Moebius layers)."""
+    """Differentiable ``Flow.inverse``.  ``layers`` / ``perm_rows`` in FLOW order; the inverse pass walks them back to front."""
     plan = _plan_for(module, layers, perm_rows, rotation)
-    return _FlowInverseFn.apply(plan, getattr(module, "_rnf_grad_sync", None), rotation, feature, *train_tensors(layers))
+    side = _side_tensor(plan, layers, rotation, feature, True)
+    return _FlowFn.apply(plan, getattr(module, "_rnf_grad_sync", None), 1, rotation, feature, side, *train_tensors(layers))
 
 
 def flow_forward(module, layers, perm_rows, rotation, feature):
     """Differentiable (rotation', ldj) for a stack of layers; called by runtime.run_flow when a gradient is required."""
     plan = _plan_for(module, layers, perm_rows, rotation)
-    return _FlowForwardFn.apply(plan, getattr(module, "_rnf_grad_sync", None), rotation, feature, *train_tensors(layers))
+    side = _side_tensor(plan, layers, rotation, feature, False)
+    return _FlowFn.apply(plan, getattr(module, "_rnf_grad_sync", None), 0, rotation, feature, side, *train_tensors(layers))

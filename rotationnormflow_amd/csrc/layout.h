@@ -98,6 +98,9 @@ constexpr int RNF_KIND_COND36 = 10;
 // torch.diag) -- 4x4 on the quaternion with log-det, 4x4 orthogonal (log-det 0), 3x3 Gram-Schmidt with the tangent log-det
 constexpr int RNF_KIND_SIDE16 = 11, RNF_KIND_SIDE16_ROT = 12, RNF_KIND_SIDE9 = 13, RNF_KIND_LAST = 13;
 RNF_LAYOUT_INLINE bool kind_is_side(int kind) { return kind >= RNF_KIND_SIDE16 && kind <= RNF_KIND_SIDE9; }
+// training path only (train_kernels.h): a conditioner MLP on its own -- dL/d(outputs) comes from the caller, the kernel back-propagates it
+// to the MLP's parameters and to the feature (rnf_cond_mlp_backward; the networks of the side layers)
+constexpr int RNF_KIND_MLP_ONLY = 14;
 RNF_LAYOUT_INLINE bool kind_is_cond9(int kind) { return kind >= RNF_KIND_COND9_GS && kind <= RNF_KIND_COND9_LAST; }
 RNF_LAYOUT_INLINE bool kind_has_mlp(int kind) { return kind == RNF_KIND_MOBIUS || kind == RNF_KIND_COND16 || kind_is_cond9(kind) || kind == RNF_KIND_COND36; }
 // fc_last tiles of one layer record (KT = segments / 8 for a Moebius layer)

@@ -117,6 +117,10 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
     float *out = args.blob + L.rec_off;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     const int prec = args.prec, K = args.K, F = args.F, Fp = args.Fp;
+    if (kind_is_side(kind)) {                                          // per-sample matrices come from the caller: an empty record
+        if (tid < 4) out[tid] = 0.f;
+        return;
+    }
     if (kind == RNF_KIND_AFFINE16) {                                   // rnf_pack_affine16 / rnf_pack_rot16
         if (tid != 0) return;
         if ((L.kind >> 8) & 1) {

@@ -526,7 +526,6 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             return fail("layer %d: a conditional affine layer needs a cond_slot", l);
         if (kind_is_cond9(kind) || kind == RNF_KIND_COND36 || kind_is_side(kind)) ext = true;
         if (kind_is_side(kind) && !o.side) return fail("layer %d takes per-sample matrices: call the rnf_flow_*_side entry points with a side buffer", l);
-        if (kind_is_side(kind) && o.states) return fail("layer %d: per-sample matrix layers have no training path", l);
         if ((kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16) || slot >= 0) lean = false;
         if (kind == RNF_KIND_COND36) min_tiles = 2;
         if (slot >= 0) {
@@ -915,7 +914,7 @@ extern "C" int rnf_pack_flow_device(const float *plain, const int32_t *pdesc, in
         const int32_t *d = pdesc + (size_t)l * 4;
         const int kind = d[0] & 15;
         if ((d[0] & ~(15 | 256)) || (kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16 && kind != RNF_KIND_COND16 && kind != RNF_KIND_GS9 &&
-                                     kind != RNF_KIND_GS36 && kind != RNF_KIND_COND36 && !kind_is_cond9(kind)))
+                                     kind != RNF_KIND_GS36 && kind != RNF_KIND_COND36 && !kind_is_cond9(kind) && !kind_is_side(kind)))
             return fail("layer %d: unknown kind %d", l, d[0]);
         if (d[1] < 0 || d[2] < 0 || d[2] % 4 || (d[3] >= 0 && d[3] % 4)) return fail("layer %d: bad offsets", l);
         if ((kind == RNF_KIND_COND16 || kind == RNF_KIND_COND36 || kind_is_cond9(kind)) && F == 0) return fail("layer %d: a conditional affine layer needs a feature", l);
@@ -931,14 +930,20 @@ extern "C" size_t rnf_plain_layer_floats(int32_t kind, int32_t segments, int32_t
     if (kind == RNF_KIND_AFFINE16) return 16;
     if (kind == RNF_KIND_GS9) return 12;
     if (kind == RNF_KIND_GS36) return 36;
+    if (kind_is_side(kind)) return 0;
     const size_t ni = (kind == RNF_KIND_MOBIUS ? 3 : 0) + (size_t)feature_dim,
                  no = kind == RNF_KIND_MOBIUS ? 4 * (size_t)segments : (kind_is_cond9(kind) ? 9 : (kind == RNF_KIND_COND36 ? 36 : 16));
     return 64 * ni + 64 + 3 * (4096 + 64) + no * 64 + no;
 }
 
+struct BackwardExtra {
+    const float *side = nullptr;       // [n_side][n][16] per-sample matrices of the side layers
+    float *side_grad = nullptr;        // [n_side][n][16] out: dL/d(matrix)
+    const float *g_out_ext = nullptr;  // RNF_KIND_MLP_ONLY: dL/d(outputs) [n][NO]
+};
 static int run_backward(const float *states, const float *rot_final, int dir, const float *feat, int64_t n, int32_t F, const float *plain,
                         const int32_t *tdesc, int32_t n_layers, int32_t K, const float *g_rot_out, const float *g_ldj, float *grads,
-                        float *g_rot_in, float *g_feature, float *g_ldj_sum, void *stream_v);
+                        float *g_rot_in, float *g_feature, float *g_ldj_sum, void *stream_v, const BackwardExtra &x = BackwardExtra());
 
 extern "C" int rnf_flow_backward(const float *states, const float *feat, int64_t n, int32_t F, const float *plain, const int32_t *tdesc,
                                  int32_t n_layers, int32_t K, const float *g_rot_out, const float *g_ldj, float *grads,
@@ -955,28 +960,34 @@ extern "C" int rnf_flow_inverse_backward(const float *states, const float *rot_o
 
 static int run_backward(const float *states, const float *rot_final, int dir, const float *feat, int64_t n, int32_t F, const float *plain,
                         const int32_t *tdesc, int32_t n_layers, int32_t K, const float *g_rot_out, const float *g_ldj, float *grads,
-                        float *g_rot_in, float *g_feature, float *g_ldj_sum, void *stream_v) {
+                        float *g_rot_in, float *g_feature, float *g_ldj_sum, void *stream_v, const BackwardExtra &x) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     if (n < 0) return fail("n=%lld is negative", (long long)n);
     if (n_layers < 0 || n_layers > TR_MAX_LAYERS) return fail("n_layers=%d outside [0,%d] (training path)", n_layers, TR_MAX_LAYERS);
     if (K < 1 || K > 64) return fail("training path supports 1..64 segments, got %d", K);
     if (F < 0) return fail("feature_dim %d is negative", F);
     if (n == 0) return 0;
-    if (!states || !plain || !tdesc || !g_ldj || !g_rot_in || !g_ldj_sum) return fail("null pointer argument");
+    const bool mlp_only = n_layers == 1 && (tdesc[0] & 15) == RNF_KIND_MLP_ONLY;
+    if (!plain || !tdesc || !g_ldj_sum) return fail("null pointer argument");
+    if (!mlp_only && (!states || !g_ldj || !g_rot_in)) return fail("null pointer argument");
     TrainArgs a;
     std::memset(&a, 0, sizeof(a));
     for (int l = 0; l < n_layers; ++l) {
         const int32_t *d = tdesc + (size_t)l * 3;
-        const int kind = d[0] & 15, orth = (d[0] >> 8) & 1;
-        if ((d[0] & ~(15 | 256)) || (kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16 && kind != RNF_KIND_COND16 && kind != RNF_KIND_GS9 &&
-                                     kind != RNF_KIND_GS36 && kind != RNF_KIND_COND36 && !kind_is_cond9(kind)))
+        const int kind = d[0] & 15, orth = (d[0] >> 8) & 1, aux = (d[0] >> 16) & 255;
+        if ((d[0] & ~(15 | 256 | (255 << 16))) ||
+            (kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16 && kind != RNF_KIND_COND16 && kind != RNF_KIND_GS9 && kind != RNF_KIND_GS36 &&
+             kind != RNF_KIND_COND36 && !kind_is_cond9(kind) && !kind_is_side(kind) && !(kind == RNF_KIND_MLP_ONLY && mlp_only)))
             return fail("layer %d: kind %d has no backward kernel", l, d[0]);
+        if (kind_is_side(kind) && (!x.side || !x.side_grad)) return fail("layer %d is a side layer: side / side_grad buffers are needed (rnf_flow_backward_side)", l);
+        if (kind == RNF_KIND_MLP_ONLY && (aux < 1 || aux > 64 || !x.g_out_ext || F <= 0)) return fail("rnf_cond_mlp_backward: 1..64 outputs, a feature and dL/d(outputs) are needed");
         if (d[1] < 0 || d[1] > 5) return fail("layer %d: perm_row %d outside [0,5]", l, d[1]);
         if (kind_has_mlp(kind) && F > 0 && !feat) return fail("conditional layer %d but feature pointer is null", l);
         if ((kind == RNF_KIND_COND16 || kind == RNF_KIND_COND36 || kind_is_cond9(kind)) && F == 0) return fail("layer %d: a conditional affine layer needs a feature", l);
         if (d[2] < 0) return fail("layer %d: negative plain offset", l);
-        a.layers[l] = make_int2(kind | (d[1] << 4) | (orth << 8), d[2]);
+        a.layers[l] = make_int2(kind | (d[1] << 4) | (orth << 8) | (aux << 16), d[2]);
     }
+    a.side = x.side; a.side_grad = x.side_grad; a.g_out_ext = x.g_out_ext;
     a.states = states; a.feature = F ? feat : nullptr; a.plain = plain; a.grads = grads; a.g_rot_out = g_rot_out; a.g_ldj = g_ldj;
     a.g_rot_in = g_rot_in; a.g_feature = F ? g_feature : nullptr; a.g_ldj_sum = g_ldj_sum;
     a.n = n; a.n_layers = n_layers; a.K = K; a.F = F;
@@ -1007,6 +1018,47 @@ static int run_backward(const float *states, const float *rot_final, int dir, co
         HIP_TRY(hipGetLastError());
     }
     return 0;
+}
+
+// Training with side layers (Condition16TransLU / Condition9TransLU / ConditionRot): the pass that saves the layer inputs, and the
+// backward sweep that also returns dL/d(per-sample matrix) -- the caller's autograd carries it through the reference's own tensor ops
+// (einsum / torch.diag / torch.svd) into the conditioner networks, whose backward is rnf_cond_mlp_backward.
+extern "C" int rnf_flow_train_side(int32_t dir, const float *rot, const float *feat, int64_t n, int32_t F, const float *side, const float *blob,
+                                   const int32_t *desc, int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, float *states, void *ws,
+                                   size_t ws_bytes, void *stream) {
+    if (dir != 0 && dir != 1) return fail("rnf_flow_train_side: dir=%d", (int)dir);
+    if (n > 0 && (!states || !rot_out)) return fail("rnf_flow_train_side: states / rotation_out buffer is null");
+    RunOpts o{dir, nullptr, nullptr, 0, nullptr, nullptr};
+    o.states = states;
+    o.side = side;
+    return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
+}
+
+extern "C" int rnf_flow_backward_side(int32_t dir, const float *states, const float *rot_out, const float *feat, int64_t n, int32_t F,
+                                      const float *plain, const int32_t *tdesc, int32_t n_layers, int32_t K, const float *side, float *side_grad,
+                                      const float *g_rot_out, const float *g_ldj, float *grads, float *g_rot_in, float *g_feature,
+                                      float *g_ldj_sum, void *stream_v) {
+    if (dir != 0 && dir != 1) return fail("rnf_flow_backward_side: dir=%d", (int)dir);
+    if (dir == 1 && n > 0 && !rot_out) return fail("rnf_flow_backward_side: the output rotations of the inverse pass are needed (they carry the roots)");
+    BackwardExtra x;
+    x.side = side; x.side_grad = side_grad;
+    static const float dummy = 0.f;
+    return run_backward(states, dir ? rot_out : nullptr, dir, feat, n, F, plain ? plain : &dummy, tdesc, n_layers, K, g_rot_out, g_ldj, grads, g_rot_in,
+                        g_feature, g_ldj_sum, stream_v, x);
+}
+
+// Backward of ONE ConditionalTransform(feature_dim -> n_out) evaluated on its own (rnf_cond_mlp_forward; flow/condition.py:24-30): plain =
+// its parameters in reference order (fc_first.weight [64][F], .bias, layers.{1,3,5}.weight/.bias, fc_last.weight [n_out][64], .bias),
+// g_out [n][n_out] -> grads (same layout as plain, ACCUMULATED into; nullptr: feature gradient only) and g_feature [n][F] (ACCUMULATED
+// into, or nullptr).  One launch of the training backward kernel with the layer math replaced by the caller's dL/d(outputs).
+extern "C" int rnf_cond_mlp_backward(const float *feat, int64_t n, int32_t F, const float *plain, int32_t n_out, const float *g_out, float *grads,
+                                     float *g_feature, float *scratch1, void *stream_v) {
+    if (!feat || !plain || !g_out || !scratch1) return fail("rnf_cond_mlp_backward: null pointer");
+    if (n_out < 1 || n_out > 64) return fail("rnf_cond_mlp_backward: n_out=%d outside [1,64]", (int)n_out);
+    const int32_t tdesc[3] = {RNF_KIND_MLP_ONLY | (n_out << 16), 0, 0};
+    BackwardExtra x;
+    x.g_out_ext = g_out;
+    return run_backward(nullptr, nullptr, 0, feat, n, F, plain, tdesc, 1, 8, nullptr, nullptr, grads, nullptr, g_feature, scratch1, stream_v, x);
 }
 
 // Flow.inverse that also saves the rotation entering every iteration position of the inverse pass (position 0 = the last flow layer)

@@ -48,7 +48,13 @@ struct TrainArgs {
     int dir;
     const float *rot_final;
     unsigned long long *stamps;   // diagnostic builds only (RNF_STAMPS): per-phase cycle sums of wave 0, else nullptr
-    // per layer: x = kind | perm_row << 4 | orthogonal << 8, y = plain offset
+    // side layers (RNF_KIND_SIDE*: Condition16TransLU, Condition9TransLU, ConditionRot): the caller's per-sample matrices
+    // side [n_side][n][16] and, out, dL/d(matrix) side_grad [n_side][n][16]; the layer's slot sits in bits 16..23 of x
+    const float *side;
+    float *side_grad;
+    // RNF_KIND_MLP_ONLY: dL/d(outputs) of the one conditioner MLP of the call, [n][NO] row-major, NO in bits 16..23 of x
+    const float *g_out_ext;
+    // per layer: x = kind | perm_row << 4 | orthogonal << 8 | (side slot or NO) << 16, y = plain offset
     int2 layers[TR_MAX_LAYERS];
 };
 
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
         gR.c0 = v3f{0.f, 0.f, 0.f}; gR.c1 = gR.c0; gR.c2 = gR.c0;
         float g_ldj = 0.f;
         if (valid) {
-            g_ldj = args.g_ldj[sample];
+            g_ldj = args.g_ldj ? args.g_ldj[sample] : 0.f;
             if (args.g_rot_out) {
                 const float *g = args.g_rot_out + sample * 9;
                 gR.c0 = v3f{g[0], g[3], g[6]}; gR.c1 = v3f{g[1], g[4], g[7]}; gR.c2 = v3f{g[2], g[5], g[8]};
@@ -275,9 +281,86 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
             float *Gp = args.grads + d.y;
             Rot Rin;
             Rin.c0 = v3f{1.f, 0.f, 0.f}; Rin.c1 = v3f{0.f, 1.f, 0.f}; Rin.c2 = v3f{0.f, 0.f, 1.f};
-            if (valid) {
+            if (valid && args.states) {
                 const float *s = args.states + ((size_t)pos * args.n + sample) * 9;
                 Rin.c0 = v3f{s[0], s[3], s[6]}; Rin.c1 = v3f{s[1], s[4], s[7]}; Rin.c2 = v3f{s[2], s[5], s[8]};
+            }
+            if (kind_is_side(kind)) {                     // per-sample matrix from the caller; its gradient goes back to the caller
+                const int slot = (d.x >> 16) & 255;
+                const float *m = args.side + ((size_t)slot * args.n + (valid ? sample : 0)) * 16;
+                float gM[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) gM[i] = 0.f;
+                Rot gRin;
+                if (kind == RNF_KIND_SIDE9) {             // Condition9TransLU (squeezetrans.py:264-277): calculate_9, inverse pass M^-1
+                    float M9[9], g9[9];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) { M9[i] = m[i]; g9[i] = 0.f; }
+                    if (args.dir) {
+                        float Mi[9], gMi[9];
+                        inv3(M9, Mi);
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) gMi[i] = 0.f;
+                        gs9_backward(Mi, Rin, gR, g_ldj, gMi, gRin);
+                        inverse_matrix_grad<3>(Mi, gMi, g9);
+                    } else {
+                        gs9_backward(M9, Rin, gR, g_ldj, g9, gRin);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) gM[i] = g9[i];
+                } else {
+                    float M[16], Mi[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) M[i] = m[i];
+                    const bool orth = kind == RNF_KIND_SIDE16_ROT;      // ConditionRot (rottrans.py:37-66): ldj = 0, inverse pass M^T
+                    Rot Rout;
+                    AffineSaved sv;
+                    float l;
+                    if (orth) {
+                        if (args.dir) {
+                            float Mt[16], gMt[16];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) { Mt[4 * i + jj] = M[4 * jj + i]; gMt[4 * i + jj] = 0.f; }
+                            affine16_forward_saved(Mt, 0.f, Rin, Rout, l, sv);
+                            affine16_backward(Mt, sv, gR, g_ldj, true, gMt, gRin);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) gM[4 * i + jj] = gMt[4 * jj + i];
+                        } else {
+                            affine16_forward_saved(M, 0.f, Rin, Rout, l, sv);
+                            affine16_backward(M, sv, gR, g_ldj, true, gM, gRin);
+                        }
+                    } else {                                // Condition16TransLU (squeezetrans.py:134-144): as Condition16Trans, M given
+                        inv4(M, Mi);
+                        if (args.dir) {
+                            float gMi[16];
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) gMi[i] = 0.f;
+                            affine16_forward_saved(Mi, 0.f, Rin, Rout, l, sv);
+                            affine16_backward(Mi, sv, gR, g_ldj, false, gMi, gRin);
+                            inverse_matrix_grad<4>(Mi, gMi, gM);
+                        } else {
+                            affine16_forward_saved(M, 0.f, Rin, Rout, l, sv);
+                            affine16_backward(M, sv, gR, g_ldj, false, gM, gRin);
+                        }
+                        const float gl = args.dir ? -g_ldj : g_ldj;      // d log|det M| / dM = M^-T
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) gM[4 * i + jj] += gl * Mi[4 * jj + i];
+                    }
+                }
+                if (wave == 0 && valid && args.side_grad) {
+                    float *o = args.side_grad + ((size_t)slot * args.n + sample) * 16;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[i] = gM[i];
+                }
+                gR = gRin;
+                RNF_TSTAMP(8)
+                continue;
             }
             if (kind == RNF_KIND_AFFINE16) {              // every wave carries the chain; wave 0 adds the parameter gradient
                 float M[16];
@@ -403,7 +486,7 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
             }
             // ---- layers with a conditioner MLP (Moebius: input y (+) feature, 4K outputs; Condition16Trans: feature, 16 outputs) ----
             const bool mob = kind == RNF_KIND_MOBIUS;
-            const int yo = mob ? 3 : 0, NI = yo + F, NO = mob ? 4 * K : (kind_is_cond9(kind) ? 9 : (kind == RNF_KIND_COND36 ? 36 : 16));
+            const int yo = mob ? 3 : 0, NI = yo + F, NO = mob ? 4 * K : (kind == RNF_KIND_MLP_ONLY ? ((d.x >> 16) & 255) : (kind_is_cond9(kind) ? 9 : (kind == RNF_KIND_COND36 ? 36 : 16)));
             const float *W0 = P, *b0 = W0 + 64 * NI, *W1 = b0 + 64, *b1 = W1 + 4096, *W3 = b1 + 64, *b3 = W3 + 4096, *W5 = b3 + 64,
                         *b5 = W5 + 4096, *WL = b5 + 64, *bL = WL + (size_t)NO * 64;
             float *gW0 = Gp, *gb0 = gW0 + 64 * NI, *gW1 = gb0 + 64, *gb1 = gW1 + 4096, *gW3 = gb1 + 64, *gb3 = gW3 + 4096, *gW5 = gb3 + 64,
@@ -586,6 +669,14 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                     mg.g_v = mg.g_v + v3f{red2[(w * 6 + 3) * 64 + lane], red2[(w * 6 + 4) * 64 + lane], red2[(w * 6 + 5) * 64 + lane]};
                 }
                 mobius_backward_tail(sv, mg, gRin);
+            } else if (kind == RNF_KIND_MLP_ONLY) {
+                // the conditioner on its own (networks of the side layers): dL/d(outputs) comes from the caller
+                gRin = gR;
+                lds_barrier();                          // every wave is past the fc_last stores into C
+                if (wave == 0) {
+                    for (int i = 0; i < NO; ++i) Cm.at(i, lane) = valid ? args.g_out_ext[sample * NO + i] : 0.f;
+                }
+                lds_barrier();
             } else if (kind == RNF_KIND_COND36) {
                 // Condition36Trans (squeezetrans.py:334-347): M = I + reshape(net(f), 6, 6) per sample; the inverse pass applies M^-1
                 float M[36], gM[36];
@@ -801,7 +892,7 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
             gR = gRin;
             RNF_TSTAMP(7)
         }
-        if (valid && wave == 0) {
+        if (valid && wave == 0 && args.g_rot_in) {
             float *o = args.g_rot_in + sample * 9;
             o[0] = gR.c0.x; o[1] = gR.c1.x; o[2] = gR.c2.x; o[3] = gR.c0.y; o[4] = gR.c1.y; o[5] = gR.c2.y; o[6] = gR.c0.z; o[7] = gR.c1.z; o[8] = gR.c2.z;
         }

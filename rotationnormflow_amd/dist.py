@@ -70,5 +70,11 @@ def data_parallel_training(flow, group=None, enabled=True):
     with one all-reduce, so that every rank steps its optimizer with the gradient of the mean loss over the GLOBAL batch (what
     nn.DataParallel's reduce_add of replica gradients gives the reference, agent.py:22,79-90, when each rank's loss is the mean over
     its equally sized shard).  Parameters must start identical on all ranks (same seed or a broadcast state dict)."""
+    if enabled:
+        side = sorted({type(m).__name__ for m in flow.modules() if getattr(m, "_rnf_side_layer", False)})
+        if side:
+            # their networks' gradients do not travel in the flow's gradient blob (they come back through the side matrices), and the LU
+            # layers' matrices depend on which rows share a batch: sharding the batch would change the model being trained
+            raise NotImplementedError(f"data-parallel training is not built for flows with {', '.join(side)} layers")
     flow._rnf_grad_sync = (lambda blob: all_reduce_mean_(blob, group)) if enabled else None
     return flow

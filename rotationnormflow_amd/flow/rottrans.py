@@ -186,10 +186,10 @@ class ConditionRot(_SideLayer):
         self._cache = runtime.PackCache()
         self._net = None
 
-    def _rnf_side(self, feature):
+    def _rnf_side(self, feature, grad=False):
         if self._net is None:
             self._net = runtime.SideNet(self.net, self.feature_dim, 16)
-        with torch.no_grad():
+        with torch.set_grad_enabled(grad):                # grad: torch differentiates its own SVD, as the reference does
             mat = self._net(feature).reshape(-1, 4, 4) + torch.eye(4, device=feature.device)
             U, S, V = torch.svd(mat.cpu())
             return (U.transpose(-1, -2) @ V).reshape(-1, 16).to(feature.device)

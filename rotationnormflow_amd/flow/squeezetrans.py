@@ -250,11 +250,17 @@ class _SideLayer(nn.Module, _SingleLayer):
     """Layers whose per-sample matrix is formed with the reference's own batched torch ops on outputs of the HIP conditioner
     (runtime.SideNet) and handed to the stack kernel in a side buffer (include/rnf_hip.h RNF_LAYER_SIDE*)."""
 
+    _rnf_side_layer = True
+    _rnf_no_graph = True           # per-batch torch ops (and, for ConditionRot, a host SVD) sit between the conditioner and the stack kernel
+
     def _rnf_pack(self, L, prec=0):
         return np.zeros(4, dtype=np.float32), None, 0, 0
 
     def _rnf_shape(self):
         return (self._rnf_kind, 0, self.feature_dim)
+
+    def _rnf_train_tensors(self):
+        return []              # no parameters in the flow's plain blob: the gradient reaches the networks through the side matrices
 
     def forward(self, rotation, permute=None, feature=None):
         return self._single(rotation, permute, feature, inverse=False)
@@ -318,8 +324,8 @@ class Condition16TransLU(_SideLayer):
         self.net = ConditionLU(4, feature_dim)
         self._cache = runtime.PackCache()
 
-    def _rnf_side(self, feature):
-        with torch.no_grad():
+    def _rnf_side(self, feature, grad=False):
+        with torch.set_grad_enabled(grad):
             return self.net(feature).reshape(-1, 16)
 
 
@@ -335,6 +341,6 @@ class Condition9TransLU(_SideLayer):
         self.net = ConditionLU(3, feature_dim)
         self._cache = runtime.PackCache()
 
-    def _rnf_side(self, feature):
-        with torch.no_grad():
+    def _rnf_side(self, feature, grad=False):
+        with torch.set_grad_enabled(grad):
             return (self.net(feature).reshape(-1, 3, 3) + torch.eye(3, device=feature.device)).reshape(-1, 9)

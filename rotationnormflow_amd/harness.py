@@ -71,7 +71,7 @@ def save_reference_checkpoint(path, flow: Flow, optimizer, epoch: int, minibatch
 def host_preprocess_layers(flow) -> list:
     """Names of the layer classes of ``flow`` whose training tensors go through host-side linear algebra (rot='16Rot' / '16UnRot',
     '9TransLSVD' / '9TransRSVD' / '9TransRSmith'): such flows cannot be captured into a HIP graph."""
-    return sorted({type(l).__name__ for l in flow.layers if getattr(l, "_rnf_host_preprocess", False)})
+    return sorted({type(l).__name__ for l in flow.layers if getattr(l, "_rnf_host_preprocess", False) or getattr(l, "_rnf_no_graph", False)})
 
 
 class GraphedTrainStep:

@@ -281,7 +281,11 @@ class SideNet:
         return (torch.from_numpy(blob).to(device), (rec.size + 3) // 4 * 4, _PRECISIONS[name])
 
     def __call__(self, feature):
-        """feature [n, F] (cuda, fp32) -> [n, n_out]"""
+        """feature [n, F] (cuda, fp32) -> [n, n_out].  With autograd on and a parameter (or the feature) requiring grad: the differentiable
+        route (autograd.cond_mlp: device packer + rnf_cond_mlp_forward, backward rnf_cond_mlp_backward)."""
+        if torch.is_grad_enabled() and (feature.requires_grad or any(p.requires_grad for p in self.net.parameters())):
+            from . import autograd
+            return autograd.cond_mlp(self.net, feature, self.n_out)
         dev = feature.device
         blob, feat_off, prec = self.cache.get(self.net, dev, lambda: self._pack(dev))
         L = _lib.lib()
@@ -319,7 +323,7 @@ def build_side_buffer(packed, feature, n, device, inverse):
     feat = feature.reshape(n, -1).to(device=device, dtype=torch.float32)
     side = torch.zeros((len(packed.side_layers), n, 16), dtype=torch.float32, device=device)
     for slot, layer in enumerate(packed.side_layers):
-        m = layer._rnf_side(feat)                                # [n, 16] or [n, 9]
+        m = layer._rnf_side(feat, grad=False)                    # [n, 16] or [n, 9]
         side[slot, :, : m.shape[1]] = m
     return side
 

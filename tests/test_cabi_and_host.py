@@ -183,7 +183,7 @@ def test_argument_validation_happens_before_any_gpu_work():
     assert L.rnf_flow_backward(*args) != 0 and "n_layers" in err()
     args = (None, None, 0, 0, None, tdesc.ctypes.data, 1, 64, None, None, None, None, None, None, None)
     assert L.rnf_flow_backward(*args) == 0                                  # empty batch: nothing to do
-    pdesc = np.array([[11, 0, 0, -1]], np.int32)
+    pdesc = np.array([[15, 0, 0, -1]], np.int32)
     assert L.rnf_pack_flow_device(buf.ctypes.data, pdesc.ctypes.data, 1, 64, 0, 1, buf.ctypes.data, buf.ctypes.data, None) != 0 and "kind" in err()
     assert L.rnf_pack_flow_device(buf.ctypes.data, pdesc.ctypes.data, 1, 60, 0, 1, buf.ctypes.data, buf.ctypes.data, None) != 0 and "multiple of 8" in err()
     assert L.rnf_plain_layer_floats(1, 64, 0) == 29376 and L.rnf_plain_layer_floats(2, 64, 0) == 16

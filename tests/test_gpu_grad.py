@@ -22,13 +22,13 @@ def tangent(R, G):
     return A - A.transpose(0, 2, 1)
 
 
-def oracle_grads(cfg, w, R, feat, gR, gl):
-    p = {k: torch.from_numpy(v).double().requires_grad_(v.dtype.kind == "f" and not k.split(".")[-1] in
+def oracle_grads(cfg, w, R, feat, gR, gl, dtype=torch.float64):
+    p = {k: torch.from_numpy(v).to(dtype).requires_grad_(v.dtype.kind == "f" and not k.split(".")[-1] in
                                                           ("w_p", "u_mask", "l_mask", "s_sign", "l_eye")) for k, v in w.items()}
-    Rt = torch.from_numpy(R).double().requires_grad_(True)
-    ft = None if feat is None else torch.from_numpy(feat).double().requires_grad_(True)
-    Ro, ldj = orc.flow_forward(cfg, p, Rt, ft, dtype=torch.float64, grad=True)
-    loss = (Ro * torch.from_numpy(gR).double()).sum() + (ldj * torch.from_numpy(gl).double()).sum()
+    Rt = torch.from_numpy(R).to(dtype).requires_grad_(True)
+    ft = None if feat is None else torch.from_numpy(feat).to(dtype).requires_grad_(True)
+    Ro, ldj = orc.flow_forward(cfg, p, Rt, ft, dtype=dtype, grad=True)
+    loss = (Ro * torch.from_numpy(gR).to(dtype)).sum() + (ldj * torch.from_numpy(gl).to(dtype)).sum()
     leaves = [t for t in p.values() if t.requires_grad] + [Rt] + ([ft] if ft is not None else [])
     grads = torch.autograd.grad(loss, leaves, allow_unused=True)
     names = [k for k, t in p.items() if t.requires_grad]
@@ -62,6 +62,11 @@ CASES = {
     # 6x6 Gram-Schmidt layers (closed-form log-det of so3_grad.h, hand-written reverse mode): one shared M / per-sample M
     "gs36": (dict(layers=2, segments=16, rot="36Trans"), 110, "trained"),
     "cgs36": (dict(layers=2, segments=16, condition=1, feature_dim=24, rot="36Trans", last_affine=1), 90, "trained"),
+    # side layers: per-sample matrices built with the reference's own tensor ops (batch-coupled torch.diag of ConditionLU); the kernel
+    # returns dL/d(matrix), torch carries it through those ops, rnf_cond_mlp_backward takes it into the three networks
+    "clu16": (dict(layers=2, segments=16, condition=1, feature_dim=24, rot="16Trans", lu=1), 96, "trained"),
+    "clu9": (dict(layers=2, segments=16, condition=1, feature_dim=24, rot="9TransLSmith", lu=1), 70, "trained"),
+    "clu16_first": (dict(layers=2, segments=16, condition=1, feature_dim=24, rot="16UnTrans", lu=1, last_affine=1, first_affine=0), 130, "default"),
 }
 
 
@@ -84,13 +89,25 @@ def test_gradients_match_oracle_autograd(name):
         want, want_gR, want_gf, want_Ro, want_ldj = oracle_grads(cfg, w, R, feat, gR, gl)
     except KeyError as e:                                   # pragma: no cover
         pytest.skip(f"oracle has no such layer: {e}")
+    # Condition16TransLU: the batch-coupled torch.diag of ConditionLU (squeezetrans.py:127) puts the same row vector on EVERY row of the
+    # upper factor, so the per-sample 4x4 matrices are badly conditioned by construction (cond 1e3 typical, 1e6 worst case here) and an
+    # fp32 evaluation -- the reference's included -- carries few digits: those cases are gated relative to the oracle's OWN fp32-vs-fp64
+    # difference (the SIDE16 kernel math itself is checked to 2e-4 on well-conditioned matrices in test_side_kernels_in_isolation)
+    noisy = name.startswith("clu16")
+    w32 = oracle_grads(cfg, w, R, feat, gR, gl, dtype=torch.float32) if noisy else None
+
+    def tol(key, want_arr, base):
+        if not noisy:
+            return base
+        ref32 = {"R": w32[1], "f": w32[2], "Ro": w32[3], "ldj": w32[4]}.get(key, w32[0].get(key))
+        return max(base, 4.0 * np.abs(np.asarray(ref32, np.float64) - want_arr).max() / max(np.abs(want_arr).max(), 1e-3))
     fl = product_flow(cfg, w).train()
     Rd = torch.from_numpy(R).cuda().requires_grad_(True)
     fd = None if feat is None else torch.from_numpy(feat).cuda().requires_grad_(True)
     Ro, ldj = fl(Rd, fd)
     assert Ro.requires_grad and ldj.requires_grad
-    assert np.abs(Ro.detach().cpu().numpy() - want_Ro).max() < 2e-5
-    assert np.abs(ldj.detach().cpu().numpy() - want_ldj).max() < 5e-5 * max(1.0, np.abs(want_ldj).max())
+    assert np.abs(Ro.detach().cpu().numpy() - want_Ro).max() < max(2e-5, tol("Ro", want_Ro, 0.0))
+    assert np.abs(ldj.detach().cpu().numpy() - want_ldj).max() < max(5e-5, tol("ldj", want_ldj, 0.0)) * max(1.0, np.abs(want_ldj).max())
     loss = (Ro * torch.from_numpy(gR).cuda()).sum() + (ldj * torch.from_numpy(gl).cuda()).sum()
     loss.backward()
     torch.cuda.synchronize()
@@ -103,17 +120,65 @@ def test_gradients_match_oracle_autograd(name):
         g = got[k].cpu().numpy().astype(np.float64)
         scale = max(np.abs(g_want).max(), 1e-3)
         err = np.abs(g - g_want).max() / scale
-        assert err < REL, (k, err)
+        assert err < tol(k, g_want, REL), (k, err)
         checked += 1
     assert checked == sum(1 for v in want.values() if v is not None) and checked > 0
     tg, tw = tangent(R.astype(np.float64), Rd.grad.cpu().numpy().astype(np.float64)), tangent(R.astype(np.float64), want_gR)
-    assert np.abs(tg - tw).max() / max(np.abs(tw).max(), 1e-3) < REL
+    assert np.abs(tg - tw).max() / max(np.abs(tw).max(), 1e-3) < tol("R", want_gR, REL)
     if feat is not None:
         gf = fd.grad.cpu().numpy().astype(np.float64)
-        assert np.abs(gf - want_gf).max() / max(np.abs(want_gf).max(), 1e-3) < REL
+        assert np.abs(gf - want_gf).max() / max(np.abs(want_gf).max(), 1e-3) < tol("f", want_gf, REL)
 
 
-INVERSE_CASES = ["uncond_k16", "cond_k32", "cond_first_affine", "mobius_only", "lu", "rot", "gs9", "svdl9", "cgs9", "csvdl9", "csvdr9", "csmithr9", "gs36", "cgs36"]
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("kind", ["lu16", "rot16", "lu9"])
+def test_side_kernels_in_isolation(kind, inverse):
+    """The kernel half of side-layer training on WELL-CONDITIONED per-sample matrices given as a leaf tensor: outputs, dL/d(matrix)
+    (rnf_flow_backward_side's side_grad) and dL/dR against fp64 autograd of the oracle's layer functions, forward and inverse pass."""
+    from rotationnormflow_amd.flow.squeezetrans import Condition16TransLU, Condition9TransLU
+    from rotationnormflow_amd.flow.rottrans import ConditionRot
+    n = 70
+    rng = np.random.RandomState(3)
+    R = synth.uniform_rotations(n, seed=1)
+    gR = rng.randn(n, 3, 3).astype(np.float32)
+    gl = rng.randn(n).astype(np.float32)
+    Rt = torch.from_numpy(R).double().requires_grad_(True)
+    if kind == "lu9":
+        M = (np.eye(3)[None] + 0.25 * rng.randn(n, 3, 3)).astype(np.float32)
+        Mt = torch.from_numpy(M).double().requires_grad_(True)
+        Ro_w, l_w = orc.gs9(torch.linalg.inv(Mt) if inverse else Mt, Rt)
+        layer = Condition9TransLU(24)
+    elif kind == "lu16":
+        M = (np.eye(4)[None] + 0.25 * rng.randn(n, 4, 4)).astype(np.float32)
+        Mt = torch.from_numpy(M).double().requires_grad_(True)
+        Ro_w, l_w = orc.affine16(torch.linalg.inv(Mt) if inverse else Mt, Rt)
+        layer = Condition16TransLU(24)
+    else:
+        Q = np.linalg.qr(rng.randn(n, 4, 4))[0].astype(np.float32)
+        M = Q
+        Mt = torch.from_numpy(M).double().requires_grad_(True)
+        Ro_w, l_w = orc.rot16_apply(Mt.transpose(-1, -2) if inverse else Mt, Rt)
+        layer = ConditionRot(24)
+    ((Ro_w * torch.from_numpy(gR).double()).sum() + (l_w * torch.from_numpy(gl).double()).sum()).backward()
+    layer = layer.cuda().train()
+    Ml = torch.from_numpy(M).reshape(n, -1).cuda().requires_grad_(True)
+    layer._rnf_side = lambda feat, grad=False: Ml
+    Rd = torch.from_numpy(R).cuda().requires_grad_(True)
+    feat = torch.zeros(n, 24).cuda()
+    Ro, l = layer.inverse(Rd, None, feat) if inverse else layer(Rd, None, feat)
+    assert (Ro.detach().cpu().double() - Ro_w.detach()).abs().max() < 1e-5
+    assert (l.detach().cpu().double() - l_w.detach()).abs().max() < 2e-5
+    ((Ro * torch.from_numpy(gR).cuda()).sum() + (l * torch.from_numpy(gl).cuda()).sum()).backward()
+    g, want = Ml.grad.cpu().double().reshape(Mt.shape), Mt.grad
+    if kind == "rot16":                                    # the layer reports ldj = 0 for an orthogonal matrix: compare on its tangent space
+        sk = lambda G: torch.einsum("nji,njk->nik", Mt.detach(), G) - torch.einsum("nji,njk->nik", G, Mt.detach())  # noqa: E731
+        g, want = sk(g), sk(want)
+    assert ((g - want).abs().amax((1, 2)) / want.abs().amax((1, 2)).clamp_min(1e-3)).max() < 2e-4
+    tg, tw = tangent(R.astype(np.float64), Rd.grad.cpu().numpy().astype(np.float64)), tangent(R.astype(np.float64), Rt.grad.numpy())
+    assert np.abs(tg - tw).max() / max(np.abs(tw).max(), 1e-3) < 2e-4
+
+
+INVERSE_CASES = ["uncond_k16", "cond_k32", "cond_first_affine", "mobius_only", "lu", "rot", "gs9", "svdl9", "cgs9", "csvdl9", "csvdr9", "csmithr9", "gs36", "cgs36", "clu9"]
 
 
 @pytest.mark.parametrize("name", INVERSE_CASES)
@@ -346,18 +411,38 @@ def test_gradient_blob_sync_hook_is_applied():
         assert torch.allclose(p.grad, 0.5 * a, rtol=1e-4, atol=1e-7)
 
 
-def test_side_layers_refuse_training():
-    """The batch-coupled / SVD-convention layers (Condition16TransLU, ConditionRot: DESIGN 3.7) are inference only: a gradient-requiring
-    call is loud, not a silent detach."""
-    cfg = orc.make_config(layers=2, segments=16, condition=1, feature_dim=24, lu=1)
-    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=3)
+def test_condition_rot_trains():
+    """ConditionRot (flow/rottrans.py:37-66): U^T V of torch.svd follows the SVD routine's sign conventions, so the checker is the oracle
+    run in the SAME arithmetic as the product's host SVD (fp32 LAPACK): outputs and every gradient against fp32 oracle autograd."""
+    cfg = orc.make_config(layers=2, segments=16, condition=1, feature_dim=24, rot="16Rot")
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=31, regime="trained")
+    n = 80
+    R = synth.uniform_rotations(n, seed=32)
+    feat = synth.features(n, 24, seed=33)
+    rng = np.random.default_rng(34)
+    gR = rng.standard_normal((n, 3, 3)).astype(np.float32)
+    gl = rng.standard_normal(n).astype(np.float32)
+    p = {k: torch.from_numpy(v).float().requires_grad_(v.dtype.kind == "f") for k, v in w.items()}
+    Rt = torch.from_numpy(R).float()
+    ft = torch.from_numpy(feat).float().requires_grad_(True)
+    Ro_w, ldj_w = orc.flow_forward(cfg, p, Rt, ft, dtype=torch.float32, grad=True)
+    ((Ro_w * torch.from_numpy(gR)).sum() + (ldj_w * torch.from_numpy(gl)).sum()).backward()
     fl = product_flow(cfg, w).train()
-    R = torch.from_numpy(synth.uniform_rotations(32, seed=4)).cuda()
-    f = torch.from_numpy(synth.features(32, 24, seed=5)).cuda()
-    with pytest.raises(NotImplementedError):
-        fl(R, f)
-    with torch.no_grad():
-        fl(R, f)
+    fd = torch.from_numpy(feat).cuda().requires_grad_(True)
+    Ro, ldj = fl(torch.from_numpy(R).cuda(), fd)
+    assert np.abs(Ro.detach().cpu().numpy() - Ro_w.detach().numpy()).max() < 2e-4
+    ((Ro * torch.from_numpy(gR).cuda()).sum() + (ldj * torch.from_numpy(gl).cuda()).sum()).backward()
+    checked = 0
+    for k, prm in fl.named_parameters():
+        if p[k].grad is None:
+            continue
+        gw = p[k].grad.numpy()
+        err = np.abs(prm.grad.cpu().numpy() - gw).max() / max(np.abs(gw).max(), 1e-3)
+        assert err < 2e-3, (k, err)
+        checked += 1
+    assert checked > 20
+    gw = ft.grad.numpy()
+    assert np.abs(fd.grad.cpu().numpy() - gw).max() / max(np.abs(gw).max(), 1e-3) < 2e-3
 
 
 def test_graphed_train_step_follows_the_oracle():

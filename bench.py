@@ -189,7 +189,9 @@ def main():
             sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # a launcher started this rank (torchrun sets RANK): the collective leg runs even at world size 1, so that RCCL initialisation, the
+    # barrier and the {sum, count} all-reduce execute on a 1-GPU box exactly as they do on N (a 1-rank communicator)
+    distributed = world > 1 or "RANK" in os.environ
     if os.environ.get("RNF_BENCH_HANG_DUMP"):                 # diagnostics: dump every thread's stack and exit after that many seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["RNF_BENCH_HANG_DUMP"]), exit=True)

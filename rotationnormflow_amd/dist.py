@@ -54,18 +54,28 @@ def flow_evaluator(flow, base=None):
     return evaluate
 
 
-def all_reduce_mean_(blob: torch.Tensor, group=None) -> torch.Tensor:
-    """In-place average of one gradient blob over the ranks of ``group`` (no-op without a process group / with one rank)."""
+def all_reduce_mean_(blob: torch.Tensor, group=None, even_alone: bool = False) -> torch.Tensor:
+    """In-place average of one gradient blob over the ranks of ``group`` (no-op without a process group / with one rank, unless
+    ``even_alone``: then the collective is issued on the one-rank communicator too -- used to exercise the RCCL call, and its capture
+    into a HIP graph, on a single-GPU box)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         world = dist.get_world_size(group)
-        if world > 1:
+        if world > 1 or even_alone:
             dist.all_reduce(blob, op=dist.ReduceOp.SUM, group=group)
-            blob.div_(world)
+            if world > 1:
+                blob.div_(world)
     return blob
 
 
-def data_parallel_training(flow, group=None, enabled=True):
+def collectives_are_capturable(group=None) -> bool:
+    """True when the process group's collectives can be recorded into a HIP graph: the nccl (= RCCL) backend enqueues them on the
+    current stream; gloo runs them on the host and cannot."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
+
+
+def data_parallel_training(flow, group=None, enabled=True, even_alone=False):
     """Mark ``flow`` for data-parallel training: its backward pass averages the gradient blob over ``group`` (default: the world)
     with one all-reduce, so that every rank steps its optimizer with the gradient of the mean loss over the GLOBAL batch (what
     nn.DataParallel's reduce_add of replica gradients gives the reference, agent.py:22,79-90, when each rank's loss is the mean over
@@ -76,5 +86,5 @@ def data_parallel_training(flow, group=None, enabled=True):
             # their networks' gradients do not travel in the flow's gradient blob (they come back through the side matrices), and the LU
             # layers' matrices depend on which rows share a batch: sharding the batch would change the model being trained
             raise NotImplementedError(f"data-parallel training is not built for flows with {', '.join(side)} layers")
-    flow._rnf_grad_sync = (lambda blob: all_reduce_mean_(blob, group)) if enabled else None
+    flow._rnf_grad_sync = (lambda blob: all_reduce_mean_(blob, group, even_alone)) if enabled else None
     return flow

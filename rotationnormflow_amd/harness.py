@@ -141,7 +141,7 @@ class GraphedTrainStep:
 
 def train_uncondition(flow: Flow, train_rotations: torch.Tensor, iterations: int, batch_size: int = 1024, lr: float = 1e-4,
                       seed: int = 42, test_rotations: torch.Tensor = None, val_every: int = 0, ckpt_path=None, save_every: int = 0,
-                      base=None, device="cuda", log=print, graph: bool = True):
+                      base=None, device="cuda", log=print, graph: bool = True, data_parallel=None):
     """Maximum-likelihood training of an unconditional flow on a ``raw`` rotation set.  One iteration = the reference's
     ``Agent.train_func`` (agent.py:75-92): loss = mean(-ldj) (- mean base log-prob if ``base`` is given), zero_grad, backward, Adam
     step -- here three HIP launches (device packer, fused forward, fused backward) plus the optimizer; with ``graph`` (default) the
@@ -153,21 +153,26 @@ def train_uncondition(flow: Flow, train_rotations: torch.Tensor, iterations: int
     n = data.shape[0]
     # data parallel: every rank draws the SAME global mini-batch (same seed) and trains on its own contiguous slice of it; the
     # gradient blob is averaged over the ranks by one all-reduce inside backward (dist.data_parallel_training), so each rank takes
-    # the optimizer step of the global batch and the replicas stay identical.  Collectives are not captured into the HIP graph.
+    # the optimizer step of the global batch and the replicas stay identical.  Over RCCL the all-reduce is captured into the HIP
+    # graph of the iteration like any other launch (stream-ordered); over gloo (host collectives) the iteration runs eagerly.
     import torch.distributed as tdist
     world = tdist.get_world_size() if (tdist.is_available() and tdist.is_initialized()) else 1
     rank = tdist.get_rank() if world > 1 else 0
-    if world > 1:
-        from .dist import data_parallel_training, shard_bounds
-        data_parallel_training(flow)
-        graph = False
+    from .dist import collectives_are_capturable, data_parallel_training, shard_bounds
+    if world > 1 or data_parallel:                       # data_parallel=True forces the gradient all-reduce on a one-rank group too
+        data_parallel_training(flow, even_alone=bool(data_parallel) and world == 1)
+        if graph and not collectives_are_capturable():    # RCCL collectives are stream-ordered and captured with the rest of the
+            graph = False                                 # iteration; gloo's run on the host: eager iterations then
     if graph and host_preprocess_layers(flow):
         log(f"train_uncondition: {', '.join(host_preprocess_layers(flow))} need host-side linear algebra every iteration; training eagerly "
             "(no HIP graph)")
         graph = False
     opt = torch.optim.Adam(flow.parameters(), lr=lr, fused=True, capturable=graph)   # one launch instead of a dozen foreach kernels
     batch_size = min(batch_size, n)
-    gstep = GraphedTrainStep(flow, opt, (batch_size, 3, 3), base=base, device=device) if graph else None
+    if graph and world > 1 and batch_size % world:        # the graph has static shapes: every rank's slice must have the same size
+        raise ValueError(f"train_uncondition: batch_size {batch_size} must be a multiple of the world size {world} for graphed "
+                         "data-parallel training (or pass graph=False)")
+    gstep = GraphedTrainStep(flow, opt, (batch_size // world, 3, 3), base=base, device=device) if graph else None
     history, it, epoch = [], 0, 0
     while it < iterations:
         perm = torch.randperm(n, generator=gen).to(device)

@@ -75,3 +75,19 @@ def test_single_gpu_line_carries_both_arithmetics_and_every_config_runs():
         assert out.returncode == 0, (cfg, out.stderr[-2000:])
         rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
         assert rec["value"] > 0 and rec["config"]["workload"].startswith(cfg)
+
+
+def test_rccl_leg_executes_under_a_launcher_on_one_gpu():
+    """torchrun --nproc-per-node 1: the rank initialises the nccl (= RCCL) process group on its GPU and the barrier and the all-reduce of
+    {sum log p, count} go through RCCL (one-rank communicator) -- the collective leg of the N-GPU run, executed on the hardware at hand."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RNF_BENCH_SHARED_GPU")}
+    env["RNF_BENCH_HANG_DUMP"] = "200"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--batch-log2", "16", "--no-cpu-baseline", "--no-secondary"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["backend"] == "nccl" and rec["rccl_ranks"] == 1 and rec["n_gpus"] == 1 and rec["value"] > 0

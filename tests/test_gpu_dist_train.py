@@ -76,3 +76,47 @@ def test_two_ranks_train_like_one():
     assert diff.max() <= 1.5 * moved, (diff.max(), moved)
     ll = harness.mean_log_likelihood(fl, _data()[:1024], device="cuda")
     assert abs(ll0 - ll) < 2e-3 and ll0 == ll1, (ll0, ll1, ll)
+
+
+def _graph_worker(port, q):
+    import torch.distributed as dist
+    from rotationnormflow_amd import harness
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        fl = _make_flow()
+        # data_parallel=True: the gradient all-reduce is issued on the one-rank RCCL communicator and CAPTURED with the iteration
+        harness.train_uncondition(fl, _data(), iterations=6, batch_size=256, lr=2e-3, seed=3, log=lambda *a: None, graph=True, data_parallel=True)
+        ll = harness.mean_log_likelihood(fl, _data()[:1024], device="cuda")
+        q.put((torch.cat([p.detach().reshape(-1) for p in fl.parameters()]).cpu().numpy(), ll))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_is_captured_into_the_training_graph():
+    """The data-parallel iteration as ONE HIP graph: packer, forward, backward, the RCCL all-reduce of the gradient blob, fused Adam.  On a
+    1-GPU box the communicator has one rank (RCCL refuses two ranks on one device), which still records and replays the collective;
+    the trajectory must equal the eager single-process run."""
+    from rotationnormflow_amd import harness
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_graph_worker, args=(port, q))
+    proc.start()
+    try:
+        got, ll0 = q.get(timeout=420)
+    finally:
+        proc.join(60)
+        if proc.is_alive():
+            proc.kill()
+    fl = _make_flow()
+    harness.train_uncondition(fl, _data(), iterations=6, batch_size=256, lr=2e-3, seed=3, graph=False, log=lambda *a: None)
+    want = torch.cat([p.detach().reshape(-1) for p in fl.parameters()]).cpu().numpy()
+    start = torch.cat([p.detach().reshape(-1) for p in _make_flow().parameters()]).numpy()
+    moved = np.abs(want - start).max()
+    diff = np.abs(got - want)
+    assert np.quantile(diff, 0.99) < 2e-2 * moved, (np.quantile(diff, 0.99), moved)
+    ll = harness.mean_log_likelihood(fl, _data()[:1024], device="cuda")
+    assert abs(ll0 - ll) < 2e-3, (ll0, ll)

@@ -241,6 +241,122 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define RNF_TSTAMP(i)
 #endif
 
+// Rarely used layer kinds (side layers, 6x6 Gram-Schmidt, conditional 3x3).  Inlined: keeping them out of line (-DRNF_RARE_OOL) to shield the
+// common loop from their register needs measured SLOWER (graphed iteration, one box: C2 batch 1024 1.655 ms inlined / 1.691 ms out of
+// line / 1.667 ms with these kinds compiled out; C4 batch 128 2.509 / 2.526 / 2.462 ms), so the shipped build inlines them.
+#ifdef RNF_RARE_OOL
+#define RNF_RARE_FN __device__ __attribute__((noinline))
+#else
+#define RNF_RARE_FN __device__ __forceinline__
+#endif
+RNF_RARE_FN void rare_side(int kind, int dir, const float *m, const Rot *Rin, const Rot *gR, float g_ldj, float *gM_out, Rot *gRin_p) {
+    Rot gRin_v;
+    Rot &gRin_ref = gRin_v;
+    float gM[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gM[i] = 0.f;
+    {
+        Rot &gRin = gRin_ref;
+        const Rot &RinV = *Rin;
+        const Rot &gRV = *gR;
+                if (kind == RNF_KIND_SIDE9) {             // Condition9TransLU (squeezetrans.py:264-277): calculate_9, inverse pass M^-1
+                    float M9[9], g9[9];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) { M9[i] = m[i]; g9[i] = 0.f; }
+                    if (dir) {
+                        float Mi[9], gMi[9];
+                        inv3(M9, Mi);
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) gMi[i] = 0.f;
+                        gs9_backward(Mi, RinV, gRV, g_ldj, gMi, gRin);
+                        inverse_matrix_grad<3>(Mi, gMi, g9);
+                    } else {
+                        gs9_backward(M9, RinV, gRV, g_ldj, g9, gRin);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) gM[i] = g9[i];
+                } else {
+                    float M[16], Mi[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) M[i] = m[i];
+                    const bool orth = kind == RNF_KIND_SIDE16_ROT;      // ConditionRot (rottrans.py:37-66): ldj = 0, inverse pass M^T
+                    Rot Rout;
+                    AffineSaved sv;
+                    float l;
+                    if (orth) {
+                        if (dir) {
+                            float Mt[16], gMt[16];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) { Mt[4 * i + jj] = M[4 * jj + i]; gMt[4 * i + jj] = 0.f; }
+                            affine16_forward_saved(Mt, 0.f, RinV, Rout, l, sv);
+                            affine16_backward(Mt, sv, gRV, g_ldj, true, gMt, gRin);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) gM[4 * i + jj] = gMt[4 * jj + i];
+                        } else {
+                            affine16_forward_saved(M, 0.f, RinV, Rout, l, sv);
+                            affine16_backward(M, sv, gRV, g_ldj, true, gM, gRin);
+                        }
+                    } else {                                // Condition16TransLU (squeezetrans.py:134-144): as Condition16Trans, M given
+                        inv4(M, Mi);
+                        if (dir) {
+                            float gMi[16];
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) gMi[i] = 0.f;
+                            affine16_forward_saved(Mi, 0.f, RinV, Rout, l, sv);
+                            affine16_backward(Mi, sv, gRV, g_ldj, false, gMi, gRin);
+                            inverse_matrix_grad<4>(Mi, gMi, gM);
+                        } else {
+                            affine16_forward_saved(M, 0.f, RinV, Rout, l, sv);
+                            affine16_backward(M, sv, gRV, g_ldj, false, gM, gRin);
+                        }
+                        const float gl = dir ? -g_ldj : g_ldj;      // d log|det M| / dM = M^-T
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) gM[4 * i + jj] += gl * Mi[4 * jj + i];
+                    }
+                }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gM_out[i] = gM[i];
+    *gRin_p = gRin_v;
+}
+// calculate_36 with M[i] = src[i * stride] (+ diag on the diagonal); the inverse pass goes through M^-1
+RNF_RARE_FN void rare_gs36(const float *src, int stride, float diag, int dir, const Rot *Rin, const Rot *gR, float g_ldj, float *gM,
+                                                   Rot *gRin) {
+    float M[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) { M[i] = src[i * stride] + ((i % 7) == 0 ? diag : 0.f); gM[i] = 0.f; }
+    Rot g;
+    if (dir) {
+        float Mi[36], gMi[36];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) gMi[i] = 0.f;
+        inv6(M, Mi);
+        gs36_backward(Mi, *Rin, *gR, g_ldj, gMi, g);
+        inverse_matrix_grad<6>(Mi, gMi, gM);
+    } else {
+        gs36_backward(M, *Rin, *gR, g_ldj, gM, g);
+    }
+    *gRin = g;
+}
+// the conditional 3x3 kinds with M = I + (src[i * stride])
+RNF_RARE_FN void rare_cond9(int kind, int dir, const float *src, int stride, const Rot *Rin, const Rot *gR, float g_ldj, float *gM,
+                                                    Rot *gRin) {
+    float M[9], g9[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) M[i] = src[i * stride] + ((i % 4) == 0 ? 1.f : 0.f);
+    Rot g;
+    cond9_backward(kind, dir != 0, M, *Rin, *gR, g_ldj, g9, g);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gM[i] = g9[i];
+    *gRin = g;
+}
+
 template <bool HAS_FEATURE>
 __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(const TrainArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -289,70 +405,8 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                 const int slot = (d.x >> 16) & 255;
                 const float *m = args.side + ((size_t)slot * args.n + (valid ? sample : 0)) * 16;
                 float gM[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) gM[i] = 0.f;
                 Rot gRin;
-                if (kind == RNF_KIND_SIDE9) {             // Condition9TransLU (squeezetrans.py:264-277): calculate_9, inverse pass M^-1
-                    float M9[9], g9[9];
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) { M9[i] = m[i]; g9[i] = 0.f; }
-                    if (args.dir) {
-                        float Mi[9], gMi[9];
-                        inv3(M9, Mi);
-#pragma unroll
-                        for (int i = 0; i < 9; ++i) gMi[i] = 0.f;
-                        gs9_backward(Mi, Rin, gR, g_ldj, gMi, gRin);
-                        inverse_matrix_grad<3>(Mi, gMi, g9);
-                    } else {
-                        gs9_backward(M9, Rin, gR, g_ldj, g9, gRin);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) gM[i] = g9[i];
-                } else {
-                    float M[16], Mi[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) M[i] = m[i];
-                    const bool orth = kind == RNF_KIND_SIDE16_ROT;      // ConditionRot (rottrans.py:37-66): ldj = 0, inverse pass M^T
-                    Rot Rout;
-                    AffineSaved sv;
-                    float l;
-                    if (orth) {
-                        if (args.dir) {
-                            float Mt[16], gMt[16];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                                for (int jj = 0; jj < 4; ++jj) { Mt[4 * i + jj] = M[4 * jj + i]; gMt[4 * i + jj] = 0.f; }
-                            affine16_forward_saved(Mt, 0.f, Rin, Rout, l, sv);
-                            affine16_backward(Mt, sv, gR, g_ldj, true, gMt, gRin);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                                for (int jj = 0; jj < 4; ++jj) gM[4 * i + jj] = gMt[4 * jj + i];
-                        } else {
-                            affine16_forward_saved(M, 0.f, Rin, Rout, l, sv);
-                            affine16_backward(M, sv, gR, g_ldj, true, gM, gRin);
-                        }
-                    } else {                                // Condition16TransLU (squeezetrans.py:134-144): as Condition16Trans, M given
-                        inv4(M, Mi);
-                        if (args.dir) {
-                            float gMi[16];
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) gMi[i] = 0.f;
-                            affine16_forward_saved(Mi, 0.f, Rin, Rout, l, sv);
-                            affine16_backward(Mi, sv, gR, g_ldj, false, gMi, gRin);
-                            inverse_matrix_grad<4>(Mi, gMi, gM);
-                        } else {
-                            affine16_forward_saved(M, 0.f, Rin, Rout, l, sv);
-                            affine16_backward(M, sv, gR, g_ldj, false, gM, gRin);
-                        }
-                        const float gl = args.dir ? -g_ldj : g_ldj;      // d log|det M| / dM = M^-T
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) gM[4 * i + jj] += gl * Mi[4 * jj + i];
-                    }
-                }
+                rare_side(kind, args.dir, m, &Rin, &gR, g_ldj, gM, &gRin);
                 if (wave == 0 && valid && args.side_grad) {
                     float *o = args.side_grad + ((size_t)slot * args.n + sample) * 16;
 #pragma unroll
@@ -449,20 +503,9 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                 continue;
             }
             if (kind == RNF_KIND_GS36) {                  // Uncondition36Trans: M [36] in the plain blob (squeezetrans.py:350-361)
-                float M[36], gM[36];
-#pragma unroll
-                for (int i = 0; i < 36; ++i) { M[i] = P[i]; gM[i] = 0.f; }
+                float gM[36];
                 Rot gRin;
-                if (args.dir) {                           // the inverse pass applies M^-1 (squeezetrans.py:359-361)
-                    float Mc[36], Mi[36], gMi[36];
-#pragma unroll
-                    for (int i = 0; i < 36; ++i) { Mc[i] = M[i]; gMi[i] = 0.f; }
-                    inv6(Mc, Mi);
-                    gs36_backward(Mi, Rin, gR, g_ldj, gMi, gRin);
-                    inverse_matrix_grad<6>(Mi, gMi, gM);
-                } else {
-                    gs36_backward(M, Rin, gR, g_ldj, gM, gRin);
-                }
+                rare_gs36(P, 1, 0.f, args.dir, &Rin, &gR, g_ldj, gM, &gRin);     // the inverse pass applies M^-1 (squeezetrans.py:359-361)
                 if (want_w) {                             // batch sums through LDS, 16 entries per round (wave 0), three rounds
 #pragma unroll
                     for (int base = 0; base < 48; base += 16) {
@@ -679,19 +722,8 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                 lds_barrier();
             } else if (kind == RNF_KIND_COND36) {
                 // Condition36Trans (squeezetrans.py:334-347): M = I + reshape(net(f), 6, 6) per sample; the inverse pass applies M^-1
-                float M[36], gM[36];
-#pragma unroll
-                for (int i = 0; i < 36; ++i) { M[i] = Cm.at(i, lane) + ((i % 7) == 0 ? 1.f : 0.f); gM[i] = 0.f; }
-                if (args.dir) {
-                    float Mc[36], Mi[36], gMi[36];
-#pragma unroll
-                    for (int i = 0; i < 36; ++i) { Mc[i] = M[i]; gMi[i] = 0.f; }
-                    inv6(Mc, Mi);
-                    gs36_backward(Mi, Rin, gR, g_ldj, gMi, gRin);
-                    inverse_matrix_grad<6>(Mi, gMi, gM);
-                } else {
-                    gs36_backward(M, Rin, gR, g_ldj, gM, gRin);
-                }
+                float gM[36];
+                rare_gs36(Cm.p + lane, LROW, 1.f, args.dir, &Rin, &gR, g_ldj, gM, &gRin);
                 lds_barrier();                          // every wave has read C
                 if (wave == 0) {
 #pragma unroll
@@ -700,10 +732,8 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
                 lds_barrier();
             } else if (kind_is_cond9(kind)) {
                 // Condition9Trans / 9RotL / 9RotR / 9RotRSmith (squeezetrans.py:234-247, rottrans.py:108-181): M = I + reshape(net(f), 3, 3)
-                float M[9], gM[9];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) M[i] = Cm.at(i, lane) + ((i % 4) == 0 ? 1.f : 0.f);
-                cond9_backward(kind, args.dir != 0, M, Rin, gR, g_ldj, gM, gRin);
+                float gM[9];
+                rare_cond9(kind, args.dir, Cm.p + lane, LROW, &Rin, &gR, g_ldj, gM, &gRin);
                 lds_barrier();                          // every wave has read C
                 if (wave == 0) {
 #pragma unroll

@@ -13,6 +13,11 @@ namespace rnf {
 
 constexpr int MAX_SLOTS = 224;
 constexpr int FP_KCHUNK = 256;               // features held in registers at a time (128 VGPRs of B fragments)
+#ifdef RNF_FP_BURST
+constexpr bool FP_SPREAD = false;            // A/B switch: every global access of a tile in one burst behind its barrier
+#else
+constexpr bool FP_SPREAD = true;
+#endif
 
 struct FeatProjArgs {
     const float *feat;       // [n, F] row-major, F % 8 == 0
@@ -55,6 +60,15 @@ struct GOut {
         return c;
     }
 };
+
+// asynchronous LDS read of one 16-byte operand fragment: the data is valid only behind an s_waitcnt lgkmcnt(0) that takes `d` as an operand
+template <int OFF>
+__device__ __forceinline__ void fp_lds_read(h8 &d, unsigned lds_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(lds_addr), "n"(OFF));
+}
+__device__ __forceinline__ void fp_lds_read_at(h8 &d, unsigned lds_addr, int off) {       // `off` is a compile-time constant after unrolling
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(lds_addr), "n"(off));
+}
 
 template <int NW, int PREC>
 __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs args) {
@@ -171,20 +185,97 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
 #pragma unroll
                     for (int q = 0; q < 4; ++q) gout.store(q, make_float4(pend[4 * q], pend[4 * q + 1], pend[4 * q + 2], pend[4 * q + 3]));
                 };
+                // SPREAD (full chunks, 8 waves): the tile's 12 vector-memory instructions per wave -- 4 DMA pieces of the next weight tile, 4
+                // pieces of the next accumulator start, 4 stores of the previous result -- ride ONE PER K-STEP behind the matrix
+                // instructions instead of going out in one burst behind the barrier, where all eight waves queued 96 KB at the texture
+                // unit while the matrix pipe sat idle.
+                const bool spread = FP_SPREAD && NW == 8 && ns == FP_KCHUNK / 16 && !args.row_mode;
                 for (int t = 0; t < n_t; ++t) {
                     const float *wl = lds + (t & 1) * BUF;
                     dma_wait_all();
                     __syncthreads();                               // tile t is complete; nobody still reads the other buffer
-                    if (t + 1 < n_t) {
-                        dma_floats(lds + ((t + 1) & 1) * BUF, tile_src(t + 1), ns * 512, wave, lane, NW);
-                        nxt0 = start_of(t + 1);
+                    if (!spread) {
+                        if (t + 1 < n_t) {
+                            dma_floats(lds + ((t + 1) & 1) * BUF, tile_src(t + 1), ns * 512, wave, lane, NW);
+                            nxt0 = start_of(t + 1);
+                        }
+                        flush();                                   // tile t - 1
                     }
-                    flush();                                       // tile t - 1
                     __builtin_amdgcn_sched_barrier(0);
                     f32x16 acc1 = cur0, acc2;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-                    if (ns == FP_KCHUNK / 16) {                    // full chunk: branch-free
+                    if (spread) {
+                        const bool more = t + 1 < n_t;
+                        const float *nsrc = tile_src(more ? t + 1 : t);
+                        float *ndst = lds + ((t + 1) & 1) * BUF;
+                        const float4 *nstart;                      // the four 16-byte pieces of the next tile's accumulator start
+                        int nstride;
+                        {
+                            const int tn = more ? t + 1 : t, slot = tn >> 1, ot = tn & 1;
+                            if (kc == 0) {
+                                nstart = reinterpret_cast<const float4 *>(args.blob + args.feat_off[slot] + (size_t)2 * nsteps_all * 512 + (ot * 2 + h) * 16);
+                                nstride = 1;
+                            } else {
+                                const GOut g(args, slot, group, sample, valid, ot, lane, h);
+                                nstart = g.p;
+                                nstride = g.stride;
+                            }
+                        }
+                        const GOut pout(args, (pend_t < 0 ? 0 : pend_t) >> 1, group, sample, valid, (pend_t < 0 ? 0 : pend_t) & 1, lane, h);
+                        // one k-step of operand look-ahead: the A fragments of step s + 1 are requested BEFORE the matrix instructions of step
+                        // s.  Left to the compiler every step was "multiply, then read the next operands into the same registers, wait": the
+                        // LDS latency (eight waves ask for 2 KiB each per step) in series with the three matrix instructions, at two waves per
+                        // SIMD -- matrix pipe 41 % busy.  The compiler sinks plain LDS loads back to their use, so the reads are issued by
+                        // inline asm and consumed behind an explicit lgkmcnt(0) through which their registers pass as operands.
+                        const unsigned wl_lds = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)wl + 16u * lane;
+                        h8 ah, al;
+                        fp_lds_read<0>(ah, wl_lds);
+                        fp_lds_read<1024>(al, wl_lds);
+#pragma unroll
+                        for (int s = 0; s < FP_KCHUNK / 16; ++s) {
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah), "+v"(al) :: "memory");
+                            h8 nah = ah, nal = al;
+                            if (s + 1 < FP_KCHUNK / 16) {
+                                fp_lds_read_at(nah, wl_lds, (s + 1) * 2048);
+                                fp_lds_read_at(nal, wl_lds, (s + 1) * 2048 + 1024);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#ifndef RNF_FPKO_MFMA
+                            acc1 = RNF_MFMA_H(ah, bh[s], acc1);
+                            acc2 = RNF_MFMA_H(ah, bl[s], acc2);
+                            acc2 = RNF_MFMA_H(al, bh[s], acc2);
+#else
+                            acc1[s] += (float)ah[0] + (float)al[1];
+#endif
+                            ah = nah; al = nal;
+                            __builtin_amdgcn_sched_barrier(0);
+#ifdef RNF_FPKO_HALFDMA
+                            if (s < 2) {
+#else
+                            if (s < 4) {
+#endif
+#ifndef RNF_FPKO_DMA
+                                if (more) {
+                                    const int base = wave * 64 + s * (NW * 64);       // float4 index, wave uniform: 1 KiB per instruction
+                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nsrc + 4 * (size_t)(base + lane)),
+                                                                     (__attribute__((address_space(3))) void *)(ndst + 4 * base), 16, 0, 0);
+                                }
+#endif
+                            } else if (s < 8) {
+                                if (more) {
+                                    const float4 v = nstart[(s - 4) * nstride];
+                                    nxt0[4 * (s - 4)] = v.x; nxt0[4 * (s - 4) + 1] = v.y; nxt0[4 * (s - 4) + 2] = v.z; nxt0[4 * (s - 4) + 3] = v.w;
+                                }
+                            } else if (s < 12) {
+#ifndef RNF_FPKO_STORE
+                                if (pend_t >= 0)
+                                    pout.store(s - 8, make_float4(pend[4 * (s - 8)], pend[4 * (s - 8) + 1], pend[4 * (s - 8) + 2], pend[4 * (s - 8) + 3]));
+#endif
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else if (ns == FP_KCHUNK / 16) {             // full chunk: branch-free
 #pragma unroll
                         for (int s = 0; s < FP_KCHUNK / 16; ++s) {
                             const h8 ah = lds_h8(wl, (s * 2 + 0) * 64 + lane);

@@ -33,8 +33,9 @@ class TrainPlan:
         self.segments = ks.pop() if ks else 8
         self.feat_dim = fs.pop() if fs else 0
         self.feat_padded = runtime.pad8(self.feat_dim)
-        if self.segments > 64 or self.segments % 8:
-            raise NotImplementedError("training path: segments must be a multiple of 8, at most 64")
+        if self.segments > 64:
+            raise NotImplementedError("training path: at most 64 segments (the backward kernel keeps the conditioner outputs of 64 "
+                                      "rotations in LDS)")
         self.precision = precision
         self.prec = runtime._PRECISIONS[precision]
         self.n_layers = n

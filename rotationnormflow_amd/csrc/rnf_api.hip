@@ -901,7 +901,7 @@ extern "C" int rnf_pack_flow_device(const float *plain, const int32_t *pdesc, in
                                     float *blob, int32_t *flags, void *stream_v) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     if (n_layers < 0 || n_layers > PK_MAX_LAYERS) return fail("n_layers=%d outside [0,%d] (device packer)", n_layers, PK_MAX_LAYERS);
-    if (K <= 0 || K % 8) return fail("segments=%d must be a positive multiple of 8", K);
+    if (K <= 0) return fail("segments=%d must be positive", K);
     if (F < 0) return fail("feature_dim %d is negative", F);
     if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2) return fail("unknown precision %d", prec);
     if (n_layers == 0) return 0;

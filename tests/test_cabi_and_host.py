@@ -185,7 +185,7 @@ def test_argument_validation_happens_before_any_gpu_work():
     assert L.rnf_flow_backward(*args) == 0                                  # empty batch: nothing to do
     pdesc = np.array([[15, 0, 0, -1]], np.int32)
     assert L.rnf_pack_flow_device(buf.ctypes.data, pdesc.ctypes.data, 1, 64, 0, 1, buf.ctypes.data, buf.ctypes.data, None) != 0 and "kind" in err()
-    assert L.rnf_pack_flow_device(buf.ctypes.data, pdesc.ctypes.data, 1, 60, 0, 1, buf.ctypes.data, buf.ctypes.data, None) != 0 and "multiple of 8" in err()
+    assert L.rnf_pack_flow_device(buf.ctypes.data, pdesc.ctypes.data, 1, 0, 0, 1, buf.ctypes.data, buf.ctypes.data, None) != 0 and "must be positive" in err()
     assert L.rnf_plain_layer_floats(1, 64, 0) == 29376 and L.rnf_plain_layer_floats(2, 64, 0) == 16
     assert L.rnf_plain_layer_floats(3, 64, 40) == 64 * 40 + 64 + 3 * 4160 + 16 * 65
     # shared feature rows

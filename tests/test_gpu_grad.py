@@ -41,6 +41,8 @@ def oracle_grads(cfg, w, R, feat, gR, gl, dtype=torch.float64):
 CASES = {
     # name: (config kwargs, n, regime)
     "uncond_k16": (dict(layers=3, segments=16), 200, "trained"),
+    "uncond_k20": (dict(layers=2, segments=20), 90, "trained"),            # segment counts that are not multiples of 8 train too
+    "cond_k11": (dict(layers=2, segments=11, condition=1, feature_dim=24), 70, "trained"),
     "uncond_k64_24": (dict(layers=12, segments=64), 333, "default"),
     "cond_k32": (dict(layers=2, segments=32, condition=1, feature_dim=40), 150, "trained"),
     "cond_first_affine": (dict(layers=2, segments=16, condition=1, feature_dim=24, last_affine=1), 130, "default"),
@@ -178,7 +180,7 @@ def test_side_kernels_in_isolation(kind, inverse):
     assert np.abs(tg - tw).max() / max(np.abs(tw).max(), 1e-3) < 2e-4
 
 
-INVERSE_CASES = ["uncond_k16", "cond_k32", "cond_first_affine", "mobius_only", "lu", "rot", "gs9", "svdl9", "cgs9", "csvdl9", "csvdr9", "csmithr9", "gs36", "cgs36", "clu9"]
+INVERSE_CASES = ["uncond_k16", "uncond_k20", "cond_k11", "cond_k32", "cond_first_affine", "mobius_only", "lu", "rot", "gs9", "svdl9", "cgs9", "csvdl9", "csvdr9", "csmithr9", "gs36", "cgs36", "clu9"]
 
 
 @pytest.mark.parametrize("name", INVERSE_CASES)
@@ -356,6 +358,15 @@ def test_training_loss_with_matrix_fisher_base():
         gw = want[k].numpy()
         err = np.abs(prm.grad.cpu().numpy() - gw).max() / max(np.abs(gw).max(), 1e-3)
         assert err < REL, (k, err)
+    # the fused entry point under autograd: the same loss from Flow.log_prob's {sum, count}
+    fl.zero_grad()
+    res = fl.log_prob(torch.from_numpy(R).cuda(), base=base)
+    loss2 = -res["sum"][0] / res["sum"][1]
+    assert abs(float(loss2.detach()) - float(loss_o.detach())) < 2e-5
+    loss2.backward()
+    for k, prm in fl.named_parameters():
+        gw = want[k].numpy()
+        assert np.abs(prm.grad.cpu().numpy() - gw).max() / max(np.abs(gw).max(), 1e-3) < REL, k
     # a parameter matrix that requires grad (a predicted A, agent.py:57-65) gets its gradient, normaliser included
     A64 = torch.from_numpy(A).double().requires_grad_(True)
     (-orc.fisher_log_prob(Ro.detach(), A64, dtype=torch.float64)).mean().backward()

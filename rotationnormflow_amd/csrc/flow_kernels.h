@@ -468,36 +468,6 @@ __device__ __forceinline__ void mobius_begin(const Rot &R, int perm_row, MobiusC
     if (S7) c.f = scale_frame(c.f, kSquash);
 }
 
-// LEAN forward: the permutation row of a layer is wave uniform and only its residue mod 3 matters (the table's rows are the three cyclic
-// shifts, flow/flow.py:13-15, for which the third column is always tx x y), so the layer's begin and finish are instantiated per shift
-// and reached through a uniform branch: the column reads and writes name registers instead of going through ~30 v_cndmask per layer.
-template <int P> __device__ __forceinline__ v3f &col_of(Rot &R) { if constexpr (P == 0) return R.c0; else if constexpr (P == 1) return R.c1; else return R.c2; }
-template <int P0>
-__device__ __forceinline__ void mobius_begin_fixed(Rot &R, MobiusCtx &c) {
-    const v3f x = col_of<P0>(R);
-    c.y = col_of<(P0 + 1) % 3>(R);
-    c.p0 = P0;
-    c.p2 = (P0 + 2) % 3;
-    c.cyc = true;
-    c.zc = -1.f; c.zs = 0.f; c.zth = 3.14159265358979323846f;      // (unused by the S7 segment: the input point is (-1, 0) by construction)
-    c.target = 0.f;
-    c.f = scale_frame(make_frame(x, c.y), kSquash);
-}
-template <int P0>
-__device__ __forceinline__ void mobius_fwd_finish_fixed(const MobiusCtx &c, float S, float A, float J, Rot &R, float &ldj) {
-    S = pair_sum(S);
-    A = pair_sum(A);
-    J = pair_sum(J);
-    const float invS = hw_rcp(S);
-    float sn, cs;
-    sincos_small(2.0f * A * invS, sn, cs);
-    sn *= -kInvSquash; cs *= -kInvSquash;
-    const v3f tx = c.f.v * sn + c.f.r * cs;
-    col_of<P0>(R) = tx;
-    col_of<(P0 + 2) % 3>(R) = normalize3(cross3(tx, c.y));
-    ldj += logf(J * invS);
-}
-
 // HALF (split-precision kernels): A accumulates sp * atan(t), mobius_fwd_finish<true> adds the constant part (so3_math.h)
 template <bool HALF>
 __device__ __forceinline__ void segments4(const f32x16 &o, const MobiusCtx &c, float &S, float &A, float &J) {
@@ -999,11 +969,6 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 template <int DIR, int KT_INV, int NW, bool PIPE, int PREC, bool EXT = false, bool LEAN = false>
 __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-#ifdef RNF_NO_LEAN_FIXED
-    constexpr bool LEAN_FIXED = false;
-#else
-    constexpr bool LEAN_FIXED = LEAN && DIR == 0 && PREC == 1;       // begin / finish per cyclic shift (mobius_begin_fixed)
-#endif
     if (args.guard_mode == 2) {                                      // fp32 re-run of a split-precision call: only when its guard fired
         if (__hip_atomic_load(args.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
         if (blockIdx.x == 0 && threadIdx.x == 0) args.guard[1] = 1;
@@ -1176,14 +1141,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             MobiusCtx ctx;
             typename Mlp<PREC>::Act tt;
             if (LEAN || kind == RNF_KIND_MOBIUS) {
-                if constexpr (LEAN_FIXED) {
-                    const int sh = perm_row % 3;                  // wave uniform
-                    if (sh == 0) mobius_begin_fixed<0>(R, ctx);
-                    else if (sh == 1) mobius_begin_fixed<1>(R, ctx);
-                    else mobius_begin_fixed<2>(R, ctx);
-                } else {
-                    mobius_begin<DIR, DIR == 0 && PREC == 1>(R, perm_row, ctx);
-                }
+                mobius_begin<DIR, DIR == 0 && PREC == 1>(R, perm_row, ctx);
                 Mlp<PREC>::head(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair, bad);
             } else {
                 Mlp<PREC>::head(lds, lane, h, 0.f, 0.f, 0.f, gfrag, tt, fair, bad);
@@ -1231,13 +1189,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC, LEAN>(lds, KT, args.K, lane, h, tt, ctx, S, A, J, fair);
                     else mobius_fwd_tiles_restage<PREC>(lds, params, KT, args.K, lane, h, tt, ctx, S, A, J, tid, NT);
                     barrier2();
-                    if constexpr (LEAN_FIXED) {
-                        if (ctx.p0 == 0) mobius_fwd_finish_fixed<0>(ctx, S, A, J, R, ldj);
-                        else if (ctx.p0 == 1) mobius_fwd_finish_fixed<1>(ctx, S, A, J, R, ldj);
-                        else mobius_fwd_finish_fixed<2>(ctx, S, A, J, R, ldj);
-                    } else {
-                        mobius_fwd_finish<PREC == 1>(ctx, S, A, J, R, ldj);
-                    }
+                    mobius_fwd_finish<PREC == 1>(ctx, S, A, J, R, ldj);
                 }
             } else {
                 const f32x16 o16 = Mlp<PREC>::last(lds + MOB_LAST, lane, h, tt);

@@ -252,6 +252,22 @@ class _FlowFn(torch.autograd.Function):
         return (None, None, None, g_rotation, g_feature, g_side if needs[5] else None, *outs)
 
 
+# packer status words of _CondMLPFn calls: read back through pinned memory and checked at the next call (no step waits for the device)
+_pending_mlp_flags = []
+
+
+def _check_mlp_flags():
+    keep = []
+    for ev, host in _pending_mlp_flags:
+        if not ev.query():
+            keep.append((ev, host))
+        elif int(host[0]) & 1:
+            _pending_mlp_flags[:] = keep
+            raise runtime.HalfRangeError("a weight of a side layer's conditioner left the fp16 range during training (that step produced "
+                                         "inf/NaN); continue with rotationnormflow_amd.set_precision('fp32')")
+    _pending_mlp_flags[:] = keep
+
+
 class _CondMLPFn(torch.autograd.Function):
     """One ConditionalTransform(F -> n_out <= 16) on the GPU, differentiable: forward = device packer + rnf_cond_mlp_forward, backward =
     rnf_cond_mlp_backward (the training backward kernel with the layer math replaced by dL/d(outputs)).  The networks of the side layers
@@ -273,6 +289,9 @@ class _CondMLPFn(torch.autograd.Function):
         rec = (L.rnf_cond16_packed_floats() + 3) // 4 * 4
         blob = torch.empty(rec + L.rnf_featproj_packed_floats(Fp), dtype=f32, device=dev)
         pack_desc = np.array([[runtime.KIND_COND16, 0, 0, rec]], dtype=np.int32)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            _check_mlp_flags()
         flags = torch.zeros(1, dtype=torch.int32, device=dev)
         out = torch.empty((n, 16), dtype=f32, device=dev)
         fpad = torch.nn.functional.pad(feat, (0, Fp - F)) if Fp != F else feat
@@ -283,6 +302,12 @@ class _CondMLPFn(torch.autograd.Function):
                 _lib.check(L.rnf_pack_flow_device(plain16.data_ptr(), pack_desc.ctypes.data, 1, 8, F, prec, blob.data_ptr(), flags.data_ptr(), stream))
                 _lib.check(L.rnf_cond_mlp_forward(fpad.data_ptr(), n, Fp, blob.data_ptr(), 0, rec, prec, out.data_ptr(), ws.data_ptr(), ws.numel(),
                                                   stream))
+                if prec and not capturing and len(_pending_mlp_flags) < 64:
+                    host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                    host.copy_(flags, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    _pending_mlp_flags.append((ev, host))
         ctx.n_out = n_out
         ctx.shapes = [(t.shape, t.device, t.dtype) for t in tensors]
         ctx.sizes = [t.numel() for t in tensors]

@@ -89,3 +89,30 @@ def test_feature_overflow_falls_back_to_fp32():
     _, lw = orc.flow_forward(cfg, w, R.cpu().numpy(), feat, dtype=torch.float64)
     err = np.abs(ldj.cpu().double().numpy() - lw.numpy())
     assert np.quantile(err, 0.99) < 1e-3, err.max()
+
+
+def test_side_layer_conditioner_overflow_is_reported_one_call_later():
+    """Training a flow with a side layer (Condition16TransLU): a weight of the layer's conditioner beyond the fp16 range is reported by the
+    device packer through a status word read one call later (no step waits for the device), as for the flow's own blob."""
+    import contextlib
+    import io
+    from rotationnormflow_amd import runtime, synth
+    from rotationnormflow_amd.configs import make_config
+    from rotationnormflow_amd.flow.flow import Flow
+    if runtime.get_precision() != "f16x2":
+        pytest.skip("only the split-precision kernels have a range limit")
+    cfg = make_config(layers=1, segments=8, condition=1, feature_dim=24, lu=1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        fl = Flow(cfg)
+    shapes = {k: tuple(v.shape) for k, v in fl.state_dict().items()}
+    fl.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=7).items()})
+    fl = fl.cuda().train()
+    side = [m for m in fl.modules() if type(m).__name__ == "ConditionLU"][0]
+    with torch.no_grad():
+        side.w_l_net.layers[1].weight[0, 0] = 1.0e5
+    R = torch.from_numpy(synth.uniform_rotations(64, seed=1)).cuda()
+    f = torch.from_numpy(synth.features(64, 24, seed=2)).cuda()
+    with pytest.raises(runtime.HalfRangeError):           # surfaces at the next conditioner call whose predecessor's status word has landed
+        fl(R, f)
+        torch.cuda.synchronize()
+        fl(R, f)

@@ -191,6 +191,26 @@ def test_argument_validation_happens_before_any_gpu_work():
     # shared feature rows
     assert L.rnf_workspace_bytes_shared(1 << 20, 42, 512) == 4096 * 8 + 42 * 2048 * 64 * 4
     assert L.rnf_workspace_bytes_shared(1 << 20, 42, 0) == L.rnf_workspace_bytes(1 << 20, 42)
+    # round-2 entry points: plain-blob sizes of the new trainable kinds, side-layer training, the conditioner backward, the Fisher gradient
+    assert L.rnf_plain_layer_floats(5, 64, 0) == 36 and L.rnf_plain_layer_floats(11, 64, 24) == 0
+    assert L.rnf_plain_layer_floats(6, 64, 24) == 64 * 24 + 64 + 3 * 4160 + 9 * 65
+    assert L.rnf_plain_layer_floats(10, 64, 24) == 64 * 24 + 64 + 3 * 4160 + 36 * 65
+    sdesc = np.array([[11 | (0 << 16), 0, 0]], np.int32)
+    args = (0, buf.ctypes.data, None, None, 64, 0, buf.ctypes.data, sdesc.ctypes.data, 1, 16, None, None, None, buf.ctypes.data, None, buf.ctypes.data,
+            None, buf.ctypes.data, None)
+    assert L.rnf_flow_backward_side(*args) != 0 and "side" in err()             # a side layer without its side / side_grad buffers
+    args = (2,) + args[1:]
+    assert L.rnf_flow_backward_side(*args) != 0 and "dir" in err()
+    assert L.rnf_flow_train_side(3, None, None, 0, 0, None, None, None, 1, 8, None, None, None, None, 0, None) != 0 and "dir" in err()
+    assert L.rnf_cond_mlp_backward(buf.ctypes.data, 64, 24, buf.ctypes.data, 65, buf.ctypes.data, None, None, buf.ctypes.data, None) != 0 and "n_out" in err()
+    assert L.rnf_cond_mlp_backward(None, 64, 24, buf.ctypes.data, 16, buf.ctypes.data, None, None, buf.ctypes.data, None) != 0 and "null" in err()
+    assert L.rnf_fisher_scratch_bytes(7) == (2 + 70) * 8
+    assert L.rnf_fisher_log_const_nt(buf.ctypes.data, 3, 2, buf.ctypes.data, 16, buf.ctypes.data, None) != 0 and "norm_type" in err()
+    assert L.rnf_fisher_log_const_nt(buf.ctypes.data, 3, 0, None, 0, buf.ctypes.data, None) != 0 and "scratch" in err()
+    assert L.rnf_fisher_log_prob_backward_param(buf.ctypes.data, buf.ctypes.data, 10, buf.ctypes.data, 3, 1, buf.ctypes.data, 4096, buf.ctypes.data,
+                                                None) != 0 and "divisible" in err()
+    assert L.rnf_fisher_log_prob_backward_param(buf.ctypes.data, buf.ctypes.data, 9, buf.ctypes.data, 3, 1, buf.ctypes.data, 8, buf.ctypes.data,
+                                                None) != 0 and "scratch" in err()
     # small kernels
     assert L.rnf_min_geodesic(None, None, 5, 0, None, None) != 0
     assert L.rnf_fisher_log_const(None, 3, None, None) != 0

@@ -297,6 +297,11 @@ int rnf_fisher_log_const(const float *A_dev, int64_t B, float *c_out_dev, void *
  *   the call (batch-coupled, reproduced as is).  Types 2 (Monte-Carlo over pytorch3d random rotations) and 3 (scipy ODE; indexes rows
  *   of the [B,3] tensor) are refused.  scratch_dev: rnf_fisher_scratch_bytes(B) bytes of device memory (16 suffice here). */
 size_t rnf_fisher_scratch_bytes(int64_t B);
+/* norm_type 2 (utils/fisher.py:98-101): Monte-Carlo normaliser over approx_num uniform rotations for ONE matrix (B must be 1: the
+ * reference broadcasts [approx_num,3,3] against [N,3,3]); counter-based Philox stream keyed by `seed` (statistical parity with the
+ * reference's pytorch3d.random_rotations).  scratch_dev: 8 bytes. */
+int rnf_fisher_log_const_mc(const float *A_dev, int64_t B, int64_t approx_num, uint64_t seed, void *scratch_dev, size_t scratch_bytes,
+                            float *c_out_dev, void *stream);
 int rnf_fisher_log_const_nt(const float *A_dev, int64_t B, int32_t norm_type, void *scratch_dev, size_t scratch_bytes,
                             float *c_out_dev, void *stream);
 

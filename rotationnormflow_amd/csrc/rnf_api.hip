@@ -1187,6 +1187,58 @@ extern "C" int rnf_fisher_log_const(const float *A, int64_t B, float *c_out, voi
     return fisher_const_launch(A, B, 1, nullptr, c_out, reinterpret_cast<hipStream_t>(stream));
 }
 
+// norm_type 2 (utils/fisher.py:98-101): Monte-Carlo estimate of the normaliser over `approx_num` uniform rotations -- norm = mean_k
+// exp(tr(R_k^T A) - sum S), hence c = sum S + log norm.  The reference broadcasts [approx_num,3,3] * [N,3,3], i.e. it serves ONE matrix
+// (N = 1).  Uniform rotations from normalised Gaussian quaternions on the counter-based Philox stream of the sampler (the reference uses
+// pytorch3d.transforms.random_rotations on torch's generator: parity is statistical, error ~ 1/sqrt(approx_num)).
+__global__ void fisher_mc_accum_kernel(const float *A, long long n_mc, unsigned long long seed, double *acc /* [0] = sum exp(tr - sumS) */) {
+    double a[9], U[9], s[3], V[9];
+    for (int k = 0; k < 9; ++k) a[k] = A[k];
+    proper_svd3(a, U, s, V);
+    const float sumS = (float)(s[0] + s[1] + s[2]);
+    float af[9];
+    for (int k = 0; k < 9; ++k) af[k] = A[k];
+    const Philox rng{(unsigned)seed, (unsigned)(seed >> 32)};
+    double part = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_mc; i += (long long)gridDim.x * blockDim.x) {
+        unsigned c0[4] = {(unsigned)i, (unsigned)(i >> 32), 0x4d43u, 0u};
+        rng(c0);
+        const float r0 = sqrtf(-2.0f * logf(u01(c0[0]))), r1 = sqrtf(-2.0f * logf(u01(c0[2])));
+        float s0, k0, s1, k1;
+        sincosf(kTwoPi * u01(c0[1]), &s0, &k0);
+        sincosf(kTwoPi * u01(c0[3]), &s1, &k1);
+        const float q[4] = {r0 * k0, r0 * s0, r1 * k1, r1 * s1};
+        Rot R;
+        quat_to_rot(q, q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3], R);
+        const float tr = R.c0.x * af[0] + R.c1.x * af[1] + R.c2.x * af[2] + R.c0.y * af[3] + R.c1.y * af[4] + R.c2.y * af[5] + R.c0.z * af[6] +
+                         R.c1.z * af[7] + R.c2.z * af[8];
+        part += (double)expf(tr - sumS);
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(acc, part);
+}
+__global__ void fisher_mc_final_kernel(const float *A, long long n_mc, const double *acc, float *c_out) {
+    double a[9], U[9], s[3], V[9];
+    for (int k = 0; k < 9; ++k) a[k] = A[k];
+    proper_svd3(a, U, s, V);
+    c_out[0] = (float)(s[0] + s[1] + s[2] + log(acc[0] / (double)n_mc));
+}
+extern "C" int rnf_fisher_log_const_mc(const float *A, int64_t B, int64_t approx_num, uint64_t seed, void *scratch, size_t scratch_bytes, float *c_out,
+                                       void *stream) {
+    if (!A || !c_out || !scratch) return fail("rnf_fisher_log_const_mc: null pointer");
+    if (B != 1) return fail("rnf_fisher_log_const_mc: the reference's norm_type 2 broadcasts its random rotations against ONE matrix (got B=%lld)", (long long)B);
+    if (approx_num <= 0) return fail("rnf_fisher_log_const_mc: approx_num=%lld must be positive", (long long)approx_num);
+    if (scratch_bytes < sizeof(double)) return fail("rnf_fisher_log_const_mc: 8 bytes of scratch are needed");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(double), st));
+    long long blocks = (approx_num + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fisher_mc_accum_kernel, dim3((int)blocks), dim3(256), 0, st, A, (long long)approx_num, (unsigned long long)seed, static_cast<double *>(scratch));
+    hipLaunchKernelGGL(fisher_mc_final_kernel, dim3(1), dim3(1), 0, st, A, (long long)approx_num, static_cast<const double *>(scratch), c_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" size_t rnf_fisher_scratch_bytes(int64_t B) { return (size_t)(2 + 10 * (B > 0 ? B : 0)) * sizeof(double); }
 
 extern "C" int rnf_fisher_log_const_nt(const float *A, int64_t B, int32_t norm_type, void *scratch, size_t scratch_bytes, float *c_out, void *stream) {

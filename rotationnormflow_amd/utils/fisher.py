@@ -112,12 +112,29 @@ class MatrixFisherN(torch.nn.Module):
 
     def __init__(self, A, norm_type=1, approx_num=None):
         super().__init__()
-        if norm_type not in (0, 1):
-            raise NotImplementedError("normaliser approximations 0 and 1 (closed forms, utils/fisher.py:88-97) are built; type 2 is a Monte-Carlo "
-                                      "estimate over pytorch3d's random_rotations and type 3 indexes rows of the [N,3] singular values "
-                                      "(utils/fisher.py:98-113)")
+        if norm_type not in (0, 1, 2):
+            raise NotImplementedError("normaliser approximations 0, 1 (closed forms) and 2 (Monte-Carlo) are built; type 3 indexes ROWS of the "
+                                      "[N,3] singular values and cannot serve MatrixFisherN's batched A (utils/fisher.py:102-113)")
         self.norm_type = int(norm_type)
         self.A = A.reshape(-1, 3, 3)
+        if self.norm_type == 2:
+            # utils/fisher.py:98-101: mean over approx_num uniform rotations, ONE matrix (the reference's broadcast); on the device with
+            # a Philox stream keyed from torch's generator (statistical parity with pytorch3d.random_rotations)
+            if approx_num is None or int(approx_num) <= 0:
+                raise TypeError("norm_type=2 needs approx_num (the reference passes it to random_rotations, utils/fisher.py:99)")
+            if self.A.shape[0] != 1:
+                raise RuntimeError("norm_type=2 serves one matrix: the reference broadcasts [approx_num,3,3] against [N,3,3] (utils/fisher.py:100)")
+            if not self.A.is_cuda:
+                raise RuntimeError("rotationnormflow_amd runs on the GPU only (no CPU fallback): construct MatrixFisherN with A on the GPU")
+            A32 = self.A.detach().to(torch.float32).contiguous()
+            self._c = torch.empty(1, dtype=torch.float32, device=A32.device)
+            scratch = torch.empty(1, dtype=torch.float64, device=A32.device)
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            with torch.cuda.device(A32.device):
+                _lib.check(_lib.lib().rnf_fisher_log_const_mc(A32.data_ptr(), 1, int(approx_num), seed, scratch.data_ptr(), 8, self._c.data_ptr(),
+                                                              torch.cuda.current_stream(A32.device).cuda_stream))
+            self._norm = None
+            return
         if self.A.is_cuda:
             # per-sample A from a network (agent.py:57-60): constants on the device, no host SVD and no device->host sync
             A32 = self.A.detach().to(torch.float32).contiguous()
@@ -139,7 +156,10 @@ class MatrixFisherN(torch.nn.Module):
         """The reference's ``self.norm`` (utils/fisher.py:215); computed lazily when A lives on the GPU (needs the singular values)."""
         if self._norm is None:
             S = proper_singular_values(self.A)
-            self._norm = _norm_from_singular_values(S, self.norm_type).to(device=self.A.device, dtype=self.A.dtype)
+            if self.norm_type == 2:                          # c = sum S + log norm
+                self._norm = (self._c.detach().to("cpu", torch.float64) - S.sum(-1)).exp().to(device=self.A.device, dtype=self.A.dtype)
+            else:
+                self._norm = _norm_from_singular_values(S, self.norm_type).to(device=self.A.device, dtype=self.A.dtype)
         return self._norm
 
     def log_const(self):
@@ -148,6 +168,8 @@ class MatrixFisherN(torch.nn.Module):
     def _log_prob(self, inputs, context=9):
         if not inputs.is_cuda:
             raise RuntimeError("rotationnormflow_amd runs on the GPU only (no CPU fallback)")
+        if self.norm_type == 2 and torch.is_grad_enabled() and self.A.requires_grad:
+            raise NotImplementedError("rotationnormflow_amd: no gradient w.r.t. A through the Monte-Carlo normaliser (norm_type=2); use 0 or 1")
         if inputs.shape[-1] == 4:
             if torch.is_grad_enabled() and inputs.requires_grad:
                 raise NotImplementedError("rotationnormflow_amd: quaternion inputs are not differentiable here; pass rotation matrices")

@@ -71,3 +71,33 @@ def test_predicted_A_trains_through_the_flow_loss():
     assert abs(float(loss) - float(loss64)) < 1e-5 * max(1.0, abs(float(loss64)))
     assert (Wg.grad.cpu() - gW64).abs().max() < 2e-5 * max(1.0, float(gW64.abs().max()))
     assert (bg.grad.cpu() - gb64).abs().max() < 2e-5 * max(1.0, float(gb64.abs().max()))
+
+
+def test_monte_carlo_normaliser_norm_type_2():
+    """norm_type 2 (utils/fisher.py:98-101): c = log mean_k exp(tr(R_k^T A)) over uniform rotations.  Checked against the same estimator on
+    the oracle's side (torch uniform rotations from normalised Gaussian quaternions, 4e6 samples, fp64) within the Monte-Carlo error, and
+    against an independent quadrature-free identity: for A = 0 the mean is exactly 1 (c = 0)."""
+    A = synth.fisher_A("tilted")
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(4_000_000, 4, generator=g, dtype=torch.float64)
+    q = q / q.norm(dim=-1, keepdim=True)
+    Rk = orc.quaternion_to_matrix(q)
+    tr = (Rk * torch.from_numpy(A).double()).sum((-1, -2))
+    want = float(torch.logsumexp(tr, 0) - np.log(tr.numel()))
+    rel_sd = float((tr - tr.max()).exp().std() / (tr - tr.max()).exp().mean() / np.sqrt(tr.numel()))
+    torch.manual_seed(11)
+    base = MatrixFisherN(torch.from_numpy(A).cuda(), norm_type=2, approx_num=4_000_000)
+    got = float(base.log_const()[0])
+    assert abs(got - want) < 6 * rel_sd + 1e-4, (got, want, rel_sd)
+    R = torch.from_numpy(synth.uniform_rotations(256, seed=3)).cuda()
+    lp = base._log_prob(R)
+    tr_r = (R.cpu().double() * torch.from_numpy(A).double()).sum((-1, -2))
+    assert (lp.cpu().double() - (tr_r - got)).abs().max() < 1e-4
+    zero = MatrixFisherN(torch.zeros(1, 3, 3).cuda(), norm_type=2, approx_num=100_000)
+    assert abs(float(zero.log_const()[0])) < 1e-5
+    with pytest.raises(RuntimeError):
+        MatrixFisherN(torch.zeros(2, 3, 3).cuda(), norm_type=2, approx_num=10)
+    with pytest.raises(TypeError):
+        MatrixFisherN(torch.zeros(1, 3, 3).cuda(), norm_type=2)
+    with pytest.raises(NotImplementedError):
+        MatrixFisherN(torch.zeros(1, 3, 3).cuda(), norm_type=3)

@@ -317,6 +317,11 @@ int rnf_fisher_log_prob_backward_param(const float *g_logp_dev, const float *rot
 int rnf_fisher_log_prob_backward(const float *g_logp_dev, int64_t n, const float *A_dev, int64_t B, float *g_rotation_dev,
                                  void *stream);
 
+/* pytorch3d.transforms.matrix_to_quaternion as the reference calls it on sampled rotations (utils/fisher.py:242-243, context = 4) and
+ * inside calculate_16 (flow/squeezetrans.py:34): rotation_dev float[n][9] -> quaternion_dev float[n][4], real part first, the candidate
+ * with the largest component (published 0.7.5 rule). */
+int rnf_matrix_to_quaternion(const float *rotation_dev, int64_t n, float *quaternion_dev, void *stream);
+
 /* MatrixFisherN._sample (utils/fisher.py:117-207,234-243): n rotations per row of A, out [B,n,3,3].
  *   U_dev, V_dev [B,3,3]: proper SVD factors of A (det +1; utils/fisher.py:53-64); lam_dev [B,4]: the diagonal Bingham parameter
  *   (0, 2(S1+S2), 2(S0+S2), 2(S0+S1)) (utils/fisher.py:183-187).  Counter-based Philox stream keyed by `seed`: the same seed gives

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "rnf_flow_backward_side": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p,
                                          c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "rnf_cond_mlp_backward": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "rnf_matrix_to_quaternion": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p]),
     "rnf_fisher_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "rnf_fisher_log_const_mc": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_size_t, c_f32p, C.c_void_p]),
     "rnf_fisher_log_const_nt": (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_void_p, C.c_size_t, c_f32p, C.c_void_p]),

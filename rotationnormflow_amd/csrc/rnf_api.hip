@@ -1187,6 +1187,29 @@ extern "C" int rnf_fisher_log_const(const float *A, int64_t B, float *c_out, voi
     return fisher_const_launch(A, B, 1, nullptr, c_out, reinterpret_cast<hipStream_t>(stream));
 }
 
+// pytorch3d.transforms.matrix_to_quaternion (published 0.7.5 rule; call sites flow/squeezetrans.py:34, utils/fisher.py:243): real part first,
+// the candidate with the largest |q_i|, denominators floored at 0.1 (so3_math.h rot_to_quat).  rot [n][9] row-major -> quat [n][4].
+__global__ void matrix_to_quaternion_kernel(const float *rot, long long n, float *quat) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float *r = rot + i * 9;
+        Rot R;
+        R.c0 = v3f{r[0], r[3], r[6]}; R.c1 = v3f{r[1], r[4], r[7]}; R.c2 = v3f{r[2], r[5], r[8]};
+        float q[4];
+        rot_to_quat(R, q);
+        quat[i * 4] = q[0]; quat[i * 4 + 1] = q[1]; quat[i * 4 + 2] = q[2]; quat[i * 4 + 3] = q[3];
+    }
+}
+extern "C" int rnf_matrix_to_quaternion(const float *rot, int64_t n, float *quat, void *stream) {
+    if (n < 0) return fail("rnf_matrix_to_quaternion: n=%lld", (long long)n);
+    if (n == 0) return 0;
+    if (!rot || !quat) return fail("rnf_matrix_to_quaternion: null pointer");
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(matrix_to_quaternion_kernel, dim3((int)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rot, (long long)n, quat);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // norm_type 2 (utils/fisher.py:98-101): Monte-Carlo estimate of the normaliser over `approx_num` uniform rotations -- norm = mean_k
 // exp(tr(R_k^T A) - sum S), hence c = sum S + log norm.  The reference broadcasts [approx_num,3,3] * [N,3,3], i.e. it serves ONE matrix
 // (N = 1).  Uniform rotations from normalised Gaussian quaternions on the counter-based Philox stream of the sampler (the reference uses

@@ -216,8 +216,12 @@ class MatrixFisherN(torch.nn.Module):
                 _pending_flags.append((ev, host, flag))
         if context == 9:
             return out
-        if context == 4:
-            raise NotImplementedError("context=4 (quaternion output) is not built; convert with your own matrix_to_quaternion")
+        if context == 4:                                     # utils/fisher.py:242-243: matrix_to_quaternion(result)
+            quat = torch.empty(B, num_samples, 4, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().rnf_matrix_to_quaternion(out.data_ptr(), B * num_samples, quat.data_ptr(),
+                                                               torch.cuda.current_stream(dev).cuda_stream))
+            return quat
         return None
 
     def sample(self, num_samples, context=None):

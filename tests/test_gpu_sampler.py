@@ -110,3 +110,25 @@ def test_min_geodesic_distance_matches_numpy():
         mid = (want > 0.05) & (want < 3.09)
         assert np.abs(got - want)[mid].max() < 2e-5
         assert np.abs(np.cos(got) - np.cos(want)).max() < 2e-6
+
+
+def test_quaternion_output_context_4():
+    """MatrixFisherN._sample(n, context=4) = matrix_to_quaternion of the sampled rotations (utils/fisher.py:242-243): the device conversion
+    against the oracle's restatement of the pytorch3d rule on the same matrices, and quaternion inputs of _log_prob give the same density."""
+    import torch
+    from oracle import flow_oracle as orc
+    from rotationnormflow_amd import synth
+    from rotationnormflow_amd.utils.fisher import MatrixFisherN
+    A = torch.from_numpy(synth.fisher_A("tilted")).cuda()
+    dist = MatrixFisherN(A)
+    torch.manual_seed(3)
+    R = dist._sample(512)                      # [1, 512, 3, 3]
+    torch.manual_seed(3)
+    q = dist._sample(512, context=4)           # same seed -> same rotations
+    assert q.shape == (1, 512, 4)
+    want = orc.matrix_to_quaternion(R.reshape(-1, 3, 3).cpu().double())
+    assert (q.reshape(-1, 4).cpu().double() - want).abs().max() < 2e-6
+    assert (q.norm(dim=-1) - 1).abs().max() < 1e-5
+    lp_r = dist._log_prob(R.reshape(-1, 3, 3))
+    lp_q = dist._log_prob(q.reshape(-1, 4))
+    assert (lp_r - lp_q).abs().max() < 1e-4

@@ -13,6 +13,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _run(cmd, env, timeout=400):
+    """One retry when a rank hangs in rendezvous (seen once in ~40 runs on the pool: two ranks on a cold box; the hang dump of
+    RNF_BENCH_HANG_DUMP ends the stuck attempt).  A genuine failure fails twice."""
+    out = None
+    for attempt in range(2):
+        try:
+            out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+        except subprocess.TimeoutExpired as e:             # pragma: no cover
+            out = subprocess.CompletedProcess(cmd, 124, e.stdout or "", (e.stderr or "") + "\n[timeout]")
+        if out.returncode == 0:
+            break
+    return out
+
+
 def test_two_ranks_one_json_line():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -20,7 +34,7 @@ def test_two_ranks_one_json_line():
     env = dict(os.environ, RNF_BENCH_SHARED_GPU="1", RNF_BENCH_HANG_DUMP="150")     # a hung rank dumps its stacks and exits
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch-log2", "15"]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=400)
+    out = _run(cmd, env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -37,8 +51,8 @@ def test_self_launch_from_gpus_flag():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["RNF_BENCH_SHARED_GPU"] = "1"
     env["RNF_BENCH_HANG_DUMP"] = "150"
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch-log2", "15",
-                          "--no-secondary"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=400)
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch-log2", "15",
+                "--no-secondary"], env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout

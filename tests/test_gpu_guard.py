@@ -121,3 +121,25 @@ def test_side_layer_conditioner_overflow_is_reported_one_call_later():
     finally:
         torch.cuda.synchronize()
         autograd._pending_mlp_flags.clear()               # status words of this test's other calls must not surface in a later test
+
+
+def test_segment_weight_beyond_the_one_piece_softplus_falls_back():
+    """The forward split-precision segment evaluates softplus as one log2(1 + 2^(s log2 e)), which overflows for s > 88 (the reference's
+    softplus returns s itself beyond its threshold of 20): the ratios of the layer become NaN, the guard fires and the exact-fp32 kernels,
+    whose softplus is the full form, recompute the launch -- the result follows the oracle."""
+    cfg = make_config(layers=2, segments=16)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=9, regime="trained")
+    for k in w:
+        if k.endswith("conditioner.fc_last.bias"):
+            b = w[k].copy()
+            b[3] = 120.0                                           # the raw weight of segment 3: softplus(120) = 120 in the reference
+            w[k] = b
+    fl = product_flow(cfg, w)
+    R = torch.from_numpy(synth.uniform_rotations(1500, seed=13)).cuda()
+    with torch.no_grad():
+        Rt, ldj = fl(R)
+    assert runtime.fallback_fired(R.device)
+    assert torch.isfinite(ldj).all() and torch.isfinite(Rt).all()
+    Rw, lw = orc.flow_forward(cfg, w, R.cpu().numpy(), None, dtype=torch.float64)
+    assert np.abs(ldj.cpu().double().numpy() - lw.numpy()).max() < 1e-3
+    assert np.abs(Rt.cpu().double().numpy() - Rw.numpy()).max() < 1e-4

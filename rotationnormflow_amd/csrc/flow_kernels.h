@@ -474,7 +474,7 @@ __device__ __forceinline__ void segments4(const f32x16 &o, const MobiusCtx &c, f
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if constexpr (HALF) segment_fwd_s7(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, S, A, J);      // c.f is the 0.7-scaled frame
-        else segment_fwd_pi<false>(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, S, A, J);
+        else segment_fwd_pi<false>(S_UNSCALE * o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, S, A, J);
     }
 }
 
@@ -487,7 +487,7 @@ __device__ __forceinline__ void segments4_tail(const f32x16 &o, const MobiusCtx 
     for (int g = 0; g < 4; ++g) {
         float s1 = 0.f, a1 = 0.f, j1 = 0.f;
         if constexpr (HALF) segment_fwd_s7(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, s1, a1, j1);
-        else segment_fwd_pi<false>(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, s1, a1, j1);
+        else segment_fwd_pi<false>(S_UNSCALE * o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, s1, a1, j1);
         const bool real = g < nv;
         S += real ? s1 : 0.f;
         A += real ? a1 : 0.f;
@@ -518,7 +518,7 @@ __device__ __forceinline__ void tile_step(f32x16 &nxt, const float4 (&a)[8], con
     const float av = q == 0 ? a[tg].x : (q == 1 ? a[tg].y : (q == 2 ? a[tg].z : a[tg].w));
     nxt = RNF_MFMA(av, tt[K >> 4][K & 15], nxt);
     constexpr int g = K >> 3, st = K & 7;             // slice `st` of segment `g` rides behind MFMA number K
-    seg_stage<st>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, c.zc, c.zs, c.zth, S, A, J);
+    seg_stage<st>(seg[g], S_UNSCALE * cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, c.zc, c.zs, c.zth, S, A, J);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (K + 1 < 32) tile_step<K + 1>(nxt, a, tt, cur, seg, c, S, A, J);
 }
@@ -708,7 +708,7 @@ __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, sg.ur[4 * tau + g], sg.uv[4 * tau + g]);
-                float sp = PREC == 1 ? softplus_lean(o[4 * g]) : softplus(o[4 * g]);
+                float sp = PREC == 1 ? softplus_lean(S_UNSCALE * o[4 * g]) : softplus(S_UNSCALE * o[4 * g]);     // packed pre-scaled (layout.h)
                 if (8 * tau + 2 * g + h >= K) sp = 0.f;          // pad segment of a K % 8 != 0 layer: weight 0 AFTER the activation
                 sg.sp[4 * tau + g] = sp;
                 sg.q[4 * tau + g] = sp * (1.0f - fmaf(sg.uv[4 * tau + g], sg.uv[4 * tau + g], sg.ur[4 * tau + g] * sg.ur[4 * tau + g]));

@@ -35,6 +35,10 @@ namespace rnf {
 // split-precision operand pairs x = hi + lo / SCALE (flow_kernels.h): the 64-wide conditioner GEMMs keep lo UNSCALED (it lives in
 // the fp16 subnormal range, absolute resolution 2^-24) so that all three products accumulate into ONE MFMA accumulator; the
 // feature projection scales lo by 2^12 and combines two accumulators.
+// The fc_last rows (and biases) of a Moebius layer that produce the segment weights' pre-activations s_k are PACKED pre-multiplied by
+// log2(e): the forward split-precision segment evaluates softplus(s) / ln 2 = log2(1 + 2^(s log2 e)) and saves the multiply (one VALU
+// instruction per segment on the VALU-issue-bound kernel); every other consumer multiplies the matrix output by ln 2 first.
+constexpr float S_PRESCALE = 1.44269504088896341f, S_UNSCALE = 0.693147180559945309f;
 constexpr float W_LO_SCALE = 1.0f;
 constexpr float FEAT_LO_SCALE = 4096.0f;
 

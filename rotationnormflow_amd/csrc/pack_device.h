@@ -41,12 +41,14 @@ __device__ __forceinline__ float pack2(float a, float b) {           // two fp16
 }
 
 // float `r` of a [n_ot][...] weight image of 64-column rows; row_of(ot, i) -> source row or nullptr (zero row)
-template <class RowFn>
-__device__ __forceinline__ float w64_image(int r, int prec, RowFn row_of, int *flags) {
+struct UnitScale { __device__ __forceinline__ float operator()(int, int) const { return 1.0f; } };
+// scale_of(ot, i): factor applied to the source row before it is stored / split (layout.h S_PRESCALE for the fc_last rows of s)
+template <class RowFn, class ScaleFn = UnitScale>
+__device__ __forceinline__ float w64_image(int r, int prec, RowFn row_of, int *flags, ScaleFn scale_of = ScaleFn()) {
     if (!prec) {                                                       // [ot][tg 8][lane 64] float4
         const int ot = r >> 11, tg = (r >> 8) & 7, lane = (r >> 2) & 63, c = r & 3;
         const float *row = row_of(ot, lane & 31);
-        return row ? row[8 * tg + 4 * (lane >> 5) + c] : 0.f;
+        return row ? row[8 * tg + 4 * (lane >> 5) + c] * scale_of(ot, lane & 31) : 0.f;
     }
     float v[2];                                                        // [ot][s 4][hi, lo][lane 64] 8 x fp16
 #pragma unroll
@@ -54,7 +56,7 @@ __device__ __forceinline__ float w64_image(int r, int prec, RowFn row_of, int *f
         const int e = 2 * r + q;
         const int ot = e >> 12, s = (e >> 10) & 3, lo = (e >> 9) & 1, lane = (e >> 3) & 63, j = e & 7;
         const float *row = row_of(ot, lane & 31);
-        const float w = row ? row[16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)] : 0.f;
+        const float w = row ? row[16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)] * scale_of(ot, lane & 31) : 0.f;
         v[q] = half_part(w, lo, W_LO_SCALE, flags);
     }
     return pack2(v[0], v[1]);
@@ -220,12 +222,13 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
             v = hb[q >> 6][bias_row(q & 63)];
         } else {
             const int q = idx - MOB_LAST, tau = q / MOB_LAST_TILE_FLOATS, r = q % MOB_LAST_TILE_FLOATS;
+            // Moebius: the rows of the segment weights' pre-activations (source rows 0 .. K-1) are packed times log2 e (layout.h)
             if (r < MOB_LAST_TILE_BIAS) {
                 v = w64_image(r, prec, [&](int, int i) { const int s = src_row(tau, i); return s < 0 ? (const float *)nullptr : WL + (size_t)s * 64; },
-                              args.flags);
+                              args.flags, [&](int, int i) { const int s = src_row(tau, i); return (mob && s >= 0 && s < K) ? S_PRESCALE : 1.0f; });
             } else {
                 const int s = src_row(tau, bias_row(r - MOB_LAST_TILE_BIAS));
-                v = s < 0 ? 0.f : bL[s];
+                v = s < 0 ? 0.f : ((mob && s < K) ? bL[s] * S_PRESCALE : bL[s]);
             }
         }
         out[idx] = v;

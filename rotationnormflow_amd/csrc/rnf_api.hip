@@ -172,11 +172,20 @@ extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b,
         if (k >= K) return -1;
         return c == 0 ? k : K + 3 * k + (c - 1);
     };
+    // the rows that produce the segment weights' pre-activations (reference rows 0 .. K-1) are packed times log2 e (layout.h S_PRESCALE)
+    std::vector<float> s_rows((size_t)K * 64);
+    for (size_t i = 0; i < s_rows.size(); ++i) s_rows[i] = fc_last_w[i] * S_PRESCALE;
     for (int tau = 0; tau < (K + 7) / 8; ++tau) {
         float *rec = out + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS;
-        auto row_of = [&](int, int i) { const int r = src_row(tau, i); return r < 0 ? (const float *)nullptr : fc_last_w + (size_t)r * 64; };
+        auto row_of = [&](int, int i) {
+            const int r = src_row(tau, i);
+            return r < 0 ? (const float *)nullptr : (r < K ? s_rows.data() + (size_t)r * 64 : fc_last_w + (size_t)r * 64);
+        };
         if (prec) pack_w64_h(rec, 1, row_of); else pack_w64(rec, 1, row_of);
-        pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) { const int r = src_row(tau, row); return r < 0 ? 0.f : fc_last_b[r]; });
+        pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) {
+            const int r = src_row(tau, row);
+            return r < 0 ? 0.f : (r < K ? fc_last_b[r] * S_PRESCALE : fc_last_b[r]);
+        });
     }
     if (F) { if (prec) pack_featproj_h(out_feat, fc_first_w, ni, 3, F, fc_first_b); else pack_featproj(out_feat, fc_first_w, ni, 3, F, fc_first_b); }
     if (prec && g_half_overflow) return fail("rnf_pack_mobius: a weight is outside the fp16 range; use RNF_PREC_FP32") + 1;
@@ -1427,7 +1436,7 @@ __global__ __launch_bounds__(NWc * 64) void conditioner_kernel(const float *y, l
                     for (int c = 0; c < 4; ++c) {
                         const int k = 8 * tau + 2 * g + h;
                         const int row = c == 0 ? k : K + 3 * k + (c - 1);
-                        if (k < K) out[sample * 4 * K + row] = o[4 * g + c];          // (k >= K: pad rows of the last tile)
+                        if (k < K) out[sample * 4 * K + row] = c == 0 ? S_UNSCALE * o[4 * g] : o[4 * g + c];   // (k >= K: pad rows; s: layout.h S_PRESCALE)
                     }
             }
         }

@@ -357,11 +357,11 @@ RNF_HD void seg_s7_stage(SegS7 &g, float s_raw, float w0, float w1, float w2, co
         const float e = hw_exp2(-1.44269504088896341f * fabsf(s_raw));
         const float sp = fmaf(hw_log2(1.0f + e), 0.693147180559945309f, relu_bits(s_raw));
 #else
-        // softplus(s) / ln 2 = log2(1 + 2^(s log2 e)) in one piece: S, A and J all carry the common factor 1 / ln 2 and the layer only uses
+        // softplus(s) / ln 2 = log2(1 + 2^(s log2 e)) in one piece (the packers fold log2 e into the weights that produce s): S, A and J all carry the common factor 1 / ln 2 and the layer only uses
         // their ratios (theta' = pi + 2 A / S, ldj = log(J / S)).  No argument split: for s < -17 the weight rounds to 0 exactly as before
         // (< 1e-7 absolute on a term divided by the sum of K such terms); for s > 88 the exponential overflows to inf, the layer's ratios
         // become NaN and the range guard re-runs the launch on the exact-fp32 kernels, whose softplus is the full form.
-        const float sp = hw_log2(1.0f + hw_exp2(1.44269504088896341f * s_raw));
+        const float sp = hw_log2(1.0f + hw_exp2(s_raw));          // s_raw arrives multiplied by log2 e (layout.h S_PRESCALE)
 #endif
         S += sp;
         A = fmaf(sp, p * g.t, A);

@@ -13,6 +13,10 @@ H = LANES >> 5
 MOB_FIRST, MOB_HID, MOB_HB, MOB_HEAD, TILE_FLOATS, TILE_BIAS = 0, 256, 256 + 12288, 12736, 2080, 2048
 
 
+# the fc_last rows of the segment weights' pre-activations are packed times log2(e) (csrc/layout.h S_PRESCALE); consumers multiply by ln 2
+S_UNSCALE = 0.693147180559945309
+
+
 def rho(r, h):
     return (r & 3) + 8 * (r >> 2) + 4 * h
 
@@ -91,7 +95,7 @@ def conditioner_from_record(rec, y, K):
                 real = k < K
                 assert np.abs(o[4 * g + c][~real]).max(initial=0.0) == 0.0
                 row = np.where(c == 0, k, K + 3 * k + (c - 1))
-                out[J[real], row[real]] = o[4 * g + c][real]          # each (sample, row) is written by exactly one lane
+                out[J[real], row[real]] = o[4 * g + c][real] * (S_UNSCALE if c == 0 else 1.0)      # each (sample, row): exactly one lane
     return out
 
 
@@ -180,7 +184,7 @@ def conditioner_from_record_h(rec32, y, K):
                 k = 8 * tau + 2 * g + H
                 real = k < K
                 row = np.where(c == 0, k, K + 3 * k + (c - 1))
-                out[J[real], row[real]] = o[4 * g + c][real]
+                out[J[real], row[real]] = o[4 * g + c][real] * (S_UNSCALE if c == 0 else 1.0)
     return out
 
 

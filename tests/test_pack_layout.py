@@ -53,7 +53,7 @@ def test_conditional_mobius_record_and_feature_projection(F):
         for gi in range(4):
             for c in range(4):
                 k = 8 * tau + 2 * gi + emu.H
-                out[emu.J, np.where(c == 0, k, K + 3 * k + (c - 1))] = o[4 * gi + c]
+                out[emu.J, np.where(c == 0, k, K + 3 * k + (c - 1))] = o[4 * gi + c] * (emu.S_UNSCALE if c == 0 else 1.0)
     want = _oracle_mlp(m, np.concatenate([y, feat], axis=1))
     assert np.abs(out - want).max() < 1e-5 * max(1.0, np.abs(want).max())
 

@@ -708,7 +708,9 @@ __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, sg.ur[4 * tau + g], sg.uv[4 * tau + g]);
-                float sp = PREC == 1 ? softplus_lean(S_UNSCALE * o[4 * g]) : softplus(S_UNSCALE * o[4 * g]);     // packed pre-scaled (layout.h)
+                // the matrix output is s log2 e (layout.h S_PRESCALE).  Split precision: softplus / ln 2 in one piece, as the forward segment
+                // does -- the root finder and the log-det only use ratios of the weights; s > 88 overflows into the range guard
+                float sp = PREC == 1 ? hw_log2(1.0f + hw_exp2(o[4 * g])) : softplus(S_UNSCALE * o[4 * g]);
                 if (8 * tau + 2 * g + h >= K) sp = 0.f;          // pad segment of a K % 8 != 0 layer: weight 0 AFTER the activation
                 sg.sp[4 * tau + g] = sp;
                 sg.q[4 * tau + g] = sp * (1.0f - fmaf(sg.uv[4 * tau + g], sg.uv[4 * tau + g], sg.ur[4 * tau + g] * sg.ur[4 * tau + g]));

@@ -323,26 +323,28 @@ RNF_HD void seg_pi_stage(SegPi &g, float s_raw, float w0, float w1, float w2, co
 // the squashed centre of flow/mobiusflow.py:72 is u = (a, b) / D, and everything the segment needs is a ratio in which D cancels:
 //     t = uv / (1 + ur)                       = b / (D + a)
 //     c = (1 - |u|^2) / (uv^2 + (1 + ur)^2)   = (D^2 - n2) / ((D + a)^2 + b^2)
-// so 0.7 / (1 + |w|) is never formed: 37 VALU instructions with 5 transcendentals (sqrt, 2 rcp, exp2, log2) instead of 44 with 6,
+// so 0.7 / (1 + |w|) is never formed: 33 VALU instructions with 5 transcendentals (sqrt, 2 rcp, exp2, log2) instead of 44 with 6,
 // and D + a >= 1 + 0.3 |w| >= 1 is better conditioned than 1 + ur >= 0.3.  HALF convention (A accumulates sp * atan(t)).
 constexpr float kSquash = 0.7f;                         // flow/mobiusflow.py:72
 constexpr float kInvSquash = 1.0f / 0.7f;
 RNF_HD Frame scale_frame(const Frame &f, float k) { return Frame{f.r * k, f.v * k}; }
 
 struct SegS7 {
-    float a, b, n2, D, t, c, z, p;
+    float e, b, bb, num, t, c, z, p;     // four values cross each stage boundary (the pipelined tile keeps four segments in flight)
 };
 template <int STAGE>
 RNF_HD void seg_s7_stage(SegS7 &g, float s_raw, float w0, float w1, float w2, const Frame &f7, float &S, float &A, float &J) {
     if constexpr (STAGE == 0) {
-        g.a = fmaf(w2, f7.r.z, fmaf(w1, f7.r.y, w0 * f7.r.x));
+        const float a = fmaf(w2, f7.r.z, fmaf(w1, f7.r.y, w0 * f7.r.x));
         g.b = fmaf(w2, f7.v.z, fmaf(w1, f7.v.y, w0 * f7.v.x));
-        g.n2 = fmaf(g.b, g.b, g.a * g.a);
-        g.D = fmaf(hw_sqrt(g.n2), kInvSquash, 1.0f);
+        g.bb = g.b * g.b;                                           // shared by n2 and by the denominator of c (one instruction less)
+        const float n2 = fmaf(a, a, g.bb);
+        const float D = fmaf(hw_sqrt(n2), kInvSquash, 1.0f);
+        g.e = D + a;
+        g.num = fmaf(D, D, -n2);
     } else if constexpr (STAGE == 1) {
-        const float e = g.D + g.a;
-        g.t = g.b * hw_rcp(e);
-        g.c = fmaf(g.D, g.D, -g.n2) * hw_rcp(fmaf(g.b, g.b, e * e));
+        g.t = g.b * hw_rcp(g.e);
+        g.c = g.num * hw_rcp(fmaf(g.e, g.e, g.bb));
         g.z = g.t * g.t;
         float p = fmaf(2.456724578e-03f, g.z, -1.440135792e-02f);
         p = fmaf(p, g.z, 3.978122362e-02f);

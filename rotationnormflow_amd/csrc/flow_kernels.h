@@ -456,6 +456,11 @@ __device__ __forceinline__ void mobius_begin(const Rot &R, int perm_row, MobiusC
     c.cyc = (p1 - p0 == 1) || (p1 - p0 == -2);
     const v3f x = get_col(R, p0);
     c.y = get_col(R, p1);
+    if constexpr (S7 && DIR == 0) {                     // forward split-precision path: only the 0.7-scaled frame is used (the input point
+        c.f = make_frame_scaled(x, c.y, kSquash);       // is (-1, 0) in its own frame by construction)
+        c.zc = -1.f; c.zs = 0.f; c.zth = kPi; c.target = 0.f;
+        return;
+    }
     c.f = make_frame(x, c.y);
     const float xr = dot3(x, c.f.r), xv = dot3(x, c.f.v);
     const float inv = hw_rsq(fmaf(xv, xv, xr * xr));
@@ -672,7 +677,8 @@ __device__ __forceinline__ void mobius_fwd_finish(const MobiusCtx &c, float S, f
     const float invS = hw_rcp(S);
     float sn, cs;
     // HALF: theta' = pi + 2 A / S, and sin / cos of pi + d are -sin d, -cos d
-    sincos_small(HALF ? 2.0f * A * invS : A * invS, sn, cs);
+    if (HALF) sincos_twice(A * invS, sn, cs);                  // |A / S| <= atan(0.98) < pi/4: no quadrant reduction (so3_math.h)
+    else sincos_small(A * invS, sn, cs);
     if (HALF) { sn *= -kInvSquash; cs *= -kInvSquash; }                                   // the frame of the split-precision path is 0.7-scaled
     const v3f tx = c.f.v * sn + c.f.r * cs;
     const v3f tz = normalize3(c.cyc ? cross3(tx, c.y) : cross3(c.y, tx));               // mobiusflow.py:75-79

@@ -65,16 +65,24 @@ extern "C" {
 
 /* ---- arithmetic of the conditioner GEMMs --------------------------------------------------------------------
  * RNF_PREC_FP32  : exact fp32 (v_mfma_f32_32x32x2_f32; bit-for-bit an fp32 fma chain).
- * RNF_PREC_F16X2 : every fp32 operand carried as two fp16 terms (hi + unscaled lo: 22 significant bits, absolute floor 2^-24),
- *                  three fp16 MFMAs into one fp32 accumulator per product-sum; indistinguishable from fp32 at the parity bar of
- *                  this path, ~2.8x faster than the fp32-input MFMA, which shares the VALU's FMA datapath.  Operands must be
- *                  inside the fp16 range (|x| < 65504): rnf_pack_* returns 2 for such weights (pack FP32 instead).
+ * RNF_PREC_F16X2 : every fp32 operand carried as two fp16 terms (hi + unscaled lo: 22 significant bits while |x| >= 2^-3, absolute
+ *                  resolution 2^-25 below), three fp16 MFMAs into one fp32 accumulator per product-sum; ~2.8x faster than the fp32-input
+ *                  MFMA, which shares the VALU's FMA datapath.  The absolute floor is kept 2^-22 below the signal of EVERY layer by the
+ *                  packers: a ReLU network computes the same function under per-unit power-of-two rescalings of its hidden layers, and
+ *                  rnf_pack_* / rnf_pack_flow_device first move the layer to the point of that orbit where every hidden pre-activation
+ *                  has an estimated rms in (1/4, 1/2] (csrc/equalize.h; exact, power-of-two factors), THEN split.  The host packers
+ *                  audit the packed image against the exact network on probe inputs (rnf_last_pack_audit) and return 2 -- pack
+ *                  RNF_PREC_FP32 instead -- when it is off by more than 4e-6, or when a (scaled) weight leaves the fp16 range
+ *                  (|x| < 65504).  Activations beyond the fp16 range at run time are caught by the range guard (see desc columns 6, 7).
  */
 #define RNF_PREC_FP32 0
 #define RNF_PREC_F16X2 1
 
 int rnf_abi_version(void);
 const char *rnf_last_error(void);
+/* largest relative error of the conditioner outputs the last rnf_pack_mobius / rnf_pack_cond* call of this thread measured on its probe
+ * inputs (split precision only; 0 after an exact-fp32 pack) */
+double rnf_last_pack_audit(void);
 
 /* ---- parameter packing (host side, pure CPU; called once per parameter version) ------------------------------
  * Sizes are in floats.  `segments` (K) is any positive count (flow/mobiusflow.py:7-14 takes any): records hold ceil(K / 8) fc_last tiles,
@@ -136,6 +144,9 @@ int rnf_pack_cond36(const float *fc_first_w, const float *fc_first_b, const floa
  * feature_dev    [n,F] float32 row-major contiguous (F % 8 == 0), or NULL for an unconditional flow
  * rotation_out   [n,3,3] or NULL;  ldj_out [n] or NULL
  * workspace_dev  scratch of at least rnf_workspace_bytes(n, n_cond_layers) bytes (may be NULL when that is 0)
+ * Aliasing: rotation_out == rotation_dev (in place) is allowed -- every lane reads its rotation before it writes it -- but such a call
+ * runs WITHOUT the range guard (the exact-fp32 re-run would start from the already overwritten input): an fp16 overflow then shows as
+ * NaN outputs instead of being repaired.  No other overlap between inputs and outputs is supported.
  */
 size_t rnf_workspace_bytes(int64_t n, int32_t n_cond_layers);
 

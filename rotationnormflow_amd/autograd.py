@@ -102,23 +102,43 @@ class TrainPlan:
             if bits & 2:
                 raise RuntimeError("a 4x4 affine matrix became singular during training")
 
-    def pack(self, plain, stream):
-        """plain blob -> fresh kernel blob, on the device (one launch)."""
+    def pack(self, plain, stream, with_fallback=False):
+        """plain blob -> fresh kernel blob, on the device (one launch).  ``with_fallback`` (inference from live parameters: training-mode
+        modules under no_grad, nn.DataParallel replicas): a second launch appends the exact-fp32 images of the same layers, which the
+        range guard of the split-precision kernels re-runs a call on (``desc_with_fallback``)."""
         L = _lib.lib()
         capturing = torch.cuda.is_current_stream_capturing()      # inside a HIP graph capture: no event queries, no pinned read-back
         if not capturing:
             self.check_flags()
-        blob = torch.empty(self.blob_floats, dtype=torch.float32, device=plain.device)
+        both = with_fallback and self.prec == _lib.PREC_F16X2
+        blob = torch.empty(self.blob_floats * (2 if both else 1), dtype=torch.float32, device=plain.device)
         self.flags.zero_()
         if plain.numel() == 0:                             # a stack of side layers only: nothing to read, but the pointer must be valid
             plain = torch.zeros(4, dtype=torch.float32, device=blob.device)
         _lib.check(L.rnf_pack_flow_device(plain.data_ptr(), self.pack_desc.ctypes.data, self.n_layers, self.segments, self.feat_dim,
                                           self.prec, blob.data_ptr(), self.flags.data_ptr(), stream))
+        if both:
+            _lib.check(L.rnf_pack_flow_device(plain.data_ptr(), self.pack_desc.ctypes.data, self.n_layers, self.segments, self.feat_dim,
+                                              _lib.PREC_FP32, blob.data_ptr() + 4 * self.blob_floats, self.flags.data_ptr(), stream))
         if self.flags_event is None and not capturing:
             self.flags_host.copy_(self.flags, non_blocking=True)
             self.flags_event = torch.cuda.Event()
             self.flags_event.record()
         return blob
+
+
+def desc_with_fallback(plan):
+    """Layer table of a blob packed by ``plan.pack(..., with_fallback=True)``: columns 6 / 7 point at the exact-fp32 images behind the
+    split-precision ones (include/rnf_hip.h); side layers keep -1."""
+    desc = plan.desc.copy()
+    if plan.prec != _lib.PREC_F16X2:
+        return desc
+    for i in range(plan.n_layers):
+        if runtime.kind_has_mlp(int(desc[i, 0])):
+            desc[i, 6] = plan.blob_floats + desc[i, 2]
+            if desc[i, 4] >= 0:
+                desc[i, 7] = plan.blob_floats + desc[i, 4]
+    return np.ascontiguousarray(desc)
 
 
 def train_tensors(layers):

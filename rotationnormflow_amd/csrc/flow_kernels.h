@@ -474,11 +474,11 @@ __device__ __forceinline__ void mobius_begin(const Rot &R, int perm_row, MobiusC
 }
 
 // HALF (split-precision kernels): A accumulates sp * atan(t), mobius_fwd_finish<true> adds the constant part (so3_math.h)
-template <bool HALF>
+template <bool HALF, bool SAFE = true>
 __device__ __forceinline__ void segments4(const f32x16 &o, const MobiusCtx &c, float &S, float &A, float &J) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        if constexpr (HALF) segment_fwd_s7(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, S, A, J);      // c.f is the 0.7-scaled frame
+        if constexpr (HALF) segment_fwd_s7<SAFE>(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, S, A, J);      // c.f is the 0.7-scaled frame
         else segment_fwd_pi<false>(S_UNSCALE * o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, S, A, J);
     }
 }
@@ -486,12 +486,12 @@ __device__ __forceinline__ void segments4(const f32x16 &o, const MobiusCtx &c, f
 // The last fc_last tile of a layer whose segment count K is not a multiple of 8: the packer pads the tile with zero rows, and the pad
 // segments (k = 8 tau + 2 g + h >= K) must carry weight 0 -- softplus(0) = ln 2 is not 0 -- so their contribution is masked out AFTER the
 // activation.  nv = number of real segments among this lane's four (g < nv).
-template <bool HALF>
+template <bool HALF, bool SAFE = true>
 __device__ __forceinline__ void segments4_tail(const f32x16 &o, const MobiusCtx &c, float &S, float &A, float &J, int nv) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         float s1 = 0.f, a1 = 0.f, j1 = 0.f;
-        if constexpr (HALF) segment_fwd_s7(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, s1, a1, j1);
+        if constexpr (HALF) segment_fwd_s7<SAFE>(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, s1, a1, j1);
         else segment_fwd_pi<false>(S_UNSCALE * o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, s1, a1, j1);
         const bool real = g < nv;
         S += real ? s1 : 0.f;
@@ -504,10 +504,10 @@ __device__ __forceinline__ int tail_segments(int K, int h) {
     const int rem = K - 8 * ((K + 7) / 8 - 1) - h;          // segments k = base + 2 g + h, g = 0..3, real while 2 g + h < K - base
     return min(4, max(0, (rem + 1) / 2));
 }
-template <bool HALF>
+template <bool HALF, bool SAFE = true>
 __device__ __forceinline__ void segments4_last(const f32x16 &o, const MobiusCtx &c, float &S, float &A, float &J, int K, int h) {
-    if (K & 7) segments4_tail<HALF>(o, c, S, A, J, tail_segments(K, h));     // wave-uniform branch
-    else segments4<HALF>(o, c, S, A, J);
+    if (K & 7) segments4_tail<HALF, SAFE>(o, c, S, A, J, tail_segments(K, h));     // wave-uniform branch
+    else segments4<HALF, SAFE>(o, c, S, A, J);
 }
 
 // forward, all fc_last tiles resident (K <= 64): software pipelined BY HAND.  Tile tau+1's 32 dependent MFMAs (64
@@ -544,7 +544,7 @@ __device__ __forceinline__ void tile_pipe(const float *rec, int lane, int h, con
 // split-precision counterpart of tile_step: slot m = 3 * (segment g) + (slice st) carries matrix instruction m of the next tile
 // (k-step m / 3; term hi.hi, hi.lo, lo.hi) and slice st of segment g of the finished tile; the operands of k-step s + 1 are fetched
 // behind the last matrix instruction of k-step s into the same registers (one look-ahead, 8 registers instead of 32).
-template <int M>
+template <int M, bool SAFE>
 __device__ __forceinline__ void tile_step_h(const float *rec, int lane, f32x16 &nxt, h8 &ah, h8 &al, const ActFrag &in,
                                             const f32x16 &cur, SegS7 (&seg)[4], const MobiusCtx &c, float &S, float &A, float &J) {
     constexpr int ks = M / 3, term = M % 3;
@@ -561,7 +561,7 @@ __device__ __forceinline__ void tile_step_h(const float *rec, int lane, f32x16 &
     }
 #endif
     constexpr int g = M / 3, st = M % 3;
-    seg_s7_stage<st>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, S, A, J);
+    seg_s7_stage<st, SAFE>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, S, A, J);
     // NOTE: the slice's results are only consumed slots later, and sched_barrier orders the machine scheduler, not the IR passes: the
     // optimiser sinks this arithmetic past the fences into one VALU block behind the 12 matrix instructions.  Pinning each slice in
     // its slot (-DRNF_PIN_L) gives the interleaved stream the source suggests and measured 0.8 % SLOWER, so the shipped build does not.
@@ -571,9 +571,10 @@ __device__ __forceinline__ void tile_step_h(const float *rec, int lane, f32x16 &
     else asm volatile("" : "+v"(S), "+v"(A), "+v"(J));
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (M + 1 < 12) tile_step_h<M + 1>(rec, lane, nxt, ah, al, in, cur, seg, c, S, A, J);   // (rec already holds the lane offset when lane == 0 is passed)
+    if constexpr (M + 1 < 12) tile_step_h<M + 1, SAFE>(rec, lane, nxt, ah, al, in, cur, seg, c, S, A, J);   // (rec already holds the lane offset when lane == 0 is passed)
 }
 
+template <bool SAFE>
 __device__ __forceinline__ void tile_pipe_h(const float *rec, int lane, int h, const ActFrag &tt, f32x16 &nxt, const f32x16 &cur,
                                             const MobiusCtx &c, float &S, float &A, float &J) {
     nxt = load_bias16(rec + MOB_LAST_TILE_BIAS + h * 16);
@@ -581,12 +582,13 @@ __device__ __forceinline__ void tile_pipe_h(const float *rec, int lane, int h, c
     h8 al = lds_h8(rec, 1 * 64 + lane);
     SegS7 seg[4];
     __builtin_amdgcn_sched_barrier(0);
-    tile_step_h<0>(rec, lane, nxt, ah, al, tt, cur, seg, c, S, A, J);
+    tile_step_h<0, SAFE>(rec, lane, nxt, ah, al, tt, cur, seg, c, S, A, J);
 }
 // The same tile addressed through two per-lane offsets the optimiser cannot fold (woff: floats from `base` to this lane's operand slot of
 // the tile, boff: to its bias half): every LDS read of the tile then carries its position as an immediate offset.  With the tile position
 // folded into constants instead, tiles beyond 64 KiB (the fc_last part starts at 50 KiB) need a v_add per read group: the DS offset field
 // is 16 bits.
+template <bool SAFE>
 __device__ __forceinline__ void tile_pipe_h_off(const float *base, int woff, int boff, const ActFrag &tt, f32x16 &nxt, const f32x16 &cur,
                                                 const MobiusCtx &c, float &S, float &A, float &J) {
     nxt = load_bias16(base + boff);
@@ -595,7 +597,7 @@ __device__ __forceinline__ void tile_pipe_h_off(const float *base, int woff, int
     h8 al = lds_h8(rec, 1 * 64);
     SegS7 seg[4];
     __builtin_amdgcn_sched_barrier(0);
-    tile_step_h<0>(rec, 0, nxt, ah, al, tt, cur, seg, c, S, A, J);
+    tile_step_h<0, SAFE>(rec, 0, nxt, ah, al, tt, cur, seg, c, S, A, J);
 }
 
 template <int PREC, bool PINGPONG = false>
@@ -619,30 +621,31 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int K
         // tile tau+1's 12 matrix instructions and tile tau's segment math in one loop body (tile_pipe_h).  (`cur = nxt` costs 8
         // v_mov_b64 per tile; the two-tiles-per-trip ping-pong of the fp32 path avoids them but spills 10 registers under the 128
         // budget of the 16-wave instantiation and measured 1 % slower.)
-        if constexpr (PINGPONG) {          // two tiles per trip, the accumulators change roles: no register copies
+        if constexpr (PINGPONG) {          // two tiles per trip, the accumulators change roles: no register copies.  LEAN kernels only, which the
+                                           // launcher runs guarded: the one-piece softplus (so3_math.h seg_s7_stage SAFE = false)
             f32x16 bufA = Mlp<1>::last(rec, lane, h, tt), bufB;
             int tau = 1;
             int woff = MOB_LAST_TILE_FLOATS + 4 * lane, boff = MOB_LAST_TILE_FLOATS + MOB_LAST_TILE_BIAS + 16 * h;
             for (; tau + 1 < KT; tau += 2) {
                 asm volatile("" : "+v"(woff), "+v"(boff));
-                tile_pipe_h_off(rec, woff, boff, tt, bufB, bufA, c, S, A, J);
-                tile_pipe_h_off(rec, woff + MOB_LAST_TILE_FLOATS, boff + MOB_LAST_TILE_FLOATS, tt, bufA, bufB, c, S, A, J);
+                tile_pipe_h_off<false>(rec, woff, boff, tt, bufB, bufA, c, S, A, J);
+                tile_pipe_h_off<false>(rec, woff + MOB_LAST_TILE_FLOATS, boff + MOB_LAST_TILE_FLOATS, tt, bufA, bufB, c, S, A, J);
                 woff += 2 * MOB_LAST_TILE_FLOATS;
                 boff += 2 * MOB_LAST_TILE_FLOATS;
             }
             if (tau < KT) {
                 asm volatile("" : "+v"(woff), "+v"(boff));
-                tile_pipe_h_off(rec, woff, boff, tt, bufB, bufA, c, S, A, J);
-                segments4_last<true>(bufB, c, S, A, J, K, h);
+                tile_pipe_h_off<false>(rec, woff, boff, tt, bufB, bufA, c, S, A, J);
+                segments4_last<true, false>(bufB, c, S, A, J, K, h);
             } else {
-                segments4_last<true>(bufA, c, S, A, J, K, h);
+                segments4_last<true, false>(bufA, c, S, A, J, K, h);
             }
             return;
         }
         f32x16 cur = Mlp<1>::last(rec, lane, h, tt);
         for (int tau = 1; tau < KT; ++tau) {
             f32x16 nxt;
-            tile_pipe_h(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt, nxt, cur, c, S, A, J);
+            tile_pipe_h<true>(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt, nxt, cur, c, S, A, J);
             cur = nxt;
             fair.tick();
         }
@@ -669,11 +672,16 @@ __device__ __forceinline__ void mobius_fwd_tiles_restage(float *lds, const float
     }
 }
 
-template <bool HALF>
-__device__ __forceinline__ void mobius_fwd_finish(const MobiusCtx &c, float S, float A, float J, Rot &R, float &ldj) {
+// FASTSP (kernels with the one-piece softplus, launched guarded): a weight sum below kMinWeightSum * K means every segment weight is so
+// small that fl(1 + 2^s) has rounded the weights themselves (relative error 2^-24 / weight): flagged like an overflow, the exact-fp32
+// re-run evaluates the full softplus.  (!(S >= x) also catches a NaN sum.)
+constexpr float kMinWeightSum = 1.0f / 128.0f;
+template <bool HALF, bool FASTSP = false>
+__device__ __forceinline__ void mobius_fwd_finish(const MobiusCtx &c, float S, float A, float J, Rot &R, float &ldj, bool &bad, float min_s) {
     S = pair_sum(S);
     A = pair_sum(A);
     J = pair_sum(J);
+    if constexpr (FASTSP) bad |= !(S >= min_s);
     const float invS = hw_rcp(S);
     float sn, cs;
     // HALF: theta' = pi + 2 A / S, and sin / cos of pi + d are -sin d, -cos d
@@ -715,8 +723,9 @@ __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_
             for (int g = 0; g < 4; ++g) {
                 squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, sg.ur[4 * tau + g], sg.uv[4 * tau + g]);
                 // the matrix output is s log2 e (layout.h S_PRESCALE).  Split precision: softplus / ln 2 in one piece, as the forward segment
-                // does -- the root finder and the log-det only use ratios of the weights; s > 88 overflows into the range guard
-                float sp = PREC == 1 ? hw_log2(1.0f + hw_exp2(o[4 * g])) : softplus(S_UNSCALE * o[4 * g]);
+                // does -- the root finder and the log-det only use ratios of the weights -- in its overflow-safe form (once per segment and layer:
+                // free next to the root finder)
+                float sp = PREC == 1 ? softplus2_safe(o[4 * g]) : softplus(S_UNSCALE * o[4 * g]);
                 if (8 * tau + 2 * g + h >= K) sp = 0.f;          // pad segment of a K % 8 != 0 layer: weight 0 AFTER the activation
                 sg.sp[4 * tau + g] = sp;
                 sg.q[4 * tau + g] = sp * (1.0f - fmaf(sg.uv[4 * tau + g], sg.uv[4 * tau + g], sg.ur[4 * tau + g] * sg.ur[4 * tau + g]));
@@ -1197,7 +1206,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC, LEAN>(lds, KT, args.K, lane, h, tt, ctx, S, A, J, fair);
                     else mobius_fwd_tiles_restage<PREC>(lds, params, KT, args.K, lane, h, tt, ctx, S, A, J, tid, NT);
                     barrier2();
-                    mobius_fwd_finish<PREC == 1>(ctx, S, A, J, R, ldj);
+                    mobius_fwd_finish<PREC == 1, LEAN && PREC == 1>(ctx, S, A, J, R, ldj, bad, kMinWeightSum * (float)args.K);
                 }
             } else {
                 const f32x16 o16 = Mlp<PREC>::last(lds + MOB_LAST, lane, h, tt);

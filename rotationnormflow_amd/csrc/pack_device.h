@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include "layout.h"
+#include "equalize.h"
 
 namespace rnf {
 
@@ -25,6 +26,7 @@ struct PackArgs {
     float *blob;
     int *flags;      // OR of PK_FLAG_* (device int, zeroed by the caller)
     int n_layers, K, F, Fp, prec;
+    int equalise;    // 1: move every MLP to its canonical scaling before the fp16 split (equalize.h)
     PackLayer layers[PK_MAX_LAYERS];
 };
 
@@ -40,36 +42,33 @@ __device__ __forceinline__ float pack2(float a, float b) {           // two fp16
     return __uint_as_float((unsigned)ua | ((unsigned)ub << 16));
 }
 
-// float `r` of a [n_ot][...] weight image of 64-column rows; row_of(ot, i) -> source row or nullptr (zero row)
-struct UnitScale { __device__ __forceinline__ float operator()(int, int) const { return 1.0f; } };
-// scale_of(ot, i): factor applied to the source row before it is stored / split (layout.h S_PRESCALE for the fc_last rows of s)
-template <class RowFn, class ScaleFn = UnitScale>
-__device__ __forceinline__ float w64_image(int r, int prec, RowFn row_of, int *flags, ScaleFn scale_of = ScaleFn()) {
+// float `r` of a [n_ot][...] weight image of 64-column rows; val(ot, i, col) -> the (already scaled) source value of row i of out tile
+// ot, column col (0 for a padding row)
+template <class ValFn>
+__device__ __forceinline__ float w64_image(int r, int prec, ValFn val, int *flags) {
     if (!prec) {                                                       // [ot][tg 8][lane 64] float4
         const int ot = r >> 11, tg = (r >> 8) & 7, lane = (r >> 2) & 63, c = r & 3;
-        const float *row = row_of(ot, lane & 31);
-        return row ? row[8 * tg + 4 * (lane >> 5) + c] * scale_of(ot, lane & 31) : 0.f;
+        return val(ot, lane & 31, 8 * tg + 4 * (lane >> 5) + c);
     }
     float v[2];                                                        // [ot][s 4][hi, lo][lane 64] 8 x fp16
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int e = 2 * r + q;
         const int ot = e >> 12, s = (e >> 10) & 3, lo = (e >> 9) & 1, lane = (e >> 3) & 63, j = e & 7;
-        const float *row = row_of(ot, lane & 31);
-        const float w = row ? row[16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)] * scale_of(ot, lane & 31) : 0.f;
+        const float w = val(ot, lane & 31, 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3));
         v[q] = half_part(w, lo, W_LO_SCALE, flags);
     }
     return pack2(v[0], v[1]);
 }
 
 // float `r` of the feature-projection weight image: rows of W (leading dimension ldw) from column col0, F real columns
-__device__ __forceinline__ float featproj_image(int r, int prec, const float *W, int ldw, int col0, int F, int Fp, int *flags) {
+__device__ __forceinline__ float featproj_image(int r, int prec, const float *W, int ldw, int col0, int F, int Fp, int *flags, const int *e0) {
     if (!prec) {                                                       // [ot][tg Fp/8][lane] float4
         const int ng = Fp / 8;
         const int ot = r / (ng * 256), rem = r % (ng * 256);
         const int tg = rem >> 8, lane = (rem >> 2) & 63, c = rem & 3;
         const int k = 8 * tg + 4 * (lane >> 5) + c;
-        return k < F ? W[(size_t)(32 * ot + (lane & 31)) * ldw + col0 + k] : 0.f;
+        return k < F ? ldexpf(W[(size_t)(32 * ot + (lane & 31)) * ldw + col0 + k], e0[32 * ot + (lane & 31)]) : 0.f;
     }
     const int ns = (Fp + 15) / 16;                                     // [ot][s][hi, lo][lane] 8 x fp16
     float v[2];
@@ -79,7 +78,7 @@ __device__ __forceinline__ float featproj_image(int r, int prec, const float *W,
         const int ot = e / (ns * 1024), rem = e % (ns * 1024);
         const int s = rem >> 10, lo = (rem >> 9) & 1, lane = (rem >> 3) & 63, j = rem & 7;
         const int k = 16 * s + 8 * (lane >> 5) + j;
-        const float w = k < F ? W[(size_t)(32 * ot + (lane & 31)) * ldw + col0 + k] : 0.f;
+        const float w = k < F ? ldexpf(W[(size_t)(32 * ot + (lane & 31)) * ldw + col0 + k], e0[32 * ot + (lane & 31)]) : 0.f;
         v[q] = half_part(w, lo, FEAT_LO_SCALE, flags);
     }
     return pack2(v[0], v[1]);
@@ -196,6 +195,30 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
     const float *WL = hb[2] + 64, *bL = WL + (size_t)NO * 64;
     const int n_tiles = mob ? (K + 7) / 8 : (kind == RNF_KIND_COND36 ? 2 : 1);
     const int rec_floats = MOB_HEAD_FLOATS + n_tiles * MOB_LAST_TILE_FLOATS;
+    // split precision: the layer's canonical scaling (equalize.h), the same per-unit functions the host packer evaluates, one unit per
+    // thread; every workgroup of the layer computes the exponents for itself
+    __shared__ double q_prev[64], q_cur[64], q_first[64];
+    __shared__ int ex[3][64];
+    {
+        const int i = threadIdx.x;
+        if (i < 64) { ex[0][i] = ex[1][i] = ex[2][i] = 0; }
+        if (args.equalise) {
+            if (i < 64) { q_first[i] = eq_q_first(W0 + (size_t)i * ni, ni, yo, b0[i]); q_prev[i] = q_first[i]; }
+            __syncthreads();
+            for (int l = 0; l < 3; ++l) {
+                if (i < 64) q_cur[i] = eq_q_hidden(hw[l] + (size_t)i * 64, q_prev, hb[l][i]);
+                __syncthreads();
+                if (i < 64) {
+                    if (l < 2) ex[l + 1][i] = eq_exponent(q_cur[i]);
+                    else ex[0][i] = eq_exponent(q_first[i] + q_cur[i]);
+                    q_prev[i] = q_cur[i];
+                }
+                __syncthreads();
+            }
+        } else {
+            __syncthreads();
+        }
+    }
     // reference row of packed fc_last row `row` of tile tau (layout.h): Moebius: segment k = 8 tau + 2g + h, component c;
     // Condition16Trans: M[2g + h][c], rows >= 16 are zero padding
     auto src_row = [&](int tau, int row) {
@@ -211,21 +234,27 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
             const int ot = idx >> 7, lane = (idx >> 1) & 63, e = idx & 1;
             const int o = 32 * ot + (lane & 31), h = lane >> 5;
             if (!mob) v = 0.f;                                         // Condition16Trans: x0 comes from the projection
-            else if (e == 0) v = W0[(size_t)o * ni + h];
-            else v = h ? (F ? 0.f : b0[o]) : W0[(size_t)o * ni + 2];
+            else if (e == 0) v = ldexpf(W0[(size_t)o * ni + h], ex[0][o]);
+            else v = h ? (F ? 0.f : ldexpf(b0[o], ex[0][o])) : ldexpf(W0[(size_t)o * ni + 2], ex[0][o]);
         } else if (idx < MOB_HB) {
             const int q = idx - MOB_HID, Lh = q >> 12;
             const float *W = hw[Lh];
-            v = w64_image(q & 4095, prec, [&](int ot, int i) { return W + (size_t)(32 * ot + i) * 64; }, args.flags);
+            const int *eo = ex[(Lh + 1) % 3], *ei = ex[Lh];          // x1 <- x0, x2 <- x1, x3 (scaled like x0) <- x2
+            v = w64_image(q & 4095, prec, [&](int ot, int i, int col) { return ldexpf(W[(size_t)(32 * ot + i) * 64 + col], eo[32 * ot + i] - ei[col]); },
+                          args.flags);
         } else if (idx < MOB_HEAD_FLOATS) {
-            const int q = idx - MOB_HB;
-            v = hb[q >> 6][bias_row(q & 63)];
+            const int q = idx - MOB_HB, Lh = q >> 6, row = bias_row(q & 63);
+            v = ldexpf(hb[Lh][row], ex[(Lh + 1) % 3][row]);
         } else {
             const int q = idx - MOB_LAST, tau = q / MOB_LAST_TILE_FLOATS, r = q % MOB_LAST_TILE_FLOATS;
             // Moebius: the rows of the segment weights' pre-activations (source rows 0 .. K-1) are packed times log2 e (layout.h)
             if (r < MOB_LAST_TILE_BIAS) {
-                v = w64_image(r, prec, [&](int, int i) { const int s = src_row(tau, i); return s < 0 ? (const float *)nullptr : WL + (size_t)s * 64; },
-                              args.flags, [&](int, int i) { const int s = src_row(tau, i); return (mob && s >= 0 && s < K) ? S_PRESCALE : 1.0f; });
+                v = w64_image(r, prec, [&](int, int i, int col) {
+                    const int s = src_row(tau, i);
+                    if (s < 0) return 0.f;
+                    const float w = ldexpf(WL[(size_t)s * 64 + col], -ex[0][col]);
+                    return (mob && s < K) ? w * S_PRESCALE : w;
+                }, args.flags);
             } else {
                 const int s = src_row(tau, bias_row(r - MOB_LAST_TILE_BIAS));
                 v = s < 0 ? 0.f : ((mob && s < K) ? bL[s] * S_PRESCALE : bL[s]);
@@ -240,8 +269,8 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
         const int bias_at = w_floats;
         for (int idx = tid; idx < total; idx += nth) {
             float v = 0.f;
-            if (idx < w_floats) v = featproj_image(idx, prec, W0, ni, yo, F, Fp, args.flags);
-            else if (idx < bias_at + 64) v = b0[bias_row(idx - bias_at)];
+            if (idx < w_floats) v = featproj_image(idx, prec, W0, ni, yo, F, Fp, args.flags, ex[0]);
+            else if (idx < bias_at + 64) { const int row = bias_row(idx - bias_at); v = ldexpf(b0[row], ex[0][row]); }
             fo[idx] = v;
         }
     }

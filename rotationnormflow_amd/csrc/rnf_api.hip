@@ -17,6 +17,7 @@
 #include "sampler_kernel.h"
 #include "fisher_math.h"
 #include "layout.h"
+#include "equalize.h"
 
 using namespace rnf;
 
@@ -144,6 +145,143 @@ static void pack_featproj(float *out, const float *W, int ldw, int col0, int F, 
     pack_bias(out + (size_t)2 * ng * 256, 2, [&](int ot, int row) { return b0[32 * ot + row]; });
 }
 
+
+// ---- the conditioner MLP on the canonical point of its ReLU-rescaling orbit (equalize.h): what the f16x2 images are split from ----
+struct ScaledMlp {
+    int ni = 0, yo = 0, n_out = 0;
+    std::vector<float> W0, b0, hw[3], hb[3], WL;     // W0 [64][ni], hw[l] [64][64], WL [n_out][64]
+    EqExponents eq;
+};
+
+// RNF_EQUALIZE=0: split the weights as given (measurement / test switch: shows what the audit catches without the equalisation)
+static bool equalise_allowed() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = std::getenv("RNF_EQUALIZE");
+        mode = (e && e[0] == '0') ? 0 : 1;
+    }
+    return mode == 1;
+}
+
+static void scale_mlp(const float *fc_first_w, int ni, int yo, const float *fc_first_b, const float *const hw[3], const float *const hb[3],
+                      const float *fc_last_w, int n_out, bool equalise, ScaledMlp &m) {
+    m.ni = ni; m.yo = yo; m.n_out = n_out;
+    if (equalise && equalise_allowed()) eq_exponents_host(fc_first_w, ni, yo, fc_first_b, hw, hb, m.eq);
+    else std::memset(&m.eq, 0, sizeof(m.eq));
+    const int *e0 = m.eq.e[0], *e1 = m.eq.e[1], *e2 = m.eq.e[2];
+    m.W0.resize((size_t)64 * ni);
+    m.b0.resize(64);
+    for (int o = 0; o < 64; ++o) {
+        for (int c = 0; c < ni; ++c) m.W0[(size_t)o * ni + c] = std::ldexp(fc_first_w[(size_t)o * ni + c], e0[o]);
+        m.b0[o] = std::ldexp(fc_first_b[o], e0[o]);
+    }
+    const int *eo[3] = {e1, e2, e0}, *ei[3] = {e0, e1, e2};      // x1 = W1 relu(x0), x2 = W3 relu(x1), x3 = W5 relu(x2) (flow/condition.py:24-29)
+    for (int l = 0; l < 3; ++l) {
+        m.hw[l].resize(4096);
+        m.hb[l].resize(64);
+        for (int o = 0; o < 64; ++o) {
+            for (int j = 0; j < 64; ++j) m.hw[l][o * 64 + j] = std::ldexp(hw[l][o * 64 + j], eo[l][o] - ei[l][j]);
+            m.hb[l][o] = std::ldexp(hb[l][o], eo[l][o]);
+        }
+    }
+    m.WL.resize((size_t)n_out * 64);
+    for (int o = 0; o < n_out; ++o)
+        for (int j = 0; j < 64; ++j) m.WL[(size_t)o * 64 + j] = std::ldexp(fc_last_w[(size_t)o * 64 + j], -e0[j]);
+}
+
+// Pack-time AUDIT of the split-precision images: the packed network (scaled weights and every activation rounded to fp16 hi + lo pairs
+// exactly as the kernels hold them, three products per term, accumulation in double so that only the REPRESENTATION error shows) against the
+// exact network (the weights as given, double) on probe inputs: unit vectors y, feature rows N(0, 1) and N(0, 1/64) from a fixed
+// generator.  Returns max_o |out_packed - out_exact| / max(1, sum_j |Wl_oj t_j| + |bl_o|).  A layer that the equalisation could not bring into the regime
+// where the pairs carry ~22 bits (estimates far off, a degenerate checkpoint) is refused like a weight outside the fp16 range, and the
+// flow runs on the exact-fp32 kernels.
+static inline void split_h(float v, float lo_scale, double &hi, double &lo) {
+    const _Float16 h = (_Float16)v;
+    hi = (double)(float)h;
+    lo = (double)(float)(_Float16)((v - (float)h) * lo_scale) / lo_scale;
+}
+static double audit_mlp(const ScaledMlp &m, const float *fc_first_w, const float *fc_first_b, const float *const hw[3], const float *const hb[3],
+                        const float *fc_last_w, const float *fc_last_b) {
+    const int ni = m.ni, yo = m.yo, n_out = m.n_out, F = ni - yo;
+    constexpr int PROBES = 6;
+    unsigned long long rng = 0x9E3779B97F4A7C15ull;
+    auto uni = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (double)((rng >> 11) & ((1ull << 53) - 1)) / (double)(1ull << 53); };
+    auto gauss = [&]() { double s = 0.0; for (int i = 0; i < 12; ++i) s += uni(); return s - 6.0; };
+    std::vector<double> whi((size_t)3 * 4096), wlo((size_t)3 * 4096), lhi((size_t)n_out * 64), llo((size_t)n_out * 64);
+    for (int l = 0; l < 3; ++l)
+        for (int i = 0; i < 4096; ++i) split_h(m.hw[l][i], W_LO_SCALE, whi[l * 4096 + i], wlo[l * 4096 + i]);
+    for (size_t i = 0; i < (size_t)n_out * 64; ++i) split_h(m.WL[i], W_LO_SCALE, lhi[i], llo[i]);
+    std::vector<double> fhi((size_t)64 * (F > 0 ? F : 1)), flo(fhi.size());
+    for (int o = 0; o < 64; ++o)
+        for (int k = 0; k < F; ++k) split_h(m.W0[(size_t)o * ni + yo + k], FEAT_LO_SCALE, fhi[(size_t)o * F + k], flo[(size_t)o * F + k]);
+    double worst = 0.0;
+    std::vector<float> in(ni > 0 ? ni : 1);
+    for (int p = 0; p < PROBES; ++p) {
+        double y[3] = {gauss(), gauss(), gauss()};
+        const double yn = std::sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]) + 1e-30;
+        for (int c = 0; c < yo; ++c) in[c] = (float)(y[c] / yn);
+        const double fs = (p & 1) ? 0.125 : 1.0;
+        for (int k = 0; k < F; ++k) in[yo + k] = (float)(fs * gauss());
+        // exact
+        double x0[64], a[64], b[64], x3[64];
+        for (int o = 0; o < 64; ++o) {
+            double s = fc_first_b[o];
+            for (int c = 0; c < ni; ++c) s += (double)fc_first_w[(size_t)o * ni + c] * in[c];
+            x0[o] = s;
+            a[o] = s > 0 ? s : 0;
+        }
+        for (int l = 0; l < 3; ++l) {
+            for (int o = 0; o < 64; ++o) {
+                double s = hb[l][o];
+                for (int j = 0; j < 64; ++j) s += (double)hw[l][o * 64 + j] * a[j];
+                b[o] = s;
+            }
+            for (int o = 0; o < 64; ++o) { x3[o] = b[o]; a[o] = b[o] > 0 ? b[o] : 0; }
+        }
+        double t[64];
+        for (int o = 0; o < 64; ++o) { const double v = x0[o] + x3[o]; t[o] = v > 0 ? v : 0; }
+        // packed arithmetic
+        float px0[64], pa[64], pb[64];
+        std::vector<double> ph(F > 0 ? F : 1), pl(ph.size());
+        for (int k = 0; k < F; ++k) split_h(in[yo + k], FEAT_LO_SCALE, ph[k], pl[k]);
+        for (int o = 0; o < 64; ++o) {
+            double s = m.b0[o];
+            for (int c = 0; c < yo; ++c) s += (double)m.W0[(size_t)o * ni + c] * in[c];
+            for (int k = 0; k < F; ++k) s += fhi[(size_t)o * F + k] * ph[k] + fhi[(size_t)o * F + k] * pl[k] + flo[(size_t)o * F + k] * ph[k];
+            px0[o] = (float)s;
+            pa[o] = px0[o] > 0 ? px0[o] : 0.f;
+        }
+        for (int l = 0; l < 3; ++l) {
+            double ah[64], al[64];
+            for (int j = 0; j < 64; ++j) split_h(pa[j], W_LO_SCALE, ah[j], al[j]);
+            for (int o = 0; o < 64; ++o) {
+                double s = m.hb[l][o];
+                const double *wh = &whi[l * 4096 + o * 64], *wl = &wlo[l * 4096 + o * 64];
+                for (int j = 0; j < 64; ++j) s += wh[j] * ah[j] + wh[j] * al[j] + wl[j] * ah[j];
+                pb[o] = (float)s;
+            }
+            for (int o = 0; o < 64; ++o) pa[o] = pb[o] > 0 ? pb[o] : 0.f;
+        }
+        double th[64], tl[64];
+        for (int j = 0; j < 64; ++j) { const float v = px0[j] + pb[j]; split_h(v > 0 ? v : 0.f, W_LO_SCALE, th[j], tl[j]); }
+        for (int o = 0; o < n_out; ++o) {
+            double se = fc_last_b[o], sp = fc_last_b[o], mag = std::fabs((double)fc_last_b[o]);
+            for (int j = 0; j < 64; ++j) {
+                se += (double)fc_last_w[(size_t)o * 64 + j] * t[j];
+                mag += std::fabs((double)fc_last_w[(size_t)o * 64 + j] * t[j]);
+                sp += lhi[(size_t)o * 64 + j] * th[j] + lhi[(size_t)o * 64 + j] * tl[j] + llo[(size_t)o * 64 + j] * th[j];
+            }
+            const double err = std::fabs(sp - se) / std::fmax(1.0, mag);       // relative to the un-cancelled magnitude of the output's sum
+            if (!(err <= worst)) worst = err;          // NaN lands here too
+        }
+    }
+    return worst;
+}
+// largest audited error a split-precision layer may show (conditioner outputs, relative above 1); a balanced layer sits at ~2e-7
+constexpr double AUDIT_MAX_ERR = 4.0e-6;
+static thread_local double g_last_audit = 0.0;     // per calling thread, like g_half_overflow
+extern "C" double rnf_last_pack_audit(void) { return g_last_audit; }
+
 extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b, const float *l1_w, const float *l1_b,
                                const float *l3_w, const float *l3_b, const float *l5_w, const float *l5_b,
                                const float *fc_last_w, const float *fc_last_b, int32_t K, int32_t F, int32_t prec,
@@ -151,19 +289,25 @@ extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b,
     if (K <= 0) return fail("rnf_pack_mobius: segments=%d must be positive", K);
     if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2) return fail("rnf_pack_mobius: unknown precision %d", prec);
     g_half_overflow = false;
+    g_last_audit = 0.0;
     if (F < 0 || F % 8) return fail("rnf_pack_mobius: feature_dim=%d must be a multiple of 8 (pad on the host)", F);
     const int ni = 3 + F;
+    const float *hw[3] = {l1_w, l3_w, l5_w};
+    const float *hb[3] = {l1_b, l3_b, l5_b};
+    // split precision: the layer is first moved to the canonical point of its ReLU-rescaling orbit (equalize.h); exact fp32: packed as given
+    ScaledMlp m;
+    scale_mlp(fc_first_w, ni, 3, fc_first_b, hw, hb, fc_last_w, 4 * K, prec == RNF_PREC_F16X2, m);
     // fc_first: float2 per lane = (W0[o][h], h ? b0[o] : W0[o][2]); conditional layers carry b0 in the projection
     for (int ot = 0; ot < 2; ++ot)
         for (int lane = 0; lane < 64; ++lane) {
             const int o = 32 * ot + (lane & 31), h = lane >> 5;
             float *dst = out + MOB_FIRST + (ot * 64 + lane) * 2;
-            dst[0] = fc_first_w[(size_t)o * ni + h];
-            dst[1] = h ? (F ? 0.f : fc_first_b[o]) : fc_first_w[(size_t)o * ni + 2];
+            dst[0] = m.W0[(size_t)o * ni + h];
+            dst[1] = h ? (F ? 0.f : m.b0[o]) : m.W0[(size_t)o * ni + 2];
         }
-    const float *hw[3] = {l1_w, l3_w, l5_w};
-    const float *hb[3] = {l1_b, l3_b, l5_b};
-    pack_hidden(out, hw, hb, prec);
+    const float *shw[3] = {m.hw[0].data(), m.hw[1].data(), m.hw[2].data()};
+    const float *shb[3] = {m.hb[0].data(), m.hb[1].data(), m.hb[2].data()};
+    pack_hidden(out, shw, shb, prec);
     // fc_last: packed row P = 32*tau + 8g + 4h + c  <->  segment k = 8*tau + 2g + h, component c
     // (K % 8 != 0: the last tile is padded with zero rows for segments k >= K; the kernels give those segments weight 0)
     auto src_row = [&](int tau, int row) {
@@ -173,13 +317,12 @@ extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b,
         return c == 0 ? k : K + 3 * k + (c - 1);
     };
     // the rows that produce the segment weights' pre-activations (reference rows 0 .. K-1) are packed times log2 e (layout.h S_PRESCALE)
-    std::vector<float> s_rows((size_t)K * 64);
-    for (size_t i = 0; i < s_rows.size(); ++i) s_rows[i] = fc_last_w[i] * S_PRESCALE;
+    for (size_t i = 0; i < (size_t)K * 64; ++i) m.WL[i] *= S_PRESCALE;
     for (int tau = 0; tau < (K + 7) / 8; ++tau) {
         float *rec = out + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS;
         auto row_of = [&](int, int i) {
             const int r = src_row(tau, i);
-            return r < 0 ? (const float *)nullptr : (r < K ? s_rows.data() + (size_t)r * 64 : fc_last_w + (size_t)r * 64);
+            return r < 0 ? (const float *)nullptr : m.WL.data() + (size_t)r * 64;
         };
         if (prec) pack_w64_h(rec, 1, row_of); else pack_w64(rec, 1, row_of);
         pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) {
@@ -187,8 +330,15 @@ extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b,
             return r < 0 ? 0.f : (r < K ? fc_last_b[r] * S_PRESCALE : fc_last_b[r]);
         });
     }
-    if (F) { if (prec) pack_featproj_h(out_feat, fc_first_w, ni, 3, F, fc_first_b); else pack_featproj(out_feat, fc_first_w, ni, 3, F, fc_first_b); }
+    if (F) { if (prec) pack_featproj_h(out_feat, m.W0.data(), ni, 3, F, m.b0.data()); else pack_featproj(out_feat, m.W0.data(), ni, 3, F, m.b0.data()); }
     if (prec && g_half_overflow) return fail("rnf_pack_mobius: a weight is outside the fp16 range; use RNF_PREC_FP32") + 1;
+    if (prec) {
+        for (size_t i = 0; i < (size_t)K * 64; ++i) m.WL[i] = std::ldexp(fc_last_w[i], -m.eq.e[0][i & 63]);      // the audit compares unscaled outputs
+        g_last_audit = audit_mlp(m, fc_first_w, fc_first_b, hw, hb, fc_last_w, fc_last_b);
+        if (!(g_last_audit <= AUDIT_MAX_ERR))
+            return fail("rnf_pack_mobius: the split-precision image of this layer is off by %.2e on the probe inputs (limit %.1e): its scales "
+                        "are outside what fp16 pairs resolve; use RNF_PREC_FP32", g_last_audit, AUDIT_MAX_ERR) + 1;
+    }
     return 0;
 }
 
@@ -227,10 +377,15 @@ static int pack_cond(const float *fc_first_w, const float *fc_first_b, const flo
     if (F <= 0 || F % 8) return fail("rnf_pack_cond16: feature_dim=%d must be a positive multiple of 8", F);
     if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2) return fail("rnf_pack_cond16: unknown precision %d", prec);
     g_half_overflow = false;
+    g_last_audit = 0.0;
     std::memset(out, 0, sizeof(float) * (n_out == 36 ? COND36_FLOATS : COND16_FLOATS));   // zero fc_first image: x0 comes from the projection
     const float *hw[3] = {l1_w, l3_w, l5_w};
     const float *hb[3] = {l1_b, l3_b, l5_b};
-    pack_hidden(out, hw, hb, prec);
+    ScaledMlp m;                                       // equalize.h: canonical scaling before the fp16 split (split precision only)
+    scale_mlp(fc_first_w, F, 0, fc_first_b, hw, hb, fc_last_w, n_out, prec == RNF_PREC_F16X2, m);
+    const float *shw[3] = {m.hw[0].data(), m.hw[1].data(), m.hw[2].data()};
+    const float *shb[3] = {m.hb[0].data(), m.hb[1].data(), m.hb[2].data()};
+    pack_hidden(out, shw, shb, prec);
     // one fc_last tile: packed row 8g + 4h + c (g = 0,1) <-> output 4*(2g+h) + c (= M[2g + h][c] of the 4x4); rows >= 16 and outputs
     // >= n_out are zero
     auto src_row = [&](int row) {
@@ -242,12 +397,18 @@ static int pack_cond(const float *fc_first_w, const float *fc_first_b, const flo
     for (int tau = 0; tau < (n_out == 36 ? 2 : 1); ++tau) {
         auto src = [&](int row) { return n_out == 36 ? (tau == 0 ? row : (row < 4 ? 32 + row : -1)) : src_row(row); };
         float *rec = out + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS;
-        auto row_of = [&](int, int i) { int s = src(i); return s < 0 ? (const float *)nullptr : fc_last_w + (size_t)s * 64; };
+        auto row_of = [&](int, int i) { int s = src(i); return s < 0 ? (const float *)nullptr : m.WL.data() + (size_t)s * 64; };
         if (prec) pack_w64_h(rec, 1, row_of); else pack_w64(rec, 1, row_of);
         pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) { int s = src(row); return s < 0 ? 0.f : fc_last_b[s]; });
     }
-    if (prec) pack_featproj_h(out_feat, fc_first_w, F, 0, F, fc_first_b); else pack_featproj(out_feat, fc_first_w, F, 0, F, fc_first_b);
+    if (prec) pack_featproj_h(out_feat, m.W0.data(), F, 0, F, m.b0.data()); else pack_featproj(out_feat, m.W0.data(), F, 0, F, m.b0.data());
     if (prec && g_half_overflow) return fail("rnf_pack_cond16: a weight is outside the fp16 range; use RNF_PREC_FP32") + 1;
+    if (prec) {
+        g_last_audit = audit_mlp(m, fc_first_w, fc_first_b, hw, hb, fc_last_w, fc_last_b);
+        if (!(g_last_audit <= AUDIT_MAX_ERR))
+            return fail("rnf_pack_cond16: the split-precision image of this layer is off by %.2e on the probe inputs (limit %.1e): its scales "
+                        "are outside what fp16 pairs resolve; use RNF_PREC_FP32", g_last_audit, AUDIT_MAX_ERR) + 1;
+    }
     return 0;
 }
 
@@ -638,7 +799,9 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     }
     const int fair_off = a.fair_off;
     // guarded split-precision call: every chunk is followed by the exact-fp32 kernels, which return at once unless the chunk's guard fired
-    const bool guarded = prec == 1 && any_mlp && have_fb && ws && ws_bytes >= PARTIALS_BYTES && guard_allowed();
+    // (an in-place call -- rotation_out == rotation -- cannot be re-run from its own overwritten input: it runs unguarded, on the kernel
+    // instantiations whose softplus is overflow-safe on its own; include/rnf_hip.h "aliasing")
+    const bool guarded = prec == 1 && any_mlp && have_fb && ws && ws_bytes >= PARTIALS_BYTES && guard_allowed() && !(rot_out && rot_out == rot);
     int *guard = guarded ? reinterpret_cast<int *>(reinterpret_cast<double *>(ws) + GUARD_AT) : nullptr;
     FlowArgs afb;
     if (guarded) {
@@ -718,7 +881,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
                         : launch_stack<DIR_, KT_, true, 0, true>(a, grid, lds_bytes, stream, nwk))                  \
                 : (prec ? launch_stack<DIR_, KT_, false, 1, true>(a, grid, lds_bytes, stream, nwk)                  \
                         : launch_stack<DIR_, KT_, false, 0, true>(a, grid, lds_bytes, stream, nwk))) :              \
-    (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1>(a, grid, lds_bytes, stream, nwk, lean && a.tab_off >= 0)       \
+    (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1>(a, grid, lds_bytes, stream, nwk, lean && guarded && a.tab_off >= 0)       \
                   : launch_stack<DIR_, KT_, true, 0>(a, grid, lds_bytes, stream, nwk))                              \
           : (prec ? launch_stack<DIR_, KT_, false, 1>(a, grid, lds_bytes, stream, nwk)                              \
                   : launch_stack<DIR_, KT_, false, 0>(a, grid, lds_bytes, stream, nwk)))
@@ -919,6 +1082,7 @@ extern "C" int rnf_pack_flow_device(const float *plain, const int32_t *pdesc, in
     std::memset(&a, 0, sizeof(a));
     a.plain = plain; a.blob = blob; a.flags = flags;
     a.n_layers = n_layers; a.K = K; a.F = F; a.Fp = (F + 7) / 8 * 8; a.prec = prec;
+    a.equalise = (prec == RNF_PREC_F16X2 && equalise_allowed()) ? 1 : 0;
     for (int l = 0; l < n_layers; ++l) {
         const int32_t *d = pdesc + (size_t)l * 4;
         const int kind = d[0] & 15;

@@ -353,7 +353,18 @@ RNF_HD Frame make_frame_scaled(v3f x, v3f y, float k) {
 struct SegS7 {
     float e, b, bb, num, t, c, z, p;     // four values cross each stage boundary (the pipelined tile keeps four segments in flight)
 };
-template <int STAGE>
+// log2(1 + 2^x) that is finite for every finite x and keeps its RELATIVE accuracy for x << 0 (the kernels that cannot rely on the range
+// guard's exact-fp32 re-run: training passes, device-packed blobs, RNF_GUARD=0, C-ABI callers without fallback images): the
+// exponent is clamped (log2(1 + 2^126) = 126 exactly: the reference's softplus is linear there), and below 2^x = 2^-6 -- where
+// fl(1 + e) would round e to a few bits -- the series log2 e * (e - e^2/2 + e^3/3) takes over (truncation 2^-20 relative at the switch).
+RNF_HD float softplus2_safe(float x) {
+    const float e = hw_exp2(fminf(x, 126.0f));
+    const float big = hw_log2(1.0f + e);
+    const float small = 1.44269504088896341f * e * fmaf(e, fmaf(e, 0.333333333f, -0.5f), 1.0f);
+    return e < 0.015625f ? small : big;
+}
+
+template <int STAGE, bool SAFE = true>
 RNF_HD void seg_s7_stage(SegS7 &g, float s_raw, float w0, float w1, float w2, const Frame &f7, float &S, float &A, float &J) {
     if constexpr (STAGE == 0) {
         const float a = fmaf(w2, f7.r.z, fmaf(w1, f7.r.y, w0 * f7.r.x));
@@ -384,18 +395,21 @@ RNF_HD void seg_s7_stage(SegS7 &g, float s_raw, float w0, float w1, float w2, co
         // their ratios (theta' = pi + 2 A / S, ldj = log(J / S)).  No argument split: for s < -17 the weight rounds to 0 exactly as before
         // (< 1e-7 absolute on a term divided by the sum of K such terms); for s > 88 the exponential overflows to inf, the layer's ratios
         // become NaN and the range guard re-runs the launch on the exact-fp32 kernels, whose softplus is the full form.
-        const float sp = hw_log2(1.0f + hw_exp2(s_raw));          // s_raw arrives multiplied by log2 e (layout.h S_PRESCALE)
+        // That form (SAFE = false) is only instantiated by kernels the launcher runs GUARDED (flow_kernels.h: LEAN / FUSED); their layer
+        // finish also flags a weight sum so small that fl(1 + e) has rounded the weights themselves (mobius_fwd_finish: kMinWeightSum).
+        const float sp = SAFE ? softplus2_safe(s_raw) : hw_log2(1.0f + hw_exp2(s_raw));          // s_raw arrives multiplied by log2 e (layout.h S_PRESCALE)
 #endif
         S += sp;
         A = fmaf(sp, p * g.t, A);
         J = fmaf(sp, g.c, J);
     }
 }
+template <bool SAFE = true>
 RNF_HD void segment_fwd_s7(float s_raw, float w0, float w1, float w2, const Frame &f7, float &S, float &A, float &J) {
     SegS7 g;
-    seg_s7_stage<0>(g, s_raw, w0, w1, w2, f7, S, A, J);
-    seg_s7_stage<1>(g, s_raw, w0, w1, w2, f7, S, A, J);
-    seg_s7_stage<2>(g, s_raw, w0, w1, w2, f7, S, A, J);
+    seg_s7_stage<0, SAFE>(g, s_raw, w0, w1, w2, f7, S, A, J);
+    seg_s7_stage<1, SAFE>(g, s_raw, w0, w1, w2, f7, S, A, J);
+    seg_s7_stage<2, SAFE>(g, s_raw, w0, w1, w2, f7, S, A, J);
 }
 
 // pytorch3d.transforms.matrix_to_quaternion (published 0.7.5 rule; call site flow/squeezetrans.py:34):

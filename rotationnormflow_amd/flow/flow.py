@@ -94,8 +94,15 @@ class Flow(nn.Module):
             plain = torch.cat([t.reshape(-1) if (t.is_cuda and t.dtype is f32) else t.to(device=device, dtype=f32).reshape(-1)
                                for t in tensors]) if tensors else torch.zeros(0, device=device)
             with torch.cuda.device(device):
-                blob = plan.pack(plain, torch.cuda.current_stream(device).cuda_stream)
-        return runtime.PackedFlow(blob, plan.desc, plan.n_cond, plan.feat_dim, plan.feat_padded, plan.segments, plan.precision)
+                blob = plan.pack(plain, torch.cuda.current_stream(device).cuda_stream, with_fallback=runtime._guard_fallback)
+        desc = autograd.desc_with_fallback(plan) if runtime._guard_fallback else plan.desc
+        packed = runtime.PackedFlow(blob, desc, plan.n_cond, plan.feat_dim, plan.feat_padded, plan.segments, plan.precision)
+        # layers whose per-sample matrices the host builds (ConditionRot / ConditionLU): in side-slot order, as runtime.pack_layers does
+        packed.side_layers = [layer for layer in layers if layer._rnf_kind in runtime.SIDE_KINDS]
+        if packed.side_layers and not packed.feat_dim:
+            packed.feat_dim = packed.side_layers[0].feature_dim
+            packed.feat_padded = runtime.pad8(packed.feat_dim)
+        return packed
 
     def _packed(self, device):
         if (self.training or getattr(self, "_is_replica", False)) and torch.device(device).type == "cuda":

@@ -350,29 +350,43 @@ def params_key(module, device, params=None):
 
 class PackCache:
     """Packed blobs of one module, one entry per device, keyed on the parameter versions; thread safe (nn.DataParallel replicas share
-    this object and call from worker threads).  The list of parameters is walked once and kept (rebuilt when a parameter OBJECT is
-    replaced, which changes ``len`` or the ids found by a cheap spot check of ``module._parameters`` -- flows register no parameters
-    after construction).  ``invalidate()`` drops everything: the hook for parameter edits the key cannot see (``p.data.copy_()``, EMA
-    swaps, fused optimizers stepped outside this library's backward)."""
+    this object and call from worker threads).  The module tree is walked once and kept as a flat list of ``(submodule._parameters,
+    name)`` slots; every call checks that each slot still holds the SAME Parameter object (a flat loop of identity tests, no tree walk)
+    and re-walks when one was replaced (``module.weight = nn.Parameter(...)``, parametrize / prune, conversions that swap parameter
+    objects): the versions and addresses of the OLD objects never change, so without this check the stale blob would be served (ADVICE
+    r2).  Flows register no parameters after construction.  ``invalidate()`` drops everything: the hook for parameter edits the key cannot
+    see (``p.data.copy_()``, EMA swaps, fused optimizers stepped outside this library's backward)."""
 
     def __init__(self):
         self._lock = threading.Lock()
         self._entries = {}            # str(device) -> (key, packed)
         self._params = None
+        self._slots = None
 
     def invalidate(self):
         with self._lock:
             self._entries.clear()
             self._params = None
+            self._slots = None
+
+    def _walk(self, module):
+        self._slots = [(m._parameters, name) for m in module.modules() for name, p in m._parameters.items() if p is not None]
+        self._params = [d[name] for d, name in self._slots]
+
+    def _live(self):
+        for (d, name), p in zip(self._slots, self._params):
+            if d.get(name) is not p:
+                return False
+        return True
 
     def get(self, module, device, builder):
         with self._lock:
-            if self._params is None:
-                self._params = list(module.parameters())
+            if self._params is None or not self._live():
+                self._walk(module)
             key = params_key(module, device, self._params)
             hit = self._entries.get(str(device))
             if hit is None or hit[0] != key:
-                self._params = list(module.parameters())          # a miss is rare (once per parameter version): re-walk, then pack
+                self._walk(module)                                # a miss is rare (once per parameter version): re-walk, then pack
                 key = params_key(module, device, self._params)
                 hit = (key, builder())
                 self._entries[str(device)] = hit

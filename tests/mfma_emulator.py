@@ -156,8 +156,9 @@ def gemm_tile64_h(rec32, off_floats, act, acc):
     return acc
 
 
-def conditioner_from_record_h(rec32, y, K):
-    """ConditionalTransform output [32, 4K] through the split-precision dataflow of Mlp<1> (fc_first stays fp32)."""
+def conditioner_from_record_h(rec32, y, K, cinit=None):
+    """ConditionalTransform output [32, 4K] through the split-precision dataflow of Mlp<1> (fc_first stays fp32).
+    cinit: feature-projection fragments (featproj_from_record_h) that initialise the fc_first accumulator of a conditional layer."""
     rec32 = np.ascontiguousarray(rec32, dtype=np.float32)
     rec = rec32.astype(np.float64)
     y = np.asarray(y, np.float64)
@@ -166,7 +167,7 @@ def conditioner_from_record_h(rec32, y, K):
     x0 = []
     for ot in range(2):
         a2 = rec[MOB_FIRST + ((ot * 64 + LANES)[:, None] * 2 + np.arange(2)[None, :])]
-        c = mfma(a2[:, 0], bA, np.zeros((16, 64)))
+        c = mfma(a2[:, 0], bA, np.zeros((16, 64)) if cinit is None else cinit[ot].copy())
         x0.append(mfma(a2[:, 1], bB, c))
     act = split_act(x0)
     hcur = x0

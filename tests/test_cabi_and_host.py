@@ -243,3 +243,24 @@ def test_pmc_summary_tool(tmp_path):
     assert s["counters"]["FETCH_SIZE"] == 200.0 and s["counters"]["WRITE_SIZE"] == 8.0        # the two big-grid dispatches only
     assert s["hbm_fetch_bytes_per_launch"] == 200.0 * 1024 * 2 and s["hbm_write_bytes_per_launch"] == 8.0 * 1024
     assert s["workgroup_size"] == 1024
+
+
+def test_pack_cache_sees_a_replaced_parameter_object():
+    """replacing a Parameter OBJECT (module.weight = nn.Parameter(...)) leaves the old object's id / _version / data_ptr
+    untouched; the cache must notice through its identity check of the live ``_parameters`` slots."""
+    import torch
+    from rotationnormflow_amd import runtime
+    m = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2))
+    cache, calls = runtime.PackCache(), []
+
+    def build():
+        calls.append(1)
+        return len(calls)
+    assert cache.get(m, "cpu", build) == 1 and cache.get(m, "cpu", build) == 1
+    m[0].weight = torch.nn.Parameter(torch.zeros(4, 3))
+    assert cache.get(m, "cpu", build) == 2 and cache.get(m, "cpu", build) == 2
+    with torch.no_grad():
+        m[1].bias.add_(1.0)                                  # in-place edit: version bump
+    assert cache.get(m, "cpu", build) == 3
+    cache.invalidate()
+    assert cache.get(m, "cpu", build) == 4

@@ -68,10 +68,16 @@ def test_split_precision_feature_projection(F):
     g = emu.featproj_from_record_h(frec, feat.astype(np.float64), F)
     W0 = m.fc_first.weight.detach().double().numpy()
     want = feat.astype(np.float64) @ W0[:, 3:].T + m.fc_first.bias.detach().double().numpy()      # [32, 64]
+    # the packer scales row i of the projection (with x0_i) by a power of two (csrc/equalize.h): recover it per row, then compare
+    got = np.zeros_like(want)
     for ot in range(2):
         for r in range(16):
-            rows = 32 * ot + emu.rho(r, emu.H)
-            assert np.abs(g[ot][r] - want[emu.J, rows]).max() < 3e-6 * max(1.0, np.abs(want).max())
+            got[emu.J, 32 * ot + emu.rho(r, emu.H)] = g[ot][r]
+    for i in range(64):
+        k = np.argmax(np.abs(want[:, i]))
+        e = np.log2(got[k, i] / want[k, i])
+        assert abs(e - round(e)) < 1e-4, (i, e)
+        assert np.abs(got[:, i] * 2.0 ** -round(e) - want[:, i]).max() < 3e-6 * max(1.0, np.abs(want).max())
 
 
 def test_cond16_record_yields_matrix_rows_on_lane_halves():
@@ -147,3 +153,75 @@ def test_pack_rejects_bad_sizes():
     L = _lib.lib()
     assert L.rnf_mobius_packed_floats(0) == -1 and L.rnf_featproj_packed_floats(12) == -1
     assert L.rnf_mobius_packed_floats(10) == 12736 + 2 * 2080
+
+
+# ---- pack-time equalisation of the split-precision images (csrc/equalize.h) --------------------------------------------
+def _relu_rescale(m, c0, c1, c2):
+    """Move a ConditionalTransform along its ReLU-rescaling orbit (same function, flow/condition.py:24-30): x0 -> c0 x0, x1 -> c1 x1,
+    x2 -> c2 x2, x3 -> c0 x3 (the residual ties x3 to x0), fc_last undoes c0.  c* are scalars or per-unit vectors [64]."""
+    c0, c1, c2 = (torch.as_tensor(c, dtype=torch.float32) * torch.ones(64) for c in (c0, c1, c2))
+    with torch.no_grad():
+        m.fc_first.weight.mul_(c0[:, None]); m.fc_first.bias.mul_(c0)
+        m.layers[1].weight.mul_(c1[:, None] / c0[None, :]); m.layers[1].bias.mul_(c1)
+        m.layers[3].weight.mul_(c2[:, None] / c1[None, :]); m.layers[3].bias.mul_(c2)
+        m.layers[5].weight.mul_(c0[:, None] / c2[None, :]); m.layers[5].bias.mul_(c0)
+        m.fc_last.weight.div_(c0[None, :])
+    return m
+
+
+@pytest.mark.parametrize("s", [2.0 ** -8, 2.0 ** -4, 2.0 ** 6])
+def test_split_precision_record_is_invariant_under_power_of_two_relu_rescaling(s):
+    """The verdict's counter-example: hidden layer 1 x s, layer 2 x s, layer 3 x s^-2 (identical function).  Without the equalisation
+    the unscaled fp16 lo terms lose 8 bits at s = 2^-8 (conditioner error 9e-3); with it the packer lands on the SAME canonical record."""
+    K = 64
+    base = _filled_mlp(3, 4 * K, seed=77)
+    rec1, _ = runtime.pack_mobius(_lib.lib(), base, K, 0, _lib.PREC_F16X2)
+    m = _relu_rescale(_filled_mlp(3, 4 * K, seed=77), 1.0, s, s * s)
+    rec, _ = runtime.pack_mobius(_lib.lib(), m, K, 0, _lib.PREC_F16X2)
+    assert np.array_equal(rec.view(np.uint32), rec1.view(np.uint32))
+    y = synth.uniform_rotations(32, seed=3)[:, :, 1]
+    want = _oracle_mlp(base, y)
+    assert np.abs(emu.conditioner_from_record_h(rec, y, K) - want).max() < 2e-6 * max(1.0, np.abs(want).max())
+    assert _lib.lib().rnf_last_pack_audit() < 1e-6
+
+
+def test_split_precision_survives_per_unit_imbalance_with_features():
+    """Per-unit, non-power-of-two orbit elements over 12 binades, conditional layer (feature projection rows scale with x0)."""
+    K, F = 16, 40
+    rng = np.random.default_rng(5)
+    base = _filled_mlp(3 + F, 4 * K, seed=81)
+    m = _relu_rescale(_filled_mlp(3 + F, 4 * K, seed=81), *(2.0 ** rng.uniform(-8, 4, 64) for _ in range(3)))
+    rec, frec = runtime.pack_mobius(_lib.lib(), m, K, F, _lib.PREC_F16X2)
+    assert _lib.lib().rnf_last_pack_audit() < 1.5e-6
+    y = synth.uniform_rotations(32, seed=4)[:, :, 2]
+    feat = synth.features(32, F, seed=9)
+    g = emu.featproj_from_record_h(frec, feat.astype(np.float64), F)
+    got = emu.conditioner_from_record_h(rec, y, K, cinit=g)
+    want = _oracle_mlp(base, np.concatenate([y, feat], axis=1))
+    want_m = _oracle_mlp(m, np.concatenate([y, feat], axis=1))
+    assert np.abs(want_m - want).max() < 1e-4 * np.abs(want).max()             # same function (fp32 rounding of the rescaled weights)
+    assert np.abs(got - want_m).max() < 3e-6 * max(1.0, np.abs(want_m).max())
+
+
+def test_audit_refuses_an_unequalised_imbalanced_layer():
+    """RNF_EQUALIZE=0 splits the weights as given: the pack-time audit must then refuse the s = 2^-8 layer (return code 2 ->
+    HalfRangeError -> the flow is packed for the exact-fp32 kernels), and accept the balanced one."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from rotationnormflow_amd import _lib, runtime\n"
+        "from tests.test_pack_layout import _filled_mlp, _relu_rescale\n"
+        "L = _lib.lib()\n"
+        "runtime.pack_mobius(L, _filled_mlp(3, 256, seed=77), 64, 0, _lib.PREC_F16X2)\n"
+        "a0 = L.rnf_last_pack_audit()\n"
+        "try:\n"
+        "    runtime.pack_mobius(L, _relu_rescale(_filled_mlp(3, 256, seed=77), 1.0, 2.0 ** -8, 2.0 ** -16), 64, 0, _lib.PREC_F16X2)\n"
+        "    print('ACCEPTED', a0, L.rnf_last_pack_audit())\n"
+        "except runtime.HalfRangeError as e:\n"
+        "    print('REFUSED', a0, L.rnf_last_pack_audit())\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RNF_EQUALIZE="0"), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    word, a0, a1 = out.stdout.split()[-3:]
+    assert word == "REFUSED" and float(a0) < 1e-6 and float(a1) > 1e-4, out.stdout

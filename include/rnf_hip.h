@@ -83,6 +83,10 @@ const char *rnf_last_error(void);
 /* largest relative error of the conditioner outputs the last rnf_pack_mobius / rnf_pack_cond* call of this thread measured on its probe
  * inputs (split precision only; 0 after an exact-fp32 pack) */
 double rnf_last_pack_audit(void);
+/* Process-wide measurement / test switches; both return the previous setting.  rnf_set_equalize(0): the packers split the weights as given
+ * (also RNF_EQUALIZE=0 in the environment).  rnf_set_pack_audit(0): the host packers still measure, but no longer refuse. */
+int rnf_set_equalize(int on);
+int rnf_set_pack_audit(int on);
 
 /* ---- parameter packing (host side, pure CPU; called once per parameter version) ------------------------------
  * Sizes are in floats.  `segments` (K) is any positive count (flow/mobiusflow.py:7-14 takes any): records hold ceil(K / 8) fc_last tiles,

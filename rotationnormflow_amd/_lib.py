@@ -20,6 +20,8 @@ _SIGNATURES = {
     "rnf_abi_version": (C.c_int, []),
     "rnf_last_error": (C.c_char_p, []),
     "rnf_last_pack_audit": (C.c_double, []),
+    "rnf_set_equalize": (C.c_int, [C.c_int]),
+    "rnf_set_pack_audit": (C.c_int, [C.c_int]),
     "rnf_mobius_packed_floats": (C.c_int64, [C.c_int32]),
     "rnf_affine16_packed_floats": (C.c_int64, []),
     "rnf_cond16_packed_floats": (C.c_int64, []),

@@ -153,14 +153,27 @@ struct ScaledMlp {
     EqExponents eq;
 };
 
-// RNF_EQUALIZE=0: split the weights as given (measurement / test switch: shows what the audit catches without the equalisation)
+// RNF_EQUALIZE=0 / rnf_set_equalize(0): split the weights as given (measurement / test switch: what the audit and the range guard
+// catch without the equalisation)
+static int g_equalize = -1;
 static bool equalise_allowed() {
-    static int mode = -1;
-    if (mode < 0) {
+    if (g_equalize < 0) {
         const char *e = std::getenv("RNF_EQUALIZE");
-        mode = (e && e[0] == '0') ? 0 : 1;
+        g_equalize = (e && e[0] == '0') ? 0 : 1;
     }
-    return mode == 1;
+    return g_equalize == 1;
+}
+extern "C" int rnf_set_equalize(int on) {
+    const int old = equalise_allowed() ? 1 : 0;
+    g_equalize = on ? 1 : 0;
+    return old;
+}
+// the audit's refusal can be switched off separately (tests of the run-time guard need an unequalised, unaudited image)
+static int g_audit = 1;
+extern "C" int rnf_set_pack_audit(int on) {
+    const int old = g_audit;
+    g_audit = on ? 1 : 0;
+    return old;
 }
 
 static void scale_mlp(const float *fc_first_w, int ni, int yo, const float *fc_first_b, const float *const hw[3], const float *const hb[3],
@@ -335,7 +348,7 @@ extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b,
     if (prec) {
         for (size_t i = 0; i < (size_t)K * 64; ++i) m.WL[i] = std::ldexp(fc_last_w[i], -m.eq.e[0][i & 63]);      // the audit compares unscaled outputs
         g_last_audit = audit_mlp(m, fc_first_w, fc_first_b, hw, hb, fc_last_w, fc_last_b);
-        if (!(g_last_audit <= AUDIT_MAX_ERR))
+        if (g_audit && !(g_last_audit <= AUDIT_MAX_ERR))
             return fail("rnf_pack_mobius: the split-precision image of this layer is off by %.2e on the probe inputs (limit %.1e): its scales "
                         "are outside what fp16 pairs resolve; use RNF_PREC_FP32", g_last_audit, AUDIT_MAX_ERR) + 1;
     }
@@ -405,7 +418,7 @@ static int pack_cond(const float *fc_first_w, const float *fc_first_b, const flo
     if (prec && g_half_overflow) return fail("rnf_pack_cond16: a weight is outside the fp16 range; use RNF_PREC_FP32") + 1;
     if (prec) {
         g_last_audit = audit_mlp(m, fc_first_w, fc_first_b, hw, hb, fc_last_w, fc_last_b);
-        if (!(g_last_audit <= AUDIT_MAX_ERR))
+        if (g_audit && !(g_last_audit <= AUDIT_MAX_ERR))
             return fail("rnf_pack_cond16: the split-precision image of this layer is off by %.2e on the probe inputs (limit %.1e): its scales "
                         "are outside what fp16 pairs resolve; use RNF_PREC_FP32", g_last_audit, AUDIT_MAX_ERR) + 1;
     }

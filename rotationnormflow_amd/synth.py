@@ -45,7 +45,37 @@ REGIMES = {
     # name: (gain on Mobius conditioner fc_last, sigma of the 4x4 affine perturbation)
     "default": (1.0, 1e-3),
     "trained": (8.0, 0.2),
+    # the "trained" weights moved to a random point of every conditioner MLP's ReLU-rescaling orbit (per hidden layer 2^U(-8,4), per unit
+    # another 2^U(-2,2); flow/condition.py:24-30 computes the same function there up to fp32 rounding) and with the feature inputs of every
+    # fc_first divided by FEATURE_SCALE while the features themselves are multiplied by it: what a checkpoint trained without weight
+    # decay on un-normalised backbone features may look like.  Adversarial for arithmetic with an absolute floor.
+    "imbalanced": (8.0, 0.2),
 }
+FEATURE_SCALE = {"imbalanced": 30.0}
+
+
+def feature_scale(regime: str) -> float:
+    """Factor the benchmark / fixture features of this weight regime are multiplied by (1 except for "imbalanced")."""
+    return FEATURE_SCALE.get(regime, 1.0)
+
+
+def _apply_relu_orbit(weights: dict, seed: int, fscale: float) -> None:
+    """In place: every ConditionalTransform (keys <prefix>.fc_first / .layers.{1,3,5} / .fc_last) -> x0 * c0, x1 * c1, x2 * c2, x3 * c0
+    (the residual x0 + x3 ties them), fc_last / c0; feature columns of fc_first / fscale."""
+    prefixes = sorted(k[: -len(".fc_first.weight")] for k in weights if k.endswith(".fc_first.weight"))
+    for idx, pre in enumerate(prefixes):
+        rng = np.random.default_rng([seed, 7919, idx])
+        c = (2.0 ** (rng.uniform(-8.0, 4.0, (3, 1)) + rng.uniform(-2.0, 2.0, (3, 64)))).astype(np.float32)
+        c0, c1, c2 = c[0], c[1], c[2]
+        w0 = weights[pre + ".fc_first.weight"]
+        yo = 3 if pre.endswith(".conditioner") else 0
+        w0[:, yo:] /= np.float32(fscale)
+        w0 *= c0[:, None]
+        weights[pre + ".fc_first.bias"] *= c0
+        for j, (co, ci) in zip((1, 3, 5), ((c1, c0), (c2, c1), (c0, c2))):
+            weights[pre + f".layers.{j}.weight"] *= co[:, None] / ci[None, :]
+            weights[pre + f".layers.{j}.bias"] *= co
+        weights[pre + ".fc_last.weight"] /= c0[None, :]
 
 
 def fill_state_dict(shapes: dict, seed: int = 0, regime: str = "default") -> dict:
@@ -100,6 +130,8 @@ def fill_state_dict(shapes: dict, seed: int = 0, regime: str = "default") -> dic
         else:
             raise KeyError(f"recipe has no rule for state-dict key {key!r}")
         out[key] = np.ascontiguousarray(val.astype(np.float32))
+    if regime == "imbalanced":
+        _apply_relu_orbit(out, seed, feature_scale(regime))
     return out
 
 

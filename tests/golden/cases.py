@@ -90,6 +90,25 @@ CASES.update({
 })
 
 
+# Round 3: a third, adversarial weight regime ("imbalanced": synth.REGIMES -- random points of every MLP's
+# ReLU-rescaling orbit over 12 binades, features x 30), and the BASELINE inverse configs at full depth in the trained regime.
+C5 = dict(layers=42, condition=1, feature_dim=512, rot="None", frequent_permute=1, last_affine=0, first_affine=0)
+C5U = dict(layers=42, condition=0, rot="None", last_affine=0, first_affine=0)
+CASES.update({
+    "c1_imbal":        dict(cfg=dict(layers=8), n=2048, regime="imbalanced", wseed=61, rseed=161, direction="forward", fisher=None),
+    "c1_imbal_inv":    dict(cfg=dict(layers=8), n=1024, regime="imbalanced", wseed=61, rseed=162, direction="inverse", fisher=None),
+    "c2_imbal":        dict(cfg=dict(layers=24), n=4096, regime="imbalanced", wseed=62, rseed=163, direction="forward", fisher="tilted"),
+    "c4_imbal":        dict(cfg=dict(layers=24, feature_dim=256, **SYMSOL), n=1024, regime="imbalanced", wseed=63, rseed=164, direction="forward", fisher=None),
+    "c4_imbal_inv":    dict(cfg=dict(layers=24, feature_dim=256, **SYMSOL), n=512, regime="imbalanced", wseed=63, rseed=165, direction="inverse", fisher=None),
+    "c5u_imbal_inv":   dict(cfg=C5U, n=1024, regime="imbalanced", wseed=64, rseed=166, direction="inverse", fisher=None),
+    "c5u_imbal_fwd":   dict(cfg=C5U, n=1024, regime="imbalanced", wseed=64, rseed=167, direction="forward", fisher=None),
+    "c5_imbal_inv":    dict(cfg=C5, n=256, regime="imbalanced", wseed=65, rseed=168, direction="inverse", fisher="diag531"),
+    "c4_trained_inv24": dict(cfg=dict(layers=24, feature_dim=256, **SYMSOL), n=512, regime="trained", wseed=6, rseed=169, direction="inverse", fisher=None),
+    "c5_trained_inv":  dict(cfg=C5, n=512, regime="trained", wseed=66, rseed=170, direction="inverse", fisher="diag531"),
+    "c5_trained_fwd":  dict(cfg=C5, n=512, regime="trained", wseed=66, rseed=171, direction="forward", fisher=None),
+})
+
+
 # Gradients through Flow.inverse (BinFind.backward, flow/mobiusflow.py:247-273): the reference's own autograd in fp64, loss =
 # sum(a * ldj) + sum(B * R_out) with seeded a [n], B [n,3,3] (tests/golden/make_golden.py run_inverse_grad_case).
 GRAD_CASES = {

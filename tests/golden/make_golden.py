@@ -65,7 +65,7 @@ def run_case(name, spec):
         fdim = fl.feature_dim
         feat = None
         if cfg.condition:
-            feat = torch.from_numpy(synth.features(n, fdim, seed=spec["rseed"] + 1000)).to(dtype)
+            feat = torch.from_numpy(synth.features(n, fdim, seed=spec["rseed"] + 1000) * np.float32(synth.feature_scale(spec["regime"]))).to(dtype)
         R = torch.from_numpy(rot_in).to(dtype)
         with torch.no_grad():
             if spec["direction"] == "forward":

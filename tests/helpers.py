@@ -26,5 +26,5 @@ def load_case(name):
     R = synth.uniform_rotations(spec["n"], seed=spec["rseed"])
     feat = None
     if cfg.condition:
-        feat = synth.features(spec["n"], int(fx["feature_dim"]), seed=spec["rseed"] + 1000)
+        feat = synth.features(spec["n"], int(fx["feature_dim"]), seed=spec["rseed"] + 1000) * np.float32(synth.feature_scale(spec["regime"]))
     return cfg, weights, R, feat, fx, spec

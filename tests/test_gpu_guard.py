@@ -14,6 +14,19 @@ from tests.gpu_helpers import product_flow
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def unequalised():
+    """The packers normally move every MLP to the canonical point of its ReLU-rescaling orbit (csrc/equalize.h), which also takes the
+    hidden activations of the blown-up weights below back into range: these tests of the RUN-TIME guard switch that (and the pack-time
+    audit's refusal) off."""
+    from rotationnormflow_amd import _lib
+    L = _lib.lib()
+    eq, au = L.rnf_set_equalize(0), L.rnf_set_pack_audit(0)
+    yield
+    L.rnf_set_equalize(eq)
+    L.rnf_set_pack_audit(au)
+
+
 def _weights(cfg, seed, blow_up):
     w = synth.fill_state_dict(orc.state_shapes(cfg), seed=seed, regime="trained")
     if blow_up:                       # weights stay far inside the fp16 range, the hidden activations of every Moebius layer do not
@@ -28,7 +41,7 @@ def _weights(cfg, seed, blow_up):
 
 
 @pytest.mark.parametrize("direction", ["forward", "inverse"])
-def test_activation_overflow_falls_back_to_fp32(direction):
+def test_activation_overflow_falls_back_to_fp32(direction, unequalised):
     cfg = make_config(layers=3, segments=16)
     w = _weights(cfg, 5, True)
     assert max(float(np.abs(v).max()) for v in w.values()) < 6.0e4
@@ -55,7 +68,7 @@ def test_activation_overflow_falls_back_to_fp32(direction):
     assert np.median(err) < 1e-4 and np.quantile(err, 0.99) < 2e-2, (np.median(err), err.max())
 
 
-def test_no_fallback_in_range_and_fused_sum_uses_the_rerun():
+def test_no_fallback_in_range_and_fused_sum_uses_the_rerun(unequalised):
     cfg = make_config(layers=3, segments=16)
     base = MatrixFisherN(torch.from_numpy(synth.fisher_A("diag531")))
     R = torch.from_numpy(synth.uniform_rotations(2500, seed=12)).cuda()
@@ -123,10 +136,12 @@ def test_side_layer_conditioner_overflow_is_reported_one_call_later():
         autograd._pending_mlp_flags.clear()               # status words of this test's other calls must not surface in a later test
 
 
-def test_segment_weight_beyond_the_one_piece_softplus_falls_back():
-    """The forward split-precision segment evaluates softplus as one log2(1 + 2^(s log2 e)), which overflows for s > 88 (the reference's
-    softplus returns s itself beyond its threshold of 20): the ratios of the layer become NaN, the guard fires and the exact-fp32 kernels,
-    whose softplus is the full form, recompute the launch -- the result follows the oracle."""
+@pytest.mark.parametrize("n", [1500, 70000])
+def test_segment_weight_beyond_the_one_piece_softplus(n):
+    """softplus(s) for s = 120 (the reference's softplus returns s itself beyond its threshold of 20).  Large launches run the LEAN
+    instantiation, whose one-piece log2(1 + 2^(s log2 e)) overflows: the ratios of the layer become NaN, the guard fires and the exact-fp32
+    kernels recompute the launch.  Every other instantiation clamps the exponent and needs no re-run (so3_math.h softplus2_safe).
+    Either way the result follows the oracle."""
     cfg = make_config(layers=2, segments=16)
     w = synth.fill_state_dict(orc.state_shapes(cfg), seed=9, regime="trained")
     for k in w:
@@ -135,11 +150,36 @@ def test_segment_weight_beyond_the_one_piece_softplus_falls_back():
             b[3] = 120.0                                           # the raw weight of segment 3: softplus(120) = 120 in the reference
             w[k] = b
     fl = product_flow(cfg, w)
-    R = torch.from_numpy(synth.uniform_rotations(1500, seed=13)).cuda()
+    R = torch.from_numpy(synth.uniform_rotations(n, seed=13)).cuda()
     with torch.no_grad():
         Rt, ldj = fl(R)
-    assert runtime.fallback_fired(R.device)
+    lean = n > 256 * 8 * 32                                        # rnf_api.hip: 16-wave LEAN launches once 8-wave workgroups overfill the CUs
+    assert runtime.fallback_fired(R.device) == lean
     assert torch.isfinite(ldj).all() and torch.isfinite(Rt).all()
-    Rw, lw = orc.flow_forward(cfg, w, R.cpu().numpy(), None, dtype=torch.float64)
-    assert np.abs(ldj.cpu().double().numpy() - lw.numpy()).max() < 1e-3
-    assert np.abs(Rt.cpu().double().numpy() - Rw.numpy()).max() < 1e-4
+    m = 2000
+    Rw, lw = orc.flow_forward(cfg, w, R[:m].cpu().numpy(), None, dtype=torch.float64)
+    assert np.abs(ldj[:m].cpu().double().numpy() - lw.numpy()).max() < 1e-3
+    assert np.abs(Rt[:m].cpu().double().numpy() - Rw.numpy()).max() < 1e-4
+
+
+@pytest.mark.parametrize("n", [1500, 70000])
+def test_all_segment_weights_tiny(n):
+    """Every raw segment weight at -12: softplus ~ 6e-6.  The one-piece form of the LEAN kernel would round fl(1 + e) to ~7 bits of e:
+    its layer finish flags the tiny weight SUM and the exact-fp32 kernels re-run the launch; the other instantiations switch to the series
+    of log2(1 + e) and need no re-run."""
+    cfg = make_config(layers=2, segments=16)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=10, regime="trained")
+    for k in w:
+        if k.endswith("conditioner.fc_last.weight"):
+            v = w[k].copy(); v[:16] *= np.float32(0.05); w[k] = v
+        if k.endswith("conditioner.fc_last.bias"):
+            b = w[k].copy(); b[:16] = -12.0; w[k] = b
+    fl = product_flow(cfg, w)
+    R = torch.from_numpy(synth.uniform_rotations(n, seed=14)).cuda()
+    with torch.no_grad():
+        Rt, ldj = fl(R)
+    assert runtime.fallback_fired(R.device) == (n > 256 * 8 * 32)
+    m = 2000
+    Rw, lw = orc.flow_forward(cfg, w, R[:m].cpu().numpy(), None, dtype=torch.float64)
+    err = np.abs(ldj[:m].cpu().double().numpy() - lw.numpy())
+    assert err.max() < 5e-5 and err.mean() < 5e-6, (err.max(), err.mean())

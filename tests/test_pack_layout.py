@@ -204,24 +204,15 @@ def test_split_precision_survives_per_unit_imbalance_with_features():
 
 
 def test_audit_refuses_an_unequalised_imbalanced_layer():
-    """RNF_EQUALIZE=0 splits the weights as given: the pack-time audit must then refuse the s = 2^-8 layer (return code 2 ->
+    """rnf_set_equalize(0) splits the weights as given: the pack-time audit must then refuse the s = 2^-8 layer (return code 2 ->
     HalfRangeError -> the flow is packed for the exact-fp32 kernels), and accept the balanced one."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import sys, torch; sys.path.insert(0, %r)\n"
-        "from rotationnormflow_amd import _lib, runtime\n"
-        "from tests.test_pack_layout import _filled_mlp, _relu_rescale\n"
-        "L = _lib.lib()\n"
-        "runtime.pack_mobius(L, _filled_mlp(3, 256, seed=77), 64, 0, _lib.PREC_F16X2)\n"
-        "a0 = L.rnf_last_pack_audit()\n"
-        "try:\n"
-        "    runtime.pack_mobius(L, _relu_rescale(_filled_mlp(3, 256, seed=77), 1.0, 2.0 ** -8, 2.0 ** -16), 64, 0, _lib.PREC_F16X2)\n"
-        "    print('ACCEPTED', a0, L.rnf_last_pack_audit())\n"
-        "except runtime.HalfRangeError as e:\n"
-        "    print('REFUSED', a0, L.rnf_last_pack_audit())\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RNF_EQUALIZE="0"), capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0, out.stderr
-    word, a0, a1 = out.stdout.split()[-3:]
-    assert word == "REFUSED" and float(a0) < 1e-6 and float(a1) > 1e-4, out.stdout
+    L = _lib.lib()
+    old = L.rnf_set_equalize(0)
+    try:
+        runtime.pack_mobius(L, _filled_mlp(3, 256, seed=77), 64, 0, _lib.PREC_F16X2)
+        assert L.rnf_last_pack_audit() < 1e-6
+        with pytest.raises(runtime.HalfRangeError):
+            runtime.pack_mobius(L, _relu_rescale(_filled_mlp(3, 256, seed=77), 1.0, 2.0 ** -8, 2.0 ** -16), 64, 0, _lib.PREC_F16X2)
+        assert L.rnf_last_pack_audit() > 1e-4
+    finally:
+        L.rnf_set_equalize(old)

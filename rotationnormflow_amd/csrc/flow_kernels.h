@@ -53,6 +53,12 @@ struct FlowArgs {
     int guard_mode;
     const float *side;        // per-sample matrices of the RNF_KIND_SIDE* layers: [side slot][side_n][16] floats, or nullptr
     long long side_n;         // rotations in the whole call (chunks index at sample_base)
+    // FUSED instantiation (conditional flows, feature_dim <= FUSED_MAX_F): the feature projection runs INSIDE the stack kernel
+    const float *feat;        // [n, feat_F] features of this launch
+    float *stash;             // [gridDim.x * NW][G_FLOATS_PER_GROUP]: each wave's projected features of the NEXT layer (stays in L2)
+    int feat_F;               // feature columns (multiple of 8)
+    int feat_base, feat_stride;   // blob offset (floats) of cond slot 0's projection record, and the distance between consecutive slots
+    int pa_off;               // float offset in LDS of the projection-weight buffer (FUSED_PA_FLOATS)
     // per layer: x = kind | perm_row << 4 | (cond_slot + 1) << 8 | (position of the next MLP layer + 1) << 16 ; y = param offset (floats)
     int2 layers[MAX_LAYERS];
 };
@@ -600,7 +606,7 @@ __device__ __forceinline__ void tile_pipe_h_off(const float *base, int woff, int
     tile_step_h<0, SAFE>(rec, 0, nxt, ah, al, tt, cur, seg, c, S, A, J);
 }
 
-template <int PREC, bool PINGPONG = false>
+template <int PREC, bool PINGPONG = false, bool FASTSP = PINGPONG>
 __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int K, int lane, int h, const typename Mlp<PREC>::Act &tt,
                                                  const MobiusCtx &c, float &S, float &A, float &J, Fair &fair) {
     const float *rec = lds + MOB_LAST;
@@ -645,11 +651,11 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int K
         f32x16 cur = Mlp<1>::last(rec, lane, h, tt);
         for (int tau = 1; tau < KT; ++tau) {
             f32x16 nxt;
-            tile_pipe_h<true>(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt, nxt, cur, c, S, A, J);
+            tile_pipe_h<!FASTSP>(rec + tau * MOB_LAST_TILE_FLOATS, lane, h, tt, nxt, cur, c, S, A, J);
             cur = nxt;
             fair.tick();
         }
-        segments4_last<true>(cur, c, S, A, J, K, h);
+        segments4_last<true, !FASTSP>(cur, c, S, A, J, K, h);
     }
 }
 
@@ -981,10 +987,80 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 #define RNF_STAMP_FLUSH
 #endif
 
+// ------------------------------------------------------------------------------------------------------------
+// FUSED instantiation: the feature projection of a conditional flow INSIDE the stack kernel (round 3; BASELINE configs[3]).
+// The pre-pass of featproj_kernel.h writes G_l = W_l[:, 3:] f + b_l for every conditional layer to HBM and the stack kernel reads it back
+// (12.8 KB per rotation for C4, 18x the algorithmic traffic of the whole evaluation).  Here every wave keeps the features of its 32 rotations
+// in registers for the whole layer stack, as the fp16 hi / (2^12-scaled) lo B fragments of the projection (F <= 256: 128 VGPRs of the 256 an
+// 8-wave workgroup has per lane -- MFMA B operands only, so they may sit in AGPRs), and computes G of the NEXT MLP layer while the current
+// one runs: 2 x 16 k-steps x 3 matrix instructions per layer, weights streamed by LDS-DMA through ONE 32 KB buffer in two halves
+// (out tile 0 behind barrier B1, out tile 1 behind B2; each half has a whole compute phase to land).  The 64 x 32 result goes to a
+// per-wave 8 KB stash that is rewritten every layer and therefore lives in L2; the head of the next layer loads it exactly like the
+// pre-pass scratch (GFrag).  HBM traffic: the features once (4 F bytes per rotation) instead of 2 x 256 bytes per rotation and layer.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int FUSED_MAX_F = 256;
+constexpr int FUSED_KSTEPS = FUSED_MAX_F / 16;
+constexpr int FUSED_PA_W = FUSED_KSTEPS * 512;          // floats: one out tile of projection weights, [k-step][hi, lo][lane] 8 x fp16
+constexpr int FUSED_PA_FLOATS = FUSED_PA_W + 32;        // + that out tile's bias image [2][16]
+
+struct FeatFrag {
+    h8 hi[FUSED_KSTEPS], lo[FUSED_KSTEPS];              // B fragments: k-step s covers features 16 s .. 16 s + 15, lane-half h supplies 16 s + 8 h + 0..7
+};
+
+__device__ __forceinline__ void fused_load_features(const float *feat, int F, long long sample, bool valid, int h, FeatFrag &f) {
+#pragma unroll
+    for (int s = 0; s < FUSED_KSTEPS; ++s) {
+        f2 v[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
+        const int k0 = 16 * s + 8 * h;
+        if (valid && k0 < F) {                            // F % 8 == 0: an 8-group is entirely inside or outside
+            const float4 p0 = *reinterpret_cast<const float4 *>(feat + sample * F + k0);
+            const float4 p1 = *reinterpret_cast<const float4 *>(feat + sample * F + k0 + 4);
+            v[0] = f2{p0.x, p0.y}; v[1] = f2{p0.z, p0.w}; v[2] = f2{p1.x, p1.y}; v[3] = f2{p1.z, p1.w};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const h2 ph = __builtin_convertvector(v[q], h2);
+            const h2 pl = __builtin_convertvector((v[q] - __builtin_convertvector(ph, f2)) * FEAT_LO_SCALE, h2);
+            f.hi[s][2 * q] = ph[0]; f.hi[s][2 * q + 1] = ph[1];
+            f.lo[s][2 * q] = pl[0]; f.lo[s][2 * q + 1] = pl[1];
+        }
+    }
+}
+
+// one out tile (32 of the 64 projected features) of one layer for this wave's 32 rotations: pa = the staged weights + bias of that tile
+__device__ __forceinline__ void fused_project_half(const float *pa, int ns, int lane, int h, const FeatFrag &f, float *stash_tile, bool &bad) {
+    f32x16 acc1 = load_bias16(pa + FUSED_PA_W + h * 16);
+    f32x16 acc2 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // one k-step of operand look-ahead, fenced: left alone the scheduler hoists all 32 operand reads (128 registers) to the top of the
+    // unrolled loop, on top of the 128 feature registers
+    h8 ah = lds_h8(pa, 0 * 64 + lane), al = lds_h8(pa, 1 * 64 + lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < FUSED_KSTEPS; ++s) {
+        if (s < ns) {                                     // wave uniform
+            acc1 = RNF_MFMA_H(ah, f.hi[s], acc1);
+            acc2 = RNF_MFMA_H(ah, f.lo[s], acc2);
+            acc2 = RNF_MFMA_H(al, f.hi[s], acc2);
+            if (s + 1 < ns) {
+                ah = lds_h8(pa, ((s + 1) * 2 + 0) * 64 + lane);
+                al = lds_h8(pa, ((s + 1) * 2 + 1) * 64 + lane);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float4 *dst = reinterpret_cast<float4 *>(stash_tile) + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        dst[q * 64] = make_float4(fmaf(acc2[4 * q], 1.0f / FEAT_LO_SCALE, acc1[4 * q]), fmaf(acc2[4 * q + 1], 1.0f / FEAT_LO_SCALE, acc1[4 * q + 1]),
+                                  fmaf(acc2[4 * q + 2], 1.0f / FEAT_LO_SCALE, acc1[4 * q + 2]), fmaf(acc2[4 * q + 3], 1.0f / FEAT_LO_SCALE, acc1[4 * q + 3]));
+    bad |= acc1[0] != acc1[0];                            // a feature beyond the fp16 range: (inf, -inf) pair, every product NaN
+}
+
 // LEAN: the stack holds Moebius and constant 4x4 affine layers only, nothing conditional, no saved states (BASELINE configs C1 / C2 / C3):
 // every other layer kind, the feature-projection reads and the kind dispatch are compiled out.
-template <int DIR, int KT_INV, int NW, bool PIPE, int PREC, bool EXT = false, bool LEAN = false>
+template <int DIR, int KT_INV, int NW, bool PIPE, int PREC, bool EXT = false, bool LEAN = false, bool FUSED = false>
 __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args) {
+    static_assert(!FUSED || (DIR == 0 && PIPE && PREC == 1 && !EXT && !LEAN), "FUSED: forward, DMA staging, split precision");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (args.guard_mode == 2) {                                      // fp32 re-run of a split-precision call: only when its guard fired
         if (__hip_atomic_load(args.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
@@ -1026,6 +1102,18 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                                          (__attribute__((address_space(3))) void *)(lds + args.tab_off + AFF_TABLE_LDS_STRIDE * parity), 16, 0, 0);
     };
     auto has_table = [&](int q) { return args.tab_off >= 0 && q + 1 < n_layers && (args.layers[layer_at(q + 1)].x & 15) == RNF_KIND_AFFINE16; };
+    // FUSED: cond slot -> its projection record; DMA of one out tile (weights + bias image) into the LDS buffer; the slot of a position
+    const int fused_ns = FUSED ? (args.feat_F + 15) / 16 : 0;         // k-steps of 16 features
+    auto fused_dma = [&](int slot, int half) {
+        const float *rec = args.blob + args.feat_base + (size_t)slot * args.feat_stride;
+        dma_floats(lds + args.pa_off, rec + (size_t)half * fused_ns * 512, fused_ns * 512, wave, lane, NW);
+        if (wave == NW - 1 && lane < 8)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rec + (size_t)2 * fused_ns * 512 + half * 32 + 4 * lane),
+                                             (__attribute__((address_space(3))) void *)(lds + args.pa_off + FUSED_PA_W), 16, 0, 0);
+    };
+    auto slot_at = [&](int pos) { return ((args.layers[layer_at(pos)].x >> 8) & 255) - 1; };
+    auto next_in_tile = [&](int pos) { return ((args.layers[layer_at(pos)].x >> 16) & 1023) - 1; };   // next MLP position, -1 at the end
+    float *const stash = FUSED ? args.stash + ((size_t)blockIdx.x * NW + wave) * G_FLOATS_PER_GROUP : nullptr;
     int seq = 0;                                                      // MLP layers this wave has been through (across tiles)
     int tab_parity = -1;                                              // >= 0: the next affine layer's block sits in LDS buffer tab_parity
 
@@ -1035,6 +1123,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
         dma_floats(lds, args.blob + d.y, MOB_HEAD_FLOATS, wave, lane, NW);
         dma_floats(lds + MOB_LAST, args.blob + d.y + MOB_LAST, l_floats(d.x & 15), wave, lane, NW);
         stage_table(first_mlp, 0);
+        if constexpr (FUSED) fused_dma(((d.x >> 8) & 255) - 1, 0);      // out tile 0 of the first layer's projection weights
         dma_wait_all();
         __syncthreads();
     }
@@ -1062,6 +1151,26 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
         }
         float ldj = 0.f;
         bool bad = false;                                         // split-precision kernels: a hidden layer came out NaN (Mlp<1>::head)
+        FeatFrag ff;                                              // FUSED only (dead otherwise)
+        if constexpr (FUSED) {
+            // this tile's features, and the projection of the FIRST MLP layer (the layers behind it are projected one layer ahead, below):
+            // out tile 0 is in the LDS buffer (prologue / last layer of the previous tile), out tile 1 is fetched here -- the one DMA
+            // latency per tile that nothing hides
+            fused_load_features(args.feat, args.feat_F, sample0 + j, valid, h, ff);
+            const int s0 = slot_at(first_mlp);
+            dma_wait_all();
+            __syncthreads();
+            fused_project_half(lds + args.pa_off, fused_ns, lane, h, ff, stash, bad);
+            __syncthreads();
+            fused_dma(s0, 1);
+            dma_wait_all();
+            __syncthreads();
+            fused_project_half(lds + args.pa_off, fused_ns, lane, h, ff, stash + G_FLOATS_PER_GROUP / 2, bad);
+            __syncthreads();
+            int q2 = next_in_tile(first_mlp);
+            if (q2 < 0 && more_tiles) q2 = first_mlp;
+            if (q2 >= 0) fused_dma(slot_at(q2), 0);
+        }
         RNF_STAMP(7)                                              // 7: tile prologue / epilogue
 
         for (int pos = 0; pos < n_layers; ++pos) {
@@ -1130,7 +1239,9 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             if constexpr (!LEAN) {
                 gfrag.p = nullptr;
                 gfrag.rows = EXT && args.g_div > 0;
-                if (slot >= 0) {
+                if (FUSED) {
+                    gfrag.p = stash;
+                } else if (slot >= 0) {
                     if (EXT && args.g_div > 0) {
                         long long row = (args.sample_base + (valid ? sample_now() : 0)) / args.g_div;
                         if (row >= args.g_rows) row = args.g_rows - 1;
@@ -1170,6 +1281,14 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 if (nxt_off >= 0) dma_floats(lds, args.blob + nxt_off, MOB_HEAD_FLOATS, wave, lane, NW);
             }
             RNF_STAMP(2)                                          // 2: barrier B1 (+ DMA issue)
+            const int fq1 = FUSED ? next_in_tile(pos) : -1;       // FUSED: the next MLP layer of this tile, whose G is produced during this layer
+            if constexpr (FUSED) {
+                if (fq1 >= 0) {                                   // out tile 0 (its weights landed during this layer's hidden phase; B1 waited for them)
+                    fused_project_half(lds + args.pa_off, fused_ns, lane, h, ff, stash, bad);
+                    __syncthreads();                              // every wave is done with the buffer
+                    fused_dma(slot_at(fq1), 1);                   // out tile 1 lands during the fc_last phase
+                }
+            }
 
             // B2 (DMA mode): every wave is past the L part and the next layer's H part has landed; then the next L part is requested
             auto b2_sync = [&]() {
@@ -1188,7 +1307,18 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 }
                 RNF_STAMP(4)                                      // 4: barrier B2 (+ DMA issue)
             };
-            auto barrier2 = [&]() { b2_sync(); b2_issue(); };
+            auto fused_p1 = [&]() {                               // FUSED, behind B2: out tile 1 of the next layer's G, then out tile 0 of the one after
+                if constexpr (FUSED) {
+                    if (fq1 >= 0) {
+                        fused_project_half(lds + args.pa_off, fused_ns, lane, h, ff, stash + G_FLOATS_PER_GROUP / 2, bad);
+                        __syncthreads();
+                        int q2 = next_in_tile(fq1);
+                        if (q2 < 0 && more_tiles) q2 = first_mlp;
+                        if (q2 >= 0) fused_dma(slot_at(q2), 0);
+                    }
+                }
+            };
+            auto barrier2 = [&]() { b2_sync(); b2_issue(); fused_p1(); };
             if (LEAN || kind == RNF_KIND_MOBIUS) {
                 if constexpr (DIR != 0) {
                     InvSegs<KTI> sg;
@@ -1203,10 +1333,10 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     b2_issue();
                 } else {
                     float S = 0.f, A = 0.f, J = 0.f;
-                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC, LEAN>(lds, KT, args.K, lane, h, tt, ctx, S, A, J, fair);
+                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC, LEAN, LEAN || FUSED>(lds, KT, args.K, lane, h, tt, ctx, S, A, J, fair);
                     else mobius_fwd_tiles_restage<PREC>(lds, params, KT, args.K, lane, h, tt, ctx, S, A, J, tid, NT);
                     barrier2();
-                    mobius_fwd_finish<PREC == 1, LEAN && PREC == 1>(ctx, S, A, J, R, ldj, bad, kMinWeightSum * (float)args.K);
+                    mobius_fwd_finish<PREC == 1, (LEAN || FUSED) && PREC == 1>(ctx, S, A, J, R, ldj, bad, kMinWeightSum * (float)args.K);
                 }
             } else {
                 const f32x16 o16 = Mlp<PREC>::last(lds + MOB_LAST, lane, h, tt);

@@ -621,6 +621,25 @@ static bool lean_allowed() {
     return mode == 1;
 }
 
+// RNF_FUSED=0 keeps conditional forward passes on the feature-projection pre-pass + stack kernel pair (measurement switch)
+static bool fused_allowed() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = std::getenv("RNF_FUSED");
+        mode = (e && e[0] == '0') ? 0 : 1;
+    }
+    return mode == 1;
+}
+
+// forward pass of a conditional flow with the feature projection inside the stack kernel (flow_kernels.h FUSED)
+static int launch_fused(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream) {
+    auto kern = flow_stack_kernel<0, 0, NW_FWD_H, true, 1, false, false, true>;
+    HIP_TRY(allow_lds(kern, lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_FWD_H * 64), lds_bytes, stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int DIR, int KT_INV, bool PIPE, int PREC, bool EXT = false>
 static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream, int nwk, bool lean = false) {
     if constexpr (DIR == 0 && PREC == 1 && PIPE && !EXT) {
@@ -697,6 +716,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     int n_slots = 0;
     int min_tiles = 1;                       // fc_last tiles the largest non-Moebius record needs resident in LDS
     bool any_mlp = false, ext = false;       // ext: the flow contains a layer kind only the extended kernel instantiation carries
+    bool all_mlp_cond = true;                // every MLP layer consumes the feature vector (what the FUSED instantiation handles)
     int prec = -1;
     bool lean = lean_allowed() && !o.states;   // Moebius + constant 4x4 affine layers only, nothing conditional, no saved states
     for (int l = 0; l < n_layers; ++l) {
@@ -720,6 +740,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         }
         if (kind_has_mlp(kind)) {
             any_mlp = true;
+            if (slot < 0) all_mlp_cond = false;
             if (d[D_PARAM_FB] < 0 || d[D_PARAM_FB] % 4 || (slot >= 0 && (d[D_FEAT_FB] < 0 || d[D_FEAT_FB] % 4))) have_fb = false;
             fbp[l] = d[D_PARAM_FB];
             if (slot >= 0) fbf[slot] = d[D_FEAT_FB];
@@ -816,6 +837,24 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     // instantiations whose softplus is overflow-safe on its own; include/rnf_hip.h "aliasing")
     const bool guarded = prec == 1 && any_mlp && have_fb && ws && ws_bytes >= PARTIALS_BYTES && guard_allowed() && !(rot_out && rot_out == rot);
     int *guard = guarded ? reinterpret_cast<int *>(reinterpret_cast<double *>(ws) + GUARD_AT) : nullptr;
+    // FUSED: forward pass of a conditional flow whose every MLP layer is conditional, F <= 256, projection records equally spaced in the
+    // blob (both packers lay them out that way).  Guarded launches only: the instantiation uses the one-piece softplus.
+    bool fused = fused_allowed() && o.dir == 0 && prec == 1 && pipe && any_mlp && n_slots > 0 && all_mlp_cond && !shared && !ext && !o.states &&
+                 F <= FUSED_MAX_F && guarded && a.tab_off >= 0;
+    int feat_stride = (int)((featproj_packed_floats(F) + 3) / 4 * 4);
+    if (fused && n_slots > 1) feat_stride = fp_primary[1] - fp_primary[0];
+    for (int sl = 0; fused && sl < n_slots; ++sl)
+        if (fp_primary[sl] != fp_primary[0] + sl * feat_stride) fused = false;
+    size_t lds_fused = 0;
+    if (fused) {
+        lds_fused = (lds_bytes + 15) / 16 * 16;
+        a.pa_off = (int)(lds_fused / sizeof(float));
+        lds_fused += sizeof(float) * FUSED_PA_FLOATS;
+        a.feat_F = F;
+        a.feat_base = fp_primary[0];
+        a.feat_stride = feat_stride;
+        if (lds_fused > 160 * 1024) fused = false;
+    }
     FlowArgs afb;
     if (guarded) {
         HIP_TRY(hipMemsetAsync(guard, 0, 2 * sizeof(int), stream));
@@ -828,8 +867,8 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         const long long cn = (n - base) < chunk_cap ? (n - base) : chunk_cap;
         // waves per workgroup of the stack kernel: the forward split-precision kernel goes 16 wide once 8-wave workgroups would
         // no longer fit the CUs in one round
-        const bool wide = o.dir == 0 && prec == 1 && pipe && !ext && wide_allowed() && cn > (long long)cus * NW_FWD_H * 32;
-        const bool narrow = o.dir == 0 && prec == 1 && pipe && !ext && wide_allowed() && cn <= (long long)cus * NW_FWD_NARROW * 32;
+        const bool wide = !fused && o.dir == 0 && prec == 1 && pipe && !ext && wide_allowed() && cn > (long long)cus * NW_FWD_H * 32;
+        const bool narrow = !fused && o.dir == 0 && prec == 1 && pipe && !ext && wide_allowed() && cn <= (long long)cus * NW_FWD_NARROW * 32;
         const bool big_inv = o.dir == 1 && any_mlp && KT > 8;                  // 4-wave instantiation (512 registers per lane)
         const int nwk = big_inv ? NW_INV_BIG : (wide ? NW_FWD_WIDE : (narrow ? NW_FWD_NARROW : ((o.dir == 0 && prec == 1) ? NW_FWD_H : NW)));
         a.fair_off = (wide || narrow) ? -1 : fair_off;                       // the governor pairs two waves per SIMD
@@ -874,7 +913,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             HIP_TRY(hipGetLastError());
             return 0;
         };
-        if (n_slots && (!shared || base == 0)) {
+        if (n_slots && !fused && (!shared || base == 0)) {
             if (int rc = project(false)) return rc;
         }
         a.rot_in = rot + base * 9;
@@ -898,7 +937,12 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
                   : launch_stack<DIR_, KT_, true, 0>(a, grid, lds_bytes, stream, nwk))                              \
           : (prec ? launch_stack<DIR_, KT_, false, 1>(a, grid, lds_bytes, stream, nwk)                              \
                   : launch_stack<DIR_, KT_, false, 0>(a, grid, lds_bytes, stream, nwk)))
-        if (o.dir == 0) rc = RNF_LAUNCH(0, 0);
+        if (fused) {
+            a.feat = feat + base * F;
+            a.stash = G;                                   // grid * 8 waves * 8 KB <= the projection scratch the workspace is sized for
+            rc = launch_fused(a, grid, lds_fused, stream);
+        }
+        else if (o.dir == 0) rc = RNF_LAUNCH(0, 0);
         else if (kt_inv == 1) rc = RNF_LAUNCH(1, 1);
         else if (kt_inv == 2) rc = RNF_LAUNCH(1, 2);
         else if (kt_inv == 4) rc = RNF_LAUNCH(1, 4);

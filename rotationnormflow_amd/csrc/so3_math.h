@@ -289,8 +289,9 @@ RNF_HD void segment_fwd_pi(float s_raw, float w0, float w1, float w2, const Fram
     const float c = (1.0f - fmaf(uv, uv, ur * ur)) * hw_rcp(fmaf(uv, uv, e1 * e1));
     const float at = atan_unit(t);
     const float phi = HALF ? at : fmaf(2.0f, at, kPi);
-    const float e = hw_exp2(-1.44269504088896341f * fabsf(s_raw));
-    const float sp = fmaf(hw_log2(1.0f + e), 0.693147180559945309f, relu_bits(s_raw));
+    // the full softplus (log1p residue kept): these are the exact-fp32 kernels a guarded split-precision launch is re-run on when its
+    // weights were too small for fl(1 + e) -- the lean form would round them just the same
+    const float sp = softplus(s_raw);
     S += sp;
     A = fmaf(sp, phi, A);
     J = fmaf(sp, c, J);
@@ -355,11 +356,11 @@ struct SegS7 {
 };
 // log2(1 + 2^x) that is finite for every finite x and keeps its RELATIVE accuracy for x << 0 (the kernels that cannot rely on the range
 // guard's exact-fp32 re-run: training passes, device-packed blobs, RNF_GUARD=0, C-ABI callers without fallback images): the
-// exponent is clamped (log2(1 + 2^126) = 126 exactly: the reference's softplus is linear there), and below 2^x = 2^-6 -- where
+// exponent is clamped and the result floored at x (the reference's softplus is the identity there), and below 2^x = 2^-6 -- where
 // fl(1 + e) would round e to a few bits -- the series log2 e * (e - e^2/2 + e^3/3) takes over (truncation 2^-20 relative at the switch).
 RNF_HD float softplus2_safe(float x) {
     const float e = hw_exp2(fminf(x, 126.0f));
-    const float big = hw_log2(1.0f + e);
+    const float big = fmaxf(x, hw_log2(1.0f + e));              // x >= 126: the clamped form returns 126, the function is x (log2(1 + 2^x) > x always)
     const float small = 1.44269504088896341f * e * fmaf(e, fmaf(e, 0.333333333f, -0.5f), 1.0f);
     return e < 0.015625f ? small : big;
 }

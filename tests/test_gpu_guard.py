@@ -122,7 +122,7 @@ def test_side_layer_conditioner_overflow_is_reported_one_call_later():
     fl = fl.cuda().train()
     side = [m for m in fl.modules() if type(m).__name__ == "ConditionLU"][0]
     with torch.no_grad():
-        side.w_l_net.layers[1].weight[0, 0] = 1.0e5
+        side.w_l_net.layers[1].weight[0, 0] = 1.0e30           # (1e5 is no longer outside the range: the packer's equalisation rescales the unit)
     R = torch.from_numpy(synth.uniform_rotations(64, seed=1)).cuda()
     f = torch.from_numpy(synth.features(64, 24, seed=2)).cuda()
     from rotationnormflow_amd import autograd

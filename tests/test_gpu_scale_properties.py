@@ -47,13 +47,17 @@ def test_fisher24_full_batch_independence_additivity_determinism():
     with torch.no_grad():
         sub = fl.log_prob(R[idx].contiguous(), base=base)["logp"]
     assert torch.equal(sub, lp[idx])
-    # small launches run the 4-wave instantiation of the stack kernel, mid-sized ones the 8-wave one, the launches above the 16-wave
-    # one: same arithmetic
+    # small launches run the 4-wave instantiation of the stack kernel, mid-sized ones the 8-wave one: same arithmetic, bit for bit.  The
+    # 16-wave LEAN launches above them evaluate the segment weights with the one-piece softplus (so3_math.h seg_s7_stage SAFE = false; r3:
+    # the others carry the overflow-safe form), which moves a weight by <= 3e-7 absolute -- after 24 layers that is a few ulp of a
+    # log-density of magnitude 16 for most rows and up to ~1e-4 for the rows the flow stretches most, the level of the reference's own
+    # fp32-vs-fp64 noise (fixture c2_trained: p99 1.7e-5, max 7e-5) and both sit equally close to the fp64 oracle.
     with torch.no_grad():
         small = fl.log_prob(R[:4096].contiguous(), base=base)["logp"]
         mid = fl.log_prob(R[:40000].contiguous(), base=base)["logp"]
-    assert (small - lp[:4096]).abs().max().item() < 2e-6
-    assert (mid - lp[:40000]).abs().max().item() < 2e-6
+    assert torch.equal(small, mid[:4096])
+    d = (mid - lp[:40000]).abs()
+    assert d.max().item() < 2e-4 and d.mean().item() < 3e-6
     # spot check against the oracle (fp64) on a few hundred of those rows
     pick = idx[:512].cpu()
     want, _ = orc.log_prob(cfg, w, R[pick.cuda()].cpu().numpy(), None, synth.fisher_A("diag531"), torch.float64)

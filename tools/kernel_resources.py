@@ -24,7 +24,7 @@ def main():
         def g(k):
             m = re.search(k + r": (\d+)", b)
             return int(m.group(1)) if m else -1
-        rows.append((name, g("VGPRs"), g("AGPRs"), g(r"VGPR Spill"), g(r"SGPR Spill"), g(r"ScratchSize \[bytes/lane\]"),
+        rows.append((name, g("VGPRs"), g("AGPRs"), g(r"VGPRs Spill"), g(r"SGPRs Spill"), g(r"ScratchSize \[bytes/lane\]"),
                      g(r"Occupancy \[waves/SIMD\]"), g(r"LDS Size \[bytes/block\]")))
     filt = shutil.which("c++filt") or shutil.which("llvm-cxxfilt")
     names = [r[0] for r in rows]

@@ -6,7 +6,11 @@ Uncondition16Trans] x 24, K = 64 segments) + matrix-Fisher base, forward log_pro
 A "step" = one fused density evaluation of the whole per-GPU batch (inputs resident in HBM) + the mean-NLL reduction
 (on N > 1 GPUs: one RCCL all-reduce of {sum log p, count}).  Weak scaling: every rank evaluates its own 2^20 shard.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C4|C5|C5u] [--batch-log2 20] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C3|C4|C5|C5u] [--batch-log2 B] [--no-cpu-baseline]
+
+--config C3 (BASELINE.json configs[2]) is the STRONG-scaling workload: one global batch of 2^22 rotations split contiguously over the
+N ranks (2^19 per GPU at N = 8, all 2^22 on one GPU at N = 1), uniform base, one all-reduce of {sum log p, count}; every other config
+is weak scaling (2^20 rotations per GPU).
 
 With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its N ranks itself
 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` as a CHILD process, before this process
@@ -41,6 +45,9 @@ WORKLOADS = {
     "C2": dict(preset="C2", direction="forward", fisher=True, flop=24 * 57_728, bytes=36 + 4,
                text="fisher24: 24-layer MobiusAffine (48 layers, K=64) + matrix-Fisher base A=diag(5,3,1), forward log_prob only, "
                     "uniform-SO(3) inputs, trained-like random weights"),
+    "C3": dict(preset="C3", direction="forward", fisher=False, flop=24 * 57_728, bytes=36 + 4, strong=True, batch_log2=22,
+               text="cone: 24-layer MobiusAffine (48 layers, K=64), forward log_prob, ONE global batch of 2^22 uniform-SO(3) rotations "
+                    "split contiguously over the ranks (strong scaling), trained-like random weights"),
     "C4": dict(preset="C4", direction="forward", fisher=False, flop=24 * 90_496 + 59_392, bytes=36 + 4 * 256 + 4,
                text="SYMSOL-I structure: Condition16Trans + 24 Moebius (3+256 inputs) + 23 Uncondition16Trans, F=256 precomputed "
                     "features per rotation, forward log_prob"),
@@ -171,7 +178,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch-log2", type=int, default=20)
+    ap.add_argument("--batch-log2", type=int, default=None, help="log2 of the batch: per GPU (weak-scaling configs, default 20) or global (C3, default 22)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the exact-fp32 leg")
     args = ap.parse_args()
@@ -226,13 +233,26 @@ def main():
 
     wl = WORKLOADS[args.config]
     cfg, weights, fl = build_flow(device, wl["preset"])
-    n = 1 << args.batch_log2
+    strong = bool(wl.get("strong"))
+    batch_log2 = args.batch_log2 if args.batch_log2 is not None else wl.get("batch_log2", 20)
     A = synth.fisher_A("diag531")
     base = MatrixFisherN(torch.from_numpy(A).to(device)) if wl["fisher"] else None
     feat_dim = fl.feature_dim if cfg.condition else 0
-    # rank r evaluates its own shard of the global batch (seeded per rank): no data-path collective
-    R = torch.from_numpy(synth.uniform_rotations(n, seed=synth.RD_SEED + rank)).to(device)
-    feat = torch.from_numpy(synth.features(n, feat_dim, seed=synth.RD_SEED + 1000 + rank)).to(device) if feat_dim else None
+    if strong:
+        # ONE global batch, the same for every world size; rank r evaluates rows [r N / G, (r + 1) N / G) (dist.shard_bounds, the partition
+        # of torch's scatter on dim 0 = the reference's nn.DataParallel, agent.py:22): no data-path collective
+        from rotationnormflow_amd.dist import shard_bounds
+        n_global = 1 << batch_log2
+        lo, hi = shard_bounds(n_global, rank, world)
+        R = torch.from_numpy(synth.uniform_rotations(n_global, seed=synth.RD_SEED)[lo:hi].copy()).to(device)
+        feat = torch.from_numpy(synth.features(n_global, feat_dim, seed=synth.RD_SEED + 1000)[lo:hi].copy()).to(device) if feat_dim else None
+        n = hi - lo
+    else:
+        # weak scaling: rank r evaluates its own batch (seeded per rank): no data-path collective
+        n = 1 << batch_log2
+        n_global = n * world
+        R = torch.from_numpy(synth.uniform_rotations(n, seed=synth.RD_SEED + rank)).to(device)
+        feat = torch.from_numpy(synth.features(n, feat_dim, seed=synth.RD_SEED + 1000 + rank)).to(device) if feat_dim else None
 
     if wl["direction"] == "forward":
         def evaluate():
@@ -321,23 +341,23 @@ def main():
         try:
             s_steps = max(2, min(args.steps, 8))
             s_elapsed, s_kernel_ms, s_tot = timed(s_steps, 2, 4)
-            secondary = {"dtype": "f32 (exact fp32-input MFMA)", "value": n * world * s_steps / s_elapsed, "unit": "rotations/s",
+            secondary = {"dtype": "f32 (exact fp32-input MFMA)", "value": n_global * s_steps / s_elapsed, "unit": "rotations/s",
                          "steps": s_steps, "ms_per_step": s_elapsed / s_steps * 1e3, "mean_nll": -float(s_tot[0] / s_tot[1]),
                          "roofline": roofline_of("fp32", s_kernel_ms)}
         finally:
             set_precision(primary)
 
     if rank == 0:
-        value = n * world * args.steps / elapsed
+        value = n_global * args.steps / elapsed
         out = {
             "metric": "rotation log_prob evals/s (24-layer MobiusAffine + matrix-Fisher base), mean NLL alongside" if args.config == "C2"
                       else f"rotation evals/s, workload {args.config}",
             "value": value, "unit": "rotations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None,         # the reference publishes no number for this metric; see vs_cpu_baseline
             "dtype": "f32" if primary_used == "fp32" else "f32 (GEMM operands as fp16 hi+lo pairs, fp32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": f"{args.config} -- {wl['text']}", "rotations_per_gpu": n, "global_batch": n * world,
+            "config": {"workload": f"{args.config} -- {wl['text']}", "rotations_per_gpu": n, "global_batch": n_global,
                        "parallelism": (f"batch-sharded x{world}, one all-reduce of {{sum log p, count}} per step" if world > 1 else "single GPU")},
             "rccl_ranks": world, "backend": backend,
             "mean_nll": mean_nll,
@@ -349,26 +369,40 @@ def main():
         if secondary:
             out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
-            # parity spot check of the benchmarked weights/inputs against the oracle (fp64) on the first rotations
+            # parity spot check of the benchmarked weights/inputs against the oracle (fp64) on the first rotations, for BOTH arithmetics, with
+            # the error of the oracle's own fp32 evaluation (= the reference's arithmetic) of the same rows beside it
             from oracle import flow_oracle as orc
             torch.set_num_threads(host_threads())
             m = 2048 if wl["direction"] == "forward" else 256
             sub = R[:m]
             fsub = None if feat is None else feat[:m]
-            with torch.no_grad():
+            sub_np, fsub_np = sub.cpu().numpy(), None if fsub is None else fsub.cpu().numpy()
+
+            def oracle(dtype):
                 if wl["direction"] == "forward":
-                    got = fl.log_prob(sub, fsub, base=base)["logp"].cpu().double().numpy()
-                    want, _ = orc.log_prob(cfg, weights, sub.cpu().numpy(), None if fsub is None else fsub.cpu().numpy(),
-                                           A if wl["fisher"] else None, torch.float64)
-                    want = want.numpy()
-                    out["parity"] = {"samples": m, "mean_nll_abs_err": abs(float(got.mean() - want.mean())),
-                                     "max_abs_err": float(np.abs(got - want).max())}
-                else:
-                    got = fl.inverse(sub, fsub)[1].cpu().double().numpy()
-                    _, want = orc.flow_inverse(cfg, weights, sub.cpu().numpy(), None if fsub is None else fsub.cpu().numpy(), dtype=torch.float64)
-                    want = want.numpy()
-                    out["parity"] = {"samples": m, "mean_ldj_abs_err": abs(float(got.mean() - want.mean())),
-                                     "p99_abs_err": float(np.quantile(np.abs(got - want), 0.99))}
+                    return orc.log_prob(cfg, weights, sub_np, fsub_np, A if wl["fisher"] else None, dtype)[0].double().numpy()
+                return orc.flow_inverse(cfg, weights, sub_np, fsub_np, dtype=dtype)[1].double().numpy()
+
+            def product():
+                with torch.no_grad():
+                    if wl["direction"] == "forward":
+                        return fl.log_prob(sub, fsub, base=base)["logp"].cpu().double().numpy()
+                    return fl.inverse(sub, fsub)[1].cpu().double().numpy()
+
+            def stats(got, want):
+                e = np.abs(got - want)
+                return {"mean_abs_err_of_the_mean": abs(float(got.mean() - want.mean())), "mean_abs_err": float(e.mean()),
+                        "p99_abs_err": float(np.quantile(e, 0.99)), "max_abs_err": float(e.max())}
+            want = oracle(torch.float64)
+            what = "per-rotation log p (mean = -mean NLL)" if wl["direction"] == "forward" else "per-rotation log-det of the inverse pass"
+            out["parity"] = {"samples": m, "quantity": what, "against": "fp64 oracle (pinned to the reference's fp64 run to 1e-11)",
+                             **stats(product(), want), "reference_fp32": stats(oracle(torch.float32), want)}
+            if secondary:
+                set_precision("fp32")
+                try:
+                    secondary["parity"] = {"samples": m, **stats(product(), want)}
+                finally:
+                    set_precision(primary)
             out["cpu_baseline"] = cpu_baseline(cfg, weights, A, wl, feat_dim)
             out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))

@@ -105,3 +105,36 @@ def test_rccl_leg_executes_under_a_launcher_on_one_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert rec["backend"] == "nccl" and rec["rccl_ranks"] == 1 and rec["n_gpus"] == 1 and rec["value"] > 0
+
+
+def test_c3_strong_scaling_splits_one_global_batch():
+    """BASELINE configs[2] ("cone", 2^22 rotations over the ranks): --config C3 is STRONG scaling -- the same global batch whatever N, rank r
+    takes rows [r N / G, (r + 1) N / G), so the mean NLL of the two-rank run (shared-GPU rig) equals the one-rank run's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["RNF_BENCH_HANG_DUMP"] = "200"
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C3", "--steps", "2", "--warmup", "1", "--batch-log2", "17", "--no-secondary",
+            "--no-cpu-baseline"]
+    one = _run(base + ["--gpus", "1"], env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    two = _run(base + ["--gpus", "2"], dict(env, RNF_BENCH_SHARED_GPU="1"))
+    assert two.returncode == 0, two.stderr[-2000:]
+    r2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][0])
+    for r, g in ((r1, 1), (r2, 2)):
+        assert r["scaling"] == "strong" and r["n_gpus"] == g and r["rccl_ranks"] == g
+        assert r["config"]["global_batch"] == 1 << 17 and r["config"]["rotations_per_gpu"] == (1 << 17) // g
+        assert r["config"]["workload"].startswith("C3")
+    # two shards of 2^16 rows run the 8-wave kernel, the single 2^17 launch the 16-wave LEAN one (one-piece softplus): same rows, sums equal to
+    # the arithmetic's noise, far inside the 1e-5 bar
+    assert abs(r1["mean_nll"] - r2["mean_nll"]) < 2e-6 * max(1.0, abs(r1["mean_nll"]))
+
+
+def test_default_line_has_the_reference_noise_beside_its_parity():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch-log2", "16"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    p = rec["parity"]
+    assert p["mean_abs_err_of_the_mean"] < 1e-5 and p["max_abs_err"] <= 4 * p["reference_fp32"]["max_abs_err"] + 2e-5
+    assert rec["secondary"]["parity"]["mean_abs_err_of_the_mean"] < 1e-5
+    assert rec["cpu_baseline"]["kind"] == "port" and rec["vs_baseline"] is None and rec["vs_cpu_baseline"] > 100

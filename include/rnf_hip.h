@@ -87,6 +87,9 @@ double rnf_last_pack_audit(void);
  * (also RNF_EQUALIZE=0 in the environment).  rnf_set_pack_audit(0): the host packers still measure, but no longer refuse. */
 int rnf_set_equalize(int on);
 int rnf_set_pack_audit(int on);
+/* rnf_set_fused(1) (or RNF_FUSED=1): forward passes of conditional flows whose every MLP layer is conditional and feature_dim <= 256 run with
+ * the feature projection INSIDE the stack kernel (no projection scratch in HBM).  Off by default: slower than the two-kernel path on C4. */
+int rnf_set_fused(int on);
 
 /* ---- parameter packing (host side, pure CPU; called once per parameter version) ------------------------------
  * Sizes are in floats.  `segments` (K) is any positive count (flow/mobiusflow.py:7-14 takes any): records hold ceil(K / 8) fc_last tiles,

@@ -22,6 +22,7 @@ _SIGNATURES = {
     "rnf_last_pack_audit": (C.c_double, []),
     "rnf_set_equalize": (C.c_int, [C.c_int]),
     "rnf_set_pack_audit": (C.c_int, [C.c_int]),
+    "rnf_set_fused": (C.c_int, [C.c_int]),
     "rnf_mobius_packed_floats": (C.c_int64, [C.c_int32]),
     "rnf_affine16_packed_floats": (C.c_int64, []),
     "rnf_cond16_packed_floats": (C.c_int64, []),

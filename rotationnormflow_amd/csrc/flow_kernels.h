@@ -978,9 +978,9 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 // In-kernel phase stamps (diagnostic build only, -DRNF_STAMPS; cdna_hip_programming.md section 7 "In-kernel stamps").
 // The shipped library is built without them: no stamp executes in the product kernel.
 #ifdef RNF_STAMPS
-#define RNF_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = clock64();
+#define RNF_STAMP_DECL unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = clock64();
 #define RNF_STAMP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = clock64(); st_acc[i] += now_ - st_t; st_t = now_; __builtin_amdgcn_sched_barrier(0); }
-#define RNF_STAMP_FLUSH if (args.stamps && lane == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(args.stamps + i_, st_acc[i_]); }
+#define RNF_STAMP_FLUSH if (args.stamps && lane == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(args.stamps + i_, st_acc[i_]); }
 #else
 #define RNF_STAMP_DECL
 #define RNF_STAMP(i)
@@ -1008,22 +1008,33 @@ struct FeatFrag {
 };
 
 __device__ __forceinline__ void fused_load_features(const float *feat, int F, long long sample, bool valid, int h, FeatFrag &f) {
+    // four k-steps (8 x 16 bytes per lane) in flight at a time, fenced: unfenced, the scheduler issues all 32 loads first and the raw fp32
+    // values (128 registers) sit on top of the 128 fragment registers they are converted into
+    const float *row = feat + (valid ? sample : 0) * F + 8 * h;
 #pragma unroll
-    for (int s = 0; s < FUSED_KSTEPS; ++s) {
-        f2 v[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
-        const int k0 = 16 * s + 8 * h;
-        if (valid && k0 < F) {                            // F % 8 == 0: an 8-group is entirely inside or outside
-            const float4 p0 = *reinterpret_cast<const float4 *>(feat + sample * F + k0);
-            const float4 p1 = *reinterpret_cast<const float4 *>(feat + sample * F + k0 + 4);
-            v[0] = f2{p0.x, p0.y}; v[1] = f2{p0.z, p0.w}; v[2] = f2{p1.x, p1.y}; v[3] = f2{p1.z, p1.w};
+    for (int s0 = 0; s0 < FUSED_KSTEPS; s0 += 4) {
+        float4 p[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k0 = 16 * (s0 + u) + 8 * h;
+            p[2 * u] = p[2 * u + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid && k0 < F) {                        // F % 8 == 0: an 8-group is entirely inside or outside
+                p[2 * u] = *reinterpret_cast<const float4 *>(row + 16 * (s0 + u));
+                p[2 * u + 1] = *reinterpret_cast<const float4 *>(row + 16 * (s0 + u) + 4);
+            }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const h2 ph = __builtin_convertvector(v[q], h2);
-            const h2 pl = __builtin_convertvector((v[q] - __builtin_convertvector(ph, f2)) * FEAT_LO_SCALE, h2);
-            f.hi[s][2 * q] = ph[0]; f.hi[s][2 * q + 1] = ph[1];
-            f.lo[s][2 * q] = pl[0]; f.lo[s][2 * q + 1] = pl[1];
+        for (int u = 0; u < 4; ++u) {
+            const f2 v[4] = {f2{p[2 * u].x, p[2 * u].y}, f2{p[2 * u].z, p[2 * u].w}, f2{p[2 * u + 1].x, p[2 * u + 1].y}, f2{p[2 * u + 1].z, p[2 * u + 1].w}};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const h2 ph = __builtin_convertvector(v[q], h2);
+                const h2 pl = __builtin_convertvector((v[q] - __builtin_convertvector(ph, f2)) * FEAT_LO_SCALE, h2);
+                f.hi[s0 + u][2 * q] = ph[0]; f.hi[s0 + u][2 * q + 1] = ph[1];
+                f.lo[s0 + u][2 * q] = pl[0]; f.lo[s0 + u][2 * q + 1] = pl[1];
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -1056,11 +1067,14 @@ __device__ __forceinline__ void fused_project_half(const float *pa, int ns, int 
     bad |= acc1[0] != acc1[0];                            // a feature beyond the fp16 range: (inf, -inf) pair, every product NaN
 }
 
-// LEAN: the stack holds Moebius and constant 4x4 affine layers only, nothing conditional, no saved states (BASELINE configs C1 / C2 / C3):
+// LEAN = 1: the stack holds Moebius and constant 4x4 affine layers only, nothing conditional, no saved states (BASELINE configs C1 / C2 / C3):
 // every other layer kind, the feature-projection reads and the kind dispatch are compiled out.
-template <int DIR, int KT_INV, int NW, bool PIPE, int PREC, bool EXT = false, bool LEAN = false, bool FUSED = false>
+// LEAN = 2 (round 3): the CONDITIONAL counterpart (BASELINE configs[3]): Moebius, constant 4x4 affine and Condition16Trans layers, EVERY
+// MLP layer conditional (its projected features come from the scratch -- or, FUSED, from the wave's stash), no saved states, no governor.
+// Both run guarded only (one-piece softplus).
+template <int DIR, int KT_INV, int NW, bool PIPE, int PREC, bool EXT = false, int LEAN = 0, bool FUSED = false>
 __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args) {
-    static_assert(!FUSED || (DIR == 0 && PIPE && PREC == 1 && !EXT && !LEAN), "FUSED: forward, DMA staging, split precision");
+    static_assert(!FUSED || (DIR == 0 && PIPE && PREC == 1 && !EXT && LEAN == 2), "FUSED: forward, DMA staging, split precision, conditional lean stack");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (args.guard_mode == 2) {                                      // fp32 re-run of a split-precision call: only when its guard fired
         if (__hip_atomic_load(args.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
@@ -1170,6 +1184,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             int q2 = next_in_tile(first_mlp);
             if (q2 < 0 && more_tiles) q2 = first_mlp;
             if (q2 >= 0) fused_dma(slot_at(q2), 0);
+            RNF_STAMP(10)                                         // 10: FUSED tile start (features + first layer's projection)
         }
         RNF_STAMP(7)                                              // 7: tile prologue / epilogue
 
@@ -1234,9 +1249,9 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             }
 
             // ---- layers with a conditioner MLP ----
-            typedef typename std::conditional<LEAN, NoG, GFrag<EXT>>::type GF;
+            typedef typename std::conditional<LEAN == 1, NoG, GFrag<EXT>>::type GF;
             GF gfrag{};
-            if constexpr (!LEAN) {
+            if constexpr (LEAN != 1) {
                 gfrag.p = nullptr;
                 gfrag.rows = EXT && args.g_div > 0;
                 if (FUSED) {
@@ -1268,7 +1283,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
 
             MobiusCtx ctx;
             typename Mlp<PREC>::Act tt;
-            if (LEAN || kind == RNF_KIND_MOBIUS) {
+            if (LEAN == 1 || kind == RNF_KIND_MOBIUS) {
                 mobius_begin<DIR, DIR == 0 && PREC == 1>(R, perm_row, ctx);
                 Mlp<PREC>::head(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair, bad);
             } else {
@@ -1285,9 +1300,11 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             if constexpr (FUSED) {
                 if (fq1 >= 0) {                                   // out tile 0 (its weights landed during this layer's hidden phase; B1 waited for them)
                     fused_project_half(lds + args.pa_off, fused_ns, lane, h, ff, stash, bad);
+                    RNF_STAMP(8)                                  // 8: FUSED projection, out tile 0
                     __syncthreads();                              // every wave is done with the buffer
                     fused_dma(slot_at(fq1), 1);                   // out tile 1 lands during the fc_last phase
                 }
+                RNF_STAMP(11)                                     // 11: FUSED: the two extra barriers (+ DMA issue)
             }
 
             // B2 (DMA mode): every wave is past the L part and the next layer's H part has landed; then the next L part is requested
@@ -1311,15 +1328,17 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 if constexpr (FUSED) {
                     if (fq1 >= 0) {
                         fused_project_half(lds + args.pa_off, fused_ns, lane, h, ff, stash + G_FLOATS_PER_GROUP / 2, bad);
+                        RNF_STAMP(9)                              // 9: FUSED projection, out tile 1
                         __syncthreads();
                         int q2 = next_in_tile(fq1);
                         if (q2 < 0 && more_tiles) q2 = first_mlp;
                         if (q2 >= 0) fused_dma(slot_at(q2), 0);
                     }
+                    RNF_STAMP(11)
                 }
             };
             auto barrier2 = [&]() { b2_sync(); b2_issue(); fused_p1(); };
-            if (LEAN || kind == RNF_KIND_MOBIUS) {
+            if (LEAN == 1 || kind == RNF_KIND_MOBIUS) {
                 if constexpr (DIR != 0) {
                     InvSegs<KTI> sg;
                     float S = 0.f;
@@ -1333,10 +1352,10 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     b2_issue();
                 } else {
                     float S = 0.f, A = 0.f, J = 0.f;
-                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC, LEAN, LEAN || FUSED>(lds, KT, args.K, lane, h, tt, ctx, S, A, J, fair);
+                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC, LEAN == 1, LEAN != 0>(lds, KT, args.K, lane, h, tt, ctx, S, A, J, fair);
                     else mobius_fwd_tiles_restage<PREC>(lds, params, KT, args.K, lane, h, tt, ctx, S, A, J, tid, NT);
                     barrier2();
-                    mobius_fwd_finish<PREC == 1, (LEAN || FUSED) && PREC == 1>(ctx, S, A, J, R, ldj, bad, kMinWeightSum * (float)args.K);
+                    mobius_fwd_finish<PREC == 1, LEAN != 0 && PREC == 1>(ctx, S, A, J, R, ldj, bad, kMinWeightSum * (float)args.K);
                 }
             } else {
                 const f32x16 o16 = Mlp<PREC>::last(lds + MOB_LAST, lane, h, tt);
@@ -1347,7 +1366,11 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 } else {
                     barrier2();
                     if (EXT && kind != RNF_KIND_COND16) cond9_finish<DIR != 0>(kind, o16, h, R, ldj);
+#ifdef RNF_EXP_NOCOND16
+                    else if (!FUSED) cond16_finish<DIR != 0>(o16, h, R, ldj); else ldj += o16[0];
+#else
                     else cond16_finish<DIR != 0>(o16, h, R, ldj);
+#endif
                 }
             }
             RNF_STAMP(5)                                          // 5: layer finish (bisection for the inverse)

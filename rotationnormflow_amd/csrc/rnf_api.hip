@@ -621,30 +621,50 @@ static bool lean_allowed() {
     return mode == 1;
 }
 
-// RNF_FUSED=0 keeps conditional forward passes on the feature-projection pre-pass + stack kernel pair (measurement switch)
+// RNF_FUSED=1 / rnf_set_fused(1): conditional forward passes (every MLP layer conditional, F <= 256) run the FUSED instantiation of the
+// stack kernel -- feature projection inside, no scratch round trip (HBM traffic = the algorithmic bytes) -- instead of the pre-pass + stack
+// pair.  OFF by default: measured on C4 it is SLOWER (12.2 ms against 8.7 ms, profiles/r3/fused_c4.md): the features take 128 of the 256
+// registers an 8-wave workgroup has per lane, the rest of the layer does not fit beside them, and its projection phases run in lockstep
+// between workgroup barriers with nothing to overlap.
+static int g_fused = -1;
 static bool fused_allowed() {
-    static int mode = -1;
-    if (mode < 0) {
+    if (g_fused < 0) {
         const char *e = std::getenv("RNF_FUSED");
-        mode = (e && e[0] == '0') ? 0 : 1;
+        g_fused = (e && e[0] == '1') ? 1 : 0;
     }
-    return mode == 1;
+    return g_fused == 1;
+}
+extern "C" int rnf_set_fused(int on) {
+    const int old = fused_allowed() ? 1 : 0;
+    g_fused = on ? 1 : 0;
+    return old;
 }
 
 // forward pass of a conditional flow with the feature projection inside the stack kernel (flow_kernels.h FUSED)
+#ifndef RNF_NW_FUSED
+#define RNF_NW_FUSED 8
+#endif
+constexpr int NW_FUSED = RNF_NW_FUSED;
 static int launch_fused(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream) {
-    auto kern = flow_stack_kernel<0, 0, NW_FWD_H, true, 1, false, false, true>;
+    auto kern = flow_stack_kernel<0, 0, NW_FUSED, true, 1, false, 2, true>;
     HIP_TRY(allow_lds(kern, lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_FWD_H * 64), lds_bytes, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_FUSED * 64), lds_bytes, stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 template <int DIR, int KT_INV, bool PIPE, int PREC, bool EXT = false>
-static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream, int nwk, bool lean = false) {
+static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream, int nwk, int lean = 0) {
     if constexpr (DIR == 0 && PREC == 1 && PIPE && !EXT) {
-        if (nwk == NW_FWD_WIDE && lean) {        // lean instantiation: Moebius + constant-affine layers only (BASELINE C1 / C2 / C3)
-            auto kern = flow_stack_kernel<DIR, KT_INV, NW_FWD_WIDE, PIPE, PREC, false, true>;
+        if (nwk == NW_FWD_WIDE && lean == 2) {   // conditional lean instantiation: Moebius + constant-affine + Condition16Trans, every MLP conditional (C4)
+            auto kern = flow_stack_kernel<DIR, KT_INV, NW_FWD_WIDE, PIPE, PREC, false, 2>;
+            HIP_TRY(allow_lds(kern, lds_bytes));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_FWD_WIDE * 64), lds_bytes, stream, a);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+        if (nwk == NW_FWD_WIDE && lean == 1) {   // lean instantiation: Moebius + constant-affine layers only (BASELINE C1 / C2 / C3)
+            auto kern = flow_stack_kernel<DIR, KT_INV, NW_FWD_WIDE, PIPE, PREC, false, 1>;
             HIP_TRY(allow_lds(kern, lds_bytes));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_FWD_WIDE * 64), lds_bytes, stream, a);
             HIP_TRY(hipGetLastError());
@@ -719,6 +739,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     bool all_mlp_cond = true;                // every MLP layer consumes the feature vector (what the FUSED instantiation handles)
     int prec = -1;
     bool lean = lean_allowed() && !o.states;   // Moebius + constant 4x4 affine layers only, nothing conditional, no saved states
+    bool lean2 = lean_allowed() && !o.states;  // the conditional counterpart: + Condition16Trans, every MLP layer conditional (checked below)
     for (int l = 0; l < n_layers; ++l) {
         const int32_t *d = desc + (size_t)l * D_STRIDE;
         const int kind = d[D_KIND], perm = d[D_PERM], slot = d[D_SLOT];
@@ -730,6 +751,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         if (kind_is_cond9(kind) || kind == RNF_KIND_COND36 || kind_is_side(kind)) ext = true;
         if (kind_is_side(kind) && !o.side) return fail("layer %d takes per-sample matrices: call the rnf_flow_*_side entry points with a side buffer", l);
         if ((kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16) || slot >= 0) lean = false;
+        if (kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16 && kind != RNF_KIND_COND16) lean2 = false;
         if (kind == RNF_KIND_COND36) min_tiles = 2;
         if (slot >= 0) {
             if (slot >= MAX_SLOTS) return fail("layer %d: cond_slot %d >= %d", l, slot, MAX_SLOTS);
@@ -839,7 +861,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     int *guard = guarded ? reinterpret_cast<int *>(reinterpret_cast<double *>(ws) + GUARD_AT) : nullptr;
     // FUSED: forward pass of a conditional flow whose every MLP layer is conditional, F <= 256, projection records equally spaced in the
     // blob (both packers lay them out that way).  Guarded launches only: the instantiation uses the one-piece softplus.
-    bool fused = fused_allowed() && o.dir == 0 && prec == 1 && pipe && any_mlp && n_slots > 0 && all_mlp_cond && !shared && !ext && !o.states &&
+    bool fused = fused_allowed() && lean2 && o.dir == 0 && prec == 1 && pipe && any_mlp && n_slots > 0 && all_mlp_cond && !shared && !ext && !o.states &&
                  F <= FUSED_MAX_F && guarded && a.tab_off >= 0;
     int feat_stride = (int)((featproj_packed_floats(F) + 3) / 4 * 4);
     if (fused && n_slots > 1) feat_stride = fp_primary[1] - fp_primary[0];
@@ -870,8 +892,8 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         const bool wide = !fused && o.dir == 0 && prec == 1 && pipe && !ext && wide_allowed() && cn > (long long)cus * NW_FWD_H * 32;
         const bool narrow = !fused && o.dir == 0 && prec == 1 && pipe && !ext && wide_allowed() && cn <= (long long)cus * NW_FWD_NARROW * 32;
         const bool big_inv = o.dir == 1 && any_mlp && KT > 8;                  // 4-wave instantiation (512 registers per lane)
-        const int nwk = big_inv ? NW_INV_BIG : (wide ? NW_FWD_WIDE : (narrow ? NW_FWD_NARROW : ((o.dir == 0 && prec == 1) ? NW_FWD_H : NW)));
-        a.fair_off = (wide || narrow) ? -1 : fair_off;                       // the governor pairs two waves per SIMD
+        const int nwk = fused ? NW_FUSED : (big_inv ? NW_INV_BIG : (wide ? NW_FWD_WIDE : (narrow ? NW_FWD_NARROW : ((o.dir == 0 && prec == 1) ? NW_FWD_H : NW))));
+        a.fair_off = (wide || narrow || (fused && NW_FUSED != 8)) ? -1 : fair_off;                       // the governor pairs two waves per SIMD
         const long long ntiles = (cn + nwk * 32 - 1) / (nwk * 32);
         const long long ntiles_fp = (cn + NW_FP * 32 - 1) / (NW_FP * 32);
         const int nw_fb = (o.dir == 1 && any_mlp && KT > 8) ? NW_INV_BIG : NW;
@@ -933,7 +955,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
                         : launch_stack<DIR_, KT_, true, 0, true>(a, grid, lds_bytes, stream, nwk))                  \
                 : (prec ? launch_stack<DIR_, KT_, false, 1, true>(a, grid, lds_bytes, stream, nwk)                  \
                         : launch_stack<DIR_, KT_, false, 0, true>(a, grid, lds_bytes, stream, nwk))) :              \
-    (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1>(a, grid, lds_bytes, stream, nwk, lean && guarded && a.tab_off >= 0)       \
+    (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1>(a, grid, lds_bytes, stream, nwk, (guarded && a.tab_off >= 0) ? (lean ? 1 : (lean2 && all_mlp_cond && n_slots > 0 && !shared ? 2 : 0)) : 0)       \
                   : launch_stack<DIR_, KT_, true, 0>(a, grid, lds_bytes, stream, nwk))                              \
           : (prec ? launch_stack<DIR_, KT_, false, 1>(a, grid, lds_bytes, stream, nwk)                              \
                   : launch_stack<DIR_, KT_, false, 0>(a, grid, lds_bytes, stream, nwk)))
@@ -964,8 +986,8 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             {
                 FlowArgs &a = b;                          // RNF_LAUNCH names `a`, `grid`, `prec`, `nwk`
                 const int grid = grid_fb, prec = 0, nwk = NW;
-                const bool lean = false;
-                (void)lean;
+                const bool lean = false, lean2 = false;
+                (void)lean; (void)lean2;
                 if (o.dir == 0) rc = RNF_LAUNCH(0, 0);
                 else if (kt_inv == 1) rc = RNF_LAUNCH(1, 1);
                 else if (kt_inv == 2) rc = RNF_LAUNCH(1, 2);

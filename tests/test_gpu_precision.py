@@ -169,3 +169,29 @@ def test_device_packed_inference_is_guarded():
     finally:
         L.rnf_set_equalize(eq)
         L.rnf_set_pack_audit(au)
+
+
+@pytest.mark.parametrize("name", ["c4_trained", "c4_imbal", "cond16_regular", "embed_cond"])
+def test_fused_projection_kernel_matches_the_two_kernel_path(name):
+    """rnf_set_fused(1): the feature projection inside the stack kernel (features resident in registers, projected one layer ahead into an
+    L2-resident stash) -- same arithmetic as the pre-pass; gates vs the fixture too."""
+    L = _lib.lib()
+    cfg, w, R, feat, fx, spec = load_case(name)
+    _, Rt0, ldj0 = _run(cfg, w, R, feat)
+    old = L.rnf_set_fused(1)
+    try:
+        _, Rt1, ldj1 = _run(cfg, w, R, feat)
+        n_big = 70000                                                  # more than one tile per workgroup: the tile-boundary path of the pipeline
+        Rb = synth.uniform_rotations(n_big, seed=5)
+        fb = synth.features(n_big, feat.shape[1], seed=6) * np.float32(synth.feature_scale(spec["regime"]))
+        _, Rt3, ldj3 = _run(cfg, w, Rb, fb)
+    finally:
+        L.rnf_set_fused(old)
+    _, Rt2, ldj2 = _run(cfg, w, Rb, fb)
+    # large launch: the default path runs the 16-wave conditional-lean stack kernel, which evaluates the same arithmetic -> bit-identical;
+    # the fixture-sized launch runs the general instantiation (overflow-safe softplus form): equal to that form's 1e-7-per-weight difference
+    assert np.array_equal(ldj3, ldj2) and np.array_equal(Rt3, Rt2)
+    assert np.abs(ldj1 - ldj0).max() < 2e-4 and np.abs(ldj1 - ldj0).mean() < 3e-6 and np.abs(Rt1 - Rt0).max() < 2e-4
+    noise = np.abs(fx["ldj32"].astype(np.float64) - fx["ldj64"])
+    err = np.abs(ldj1 - fx["ldj64"])
+    assert err.mean() <= 2 * noise.mean() + 2e-6 and err.max() <= 4 * noise.max() + 2e-5

@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 PHASES = ["0 G-load + sync staging", "1 frame + hidden layers (H)", "2 barrier B1", "3 fc_last tiles + segments (L)",
-          "4 barrier B2", "5 layer finish", "6 affine16 layer", "7 tile prologue/epilogue"]
+          "4 barrier B2", "5 layer finish", "6 affine16 layer", "7 tile prologue/epilogue", "8 fused projection tile 0",
+          "9 fused projection tile 1", "10 fused tile start (features + first projection)", "11 fused: the two extra barriers"]
 
 
 def main():
@@ -55,7 +56,7 @@ def main():
     R = torch.from_numpy(synth.uniform_rotations(n, seed=42)).to(dev)
     feat = torch.from_numpy(synth.features(n, fl.feature_dim, seed=43)).to(dev) if cfg.condition else None
     base = MatrixFisherN(torch.from_numpy(synth.fisher_A("diag531")))
-    stamps = torch.zeros(8, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(12, dtype=torch.int64, device=dev)
     os.environ["RNF_STAMPS_PTR"] = str(stamps.data_ptr())
 
     def step():

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define RNF_ABI_VERSION 4
+#define RNF_ABI_VERSION 5
 
 /* width of the conditioner MLP's hidden layers: flow/condition.py:9 (Nh=64, never overridden by any caller) */
 #define RNF_HIDDEN 64
@@ -85,6 +85,9 @@ const char *rnf_last_error(void);
 double rnf_last_pack_audit(void);
 /* Process-wide measurement / test switches; both return the previous setting.  rnf_set_equalize(0): the packers split the weights as given
  * (also RNF_EQUALIZE=0 in the environment).  rnf_set_pack_audit(0): the host packers still measure, but no longer refuse. */
+/* Mean square of a feature entry that the packers called from THIS thread assume when they equalise a conditional layer (default 1; the
+ * one data-dependent input of csrc/equalize.h).  Returns the previous value. */
+double rnf_set_feature_ms(double mean_square);
 int rnf_set_equalize(int on);
 int rnf_set_pack_audit(int on);
 /* rnf_set_fused(1) (or RNF_FUSED=1): forward passes of conditional flows whose every MLP layer is conditional and feature_dim <= 256 run with

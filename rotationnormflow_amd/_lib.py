@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librnf_hip.so")
 
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 PREC_FP32, PREC_F16X2 = 0, 1
 
 c_f32p = C.c_void_p      # device or host float*, passed as integer addresses
@@ -21,6 +21,7 @@ _SIGNATURES = {
     "rnf_last_error": (C.c_char_p, []),
     "rnf_last_pack_audit": (C.c_double, []),
     "rnf_set_equalize": (C.c_int, [C.c_int]),
+    "rnf_set_feature_ms": (C.c_double, [C.c_double]),
     "rnf_set_pack_audit": (C.c_int, [C.c_int]),
     "rnf_set_fused": (C.c_int, [C.c_int]),
     "rnf_mobius_packed_floats": (C.c_int64, [C.c_int32]),

@@ -91,6 +91,13 @@ class TrainPlan:
         self.flags = torch.zeros(1, dtype=torch.int32, device=device)
         self.flags_host = torch.zeros(1, dtype=torch.int32).pin_memory() if torch.cuda.is_available() else torch.zeros(1, dtype=torch.int32)
         self.flags_event = None
+        self.feature_ms = None
+
+    def calibrate(self, feature):
+        """Mean square of the feature entries, measured ONCE per plan on the first batch it sees (a training run keeps its feature
+        distribution): the data-dependent input of the device packer's equalisation (csrc/equalize.h)."""
+        if self.feature_ms is None and feature is not None and not torch.cuda.is_current_stream_capturing():
+            self.feature_ms = runtime.feature_mean_square(feature)
 
     def check_flags(self):
         if self.flags_event is not None and self.flags_event.query():
@@ -115,11 +122,15 @@ class TrainPlan:
         self.flags.zero_()
         if plain.numel() == 0:                             # a stack of side layers only: nothing to read, but the pointer must be valid
             plain = torch.zeros(4, dtype=torch.float32, device=blob.device)
-        _lib.check(L.rnf_pack_flow_device(plain.data_ptr(), self.pack_desc.ctypes.data, self.n_layers, self.segments, self.feat_dim,
-                                          self.prec, blob.data_ptr(), self.flags.data_ptr(), stream))
-        if both:
+        old_ms = L.rnf_set_feature_ms(self.feature_ms or 1.0)
+        try:
             _lib.check(L.rnf_pack_flow_device(plain.data_ptr(), self.pack_desc.ctypes.data, self.n_layers, self.segments, self.feat_dim,
-                                              _lib.PREC_FP32, blob.data_ptr() + 4 * self.blob_floats, self.flags.data_ptr(), stream))
+                                              self.prec, blob.data_ptr(), self.flags.data_ptr(), stream))
+            if both:
+                _lib.check(L.rnf_pack_flow_device(plain.data_ptr(), self.pack_desc.ctypes.data, self.n_layers, self.segments, self.feat_dim,
+                                                  _lib.PREC_FP32, blob.data_ptr() + 4 * self.blob_floats, self.flags.data_ptr(), stream))
+        finally:
+            L.rnf_set_feature_ms(old_ms)
         if self.flags_event is None and not capturing:
             self.flags_host.copy_(self.flags, non_blocking=True)
             self.flags_event = torch.cuda.Event()
@@ -191,6 +202,8 @@ class _FlowFn(torch.autograd.Function):
             fptr = feat.data_ptr() if feat is not None else None
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream
+                if plan.feat_dim:
+                    plan.calibrate(feat)
                 blob = plan.pack(plain, stream)
                 if plan.n_side:
                     _lib.check(L.rnf_flow_train_side(direction, rot.data_ptr(), fptr, n, plan.feat_padded, side_c.data_ptr(), blob.data_ptr(),

@@ -14,10 +14,13 @@
 //     x0' = D0 x0 (fc_first image, its bias and the feature-projection rows scaled by D0)
 //     x1' = D1 x1,  W1' = D1 W1 D0^-1;   x2' = D2 x2,  W3' = D2 W3 D1^-1;   x3' = D0 x3,  W5' = D0 W5 D2^-1   (the residual x0 + x3
 //     of flow/condition.py:29 forces the same factor on x0 and x3);   out = Wl' relu(x0' + x3') + bl,  Wl' = Wl D0^-1.
-// Estimate of the mean squares (weights only, no data): the conditioning column y is a unit vector (E y_c^2 = 1/3), the feature entries
-// are taken as unit variance (EQ_FEATURE_VAR; SURVEY 8(d): N(0,1) features), a ReLU passes half of the second moment:
-//     q0_i = |W0y_i|^2 / 3 + |W0f_i|^2 + b0_i^2,   q_l,i = 1/2 sum_j W_l,ij^2 q_{l-1,j} + b_l,i^2,   D0 from q0 + q3, D1 from q1, D2 from q2.
-// Being off by a few binades costs nothing (the error grows only in proportion, and only when the estimate is too LARGE): the packers
+// Estimate of the mean squares: the conditioning column y is a unit vector (E y_c^2 = 1/3), a ReLU passes half of the second moment, and
+// the mean square of a feature entry, `feat_ms`, is the ONE data-dependent number: 1 unless the caller says otherwise (rnf_set_feature_ms;
+// the Python runtime measures it on the first feature batch a parameter version is packed for -- a flow evaluated on features 40x
+// larger than assumed keeps its parity but loses ~5 bits in fc_last, whose columns are scaled down with the activations feeding it):
+//     q0_i = |W0y_i|^2 / 3 + feat_ms |W0f_i|^2 + b0_i^2,   q_l,i = 1/2 sum_j W_l,ij^2 q_{l-1,j} + b_l,i^2,   D0 from q0 + q3, D1 from q1, D2 from q2.
+// Being off by a binade or two costs nothing; beyond that the error grows in proportion to the mis-estimate (measured: features 40x larger
+// than assumed -> 2.5x the mean, 7x the maximum log-det error of a 4-layer flow), which is why feat_ms is an input.  The packers
 // additionally AUDIT every packed layer on probe inputs (rnf_api.hip audit_mlp) and refuse f16x2 when the packed network does not
 // reproduce the exact one.
 //
@@ -35,7 +38,6 @@ namespace rnf {
 
 constexpr int EQ_TARGET_EXP = -1;          // scaled rms of a hidden pre-activation lands in (2^(T-1), 2^T]
 constexpr int EQ_CLAMP = 60;               // |exponent| bound: the scaled weights stay finite in fp32 for any sane checkpoint
-constexpr double EQ_FEATURE_VAR = 1.0;     // assumed second moment of a feature entry
 
 // exponent e with 2^e sqrt(q) in (2^(T-1), 2^T];  q = 0 / non-finite -> 0 (a dead unit: any factor is exact)
 RNF_EQ_HD int eq_exponent(double q) {
@@ -51,14 +53,14 @@ RNF_EQ_HD int eq_exponent(double q) {
 
 // mean square of x0_i = fc_first row i applied to (y (+) feature) + bias; `yo` = 3 (Moebius: the first three columns multiply the unit
 // vector y) or 0 (Condition16Trans and relatives: feature only)
-RNF_EQ_HD double eq_q_first(const float *w_row, int ni, int yo, float b) {
+RNF_EQ_HD double eq_q_first(const float *w_row, int ni, int yo, float b, double feat_ms) {
 #pragma clang fp contract(off)
     double sy = 0.0;
     for (int c = 0; c < yo; ++c) sy += (double)w_row[c] * (double)w_row[c];
     double s = sy * (1.0 / 3.0);
     double sf = 0.0;
     for (int c = yo; c < ni; ++c) sf += (double)w_row[c] * (double)w_row[c];
-    s += sf * EQ_FEATURE_VAR;
+    s += sf * feat_ms;
     s += (double)b * (double)b;
     return s;
 }
@@ -77,9 +79,10 @@ RNF_EQ_HD double eq_q_hidden(const float *w_row /* 64 */, const double *q_prev /
 struct EqExponents {
     int e[3][64];                          // e[0]: x0 / x3 / fc_last input, e[1]: x1, e[2]: x2
 };
-inline void eq_exponents_host(const float *W0, int ni, int yo, const float *b0, const float *const hw[3], const float *const hb[3], EqExponents &out) {
+inline void eq_exponents_host(const float *W0, int ni, int yo, const float *b0, const float *const hw[3], const float *const hb[3], double feat_ms,
+                              EqExponents &out) {
     double q0[64], q1[64], q2[64], q3[64];
-    for (int i = 0; i < 64; ++i) q0[i] = eq_q_first(W0 + (size_t)i * ni, ni, yo, b0[i]);
+    for (int i = 0; i < 64; ++i) q0[i] = eq_q_first(W0 + (size_t)i * ni, ni, yo, b0[i], feat_ms);
     for (int i = 0; i < 64; ++i) q1[i] = eq_q_hidden(hw[0] + (size_t)i * 64, q0, hb[0][i]);
     for (int i = 0; i < 64; ++i) q2[i] = eq_q_hidden(hw[1] + (size_t)i * 64, q1, hb[1][i]);
     for (int i = 0; i < 64; ++i) q3[i] = eq_q_hidden(hw[2] + (size_t)i * 64, q2, hb[2][i]);

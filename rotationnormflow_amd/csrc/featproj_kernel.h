@@ -308,4 +308,147 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// feature_dim in (256, 512] (BASELINE configs[4], F = 512), split precision: the K dimension is split over PAIRS OF WAVES instead of over
+// two passes whose partial sums travel through the scratch (round 2: G written twice and re-read once per layer, 10 of C5's 27 ms).
+// Workgroup = 8 waves = 4 pairs; pair p = wave & 3 owns one 32-sample group, wave p holds features [0, 256) of it as B fragments, wave p + 4
+// features [256, 512).  A weight tile (slot, out tile) is the whole K range (64 KB) in one of two LDS buffers; every wave multiplies its
+// half; wave p + 4 hands its 32 x 32 partial sums to wave p through a double-buffered 4 KB LDS slot (written behind the tile's matrix
+// instructions, read behind the NEXT tile's barrier: no extra synchronisation) and wave p writes the finished tile.  LDS: 2 x 64 KB
+// weights + 2 x 4 x 4 KB exchange = 160 KB.  Every global access of a tile rides one per k-step behind the matrix instructions, as above.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int FP2_BUF = 2 * (FP_KCHUNK / 16) * 512;       // floats: one weight tile, K = 512
+constexpr int FP2_X = 4 * 64 * 16;                        // floats: exchange slots of the 4 pairs for one tile
+constexpr size_t FP2_LDS_BYTES = sizeof(float) * (2 * FP2_BUF + 2 * FP2_X);
+
+__global__ __launch_bounds__(8 * 64) void featproj_ksplit_kernel(const FeatProjArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (args.only_if && __hip_atomic_load(args.only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int pair = wave & 3, khalf = wave >> 2;
+    const int F = args.F;
+    const int nsteps_all = (F + 15) / 16;                      // k-steps in a record row block (both halves, <= 32)
+    const int ns_lo = FP_KCHUNK / 16;                          // k-steps of the first half: always full
+    const int ns_mine = khalf ? nsteps_all - ns_lo : ns_lo;    // second half may be ragged
+    const long long ntiles = (args.n + 127) / 128;
+    float *xbuf = lds + 2 * FP2_BUF;
+    const int n_t = 2 * args.n_slots;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long group = tile * 4 + pair;
+        const long long sample = group * TILE_SAMPLES + j;
+        const bool valid = sample < args.n;
+        h8 bh[FP_KCHUNK / 16], bl[FP_KCHUNK / 16];
+#pragma unroll
+        for (int s = 0; s < FP_KCHUNK / 16; ++s) {
+            f2 v[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
+            const int k0 = khalf * FP_KCHUNK + 16 * s + 8 * h;
+            if (valid && k0 < F) {
+                const float4 p0 = *reinterpret_cast<const float4 *>(args.feat + sample * F + k0);
+                const float4 p1 = *reinterpret_cast<const float4 *>(args.feat + sample * F + k0 + 4);
+                v[0] = f2{p0.x, p0.y}; v[1] = f2{p0.z, p0.w}; v[2] = f2{p1.x, p1.y}; v[3] = f2{p1.z, p1.w};
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const h2 ph = __builtin_convertvector(v[q], h2);
+                const h2 pl = __builtin_convertvector((v[q] - __builtin_convertvector(ph, f2)) * FEAT_LO_SCALE, h2);
+                bh[s][2 * q] = ph[0]; bh[s][2 * q + 1] = ph[1];
+                bl[s][2 * q] = pl[0]; bl[s][2 * q + 1] = pl[1];
+            }
+        }
+        auto tile_src = [&](int t) { return args.blob + args.feat_off[t >> 1] + (size_t)(t & 1) * nsteps_all * 512; };
+        __syncthreads();                                       // every wave has finished with both buffers (previous sample tile)
+        dma_floats(lds, tile_src(0), nsteps_all * 512, wave, lane, 8);
+        f32x16 pend, cur0, nxt0;
+        {
+            const float *bias = args.blob + args.feat_off[0] + (size_t)2 * nsteps_all * 512 + h * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cur0[r] = khalf ? 0.f : bias[r];
+            nxt0 = cur0;
+        }
+        int pend_t = -1;
+        for (int t = 0; t < n_t; ++t) {
+            const float *wl = lds + (t & 1) * FP2_BUF + khalf * (ns_lo * 512);
+            dma_wait_all();
+            __syncthreads();                                   // tile t has landed; nobody still reads the other buffer; exchange slot (t - 1) & 1 is written
+            const bool more = t + 1 < n_t;
+            if (pend_t >= 0 && khalf == 0) {                   // finish tile t - 1: add the partner's half
+                const float4 *x = reinterpret_cast<const float4 *>(xbuf + (pend_t & 1) * FP2_X + pair * (64 * 16)) + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 o = x[q * 64];
+                    pend[4 * q] += o.x; pend[4 * q + 1] += o.y; pend[4 * q + 2] += o.z; pend[4 * q + 3] += o.w;
+                }
+            }
+            const float *nsrc = tile_src(more ? t + 1 : t);
+            float *ndst = lds + ((t + 1) & 1) * FP2_BUF;
+            const float4 *nstart = reinterpret_cast<const float4 *>(args.blob + args.feat_off[(more ? t + 1 : t) >> 1] + (size_t)2 * nsteps_all * 512 +
+                                                                    (((more ? t + 1 : t) & 1) * 2 + h) * 16);
+            const GOut pout(args, (pend_t < 0 ? 0 : pend_t) >> 1, group, sample, valid, (pend_t < 0 ? 0 : pend_t) & 1, lane, h);
+            const int n_dma = (nsteps_all * 128 + 511) / 512;  // 1 KiB pieces per wave of the next tile (<= 8)
+            f32x16 acc1 = cur0, acc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+            const unsigned wl_lds = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)wl + 16u * lane;
+            h8 ah, al;
+            fp_lds_read<0>(ah, wl_lds);
+            fp_lds_read<1024>(al, wl_lds);
+#pragma unroll
+            for (int s = 0; s < FP_KCHUNK / 16; ++s) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah), "+v"(al) :: "memory");
+                h8 nah = ah, nal = al;
+                if (s + 1 < FP_KCHUNK / 16) {
+                    fp_lds_read_at(nah, wl_lds, (s + 1) * 2048);
+                    fp_lds_read_at(nal, wl_lds, (s + 1) * 2048 + 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (s < ns_mine) {                              // wave uniform (a ragged second half: zero operands beyond F anyway)
+                    acc1 = RNF_MFMA_H(ah, bh[s], acc1);
+                    acc2 = RNF_MFMA_H(ah, bl[s], acc2);
+                    acc2 = RNF_MFMA_H(al, bh[s], acc2);
+                }
+                ah = nah; al = nal;
+                __builtin_amdgcn_sched_barrier(0);
+                if (s < 8) {                                   // the next weight tile: up to 8 pieces of 1 KiB per wave
+                    if (more && s < n_dma) {
+                        const int base = wave * 64 + s * 512;  // float4 index, wave uniform
+                        if (base < nsteps_all * 128)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nsrc + 4 * (size_t)(base + lane)),
+                                                             (__attribute__((address_space(3))) void *)(ndst + 4 * base), 16, 0, 0);
+                    }
+                } else if (s < 12) {                           // the next tile's accumulator start (bias; the upper k-half starts from zero)
+                    if (more && khalf == 0) {
+                        const float4 v = nstart[s - 8];
+                        nxt0[4 * (s - 8)] = v.x; nxt0[4 * (s - 8) + 1] = v.y; nxt0[4 * (s - 8) + 2] = v.z; nxt0[4 * (s - 8) + 3] = v.w;
+                    }
+                } else {                                       // the previous tile's finished result
+                    if (pend_t >= 0 && khalf == 0)
+                        pout.store(s - 12, make_float4(pend[4 * (s - 12)], pend[4 * (s - 12) + 1], pend[4 * (s - 12) + 2], pend[4 * (s - 12) + 3]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pend[r] = fmaf(acc2[r], (1.0f / FEAT_LO_SCALE), acc1[r]);
+            if (khalf) {                                       // hand the upper half's partial sums to the partner (read behind the next barrier)
+                float4 *x = reinterpret_cast<float4 *>(xbuf + (t & 1) * FP2_X + pair * (64 * 16)) + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q * 64] = make_float4(pend[4 * q], pend[4 * q + 1], pend[4 * q + 2], pend[4 * q + 3]);
+            }
+            pend_t = t;
+            cur0 = nxt0;
+        }
+        dma_wait_all();
+        __syncthreads();                                       // the last tile's exchange slot is written
+        if (khalf == 0) {
+            const float4 *x = reinterpret_cast<const float4 *>(xbuf + (pend_t & 1) * FP2_X + pair * (64 * 16)) + lane;
+            const GOut gout(args, pend_t >> 1, group, sample, valid, pend_t & 1, lane, h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 o = x[q * 64];
+                gout.store(q, make_float4(pend[4 * q] + o.x, pend[4 * q + 1] + o.y, pend[4 * q + 2] + o.z, pend[4 * q + 3] + o.w));
+            }
+        }
+    }
+}
+
 }  // namespace rnf

@@ -344,7 +344,7 @@ template <>
 struct Mlp<0> {
     struct Act { f32x16 t[2]; };
     // g: this wave's feature-projection fragments for the layer (global memory), or nullptr for an unconditional layer
-    template <class GF>
+    template <class GF, bool KEEPX0 = false>
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
                                                 const GF &g, Act &out, Fair &, bool &) {
         f32x16 cinit[2];
@@ -362,6 +362,8 @@ struct Mlp<0> {
     }
 };
 
+constexpr float kX0Guard = 64.0f;
+
 template <>
 struct Mlp<1> {
     typedef ActFrag Act;
@@ -377,7 +379,9 @@ struct Mlp<1> {
     // the next layer into NaN (each output row meets each input); the integer ReLU of split_pair would then launder a NaN with the sign
     // bit set into 0, so one accumulator register per hidden layer is tested before it is split (1 VALU each).  An overflow of the last
     // activation needs no test: the fc_last outputs, the segment sums and finally the log-det are NaN (flow_stack_kernel's guard).
-    template <class GF>
+    // KEEPX0 (instantiations with 256 registers per lane: 8-wave workgroups): x0 stays in registers for the residual, so a conditional
+    // layer reads its projected features from the scratch ONCE (round 2: twice -- C5's inverse pass moved 2 x 42 x 256 bytes per rotation).
+    template <class GF, bool KEEPX0 = false>
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
                                                 const GF &g, Act &out, Fair &fair, bool &bad) {
         const float bA = h ? y1 : y0;
@@ -386,12 +390,16 @@ struct Mlp<1> {
         float m1 = -1.0f;
         asm("" : "+s"(m1));                                     // see split_act
         ActFrag &f = out;                                       // the fragments are rewritten in place, layer after layer
+        f32x16 x0k[2];                                          // KEEPX0 only (dead otherwise)
         {
             f32x16 x0[2];
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) x0[ot] = first_tile(lds, ot, lane, bA, bB, g ? g.load(ot, lane, h) : zero);
-            if (g) bad |= x0[0][0] != x0[0][0];              // a feature beyond the fp16 range: the whole projection row is NaN
+            // a feature beyond the fp16 range (the whole projection row is NaN), or features so much larger than the packer's equalisation
+            // assumed (x0 is normalised to an rms of 1/4 .. 1/2; kX0Guard = 64) that fc_last's down-scaled columns would lose bits
+            if (g) bad |= !(fmaxf(fmaxf(fabsf(x0[0][0]), fabsf(x0[0][9])), fmaxf(fabsf(x0[1][3]), fabsf(x0[1][14]))) < kX0Guard);
             split_act<true>(x0, f);
+            if constexpr (KEEPX0) { x0k[0] = x0[0]; x0k[1] = x0[1]; }
         }
         auto w = [&](int L, int ot) { return lds + MOB_HID + (L * 2 + ot) * (8 * 64 * 4); };
         auto bias = [&](int L, int ot) { return load_bias16(lds + MOB_HB + ((L * 2 + ot) * 2 + h) * 16); };
@@ -412,19 +420,29 @@ struct Mlp<1> {
         a1 = bias(2, 1);
         hidden_tile<1>(w(2, 0), lane, f, a0, b1, m1);
         bad |= a0[0] != a0[0];
-        a0 = first_tile(lds, 0, lane, bA, bB, a0);
-        if (g) {
-            const f32x16 gg = g.load(0, lane, h);
+        if constexpr (KEEPX0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a0[r] += gg[r];
+            for (int r = 0; r < 16; ++r) a0[r] += x0k[0][r];
+        } else {
+            a0 = first_tile(lds, 0, lane, bA, bB, a0);
+            if (g) {
+                const f32x16 gg = g.load(0, lane, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a0[r] += gg[r];
+            }
         }
         hidden_tile<2>(w(2, 1), lane, f, a1, a0, m1);
         fair.tick();
-        a1 = first_tile(lds, 1, lane, bA, bB, a1);
-        if (g) {
-            const f32x16 gg = g.load(1, lane, h);
+        if constexpr (KEEPX0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a1[r] += gg[r];
+            for (int r = 0; r < 16; ++r) a1[r] += x0k[1][r];
+        } else {
+            a1 = first_tile(lds, 1, lane, bA, bB, a1);
+            if (g) {
+                const f32x16 gg = g.load(1, lane, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a1[r] += gg[r];
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1087,6 +1105,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     constexpr int NT = NW * 64;
     constexpr int TILE = NW * TILE_SAMPLES;
     constexpr int KTI = KT_INV > 0 ? KT_INV : 1;
+    constexpr bool KEEP_X0 = PREC == 1 && NW <= 8 && LEAN != 1;         // room for x0 beside the hidden layers (Mlp<1>::head), and something to re-read
     const long long ntiles = (args.n + TILE - 1) / TILE;
     const int KT = args.KT;                                          // DIR = 1: <= KT_INV, the capacity of this instantiation
     const int n_layers = args.n_layers;
@@ -1285,9 +1304,9 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             typename Mlp<PREC>::Act tt;
             if (LEAN == 1 || kind == RNF_KIND_MOBIUS) {
                 mobius_begin<DIR, DIR == 0 && PREC == 1>(R, perm_row, ctx);
-                Mlp<PREC>::head(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair, bad);
+                Mlp<PREC>::template head<GF, KEEP_X0>(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair, bad);
             } else {
-                Mlp<PREC>::head(lds, lane, h, 0.f, 0.f, 0.f, gfrag, tt, fair, bad);
+                Mlp<PREC>::template head<GF, KEEP_X0>(lds, lane, h, 0.f, 0.f, 0.f, gfrag, tt, fair, bad);
             }
             RNF_STAMP(1)                                          // 1: frame + hidden layers (H part)
             if (PIPE) {       // B1: every wave is past the H part and this layer's L part has landed

@@ -27,6 +27,7 @@ struct PackArgs {
     int *flags;      // OR of PK_FLAG_* (device int, zeroed by the caller)
     int n_layers, K, F, Fp, prec;
     int equalise;    // 1: move every MLP to its canonical scaling before the fp16 split (equalize.h)
+    double feat_ms;  // mean square of a feature entry assumed by the equalisation
     PackLayer layers[PK_MAX_LAYERS];
 };
 
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
         const int i = threadIdx.x;
         if (i < 64) { ex[0][i] = ex[1][i] = ex[2][i] = 0; }
         if (args.equalise) {
-            if (i < 64) { q_first[i] = eq_q_first(W0 + (size_t)i * ni, ni, yo, b0[i]); q_prev[i] = q_first[i]; }
+            if (i < 64) { q_first[i] = eq_q_first(W0 + (size_t)i * ni, ni, yo, b0[i], args.feat_ms); q_prev[i] = q_first[i]; }
             __syncthreads();
             for (int l = 0; l < 3; ++l) {
                 if (i < 64) q_cur[i] = eq_q_hidden(hw[l] + (size_t)i * 64, q_prev, hb[l][i]);

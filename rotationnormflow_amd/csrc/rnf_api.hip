@@ -176,10 +176,18 @@ extern "C" int rnf_set_pack_audit(int on) {
     return old;
 }
 
+// mean square of a feature entry assumed by the equalisation of the packers called from this thread (equalize.h); default 1
+static thread_local double g_feature_ms = 1.0;
+extern "C" double rnf_set_feature_ms(double ms) {
+    const double old = g_feature_ms;
+    g_feature_ms = (ms > 1.0e-20 && ms < 1.0e20) ? ms : 1.0;
+    return old;
+}
+
 static void scale_mlp(const float *fc_first_w, int ni, int yo, const float *fc_first_b, const float *const hw[3], const float *const hb[3],
                       const float *fc_last_w, int n_out, bool equalise, ScaledMlp &m) {
     m.ni = ni; m.yo = yo; m.n_out = n_out;
-    if (equalise && equalise_allowed()) eq_exponents_host(fc_first_w, ni, yo, fc_first_b, hw, hb, m.eq);
+    if (equalise && equalise_allowed()) eq_exponents_host(fc_first_w, ni, yo, fc_first_b, hw, hb, g_feature_ms, m.eq);
     else std::memset(&m.eq, 0, sizeof(m.eq));
     const int *e0 = m.eq.e[0], *e1 = m.eq.e[1], *e2 = m.eq.e[2];
     m.W0.resize((size_t)64 * ni);
@@ -233,7 +241,7 @@ static double audit_mlp(const ScaledMlp &m, const float *fc_first_w, const float
         double y[3] = {gauss(), gauss(), gauss()};
         const double yn = std::sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]) + 1e-30;
         for (int c = 0; c < yo; ++c) in[c] = (float)(y[c] / yn);
-        const double fs = (p & 1) ? 0.125 : 1.0;
+        const double fs = ((p & 1) ? 0.125 : 1.0) * std::sqrt(g_feature_ms);
         for (int k = 0; k < F; ++k) in[yo + k] = (float)(fs * gauss());
         // exact
         double x0[64], a[64], b[64], x3[64];
@@ -900,6 +908,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         const long long ntiles_fb = (cn + nw_fb * 32 - 1) / (nw_fb * 32);         // the exact-fp32 re-run uses NW-wave workgroups
         long long groups = (ntiles * nwk > ntiles_fp * NW_FP) ? ntiles * nwk : ntiles_fp * NW_FP;
         if (guarded && ntiles_fb * nw_fb > groups) groups = ntiles_fb * nw_fb;
+        if ((cn + 127) / 128 * 4 > groups) groups = (cn + 127) / 128 * 4;
         if (guarded && base > 0) HIP_TRY(hipMemsetAsync(guard, 0, sizeof(int), stream));   // per-chunk guard; guard[1] stays
         int grid = (int)(ntiles < cus ? ntiles : cus);
         const int cus_fp = cus * (8 / NW_FP);
@@ -923,7 +932,13 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             const int pprec = fb ? 0 : prec;
             const int kchunk = F < FP_KCHUNK ? F : FP_KCHUNK;
             size_t fl = sizeof(float) * (pprec ? (size_t)2 * (FP_KCHUNK / 16) * 512 : (size_t)kchunk / 8 * 256);   // f16x2: two DMA buffers
-            if (pprec) {
+            if (pprec && F > FP_KCHUNK && F <= 2 * FP_KCHUNK) {     // K split over wave pairs: no partial sums through the scratch (featproj_kernel.h)
+                const long long pt2 = (pn + 127) / 128;
+                const int grid2 = (int)(pt2 < cus ? pt2 : cus);
+                auto kern = featproj_ksplit_kernel;
+                HIP_TRY(allow_lds(kern, FP2_LDS_BYTES));
+                hipLaunchKernelGGL(kern, dim3(grid2), dim3(8 * 64), FP2_LDS_BYTES, stream, fp);
+            } else if (pprec) {
                 auto kern = featproj_kernel<NW_FP, 1>;
                 HIP_TRY(allow_lds(kern, fl));
                 hipLaunchKernelGGL(kern, dim3(grid_p), dim3(NW_FP * 64), fl, stream, fp);
@@ -1120,9 +1135,16 @@ extern "C" int rnf_cond_mlp_forward(const float *feat, int64_t n, int32_t F, con
         const size_t fl = sizeof(float) * (prec ? (size_t)2 * (FP_KCHUNK / 16) * 512 : (size_t)kchunk / 8 * 256);
         const int grid = (int)(ntiles < cus ? ntiles : cus);
         if (prec) {
-            auto kp = featproj_kernel<NW_FP, 1>;
-            HIP_TRY(allow_lds(kp, fl));
-            hipLaunchKernelGGL(kp, dim3(grid_fp), dim3(NW_FP * 64), fl, stream, fp);
+            if (F > FP_KCHUNK && F <= 2 * FP_KCHUNK) {
+                const long long pt2 = (cn + 127) / 128;
+                auto kp = featproj_ksplit_kernel;
+                HIP_TRY(allow_lds(kp, FP2_LDS_BYTES));
+                hipLaunchKernelGGL(kp, dim3((int)(pt2 < cus ? pt2 : cus)), dim3(8 * 64), FP2_LDS_BYTES, stream, fp);
+            } else {
+                auto kp = featproj_kernel<NW_FP, 1>;
+                HIP_TRY(allow_lds(kp, fl));
+                hipLaunchKernelGGL(kp, dim3(grid_fp), dim3(NW_FP * 64), fl, stream, fp);
+            }
             auto kern = cond_mlp_kernel<NW, 1>;
             HIP_TRY(allow_lds(kern, lds_bytes));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, stream, (const float *)G, groups, cn, blob + layer_off, out + base * 16);
@@ -1162,6 +1184,7 @@ extern "C" int rnf_pack_flow_device(const float *plain, const int32_t *pdesc, in
     a.plain = plain; a.blob = blob; a.flags = flags;
     a.n_layers = n_layers; a.K = K; a.F = F; a.Fp = (F + 7) / 8 * 8; a.prec = prec;
     a.equalise = (prec == RNF_PREC_F16X2 && equalise_allowed()) ? 1 : 0;
+    a.feat_ms = g_feature_ms;
     for (int l = 0; l < n_layers; ++l) {
         const int32_t *d = pdesc + (size_t)l * 4;
         const int kind = d[0] & 15;

@@ -78,7 +78,7 @@ class Flow(nn.Module):
         self._cache.invalidate()
         self.__dict__.pop("_rnf_train_plan", None)
 
-    def _device_packed(self, device):
+    def _device_packed(self, device, feature=None):
         """Kernel blob built on the device from the live parameters (rnf_pack_flow_device, one 18 us launch): used when the host cache
         cannot be trusted or would thrash -- training mode (optimizers may write through .data) and nn.DataParallel replicas (fresh
         parameter tensors on every forward, agent.py:22).  None when a layer has no device-packing support (ragged K, 3x3 / 6x6 kinds)."""
@@ -94,6 +94,8 @@ class Flow(nn.Module):
             plain = torch.cat([t.reshape(-1) if (t.is_cuda and t.dtype is f32) else t.to(device=device, dtype=f32).reshape(-1)
                                for t in tensors]) if tensors else torch.zeros(0, device=device)
             with torch.cuda.device(device):
+                if self.condition:
+                    plan.calibrate(feature)
                 blob = plan.pack(plain, torch.cuda.current_stream(device).cuda_stream, with_fallback=runtime._guard_fallback)
         desc = autograd.desc_with_fallback(plan) if runtime._guard_fallback else plan.desc
         packed = runtime.PackedFlow(blob, desc, plan.n_cond, plan.feat_dim, plan.feat_padded, plan.segments, plan.precision)
@@ -104,9 +106,11 @@ class Flow(nn.Module):
             packed.feat_padded = runtime.pad8(packed.feat_dim)
         return packed
 
-    def _packed(self, device):
+    def _packed(self, device, feature=None):
+        """``feature``: the batch at hand; its mean square calibrates the equalisation of the conditional layers when a parameter version
+        is packed (runtime.feature_mean_square; evaluations do not look at it again)."""
         if (self.training or getattr(self, "_is_replica", False)) and torch.device(device).type == "cuda":
-            packed = self._device_packed(torch.device(device))
+            packed = self._device_packed(torch.device(device), feature)
             if packed is not None:
                 return packed
 
@@ -117,7 +121,7 @@ class Flow(nn.Module):
             for layer, a, b in zip(self.layers, rows, inv):
                 if isinstance(layer, MobiusFlow) and a % 3 != b % 3:
                     raise RuntimeError("forward/inverse permutation schedules disagree (flow/flow.py:58-90)")
-            return runtime.pack_layers(list(self.layers), rows, device)
+            return runtime.pack_layers(list(self.layers), rows, device, feature_ms=runtime.feature_mean_square(feature) if self.condition else 1.0)
         return self._cache.get(self, device, build)
 
     # ---- reference API ----------------------------------------------------------------------------------------------
@@ -128,13 +132,13 @@ class Flow(nn.Module):
             return self.inverse(rotation, feature, draw, feature_repeat=feature_repeat)
         if not self.condition:
             feature = None
-        return runtime.run_flow(self, lambda: self._packed(rotation.device), rotation, feature, inverse=False,
+        return runtime.run_flow(self, lambda: self._packed(rotation.device, feature), rotation, feature, inverse=False,
                                 train_layers=list(self.layers), train_rows=self._forward_rows(), feature_repeat=feature_repeat)
 
     def inverse(self, rotation, feature=None, draw=False, feature_repeat=None):
         if not self.condition:
             feature = None
-        return runtime.run_flow(self, lambda: self._packed(rotation.device), rotation, feature, inverse=True,
+        return runtime.run_flow(self, lambda: self._packed(rotation.device, feature), rotation, feature, inverse=True,
                                 train_layers=list(self.layers), train_rows=self._inverse_rows(), feature_repeat=feature_repeat)
 
     # ---- fused density evaluation (agent.py:54-65,217-229 + utils/fisher.py:217-232) -------------------------
@@ -155,5 +159,5 @@ class Flow(nn.Module):
         A = c = None
         if base is not None:
             A, c = base.A, base.log_const()
-        return runtime.run_log_prob(self, self._packed(rotation.device), rotation, feature, A, c,
+        return runtime.run_log_prob(self, self._packed(rotation.device, feature), rotation, feature, A, c,
                                     want_rotation=return_rotation, want_ldj=False, want_logp=True, feature_repeat=feature_repeat)

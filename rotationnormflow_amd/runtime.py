@@ -93,23 +93,36 @@ class PackedFlow:
         self.feat_padded = feat_padded
         self.segments = segments
         self.side_layers = []                 # layer modules with _rnf_side(feature) -> [n, 16], in side-slot order
+        self.feature_ms = 1.0                 # mean square of a feature entry the conditional layers were equalised for
 
 
 class HalfRangeError(RuntimeError):
     """A weight does not fit the fp16 range: the flow must be packed for the exact fp32 kernels instead."""
 
 
-def pack_layers(layers, perm_rows, device, precision=None) -> PackedFlow:
+def feature_mean_square(feature) -> float:
+    """Mean square of the entries of a feature batch: the one data-dependent input of the packers' equalisation (csrc/equalize.h).
+    One device reduction + one scalar read-back; called when a parameter version is packed (which copies every parameter to the host
+    anyway), never per evaluation."""
+    if feature is None or feature.numel() == 0:
+        return 1.0
+    ms = float(feature.detach().to(torch.float32).square().mean())
+    return ms if 1e-20 < ms < 1e20 else 1.0
+
+
+def pack_layers(layers, perm_rows, device, precision=None, feature_ms=1.0) -> PackedFlow:
     """layers: product layer modules (each has ``_rnf_kind`` and ``_rnf_pack``); perm_rows: forward permutation row per layer.
-    precision None = the module-wide setting, falling back to "fp32" when a weight is outside the fp16 range."""
+    precision None = the module-wide setting, falling back to "fp32" when a weight is outside the fp16 range (or the pack-time audit
+    refuses the split-precision image).  ``feature_ms``: mean square of a feature entry the equalisation of conditional layers assumes."""
     if precision is None:
         try:
-            return pack_layers(layers, perm_rows, device, _precision)
+            return pack_layers(layers, perm_rows, device, _precision, feature_ms)
         except HalfRangeError:
-            return pack_layers(layers, perm_rows, device, "fp32")
+            return pack_layers(layers, perm_rows, device, "fp32", feature_ms)
     prec = _PRECISIONS[precision]
     L = _lib.lib()
     _prefetched.map = _prefetch_parameters(layers)
+    old_ms = L.rnf_set_feature_ms(float(feature_ms))
     try:
         blob, desc, slot, feat_dim, segments = _pack_layers(layers, perm_rows, prec, L)
         if precision == "f16x2" and _guard_fallback:
@@ -124,7 +137,9 @@ def pack_layers(layers, perm_rows, device, precision=None) -> PackedFlow:
             blob = np.concatenate([blob, blob32])
     finally:
         _prefetched.map = {}
+        L.rnf_set_feature_ms(old_ms)
     packed = PackedFlow(torch.from_numpy(blob).to(device), np.ascontiguousarray(desc), slot, feat_dim, pad8(feat_dim), segments, precision)
+    packed.feature_ms = float(feature_ms)
     for i, layer in enumerate(layers):
         if layer._rnf_kind in SIDE_KINDS:
             packed.desc[i, 2] = len(packed.side_layers)          # param offset column = slot in the side buffer
@@ -268,15 +283,19 @@ class SideNet:
         self.net, self.feature_dim, self.n_out = net, feature_dim, n_out
         self.cache = PackCache()
 
-    def _pack(self, device):
+    def _pack(self, device, feature_ms=1.0):
         L = _lib.lib()
         prec_name = _precision
-        for name in ([prec_name, "fp32"] if prec_name != "fp32" else ["fp32"]):
-            try:
-                rec, frec = pack_cond16(L, _Padded16(self.net, self.n_out), self.feature_dim, _PRECISIONS[name])
-                break
-            except HalfRangeError:
-                continue
+        old_ms = L.rnf_set_feature_ms(float(feature_ms))
+        try:
+            for name in ([prec_name, "fp32"] if prec_name != "fp32" else ["fp32"]):
+                try:
+                    rec, frec = pack_cond16(L, _Padded16(self.net, self.n_out), self.feature_dim, _PRECISIONS[name])
+                    break
+                except HalfRangeError:
+                    continue
+        finally:
+            L.rnf_set_feature_ms(old_ms)
         blob = np.concatenate([rec, np.zeros((-rec.size) % 4, np.float32), frec])
         return (torch.from_numpy(blob).to(device), (rec.size + 3) // 4 * 4, _PRECISIONS[name])
 
@@ -287,7 +306,7 @@ class SideNet:
             from . import autograd
             return autograd.cond_mlp(self.net, feature, self.n_out)
         dev = feature.device
-        blob, feat_off, prec = self.cache.get(self.net, dev, lambda: self._pack(dev))
+        blob, feat_off, prec = self.cache.get(self.net, dev, lambda: self._pack(dev, feature_mean_square(feature)))
         L = _lib.lib()
         n = feature.shape[0]
         Fp = pad8(self.feature_dim)

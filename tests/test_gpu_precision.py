@@ -102,6 +102,8 @@ def test_large_features_stay_native():
     noise = np.abs(l32.double().numpy() - lw.numpy())
     err = np.abs(ldj - lw.numpy())
     assert err.mean() <= 2 * noise.mean() + 2e-6 and err.max() <= 4 * noise.max() + 2e-5, (err.mean(), err.max(), noise.mean(), noise.max())
+    # the equalisation was calibrated on this batch: the packed flow knows its features have a mean square of ~1600
+    assert 1000.0 < fl._packed(torch.device("cuda", torch.cuda.current_device())).feature_ms < 2500.0
 
 
 def test_training_forward_with_a_huge_segment_weight_is_finite_and_differentiable():
@@ -188,9 +190,9 @@ def test_fused_projection_kernel_matches_the_two_kernel_path(name):
     finally:
         L.rnf_set_fused(old)
     _, Rt2, ldj2 = _run(cfg, w, Rb, fb)
-    # large launch: the default path runs the 16-wave conditional-lean stack kernel, which evaluates the same arithmetic -> bit-identical;
-    # the fixture-sized launch runs the general instantiation (overflow-safe softplus form): equal to that form's 1e-7-per-weight difference
-    assert np.array_equal(ldj3, ldj2) and np.array_equal(Rt3, Rt2)
+    # same arithmetic up to the order of the residual add (the 8-wave kernels keep x0 in registers) and, for the fixture-sized launch, the
+    # softplus form of the general instantiation: ulp-level differences that 24 layers stretch like the reference's own fp32 noise
+    assert np.abs(ldj3 - ldj2).max() < 2e-4 and np.abs(ldj3 - ldj2).mean() < 3e-6 and np.abs(Rt3 - Rt2).max() < 2e-4
     assert np.abs(ldj1 - ldj0).max() < 2e-4 and np.abs(ldj1 - ldj0).mean() < 3e-6 and np.abs(Rt1 - Rt0).max() < 2e-4
     noise = np.abs(fx["ldj32"].astype(np.float64) - fx["ldj64"])
     err = np.abs(ldj1 - fx["ldj64"])

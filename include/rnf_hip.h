@@ -308,6 +308,11 @@ int rnf_fisher_log_prob(const float *rotation_dev, int64_t n, const float *fishe
  * between estimate i and the closest of its k ground-truth rotations.  est_dev float[n][9], gt_dev float[n][k][9], out_dev float[n]. */
 int rnf_min_geodesic(const float *est_dev, const float *gt_dev, int64_t n, int32_t k, float *out_dev, void *stream);
 
+/* Proper SVD of B parameter matrices on the device (utils/fisher.py:53-76): A = U diag(s) V^T with U, V rotations (row-major, singular
+ * vectors as columns), s[2] carrying the sign of det A; lam [B,4] = the Bingham parameters the sampler takes (utils/fisher.py:151-158).
+ * Any output pointer may be NULL.  Stream-ordered, no host synchronisation. */
+int rnf_fisher_proper_svd(const float *A_dev, int64_t B, float *U_dev, float *V_dev, float *s_dev, float *lam_dev, void *stream);
+
 /* Log-constants c[b] of MatrixFisherN(A[b]) with the default normaliser approximation (utils/fisher.py:67-76 proper singular
  * values, :93-97 norm_type = 1): log p(R) = tr(A^T R) - c.  A_dev float[B][9], c_out_dev float[B]; fp64 inside. */
 int rnf_fisher_log_const(const float *A_dev, int64_t B, float *c_out_dev, void *stream);

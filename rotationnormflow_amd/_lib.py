@@ -75,6 +75,7 @@ _SIGNATURES = {
     "rnf_fisher_log_prob": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_void_p]),
     "rnf_min_geodesic": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_void_p]),
     "rnf_fisher_log_const": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p]),
+    "rnf_fisher_proper_svd": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "rnf_fisher_log_prob_backward": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_void_p]),
     "rnf_flow_train_side": (C.c_int, [C.c_int32, c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_f32p, c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p,
                                       c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),

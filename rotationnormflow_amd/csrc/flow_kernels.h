@@ -1105,7 +1105,11 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     constexpr int NT = NW * 64;
     constexpr int TILE = NW * TILE_SAMPLES;
     constexpr int KTI = KT_INV > 0 ? KT_INV : 1;
-    constexpr bool KEEP_X0 = PREC == 1 && NW <= 8 && LEAN != 1;         // room for x0 beside the hidden layers (Mlp<1>::head), and something to re-read
+#ifdef RNF_NO_KEEPX0
+    constexpr bool KEEP_X0 = false;
+#else
+    constexpr bool KEEP_X0 = PREC == 1 && NW <= 8 && LEAN != 1;
+#endif         // room for x0 beside the hidden layers (Mlp<1>::head), and something to re-read
     const long long ntiles = (args.n + TILE - 1) / TILE;
     const int KT = args.KT;                                          // DIR = 1: <= KT_INV, the capacity of this instantiation
     const int n_layers = args.n_layers;

@@ -1456,6 +1456,38 @@ static int fisher_const_launch(const float *A, int64_t B, int32_t norm_type, dou
     return 0;
 }
 
+// Proper SVD of every parameter matrix on the device (utils/fisher.py:53-76 proper_svd / proper_svd_N): U, V in SO(3) (vectors as columns,
+// row-major), s with the smallest value signed by det A, and the Bingham parameters of the sampler lam = (0, 2(s1+s2), 2(s0+s2), 2(s0+s1))
+// (utils/fisher.py:151-158).  fp64 Jacobi, one thread per matrix (fisher_math.h proper_svd3): MatrixFisherN._sample of a network-predicted
+// A no longer goes through host LAPACK and a device->host copy per call.
+__global__ void fisher_proper_svd_kernel(const float *A, long long B, float *U_out, float *V_out, float *s_out, float *lam_out) {
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double a[9], U[9], s[3], V[9];
+    for (int k = 0; k < 9; ++k) a[k] = A[b * 9 + k];
+    proper_svd3(a, U, s, V);
+    for (int k = 0; k < 9; ++k) {
+        if (U_out) U_out[b * 9 + k] = (float)U[k];
+        if (V_out) V_out[b * 9 + k] = (float)V[k];
+    }
+    if (s_out) { s_out[b * 3] = (float)s[0]; s_out[b * 3 + 1] = (float)s[1]; s_out[b * 3 + 2] = (float)s[2]; }
+    if (lam_out) {
+        lam_out[b * 4] = 0.f;
+        lam_out[b * 4 + 1] = (float)(2.0 * (s[1] + s[2]));
+        lam_out[b * 4 + 2] = (float)(2.0 * (s[0] + s[2]));
+        lam_out[b * 4 + 3] = (float)(2.0 * (s[0] + s[1]));
+    }
+}
+extern "C" int rnf_fisher_proper_svd(const float *A, int64_t B, float *U_out, float *V_out, float *s_out, float *lam_out, void *stream) {
+    if (B < 0) return fail("rnf_fisher_proper_svd: B=%lld", (long long)B);
+    if (B == 0) return 0;
+    if (!A) return fail("rnf_fisher_proper_svd: null pointer");
+    hipLaunchKernelGGL(fisher_proper_svd_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), A, (long long)B,
+                       U_out, V_out, s_out, lam_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int rnf_fisher_log_const(const float *A, int64_t B, float *c_out, void *stream) {
     if (!A || !c_out) return fail("rnf_fisher_log_const: null pointer");
     if (B <= 0) return fail("rnf_fisher_log_const: B=%lld", (long long)B);

@@ -150,9 +150,7 @@ class Flow(nn.Module):
         if runtime._needs_grad(rotation, feature, self) or (base is not None and torch.is_grad_enabled() and base.A.requires_grad):
             # a gradient is required (agent.py:54-65 inside train_func): the same quantity from the differentiable pieces -- the training
             # forward (states saved for the one-launch backward) and MatrixFisherN._log_prob (differentiable w.r.t. R' and A)
-            if feature_repeat:
-                runtime._refuse_autograd(rotation, feature, self, "log_prob with shared feature rows (feature_repeat)")
-            rot_out, ldj = self.forward(rotation, feature)
+            rot_out, ldj = self.forward(rotation, feature, feature_repeat=feature_repeat)      # (shared rows are expanded under autograd)
             logp = ldj if base is None else ldj + base._log_prob(rot_out)
             total = torch.stack([logp.double().sum(), torch.tensor(float(logp.numel()), dtype=torch.float64, device=logp.device)])
             return dict(logp=logp, sum=total, rotation=rot_out if return_rotation else None, ldj=None)

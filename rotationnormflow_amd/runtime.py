@@ -478,8 +478,14 @@ def run_flow(module, packed, rotation, feature, inverse=False, train_layers=None
     ``feature_repeat`` = Q: ``feature`` has N / Q rows and row r conditions rotations [r Q, (r + 1) Q) (pose estimation, agent.py:238-263;
     evaluation only) -- the feature projection then runs once per row instead of once per rotation."""
     if _needs_grad(rotation, feature, module):
-        if feature_repeat:
-            _refuse_autograd(rotation, feature, module, "a flow call with shared feature rows (feature_repeat)")
+        if feature_repeat and feature is not None:
+            # eval.py:464-480 (nll_grad) differentiates log p w.r.t. the QUERY rotations with every image feature repeated number_queries
+            # times (agent.py:240-244 materialises feature.repeat): the differentiable kernels take one feature row per rotation, so the
+            # rows are expanded here -- autograd's repeat_interleave sums the row gradients back onto the shared rows
+            n_rot = rotation.reshape(-1, 3, 3).shape[0]
+            if n_rot % feature_repeat:
+                raise ValueError(f"{n_rot} rotations are not a multiple of feature_repeat={feature_repeat}")
+            feature = feature.reshape(n_rot // feature_repeat, -1).repeat_interleave(feature_repeat, dim=0)
         from . import autograd
         if inverse:                                        # BinFind.backward (flow/mobiusflow.py:247-273) and friends
             return autograd.flow_inverse(module, train_layers, train_rows, rotation, feature)
@@ -487,8 +493,14 @@ def run_flow(module, packed, rotation, feature, inverse=False, train_layers=None
     if callable(packed):
         packed = packed()
     shared = bool(feature_repeat) and packed.n_cond > 0
-    if packed.side_layers and feature_repeat:
-        raise NotImplementedError("feature_repeat is not built for flows with ConditionRot / ConditionLU layers: pass repeated feature rows")
+    if packed.side_layers and feature_repeat and feature is not None:
+        # ConditionRot / ConditionLU build their per-sample matrices from the feature rows with batched torch ops: expand the shared rows
+        # (the reference's feature.repeat, agent.py:240-244) and take the one-row-per-rotation path
+        n_rot = rotation.reshape(-1, 3, 3).shape[0]
+        if n_rot % feature_repeat:
+            raise ValueError(f"{n_rot} rotations are not a multiple of feature_repeat={feature_repeat}")
+        feature = feature.reshape(n_rot // feature_repeat, -1).repeat_interleave(feature_repeat, dim=0)
+        feature_repeat, shared = None, False
     rot, feat = _check_inputs(rotation, feature, packed, feature_repeat if shared else None)
     n = rot.shape[0]
     L = _lib.lib()
@@ -524,6 +536,10 @@ def run_log_prob(module, packed: PackedFlow, rotation, feature, fisher_A=None, f
                  want_rotation=False, want_ldj=False, want_logp=True, feature_repeat=None):
     """Fused Flow.forward + base log-density + NLL sum.  -> dict(logp, sum [2] float64 device tensor, rotation, ldj)"""
     _refuse_autograd(rotation, feature, module, "the fused log_prob evaluation")
+    if packed.side_layers and feature_repeat and feature is not None:      # see run_flow: side layers take one feature row per rotation
+        n_rot = rotation.reshape(-1, 3, 3).shape[0]
+        feature = feature.reshape(n_rot // feature_repeat, -1).repeat_interleave(feature_repeat, dim=0)
+        feature_repeat = None
     shared = bool(feature_repeat) and packed.n_cond > 0
     rot, feat = _check_inputs(rotation, feature, packed, feature_repeat if shared else None)
     n = rot.shape[0]

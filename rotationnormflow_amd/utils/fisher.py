@@ -11,8 +11,25 @@ import torch
 from .. import _lib
 
 
+def device_proper_svd(A):
+    """A [B,3,3] on the GPU -> (U, V, s, lam) fp32 device tensors through rnf_fisher_proper_svd (fp64 Jacobi, one thread per matrix):
+    stream-ordered, no host synchronisation (utils/fisher.py:53-76,151-158)."""
+    A32 = A.detach().reshape(-1, 3, 3).to(torch.float32).contiguous()
+    B, dev = A32.shape[0], A32.device
+    U = torch.empty(B, 3, 3, dtype=torch.float32, device=dev)
+    V = torch.empty(B, 3, 3, dtype=torch.float32, device=dev)
+    s = torch.empty(B, 3, dtype=torch.float32, device=dev)
+    lam = torch.empty(B, 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().rnf_fisher_proper_svd(A32.data_ptr(), B, U.data_ptr(), V.data_ptr(), s.data_ptr(), lam.data_ptr(),
+                                                    torch.cuda.current_stream(dev).cuda_stream))
+    return U, V, s, lam
+
+
 def proper_singular_values(A):
-    """[B,3,3] -> [B,3] (utils/fisher.py:67-76).  O(B) host-side parameter preprocessing in torch, fp64 internally."""
+    """[B,3,3] -> [B,3] (utils/fisher.py:67-76).  GPU-resident A: on the device (no host round trip); CPU A: host LAPACK, fp64."""
+    if A.is_cuda:
+        return device_proper_svd(A)[2].to(torch.float64)
     A64 = A.detach().to("cpu", torch.float64)               # tiny [B,3,3]: LAPACK on the host (no rocSOLVER start-up cost)
     U, S, Vh = torch.linalg.svd(A64)
     S = S.clone()
@@ -157,7 +174,7 @@ class MatrixFisherN(torch.nn.Module):
         if self._norm is None:
             S = proper_singular_values(self.A)
             if self.norm_type == 2:                          # c = sum S + log norm
-                self._norm = (self._c.detach().to("cpu", torch.float64) - S.sum(-1)).exp().to(device=self.A.device, dtype=self.A.dtype)
+                self._norm = (self._c.detach().to(S.device, torch.float64) - S.sum(-1)).exp().to(device=self.A.device, dtype=self.A.dtype)
             else:
                 self._norm = _norm_from_singular_values(S, self.norm_type).to(device=self.A.device, dtype=self.A.dtype)
         return self._norm
@@ -190,16 +207,7 @@ class MatrixFisherN(torch.nn.Module):
         if not A.is_cuda:
             raise RuntimeError("rotationnormflow_amd runs on the GPU only (no CPU fallback): construct MatrixFisherN with A on the GPU")
         dev = A.device
-        A64 = A.detach().to("cpu", torch.float64)           # host LAPACK for the tiny SVDs, as in proper_singular_values
-        U, S, Vh = torch.linalg.svd(A64)
-        V = Vh.transpose(-1, -2)
-        dU, dV = torch.det(U), torch.det(V)
-        U = U.clone(); V = V.clone(); S = S.clone()
-        U[:, :, 2] *= dU[:, None]                                   # proper SVD, utils/fisher.py:53-64
-        V[:, :, 2] *= dV[:, None]
-        S[:, 2] *= dU * dV
-        lam = torch.stack([torch.zeros_like(S[:, 0]), 2 * (S[:, 1] + S[:, 2]), 2 * (S[:, 0] + S[:, 2]), 2 * (S[:, 0] + S[:, 1])], -1)
-        U32, V32, lam32 = (t.to(dev, torch.float32).contiguous() for t in (U, V, lam))
+        U32, V32, _, lam32 = device_proper_svd(A)            # proper SVD + Bingham parameters on the device: no host LAPACK, no sync
         B = A.shape[0]
         out = torch.empty(B, num_samples, 3, 3, dtype=torch.float32, device=dev)
         _check_sampler_flag()                                # a failure of an EARLIER call surfaces here, without a device wait now

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from oracle import flow_oracle as orc
-from rotationnormflow_amd import _lib, runtime, synth
+from rotationnormflow_amd import _lib, make_config, runtime, synth
 from rotationnormflow_amd.utils.fisher import MatrixFisherN
 from tests.golden.cases import CASES
 from tests.gpu_helpers import product_flow, run_case
@@ -195,8 +195,8 @@ def test_errors_are_loud():
             fl(R.cpu(), torch.zeros(8, 16))                         # no CPU fallback
     Rb, lb = fl.inverse(R, torch.zeros(8, 16, device="cuda"))       # grad mode on, parameters require grad: differentiable (round 2)
     assert lb.requires_grad
-    with pytest.raises(NotImplementedError):                        # shared feature rows have no backward: refuses instead of detaching
-        fl(R, torch.zeros(2, 16, device="cuda"), feature_repeat=4)
+    Rc, lc = fl(R, torch.zeros(2, 16, device="cuda"), feature_repeat=4)   # shared feature rows under autograd: expanded, differentiable (round 3)
+    assert lc.requires_grad
 
 
 @pytest.mark.parametrize("direction", ["forward", "inverse"])
@@ -259,3 +259,30 @@ def test_condition_lu_is_batch_coupled_like_the_reference():
     from rotationnormflow_amd import dist
     with pytest.raises(NotImplementedError, match="batch"):
         dist.sharded_mean_nll(dist.flow_evaluator(fl), torch.from_numpy(R).cuda(), torch.from_numpy(feat).cuda(), rank=0, world=2)
+
+
+def test_shared_feature_rows_are_differentiable():
+    """eval.py:464-480 (nll_grad): d log p / d(query rotation) with every image feature repeated over its queries (agent.py:240-244).
+    feature_repeat under autograd = the materialised repeat: same values, same gradients, and the feature gradient is summed per row."""
+    cfg = make_config(layers=2, segments=16, condition=1, feature_dim=24, rot="16UnTrans", frequent_permute=1, last_affine=1, first_affine=0)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=71, regime="trained")
+    fl = product_flow(cfg, w)
+    Q, n_img = 16, 12
+    R = torch.from_numpy(synth.uniform_rotations(Q * n_img, seed=72)).cuda()
+    f = torch.from_numpy(synth.features(n_img, 24, seed=73)).cuda()
+    Ra, fa = R.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    _, la = fl(Ra, fa, feature_repeat=Q)
+    la.sum().backward()
+    Rb, fb = R.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    _, lb = fl(Rb, fb.repeat_interleave(Q, dim=0))
+    lb.sum().backward()
+    assert torch.allclose(la, lb, atol=1e-6) and torch.allclose(Ra.grad, Rb.grad, atol=1e-5) and torch.allclose(fa.grad, fb.grad, atol=1e-4)
+    assert fa.grad.shape == (n_img, 24) and float(fa.grad.abs().max()) > 0
+    # side layers (ConditionRot) accept shared rows too: expanded on the host side of the launch
+    cfg2 = make_config(layers=2, segments=16, condition=1, feature_dim=24, rot="16Rot")
+    fl2 = product_flow(cfg2, synth.fill_state_dict(orc.state_shapes(cfg2), seed=74, regime="trained"))
+    with torch.no_grad():
+        _, l1 = fl2(R, f, feature_repeat=Q)
+        _, l2 = fl2(R, f.repeat_interleave(Q, dim=0))
+        l3 = fl2.log_prob(R, f, feature_repeat=Q)["logp"]
+    assert torch.allclose(l1, l2, atol=1e-6) and torch.allclose(l3, l2, atol=1e-5)

@@ -140,24 +140,36 @@ def cpu_baseline(cfg, weights, A, wl, feat_dim, budget_s=12.0):
 def committed_pmc(workload, precision, n):
     """Counters of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload (tools/profile_round.sh collects
     FETCH_SIZE and WRITE_SIZE each in its own run; tools/pmc_summary.py applies the gfx950 correction).  A summary is only replayed when
-    it was taken from the kernel sources this build was made from (`csrc_sha` recorded by pmc_summary.py) at the batch size of this
-    run; otherwise (None, reason)."""
+    it was taken from the kernel sources this build was made from (`csrc_sha` recorded by pmc_summary.py) and its launch size divides
+    this run's batch (the conditional / inverse configs run in chunks of 2^18 rotations: the per-launch bytes of the projection pre-pass
+    and of the stack kernel are added and scaled to the step); otherwise (None, reason)."""
     from rotationnormflow_amd.build import source_hash
-    for rnd in ("r2", "r1"):
-        path = os.path.join(ROOT, "profiles", rnd, f"pmc_{workload}_{precision}.json")
-        if os.path.exists(path):
+    names = [f"pmc_{workload}_{precision}.json"] if precision == "f16x2" else []
+    names += [f"pmc_{workload}_stack.json", f"pmc_{workload}_featproj.json"] if precision == "f16x2" else []
+    found = []
+    for rnd in ("r3", "r2", "r1"):
+        found = [os.path.join(ROOT, "profiles", rnd, nm) for nm in names if os.path.exists(os.path.join(ROOT, "profiles", rnd, nm))]
+        if found:
             break
-    else:
+    if not found:
         return None, "no committed PMC summary for this workload"
-    with open(path) as fh:
-        d = json.load(fh)
-    rel = os.path.relpath(path, ROOT)
-    if d.get("csrc_sha") != source_hash():
-        return None, f"{rel} was collected from other kernel sources (csrc_sha {d.get('csrc_sha')} != {source_hash()}): not replayed"
-    if d.get("rotations_per_launch") != n:
-        return None, f"{rel} was collected at another batch size: not replayed"
-    d["source"] = rel
-    return d, None
+    total, primary = 0.0, None
+    for path in found:
+        with open(path) as fh:
+            d = json.load(fh)
+        rel = os.path.relpath(path, ROOT)
+        if d.get("csrc_sha") != source_hash():
+            return None, f"{rel} was collected from other kernel sources (csrc_sha {d.get('csrc_sha')} != {source_hash()}): not replayed"
+        per = d.get("rotations_per_launch") or 0
+        if per <= 0 or n % per:
+            return None, f"{rel} was collected at another launch size: not replayed"
+        if "hbm_bytes_per_launch" in d:
+            total += d["hbm_bytes_per_launch"] * (n // per)
+        if primary is None:
+            primary = dict(d, source=rel)
+    primary["hbm_bytes_per_launch"] = total
+    primary["source"] = ", ".join(os.path.relpath(p, ROOT) for p in found)
+    return primary, None
 
 
 def pmc_fractions(d):
@@ -322,7 +334,7 @@ def main():
                  "note": "exact fp32-input MFMA; shares the FMA datapath with the VALU segment math on gfx950"}
         pmc, why = committed_pmc(args.config, precision, n)
         if pmc:
-            r["traffic"] = pmc.get("hbm_bytes_per_launch")
+            r["traffic"] = pmc.get("hbm_bytes_per_launch")          # HBM bytes of one step (all launches of the step, all its kernels)
             r["traffic_source"] = f"committed profile {pmc['source']} (csrc_sha {pmc['csrc_sha']}, kernel {pmc.get('kernel')})"
             r.update(pmc_fractions(pmc))
         else:

@@ -346,7 +346,7 @@ struct Mlp<0> {
     // g: this wave's feature-projection fragments for the layer (global memory), or nullptr for an unconditional layer
     template <class GF, bool KEEPX0 = false>
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
-                                                const GF &g, Act &out, Fair &, bool &) {
+                                                const GF &g, Act &out, Fair &, bool &, const f32x16 * = nullptr) {
         f32x16 cinit[2];
         if (g) {
             cinit[0] = g.load(0, lane, h);
@@ -381,9 +381,12 @@ struct Mlp<1> {
     // activation needs no test: the fc_last outputs, the segment sums and finally the log-det are NaN (flow_stack_kernel's guard).
     // KEEPX0 (instantiations with 256 registers per lane: 8-wave workgroups): x0 stays in registers for the residual, so a conditional
     // layer reads its projected features from the scratch ONCE (round 2: twice -- C5's inverse pass moved 2 x 42 x 256 bytes per rotation).
+    // pre != nullptr: the projected features of this layer were already fetched into registers (flow_stack_kernel, LEAN = 2: issued behind
+    // the previous layer's barrier B2, so that the HBM latency of the scratch read -- the first instruction of the hidden phase otherwise,
+    // +11 k cycles per layer in the round-2 stamps -- is spent under the layer finish and the affine layer)
     template <class GF, bool KEEPX0 = false>
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
-                                                const GF &g, Act &out, Fair &fair, bool &bad) {
+                                                const GF &g, Act &out, Fair &fair, bool &bad, const f32x16 *pre = nullptr) {
         const float bA = h ? y1 : y0;
         const float bB = h ? 1.0f : y2;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -394,7 +397,7 @@ struct Mlp<1> {
         {
             f32x16 x0[2];
 #pragma unroll
-            for (int ot = 0; ot < 2; ++ot) x0[ot] = first_tile(lds, ot, lane, bA, bB, g ? g.load(ot, lane, h) : zero);
+            for (int ot = 0; ot < 2; ++ot) x0[ot] = first_tile(lds, ot, lane, bA, bB, (pre && ot == 0) ? pre[0] : (g ? g.load(ot, lane, h) : zero));
             // a feature beyond the fp16 range (the whole projection row is NaN), or features so much larger than the packer's equalisation
             // assumed (x0 is normalised to an rms of 1/4 .. 1/2; kX0Guard = 64) that fc_last's down-scaled columns would lose bits
             if (g) bad |= !(fmaxf(fmaxf(fabsf(x0[0][0]), fabsf(x0[0][9])), fmaxf(fabsf(x0[1][3]), fabsf(x0[1][14]))) < kX0Guard);
@@ -1188,6 +1191,8 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
         }
         float ldj = 0.f;
         bool bad = false;                                         // split-precision kernels: a hidden layer came out NaN (Mlp<1>::head)
+        f32x16 gpre[1];                                           // LEAN = 2: out tile 0 of the next MLP layer's projected features, fetched one layer ahead
+        bool have_gpre = false;
         FeatFrag ff;                                              // FUSED only (dead otherwise)
         if constexpr (FUSED) {
             // this tile's features, and the projection of the FIRST MLP layer (the layers behind it are projected one layer ahead, below):
@@ -1308,10 +1313,11 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             typename Mlp<PREC>::Act tt;
             if (LEAN == 1 || kind == RNF_KIND_MOBIUS) {
                 mobius_begin<DIR, DIR == 0 && PREC == 1>(R, perm_row, ctx);
-                Mlp<PREC>::template head<GF, KEEP_X0>(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair, bad);
+                Mlp<PREC>::template head<GF, KEEP_X0>(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair, bad, have_gpre ? gpre : nullptr);
             } else {
-                Mlp<PREC>::template head<GF, KEEP_X0>(lds, lane, h, 0.f, 0.f, 0.f, gfrag, tt, fair, bad);
+                Mlp<PREC>::template head<GF, KEEP_X0>(lds, lane, h, 0.f, 0.f, 0.f, gfrag, tt, fair, bad, have_gpre ? gpre : nullptr);
             }
+            have_gpre = false;
             RNF_STAMP(1)                                          // 1: frame + hidden layers (H part)
             if (PIPE) {       // B1: every wave is past the H part and this layer's L part has landed
                 dma_wait_all();
@@ -1360,7 +1366,20 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     RNF_STAMP(11)
                 }
             };
-            auto barrier2 = [&]() { b2_sync(); b2_issue(); fused_p1(); };
+            auto prefetch_g = [&]() {                             // LEAN = 2 (scratch path): the next MLP layer's G tiles, one layer ahead
+#ifdef RNF_GPRE      // measured and NOT shipped (profiles/r3/README.md): the 16 prefetch registers do not fit beside the finish / affine layer in the
+                     // 128-register instantiation (31 spills): 9.10 ms against 7.99 ms on C4
+                if constexpr (LEAN == 2 && !FUSED && DIR == 0) {
+                    const int q1 = next_in_tile(pos);
+                    if (q1 >= 0) {
+                        const float *gp = args.G + ((size_t)slot_at(q1) * args.g_groups + group) * G_FLOATS_PER_GROUP;
+                        gpre[0] = load_g16(gp, lane);             // (both tiles: 32 registers across the finish / affine layer spill 51 of them)
+                        have_gpre = true;
+                    }
+                }
+#endif
+            };
+            auto barrier2 = [&]() { b2_sync(); b2_issue(); fused_p1(); prefetch_g(); };
             if (LEAN == 1 || kind == RNF_KIND_MOBIUS) {
                 if constexpr (DIR != 0) {
                     InvSegs<KTI> sg;

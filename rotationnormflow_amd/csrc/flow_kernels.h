@@ -397,7 +397,7 @@ struct Mlp<1> {
         {
             f32x16 x0[2];
 #pragma unroll
-            for (int ot = 0; ot < 2; ++ot) x0[ot] = first_tile(lds, ot, lane, bA, bB, (pre && ot == 0) ? pre[0] : (g ? g.load(ot, lane, h) : zero));
+            for (int ot = 0; ot < 2; ++ot) x0[ot] = first_tile(lds, ot, lane, bA, bB, pre ? pre[ot] : (g ? g.load(ot, lane, h) : zero));
             // a feature beyond the fp16 range (the whole projection row is NaN), or features so much larger than the packer's equalisation
             // assumed (x0 is normalised to an rms of 1/4 .. 1/2; kX0Guard = 64) that fc_last's down-scaled columns would lose bits
             if (g) bad |= !(fmaxf(fmaxf(fabsf(x0[0][0]), fabsf(x0[0][9])), fmaxf(fabsf(x0[1][3]), fabsf(x0[1][14]))) < kX0Guard);
@@ -1191,7 +1191,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
         }
         float ldj = 0.f;
         bool bad = false;                                         // split-precision kernels: a hidden layer came out NaN (Mlp<1>::head)
-        f32x16 gpre[1];                                           // LEAN = 2: out tile 0 of the next MLP layer's projected features, fetched one layer ahead
+        f32x16 gpre[2];                                           // LEAN = 2: the next MLP layer's projected features, fetched at the top of the affine layer in front of it
         bool have_gpre = false;
         FeatFrag ff;                                              // FUSED only (dead otherwise)
         if constexpr (FUSED) {
@@ -1228,6 +1228,18 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             }
 
             if (kind == RNF_KIND_AFFINE16) {
+#ifdef RNF_GPRE      // measured and NOT shipped (profiles/r3/README.md): 32 (or 16) prefetch registers do not fit beside the table math / layer finish of the
+                     // 128-register instantiation (51 / 31 spills): 9.10 ms against 7.99 ms on C4 with the 16-register variant issued behind B2
+                if constexpr (LEAN == 2 && !FUSED && DIR == 0) {      // the scratch read of the NEXT MLP layer flies under this layer's table math
+                    const int q1 = ((d.x >> 16) & 1023) - 1;
+                    if (q1 >= 0) {
+                        const float *gp = args.G + ((size_t)slot_at(q1) * args.g_groups + group) * G_FLOATS_PER_GROUP;
+                        gpre[0] = load_g16(gp, lane);
+                        gpre[1] = load_g16(gp + 4 * 64 * 4, lane);
+                        have_gpre = true;
+                    }
+                }
+#endif
                 if (PIPE && tab_parity >= 0) {                    // block staged in LDS together with the previous layer's fc_last image
                     affine16_table_apply_pair(lds + args.tab_off + AFF_TABLE_LDS_STRIDE * tab_parity, h, R, ldj);
                     tab_parity = -1;
@@ -1366,20 +1378,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     RNF_STAMP(11)
                 }
             };
-            auto prefetch_g = [&]() {                             // LEAN = 2 (scratch path): the next MLP layer's G tiles, one layer ahead
-#ifdef RNF_GPRE      // measured and NOT shipped (profiles/r3/README.md): the 16 prefetch registers do not fit beside the finish / affine layer in the
-                     // 128-register instantiation (31 spills): 9.10 ms against 7.99 ms on C4
-                if constexpr (LEAN == 2 && !FUSED && DIR == 0) {
-                    const int q1 = next_in_tile(pos);
-                    if (q1 >= 0) {
-                        const float *gp = args.G + ((size_t)slot_at(q1) * args.g_groups + group) * G_FLOATS_PER_GROUP;
-                        gpre[0] = load_g16(gp, lane);             // (both tiles: 32 registers across the finish / affine layer spill 51 of them)
-                        have_gpre = true;
-                    }
-                }
-#endif
-            };
-            auto barrier2 = [&]() { b2_sync(); b2_issue(); fused_p1(); prefetch_g(); };
+            auto barrier2 = [&]() { b2_sync(); b2_issue(); fused_p1(); };
             if (LEAN == 1 || kind == RNF_KIND_MOBIUS) {
                 if constexpr (DIR != 0) {
                     InvSegs<KTI> sg;

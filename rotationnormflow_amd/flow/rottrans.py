@@ -1,11 +1,17 @@
-"""Mirror of the reference's flow/rottrans.py (SVD / Smith rotation layers, ldj = 0).  The unconditional layers are built: each is a
-constant orthogonal 4x4 on the quaternion, prepared on the host from its 3x3 / 4x4 parameter and run by the quaternion kernel.  The
-conditional ones (a per-sample SVD) are declared for the registry and fail loudly at construction."""
+"""Mirror of the reference's flow/rottrans.py (SVD / Smith rotation layers, ldj = 0).  Every class of the registry is built (DESIGN.md
+section 3.7).  Unconditional layers: a constant orthogonal 4x4 on the quaternion, prepared on the host from the 3x3 / 4x4 parameter and
+run by the quaternion kernel.  Conditional 3x3 layers: per-sample polar / Smith rotation inside the fused stack kernel.  ConditionRot:
+the per-sample matrices U^T V are built by the reference's own ``torch.svd`` call (its result depends on the SVD routine's sign
+conventions) and handed to the kernel as a side buffer."""
+import os
+
 import torch
 import torch.nn as nn
 
 from .. import runtime
 from .mobiusflow import _SingleLayer
+
+_CONDROT_SVD_ON_DEVICE = os.environ.get("RNF_CONDROT_SVD", "host") == "device"
 
 
 class UnconditionRot(nn.Module, _SingleLayer):
@@ -191,5 +197,11 @@ class ConditionRot(_SideLayer):
             self._net = runtime.SideNet(self.net, self.feature_dim, 16)
         with torch.set_grad_enabled(grad):                # grad: torch differentiates its own SVD, as the reference does
             mat = self._net(feature).reshape(-1, 4, 4) + torch.eye(4, device=feature.device)
+            # RNF_CONDROT_SVD=device: the batched SVD of the GPU tensor itself (hipSOLVER through torch): no device->host copy, no host
+            # LAPACK -- and the sign conventions of THAT routine, i.e. what the reference produces when it runs on a GPU; the golden fixtures
+            # (and the default here) are the reference's CPU run
+            if _CONDROT_SVD_ON_DEVICE:
+                U, S, V = torch.svd(mat)
+                return (U.transpose(-1, -2) @ V).reshape(-1, 16)
             U, S, V = torch.svd(mat.cpu())
             return (U.transpose(-1, -2) @ V).reshape(-1, 16).to(feature.device)

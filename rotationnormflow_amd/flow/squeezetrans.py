@@ -1,6 +1,6 @@
 """Mirror of the reference's flow/squeezetrans.py: the 4x4 quaternion-affine family (constant, LU-parameterised, feature-conditioned)
-and the unconditional 3x3 / 6x6 Gram-Schmidt ablation layers.  The remaining conditional variants are declared for the registry and
-fail loudly at construction."""
+and the 3x3 / 6x6 Gram-Schmidt ablation layers, unconditional and conditional -- every class of the registry is built (DESIGN.md
+section 3.7; the conditional LU layers hand their batch-coupled per-sample matrices to the kernels as a side buffer)."""
 import numpy as np
 import torch
 import torch.nn as nn

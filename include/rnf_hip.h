@@ -186,6 +186,12 @@ int rnf_flow_log_prob_side(const float *rotation_dev, const float *feature_dev, 
                            const float *fisher_c_dev, int64_t fisher_B, float *rotation_out_dev, float *ldj_out_dev, float *logp_out_dev,
                            double *sum_out_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* ConditionRot (flow/rottrans.py:37-66): the per-sample orthogonal 4x4 matrices U^T V of svd(I + reshape(mlp_out, 4, 4)), with the sign
+ * conventions of the reference's torch.svd (LAPACK's dense-SVD path restated for 4x4, csrc/svd4_lapack.h; identical for >= 99.8 % of
+ * random matrices, the rest differ like two LAPACK builds do).  mlp_out_dev [n][16] from rnf_cond_mlp_forward, rot_out_dev [n][16] = one
+ * slot of the side buffer of an RNF_LAYER_SIDE16_ROT layer.  Stream-ordered, no host synchronisation. */
+int rnf_condrot_matrices(const float *mlp_out_dev, int64_t n, float *rot_out_dev, void *stream);
+
 /* ConditionalTransform(feature_dim, <= 16 outputs)(feature) alone (flow/condition.py:24-30): records packed by rnf_pack_cond16 at
  * layer_offset / feat_offset (floats) of blob_dev; out_dev float[n][16], output o in column o.  Workspace: rnf_workspace_bytes(n, 1). */
 int rnf_cond_mlp_forward(const float *feature_dev, int64_t n, int32_t feature_dim, const float *blob_dev, int32_t layer_offset,

@@ -51,6 +51,7 @@ _SIGNATURES = {
                                          C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnf_cond_mlp_forward": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
                                        C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rnf_condrot_matrices": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p]),
     "rnf_pack_flow_device": (C.c_int, [c_f32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_i32p, C.c_void_p]),
     "rnf_plain_layer_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rnf_flow_forward_train": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,

@@ -18,6 +18,7 @@
 #include "fisher_math.h"
 #include "layout.h"
 #include "equalize.h"
+#include "svd4_lapack.h"
 
 using namespace rnf;
 
@@ -1158,6 +1159,27 @@ extern "C" int rnf_cond_mlp_forward(const float *feat, int64_t n, int32_t F, con
         }
         HIP_TRY(hipGetLastError());
     }
+    return 0;
+}
+
+// ConditionRot (flow/rottrans.py:37-66): rot = U^T V of svd(I + reshape(net(feature), 4, 4)) per sample, with the SIGN CONVENTIONS of the
+// reference's torch.svd (LAPACK sgesdd; svd4_lapack.h restates that path for 4x4).  mlp_out [n][16] = the conditioner's outputs (row-major
+// 4x4 per sample), rot_out [n][16] = the orthogonal matrix the RNF_LAYER_SIDE16_ROT layer applies to the quaternion.  One thread per sample.
+__global__ void condrot_utv_kernel(const float *mlp_out, long long n, float *rot_out, int *fail_flag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float A[16], R[16];
+    for (int k = 0; k < 16; ++k) A[k] = mlp_out[i * 16 + k] + ((k % 5 == 0) ? 1.0f : 0.0f);
+    if (!svd4::utv(A, R) && fail_flag) atomicOr(fail_flag, 1);
+    for (int k = 0; k < 16; ++k) rot_out[i * 16 + k] = R[k];
+}
+extern "C" int rnf_condrot_matrices(const float *mlp_out, int64_t n, float *rot_out, void *stream) {
+    if (n < 0) return fail("rnf_condrot_matrices: n=%lld", (long long)n);
+    if (n == 0) return 0;
+    if (!mlp_out || !rot_out) return fail("rnf_condrot_matrices: null pointer");
+    hipLaunchKernelGGL(condrot_utv_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), mlp_out, (long long)n,
+                       rot_out, (int *)nullptr);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

@@ -180,8 +180,10 @@ class Condition9RotRSmith(_Conditional9):
 class ConditionRot(_SideLayer):
     """flow/rottrans.py:37-66: rot = U^T V of the batched SVD of I + reshape(net(feature), 4, 4), applied to the quaternion; log-det 0;
     the inverse pass applies its transpose.  U^T V (not the polar factor U V^T) depends on the sign conventions of the SVD routine, so
-    the layer is defined by the routine: the SVD here is the SAME ``torch.svd`` call as the reference's, on the host in fp32 (LAPACK), as
-    UnconditionRot does for its one matrix -- the conventions of the reference's CPU run.  net(feature) itself runs on the GPU."""
+    the layer is defined by the routine.  Evaluation: net(feature) and the per-sample U^T V both run on the GPU, the latter through
+    csrc/svd4_lapack.h -- LAPACK's dense-SVD path (sgebd2, sorgbr, sbdsqr) restated for 4x4 so that its sign conventions are those of the
+    reference's ``torch.svd`` (tests/test_svd4.py).  Training: torch differentiates its own ``torch.svd`` on the host, as the reference does
+    (RNF_CONDROT_SVD=device keeps that call on the GPU, with hipSOLVER's conventions)."""
     _rnf_kind = runtime.KIND_SIDE16_ROT
     _rnf_host_preprocess = True
 
@@ -195,11 +197,20 @@ class ConditionRot(_SideLayer):
     def _rnf_side(self, feature, grad=False):
         if self._net is None:
             self._net = runtime.SideNet(self.net, self.feature_dim, 16)
-        with torch.set_grad_enabled(grad):                # grad: torch differentiates its own SVD, as the reference does
+        if not grad:
+            # inference: the conditioner on the GPU, then U^T V per sample on the GPU with LAPACK's sign conventions (csrc/svd4_lapack.h):
+            # no device -> host copy, no host LAPACK, stream-ordered (round 2 ran torch.svd on the host here)
+            from .. import _lib
+            with torch.no_grad():
+                out = self._net(feature).to(torch.float32).contiguous()          # [n, 16]
+                rot = torch.empty_like(out)
+                if out.shape[0]:
+                    with torch.cuda.device(out.device):
+                        _lib.check(_lib.lib().rnf_condrot_matrices(out.data_ptr(), out.shape[0], rot.data_ptr(),
+                                                                   torch.cuda.current_stream(out.device).cuda_stream))
+            return rot
+        with torch.set_grad_enabled(True):                # training: torch differentiates its own SVD, as the reference does (host LAPACK)
             mat = self._net(feature).reshape(-1, 4, 4) + torch.eye(4, device=feature.device)
-            # RNF_CONDROT_SVD=device: the batched SVD of the GPU tensor itself (hipSOLVER through torch): no device->host copy, no host
-            # LAPACK -- and the sign conventions of THAT routine, i.e. what the reference produces when it runs on a GPU; the golden fixtures
-            # (and the default here) are the reference's CPU run
             if _CONDROT_SVD_ON_DEVICE:
                 U, S, V = torch.svd(mat)
                 return (U.transpose(-1, -2) @ V).reshape(-1, 16)

@@ -197,3 +197,35 @@ def test_fused_projection_kernel_matches_the_two_kernel_path(name):
     noise = np.abs(fx["ldj32"].astype(np.float64) - fx["ldj64"])
     err = np.abs(ldj1 - fx["ldj64"])
     assert err.mean() <= 2 * noise.mean() + 2e-6 and err.max() <= 4 * noise.max() + 2e-5
+
+
+def test_evaluations_do_not_synchronise_the_host():
+    """after the first call (which packs the parameters) an evaluation must not wait for the device anywhere --
+    ConditionRot's per-sample SVD and the matrix-Fisher sampler's proper SVD used to go through host LAPACK and a device->host copy.
+    torch's sync debug mode raises on every synchronising call."""
+    from rotationnormflow_amd.utils.fisher import MatrixFisherN
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cfg = make_config(layers=2, segments=16, condition=1, feature_dim=24, rot="16Rot")           # ConditionRot layers
+    fl = product_flow(cfg, synth.fill_state_dict(orc.state_shapes(cfg), seed=54, regime="trained"))
+    R = torch.from_numpy(synth.uniform_rotations(2048, seed=156)).cuda()
+    f = torch.from_numpy(synth.features(2048, 24, seed=1156)).cuda()
+    cfg5 = make_config("C5", layers=3)
+    fl5 = product_flow(cfg5, synth.fill_state_dict(orc.state_shapes(cfg5), seed=55, regime="trained"))
+    f5 = torch.from_numpy(synth.features(2048, 512, seed=7)).cuda()
+    base = MatrixFisherN(torch.from_numpy(synth.fisher_A("diag531")).to(dev))
+    with torch.no_grad():
+        fl(R, f); fl.inverse(R, f); fl5.inverse(R, f5); base._sample(16)        # first calls: packing, workspace allocation
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            a = fl(R, f)
+            b = fl.inverse(R, f)
+            z = base._sample(2048).reshape(-1, 3, 3)                             # eval.py:327-347: base samples, their density, inverse pass
+            lp = base._log_prob(z)
+            c = fl5.inverse(z, f5)
+            d = fl5.log_prob(R, f5, base=base)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert torch.isfinite(a[1]).all() and torch.isfinite(b[1]).all() and torch.isfinite(c[1]).all() and torch.isfinite(lp).all()
+    assert torch.isfinite(d["logp"]).all()

@@ -76,6 +76,7 @@ class Flow(nn.Module):
         while the module is in eval mode.  (In training mode, and for nn.DataParallel replicas, every call re-packs on the device from
         the live parameters, so nothing can go stale there.)"""
         self._cache.invalidate()
+        self._cache.feature_ms = None
         self.__dict__.pop("_rnf_train_plan", None)
 
     def _device_packed(self, device, feature=None):
@@ -95,7 +96,12 @@ class Flow(nn.Module):
                                for t in tensors]) if tensors else torch.zeros(0, device=device)
             with torch.cuda.device(device):
                 if self.condition:
+                    # one measurement per flow, not per replica / per call: nn.DataParallel replicas are rebuilt every forward, but they
+                    # share this cache object (runtime.PackCache)
+                    if plan.feature_ms is None:
+                        plan.feature_ms = getattr(self._cache, "feature_ms", None)
                     plan.calibrate(feature)
+                    self._cache.feature_ms = plan.feature_ms
                 blob = plan.pack(plain, torch.cuda.current_stream(device).cuda_stream, with_fallback=runtime._guard_fallback)
         desc = autograd.desc_with_fallback(plan) if runtime._guard_fallback else plan.desc
         packed = runtime.PackedFlow(blob, desc, plan.n_cond, plan.feat_dim, plan.feat_padded, plan.segments, plan.precision)

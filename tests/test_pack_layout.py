@@ -216,3 +216,37 @@ def test_audit_refuses_an_unequalised_imbalanced_layer():
         assert L.rnf_last_pack_audit() > 1e-4
     finally:
         L.rnf_set_equalize(old)
+
+
+def test_feature_mean_square_is_an_input_of_the_equalisation():
+    """rnf_set_feature_ms: a layer whose features are 40x larger than unit scale (and whose feature weights are 40x smaller).  Told the
+    features' mean square, the packer lands on (almost) the record of the unit-scale twin -- the same canonical point of the orbit; left at
+    the default it scales x0 up by 2^5 too much and pushes fc_last's columns 2^5 towards the fp16 floor."""
+    K, F = 16, 40
+    L = _lib.lib()
+    base = _filled_mlp(3 + F, 4 * K, seed=91)
+    twin = _filled_mlp(3 + F, 4 * K, seed=91)
+    with torch.no_grad():
+        twin.fc_first.weight[:, 3:] /= 40.0
+    rec0, frec0 = runtime.pack_mobius(L, base, K, F, _lib.PREC_F16X2)
+    old = L.rnf_set_feature_ms(1600.0)
+    try:
+        rec1, frec1 = runtime.pack_mobius(L, twin, K, F, _lib.PREC_F16X2)
+    finally:
+        L.rnf_set_feature_ms(old)
+    rec2, _ = runtime.pack_mobius(L, twin, K, F, _lib.PREC_F16X2)                       # default: mean square 1
+    tile0 = slice(emu.MOB_HEAD, emu.MOB_HEAD + emu.TILE_BIAS)                            # first fc_last tile: fp16 hi / lo images
+    last0 = rec0[tile0].view(np.float16).astype(np.float64)
+    last2 = rec2[tile0].view(np.float16).astype(np.float64)
+    assert np.array_equal(rec0[emu.MOB_HID:], rec1[emu.MOB_HID:])                        # hidden layers and fc_last: the same canonical images
+    assert np.abs(last2).max() <= np.abs(last0).max() / 2                               # uncalibrated: x0 scaled up, fc_last's columns scaled down
+    assert L.rnf_set_feature_ms(1.0) == 1.0                                             # restored; out-of-range values fall back to 1
+    L.rnf_set_feature_ms(float("nan"))
+    assert L.rnf_set_feature_ms(1.0) == 1.0
+    # and the calibrated record reproduces the oracle on 40x features
+    y = synth.uniform_rotations(32, seed=4)[:, :, 2]
+    feat = synth.features(32, F, seed=9) * np.float32(40.0)
+    g = emu.featproj_from_record_h(frec1, feat.astype(np.float64), F)
+    got = emu.conditioner_from_record_h(rec1, y, K, cinit=g)
+    want = _oracle_mlp(twin, np.concatenate([y, feat], axis=1))
+    assert np.abs(got - want).max() < 3e-6 * max(1.0, np.abs(want).max())

@@ -97,7 +97,8 @@ int rnf_set_fused(int on);
 /* ---- parameter packing (host side, pure CPU; called once per parameter version) ------------------------------
  * Sizes are in floats.  `segments` (K) is any positive count (flow/mobiusflow.py:7-14 takes any): records hold ceil(K / 8) fc_last tiles,
  * the last one zero padded, and the kernels give the pad segments weight 0.  rnf_flow_inverse keeps a layer's segment parameters in
- * registers and supports K <= 128; the training entry points need K % 8 == 0, K <= 64.  `feature_dim` (F) is the number of
+ * registers (64 per lane; beyond K = 128 the rest streams through a per-wave stash, see rnf_workspace_bytes_segments); the training entry
+ * points need K <= 64.  `feature_dim` (F) is the number of
  * feature inputs of the layer's MLP (0 for an unconditional Moebius layer).
  */
 int64_t rnf_mobius_packed_floats(int32_t segments);
@@ -159,6 +160,8 @@ int rnf_pack_cond36(const float *fc_first_w, const float *fc_first_b, const floa
  * NaN outputs instead of being repaired.  No other overlap between inputs and outputs is supported.
  */
 size_t rnf_workspace_bytes(int64_t n, int32_t n_cond_layers);
+/* the same plus the per-wave stash an INVERSE pass with more than 128 segments needs (equal to rnf_workspace_bytes up to 128) */
+size_t rnf_workspace_bytes_segments(int64_t n, int32_t n_cond_layers, int32_t segments);
 
 /* Flow.forward (flow/flow.py:53-72): ldj = sum of forward log-det-Jacobians. */
 int rnf_flow_forward(const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim,

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "rnf_cond36_packed_floats": (C.c_int64, []),
     "rnf_pack_cond36": (C.c_int, [c_f32p] * 10 + [C.c_int32, C.c_int32, c_f32p, c_f32p]),
     "rnf_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "rnf_workspace_bytes_segments": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "rnf_flow_forward": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
                                    c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnf_flow_inverse": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,

@@ -54,6 +54,9 @@ struct FlowArgs {
     const float *side;        // per-sample matrices of the RNF_KIND_SIDE* layers: [side slot][side_n][16] floats, or nullptr
     long long side_n;         // rotations in the whole call (chunks index at sample_base)
     // FUSED instantiation (conditional flows, feature_dim <= FUSED_MAX_F): the feature projection runs INSIDE the stack kernel
+    // inverse with more than 128 segments (KT > 16, the 4-wave instantiation): the parameters of the segments beyond the 64 per lane that fit in
+    // registers live in this stash, [gridDim.x * NW][4 (KT - 16)][64 lanes] float4 (sp, ur, uv, q), rewritten every layer (L2-resident)
+    float4 *inv_stash;
     const float *feat;        // [n, feat_F] features of this launch
     float *stash;             // [gridDim.x * NW][G_FLOATS_PER_GROUP]: each wave's projected features of the NEXT layer (stays in L2)
     int feat_F;               // feature columns (multiple of 8)
@@ -733,7 +736,7 @@ struct InvSegs {
 // KT > MOB_MAX_TILES_IN_LDS (K > 64, synchronous staging only): the second half of the fc_last image is staged in the middle.
 template <int KT, int PREC>
 __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_params, int kt, int K, int lane, int h, const typename Mlp<PREC>::Act &tt,
-                                                 const MobiusCtx &c, InvSegs<KT> &sg, float &S, int tid, int nthreads) {
+                                                 const MobiusCtx &c, InvSegs<KT> &sg, float &S, int tid, int nthreads, float4 *stash = nullptr) {
 #pragma unroll
     for (int tau = 0; tau < KT; ++tau) {
         if (tau < kt) {                                         // wave uniform
@@ -766,6 +769,28 @@ __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_
         // 96 live segment registers spills; the inverse is VALU-bound in the bisection anyway
         __builtin_amdgcn_sched_barrier(0);
     }
+    // K > 8 KT segments (the largest instantiation only, KT = 16: K > 128): the remaining tiles' segment parameters go to the wave's stash
+    if constexpr (KT == 16) {
+        for (int tau = KT; tau < kt; ++tau) {
+            if ((tau % MOB_MAX_TILES_IN_LDS) == 0) {
+                __syncthreads();
+                stage_floats(lds + MOB_LAST, layer_params + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS,
+                             min(MOB_MAX_TILES_IN_LDS, kt - tau) * MOB_LAST_TILE_FLOATS, tid, nthreads);
+                __syncthreads();
+            }
+            const f32x16 o = Mlp<PREC>::last(lds + MOB_LAST + (tau % MOB_MAX_TILES_IN_LDS) * MOB_LAST_TILE_FLOATS, lane, h, tt);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float ur, uv;
+                squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, ur, uv);
+                float sp = PREC == 1 ? softplus2_safe(o[4 * g]) : softplus(S_UNSCALE * o[4 * g]);
+                if (8 * tau + 2 * g + h >= K) sp = 0.f;
+                stash[(size_t)(4 * (tau - KT) + g) * 64 + lane] = make_float4(sp, ur, uv, sp * (1.0f - fmaf(uv, uv, ur * ur)));
+                S += sp;
+            }
+        }
+        if (kt > KT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the root finder reads the stash back (same lane, same addresses)
+    }
 }
 
 // Root of BinFind (flow/mobiusflow.py:189-224).  The reference bisects f(theta) = sum_k wt_k phi_k(theta) - target on
@@ -777,8 +802,11 @@ __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_
 // segments the kernel finds theta* with a bracket-safeguarded Newton iteration (phi_k and its derivative c_k come out of the
 // same evaluation) and then snaps it to that grid: the same returned iterate as the reference's bisection, except when
 // theta* lies within rounding error of a cell boundary -- where the reference's own fp32 and fp64 runs disagree too.
+// n_over > 0 (KT = 16 only): `stash` holds the parameters of this lane's segments beyond the 4 KT in registers (mobius_inv_tiles); every
+// sum over the segments continues over them (one float4 load per segment and pass: a K > 128 inverse is rare, L2 absorbs it)
 template <int KT>
-__device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvSegs<KT> &sg, float S, Rot &R, float &ldj) {
+__device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvSegs<KT> &sg, float S, Rot &R, float &ldj, const float4 *stash = nullptr,
+                                                  int n_over = 0, int lane = 0) {
     S = pair_sum(S);
     const float invS = hw_rcp(S);
     float lo = 0.5f * kPi, hi = 1.5f * kPi, th;
@@ -792,6 +820,12 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
             mr2 = __builtin_elementwise_fma(sp, f2{sg.ur[s], sg.ur[s + 1]}, mr2);
             mv2 = __builtin_elementwise_fma(sp, f2{sg.uv[s], sg.uv[s + 1]}, mv2);
         }
+        if constexpr (KT == 16)
+            for (int s = 0; s < n_over; ++s) {
+                const float4 p = stash[(size_t)s * 64 + lane];
+                mr2.x = fmaf(p.x, p.y, mr2.x);
+                mv2.x = fmaf(p.x, p.z, mv2.x);
+            }
         const float mr = pair_sum(mr2.x + mr2.y) * invS;
         const float mv = pair_sum(mv2.x + mv2.y) * invS;
         float st, ct;
@@ -841,6 +875,15 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
             acc = acc2.x + acc2.y;
             der = der2.x + der2.y;
         }
+        if constexpr (KT == 16)
+            for (int s = 0; s < n_over; ++s) {                         // the same per-segment evaluation on the stashed parameters
+                const float4 p = stash[(size_t)s * 64 + lane];
+                const float a = fmaf(p.z, sn, p.y * cs), b = fmaf(p.z, cs, -(p.y * sn));
+                const float e1 = 1.0f - a;
+                const float t = -b * hw_rcp(e1);
+                acc = fmaf(p.x, atan_unit(t), acc);
+                der = fmaf(p.w, hw_rcp(fmaf(b, b, e1 * e1)), der);
+            }
 
         const float fx = fmaf(2.0f * pair_sum(acc), invS, th) - c.target;
         const float dfx = pair_sum(der) * invS;
@@ -875,6 +918,13 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
         }
         J = J2.x + J2.y;
     }
+    if constexpr (KT == 16)
+        for (int s = 0; s < n_over; ++s) {
+            const float4 p = stash[(size_t)s * 64 + lane];
+            const float a = fmaf(p.z, sn, p.y * cs), b = fmaf(p.z, cs, -(p.y * sn));
+            const float e1 = 1.0f - a;
+            J = fmaf(p.w, hw_rcp(fmaf(b, b, e1 * e1)), J);
+        }
     J = pair_sum(J);
     const v3f xx = c.f.v * sn + c.f.r * cs;
     const v3f zz = normalize3(c.cyc ? cross3(xx, c.y) : cross3(c.y, xx));               // mobiusflow.py:172-176
@@ -1383,13 +1433,14 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 if constexpr (DIR != 0) {
                     InvSegs<KTI> sg;
                     float S = 0.f;
-                    mobius_inv_tiles<KTI, PREC>(lds, params, KT, args.K, lane, h, tt, ctx, sg, S, tid, NT);
+                    float4 *const istash = (KTI == 16 && args.inv_stash) ? args.inv_stash + ((size_t)blockIdx.x * NW + wave) * (size_t)(4 * max(KT - KTI, 0)) * 64 : nullptr;
+                    mobius_inv_tiles<KTI, PREC>(lds, params, KT, args.K, lane, h, tt, ctx, sg, S, tid, NT, istash);
                     // the barrier right behind the tiles (the root finder does not touch LDS, and its pass count differs from wave to wave:
                     // a barrier behind it was 19 % of the wave time), the DMA request of the next fc_last image behind the root finder:
                     // in front of it the DMA address arithmetic would sit on top of the 96 live segment registers (36 spills at K = 64);
                     // the image still has the whole hidden-layer phase of the next layer to land
                     b2_sync();
-                    mobius_inv_finish<KTI>(ctx, sg, S, R, ldj);
+                    mobius_inv_finish<KTI>(ctx, sg, S, R, ldj, istash, KTI == 16 ? 4 * max(KT - KTI, 0) : 0, lane);
                     b2_issue();
                 } else {
                     float S = 0.f, A = 0.f, J = 0.f;

@@ -567,6 +567,15 @@ extern "C" size_t rnf_workspace_bytes_shared(int64_t n, int32_t n_cond_layers, i
     return PARTIALS_BYTES + (size_t)n_cond_layers * rows * 64 * sizeof(float);
 }
 
+// K > 128: the inverse pass keeps the parameters of 64 segments per lane in registers and the rest in a per-wave stash behind the scratch
+static size_t inv_stash_bytes(int32_t K) {
+    const int KT = (K + 7) / 8;
+    return KT > 16 ? (size_t)device_cus() * NW_INV_BIG * (size_t)(4 * (KT - 16)) * 64 * sizeof(float4) : 0;
+}
+extern "C" size_t rnf_workspace_bytes_segments(int64_t n, int32_t n_cond_layers, int32_t segments) {
+    return rnf_workspace_bytes(n, n_cond_layers) + inv_stash_bytes(segments);
+}
+
 extern "C" size_t rnf_workspace_bytes(int64_t n, int32_t n_cond_layers) {
     size_t bytes = PARTIALS_BYTES;
     if (n_cond_layers > 0) {
@@ -811,11 +820,16 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     // inverse: the segment parameters of a layer stay in registers through the root finder; instantiations hold 1, 2, 4, 8 tiles
     // (8-wave workgroups) or 16 (K <= 128: 4-wave workgroups with the whole register file, fc_last staged in two halves)
     const int kt_inv = KT <= 1 ? 1 : (KT <= 2 ? 2 : (KT <= 4 ? 4 : (KT <= 8 ? 8 : 16)));
-    if (o.dir == 1 && any_mlp && KT > 16)
-        return fail("inverse pass supports segments <= 128; got %d", K);
     if (o.dir == 1 && any_mlp && KT > 8 && (ext || o.feature_div > 0))
         return fail("inverse pass with segments > 64 is not built for conditional 3x3 / 6x6 layers or shared feature rows; got %d", K);
 
+    if (o.dir == 1 && any_mlp && KT > 16) {            // overflow stash of the K > 128 inverse (flow_kernels.h mobius_inv_tiles), behind everything else
+        if (shared) return fail("inverse pass with segments > 128 is not built for shared feature rows; got %d", K);
+        if (!ws || ws_bytes < ws_need + inv_stash_bytes(K))
+            return fail("workspace of %zu bytes is smaller than the %zu an inverse pass with %d segments needs (rnf_workspace_bytes_segments)",
+                        ws_bytes, ws_need + inv_stash_bytes(K), K);
+        a.inv_stash = reinterpret_cast<float4 *>(reinterpret_cast<char *>(ws) + ws_need);
+    }
     double *partials = reinterpret_cast<double *>(ws);
     float *G = n_slots ? reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + PARTIALS_BYTES) : nullptr;
     int tiles_in_lds = any_mlp ? (KT < MOB_MAX_TILES_IN_LDS ? KT : MOB_MAX_TILES_IN_LDS) : 0;

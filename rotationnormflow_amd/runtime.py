@@ -524,7 +524,7 @@ def run_flow(module, packed, rotation, feature, inverse=False, train_layers=None
                           packed.blob.data_ptr(), packed.desc.ctypes.data, packed.n_layers, packed.segments,
                           out_rot.data_ptr(), out_ldj.data_ptr(), ws.data_ptr(), ws.numel(), stream))
         else:
-            ws = workspace(rot.device, L.rnf_workspace_bytes(n, packed.n_cond))
+            ws = workspace(rot.device, L.rnf_workspace_bytes_segments(n, packed.n_cond, packed.segments) if inverse else L.rnf_workspace_bytes(n, packed.n_cond))
             fn = L.rnf_flow_inverse if inverse else L.rnf_flow_forward
             _lib.check(fn(rot.data_ptr(), feat.data_ptr() if feat is not None else None, n, packed.feat_padded,
                           packed.blob.data_ptr(), packed.desc.ctypes.data, packed.n_layers, packed.segments,

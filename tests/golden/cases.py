@@ -106,6 +106,13 @@ CASES.update({
     "c4_trained_inv24": dict(cfg=dict(layers=24, feature_dim=256, **SYMSOL), n=512, regime="trained", wseed=6, rseed=169, direction="inverse", fisher=None),
     "c5_trained_inv":  dict(cfg=C5, n=512, regime="trained", wseed=66, rseed=170, direction="inverse", fisher="diag531"),
     "c5_trained_fwd":  dict(cfg=C5, n=512, regime="trained", wseed=66, rseed=171, direction="forward", fisher=None),
+    # more than 128 segments (flow/mobiusflow.py:7-14 takes any `segments`): the inverse keeps 64 segments per lane in registers and streams
+    # the rest through a per-wave stash (round 3; round 2 refused K > 128); K = 196: 25 fc_last tiles, the last one half padding
+    "k192_inv":        dict(cfg=dict(layers=2, segments=192), n=256, regime="trained", wseed=67, rseed=172, direction="inverse", fisher=None),
+    "k196_cond_inv":   dict(cfg=dict(layers=2, segments=196, condition=1, feature_dim=24, rot="None", frequent_permute=1, last_affine=0, first_affine=0),
+                            n=256, regime="trained", wseed=68, rseed=173, direction="inverse", fisher=None),
+    "k196_cond_fwd":   dict(cfg=dict(layers=2, segments=196, condition=1, feature_dim=24, rot="None", frequent_permute=1, last_affine=0, first_affine=0),
+                            n=256, regime="trained", wseed=68, rseed=174, direction="forward", fisher=None),
 })
 
 

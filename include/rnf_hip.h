@@ -93,12 +93,15 @@ int rnf_set_pack_audit(int on);
 /* rnf_set_fused(1) (or RNF_FUSED=1): forward passes of conditional flows whose every MLP layer is conditional and feature_dim <= 256 run with
  * the feature projection INSIDE the stack kernel (no projection scratch in HBM).  Off by default: slower than the two-kernel path on C4. */
 int rnf_set_fused(int on);
+/* Block size of the training backward sweep: 16-rotation workgroups (csrc/train_block16.h) or 64-rotation ones (csrc/train_kernels.h, K <= 64
+ * only); 0 (default) picks by batch size.  RNF_TRAIN_BLOCK=16|64 in the environment does the same.  Returns the previous setting. */
+int rnf_set_train_block(int rotations);
 
 /* ---- parameter packing (host side, pure CPU; called once per parameter version) ------------------------------
  * Sizes are in floats.  `segments` (K) is any positive count (flow/mobiusflow.py:7-14 takes any): records hold ceil(K / 8) fc_last tiles,
  * the last one zero padded, and the kernels give the pad segments weight 0.  rnf_flow_inverse keeps a layer's segment parameters in
  * registers (64 per lane; beyond K = 128 the rest streams through a per-wave stash, see rnf_workspace_bytes_segments); the training entry
- * points need K <= 64.  `feature_dim` (F) is the number of
+ * points take K <= 512 (the conditioner outputs of a 16-rotation block live in LDS).  `feature_dim` (F) is the number of
  * feature inputs of the layer's MLP (0 for an unconditional Moebius layer).
  */
 int64_t rnf_mobius_packed_floats(int32_t segments);

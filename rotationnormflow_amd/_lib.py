@@ -24,6 +24,7 @@ _SIGNATURES = {
     "rnf_set_feature_ms": (C.c_double, [C.c_double]),
     "rnf_set_pack_audit": (C.c_int, [C.c_int]),
     "rnf_set_fused": (C.c_int, [C.c_int]),
+    "rnf_set_train_block": (C.c_int, [C.c_int]),
     "rnf_mobius_packed_floats": (C.c_int64, [C.c_int32]),
     "rnf_affine16_packed_floats": (C.c_int64, []),
     "rnf_cond16_packed_floats": (C.c_int64, []),

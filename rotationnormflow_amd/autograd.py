@@ -33,9 +33,9 @@ class TrainPlan:
         self.segments = ks.pop() if ks else 8
         self.feat_dim = fs.pop() if fs else 0
         self.feat_padded = runtime.pad8(self.feat_dim)
-        if self.segments > 64:
-            raise NotImplementedError("training path: at most 64 segments (the backward kernel keeps the conditioner outputs of 64 "
-                                      "rotations in LDS)")
+        if self.segments > 512:
+            raise NotImplementedError("training path: at most 512 segments (the backward kernel keeps the conditioner outputs of a "
+                                      "16-rotation block in LDS)")
         self.precision = precision
         self.prec = runtime._PRECISIONS[precision]
         self.n_layers = n
@@ -198,7 +198,7 @@ class _FlowFn(torch.autograd.Function):
                 raise RuntimeError("side-layer matrices are missing or mis-shaped")
             side_c = side.to(device=dev, dtype=f32).contiguous()
         if n:
-            ws = runtime.workspace(dev, L.rnf_workspace_bytes(n, plan.n_cond))
+            ws = runtime.workspace(dev, L.rnf_workspace_bytes_segments(n, plan.n_cond, plan.segments))     # (+ the K > 128 stash of an inverse pass)
             fptr = feat.data_ptr() if feat is not None else None
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream

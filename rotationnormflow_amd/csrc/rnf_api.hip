@@ -13,6 +13,7 @@
 #include "featproj_kernel.h"
 #include "flow_kernels.h"
 #include "train_kernels.h"
+#include "train_block16.h"
 #include "pack_device.h"
 #include "sampler_kernel.h"
 #include "fisher_math.h"
@@ -658,6 +659,23 @@ extern "C" int rnf_set_fused(int on) {
     return old;
 }
 
+// Block size of the training backward sweep: 0 = by batch size (default), 16 / 64 = force (RNF_TRAIN_BLOCK in the environment).
+constexpr int64_t kTrainBlock64From = 6144;     // batches from this size on use the 64-rotation kernel (measured crossover: profiles/README.md)
+static int g_train_block = -1;
+static int train_block() {
+    if (g_train_block < 0) {
+        const char *e = std::getenv("RNF_TRAIN_BLOCK");
+        const int v = e ? std::atoi(e) : 0;
+        g_train_block = (v == 16 || v == 64) ? v : 0;
+    }
+    return g_train_block;
+}
+extern "C" int rnf_set_train_block(int rotations) {
+    const int prev = train_block();
+    g_train_block = (rotations == 16 || rotations == 64) ? rotations : 0;
+    return prev;
+}
+
 // forward pass of a conditional flow with the feature projection inside the stack kernel (flow_kernels.h FUSED)
 #ifndef RNF_NW_FUSED
 #define RNF_NW_FUSED 8
@@ -1275,7 +1293,7 @@ static int run_backward(const float *states, const float *rot_final, int dir, co
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     if (n < 0) return fail("n=%lld is negative", (long long)n);
     if (n_layers < 0 || n_layers > TR_MAX_LAYERS) return fail("n_layers=%d outside [0,%d] (training path)", n_layers, TR_MAX_LAYERS);
-    if (K < 1 || K > 64) return fail("training path supports 1..64 segments, got %d", K);
+    if (K < 1 || K > 512) return fail("training path supports 1..512 segments, got %d", K);
     if (F < 0) return fail("feature_dim %d is negative", F);
     if (n == 0) return 0;
     const bool mlp_only = n_layers == 1 && (tdesc[0] & 15) == RNF_KIND_MLP_ONLY;
@@ -1283,9 +1301,11 @@ static int run_backward(const float *states, const float *rot_final, int dir, co
     if (!mlp_only && (!states || !g_ldj || !g_rot_in)) return fail("null pointer argument");
     TrainArgs a;
     std::memset(&a, 0, sizeof(a));
+    bool rare = false;        // side / Gram-Schmidt / conditional 3x3 layers present: the instantiation that carries them (train_block16.h)
     for (int l = 0; l < n_layers; ++l) {
         const int32_t *d = tdesc + (size_t)l * 3;
         const int kind = d[0] & 15, orth = (d[0] >> 8) & 1, aux = (d[0] >> 16) & 255;
+        rare = rare || kind_is_side(kind) || kind == RNF_KIND_GS9 || kind == RNF_KIND_GS36 || kind == RNF_KIND_COND36 || kind_is_cond9(kind);
         if ((d[0] & ~(15 | 256 | (255 << 16))) ||
             (kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16 && kind != RNF_KIND_COND16 && kind != RNF_KIND_GS9 && kind != RNF_KIND_GS36 &&
              kind != RNF_KIND_COND36 && !kind_is_cond9(kind) && !kind_is_side(kind) && !(kind == RNF_KIND_MLP_ONLY && mlp_only)))
@@ -1310,18 +1330,40 @@ static int run_backward(const float *states, const float *rot_final, int dir, co
     }
 #endif
     const size_t rows = (4 * (size_t)K + 63) / 64 * 64;      // conditioner-output rows, padded to whole 64-row slabs (train_kernels.h)
-    const size_t lds_bytes = sizeof(float) * (TR_LDS_HEAD_FLOATS + rows * LROW);
-    const long long nblocks = (n + 63) / 64;
-    const int cap = device_cus() * 4;
-    const dim3 grid((unsigned)(nblocks < cap ? nblocks : cap)), block(TR_WAVES * 64);
-    if (F) {
-        auto kern = flow_train_backward_kernel<true>;
-        HIP_TRY(allow_lds(kern, lds_bytes));
-        hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+    // Block size of the sweep: 16-rotation workgroups (train_block16.h: a quarter of the dependent matrix chain per workgroup, four times
+    // as many workgroups, K up to 512) or 64-rotation ones (train_kernels.h: a quarter of the weight traffic and gradient atomics, K <= 64).
+    const int blk_sel = train_block();
+    const bool block16 = blk_sel == 16 || K > 64 || (blk_sel == 0 && n < kTrainBlock64From);
+    if (blk_sel == 64 && K > 64) return fail("RNF_TRAIN_BLOCK=64: the 64-rotation backward kernel holds at most 64 segments, got %d", K);
+    if (block16) {
+        const size_t lds_bytes = sizeof(float) * (b16::HEAD_FLOATS + rows * b16::LR);
+        const long long nblocks = (n + b16::SB - 1) / b16::SB;
+        const long long per_cu = (long long)(160 * 1024 / lds_bytes) < 4 ? (long long)(160 * 1024 / lds_bytes) : 4;
+        const long long cap = (long long)device_cus() * (per_cu < 1 ? 1 : per_cu) * 2;
+        const dim3 grid((unsigned)(nblocks < cap ? nblocks : cap)), block(b16::WAVES * 64);
+        auto launch16 = [&](auto kern) -> int {
+            HIP_TRY(allow_lds(kern, lds_bytes));
+            hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+            return 0;
+        };
+        int rc;
+        if (F) rc = rare ? launch16(b16::flow_train_backward16_kernel<true, true>) : launch16(b16::flow_train_backward16_kernel<true, false>);
+        else rc = rare ? launch16(b16::flow_train_backward16_kernel<false, true>) : launch16(b16::flow_train_backward16_kernel<false, false>);
+        if (rc) return rc;
     } else {
-        auto kern = flow_train_backward_kernel<false>;
-        HIP_TRY(allow_lds(kern, lds_bytes));
-        hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+        const size_t lds_bytes = sizeof(float) * (TR_LDS_HEAD_FLOATS + rows * LROW);
+        const long long nblocks = (n + 63) / 64;
+        const int cap = device_cus() * 4;
+        const dim3 grid((unsigned)(nblocks < cap ? nblocks : cap)), block(TR_WAVES * 64);
+        if (F) {
+            auto kern = flow_train_backward_kernel<true>;
+            HIP_TRY(allow_lds(kern, lds_bytes));
+            hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+        } else {
+            auto kern = flow_train_backward_kernel<false>;
+            HIP_TRY(allow_lds(kern, lds_bytes));
+            hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+        }
     }
     HIP_TRY(hipGetLastError());
     if (n_layers) {

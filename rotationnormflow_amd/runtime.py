@@ -518,7 +518,7 @@ def run_flow(module, packed, rotation, feature, inverse=False, train_layers=None
                           ws.data_ptr(), ws.numel(), stream))
         elif packed.side_layers:
             side = build_side_buffer(packed, feature, n, rot.device, inverse)
-            ws = workspace(rot.device, L.rnf_workspace_bytes(n, max(packed.n_cond, 1)))
+            ws = workspace(rot.device, L.rnf_workspace_bytes_segments(n, max(packed.n_cond, 1), packed.segments if inverse else 0))
             fn = L.rnf_flow_inverse_side if inverse else L.rnf_flow_forward_side
             _lib.check(fn(rot.data_ptr(), feat.data_ptr() if feat is not None else None, n, packed.feat_padded, side.data_ptr(),
                           packed.blob.data_ptr(), packed.desc.ctypes.data, packed.n_layers, packed.segments,

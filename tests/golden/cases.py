@@ -123,4 +123,10 @@ GRAD_CASES = {
     "invgrad_mobius_only": dict(cfg=dict(layers=3, segments=8, rot="None", first_affine=0), n=160, regime="trained", wseed=42, rseed=142),
     "invgrad_cond":        dict(cfg=dict(layers=2, segments=16, condition=1, feature_dim=24, rot="16UnTrans", frequent_permute=1,
                                          last_affine=1, first_affine=0), n=160, regime="trained", wseed=43, rseed=143),
+    # segment counts beyond 64 (round 3: the 16-rotation backward kernel, csrc/train_block16.h, holds up to 512): gradients through
+    # Flow.forward -- the training direction -- and through Flow.inverse
+    "k96_train":           dict(cfg=dict(layers=2, segments=96), n=100, regime="trained", wseed=44, rseed=144, direction="forward"),
+    "k200_cond_train":     dict(cfg=dict(layers=1, segments=200, condition=1, feature_dim=24, rot="16UnTrans", frequent_permute=1,
+                                         last_affine=1, first_affine=0), n=72, regime="trained", wseed=45, rseed=145, direction="forward"),
+    "k96_invgrad":         dict(cfg=dict(layers=2, segments=96, rot="None", first_affine=0), n=80, regime="trained", wseed=46, rseed=146),
 }

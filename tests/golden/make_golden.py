@@ -102,7 +102,8 @@ def grad_case_loss_weights(n, seed):
 
 
 def run_inverse_grad_case(name, spec):
-    """Gradients of loss = sum(a * ldj) + sum(B * R_out) through the reference's Flow.inverse (BinFind.backward), fp64."""
+    """Gradients of loss = sum(a * ldj) + sum(B * R_out) through the reference's Flow.inverse (BinFind.backward) or, with
+    direction="forward", Flow.forward; fp64."""
     cfg = make_config(**spec["cfg"])
     n = spec["n"]
     dtype = torch.float64
@@ -115,7 +116,8 @@ def run_inverse_grad_case(name, spec):
     if cfg.condition:
         feat = torch.from_numpy(synth.features(n, fl.feature_dim, seed=spec["rseed"] + 1000)).to(dtype).requires_grad_(True)
     a, B = grad_case_loss_weights(n, spec["rseed"] + 7)
-    Rt, ldj = fl.inverse(R, feat)
+    # direction "forward": what agent.py:75-92 differentiates (Flow.forward); default: Flow.inverse
+    Rt, ldj = fl(R, feat) if spec.get("direction") == "forward" else fl.inverse(R, feat)
     loss = (torch.from_numpy(a) * ldj).sum() + (torch.from_numpy(B) * Rt).sum()
     loss.backward()
     out = {"loss": np.float64(loss.item()), "g_rot": R.grad.numpy().copy(), "rot_out": Rt.detach().numpy().copy(), "ldj": ldj.detach().numpy().copy()}

@@ -177,7 +177,7 @@ def test_argument_validation_happens_before_any_gpu_work():
     assert L.rnf_cond36_packed_floats() == L.rnf_cond16_packed_floats() + 2080
     # training entry points
     tdesc = np.array([[1, 0, 0]], np.int32)
-    args = (None, None, 64, 0, None, tdesc.ctypes.data, 1, 72, None, None, None, None, None, None, None)
+    args = (None, None, 64, 0, None, tdesc.ctypes.data, 1, 513, None, None, None, None, None, None, None)      # K <= 512 (LDS of a 16-rotation block)
     assert L.rnf_flow_backward(*args) != 0 and "segments" in err()
     args = (None, None, 64, 0, None, tdesc.ctypes.data, 300, 64, None, None, None, None, None, None, None)
     assert L.rnf_flow_backward(*args) != 0 and "n_layers" in err()

@@ -44,6 +44,10 @@ CASES = {
     "uncond_k20": (dict(layers=2, segments=20), 90, "trained"),            # segment counts that are not multiples of 8 train too
     "cond_k11": (dict(layers=2, segments=11, condition=1, feature_dim=24), 70, "trained"),
     "uncond_k64_24": (dict(layers=12, segments=64), 333, "default"),
+    # beyond 64 segments (round 3: only the 16-rotation backward kernel holds them, csrc/train_block16.h; K <= 512 by LDS)
+    "uncond_k96": (dict(layers=3, segments=96), 150, "trained"),
+    "cond_k130": (dict(layers=2, segments=130, condition=1, feature_dim=24), 60, "trained"),
+    "uncond_k512": (dict(layers=1, segments=512), 40, "trained"),
     "cond_k32": (dict(layers=2, segments=32, condition=1, feature_dim=40), 150, "trained"),
     "cond_first_affine": (dict(layers=2, segments=16, condition=1, feature_dim=24, last_affine=1), 130, "default"),
     "mobius_only": (dict(layers=4, segments=8, rot="None"), 64, "trained"),
@@ -182,7 +186,7 @@ def test_side_kernels_in_isolation(kind, inverse):
     assert np.abs(tg - tw).max() / max(np.abs(tw).max(), 1e-3) < 2e-4
 
 
-INVERSE_CASES = ["uncond_k16", "uncond_k20", "cond_k11", "cond_k32", "cond_first_affine", "mobius_only", "lu", "rot", "gs9", "svdl9", "cgs9", "csvdl9", "csvdr9", "csmithr9", "gs36", "cgs36", "clu9"]
+INVERSE_CASES = ["uncond_k16", "uncond_k20", "cond_k11", "cond_k32", "uncond_k96", "cond_k130", "cond_first_affine", "mobius_only", "lu", "rot", "gs9", "svdl9", "cgs9", "csvdl9", "csvdr9", "csmithr9", "gs36", "cgs36", "clu9"]
 
 
 @pytest.mark.parametrize("name", INVERSE_CASES)
@@ -225,9 +229,11 @@ def test_inverse_gradients_match_oracle_autograd(name):
         assert np.abs(fd.grad.cpu().numpy().astype(np.float64) - ft.grad.numpy()).max() / max(np.abs(ft.grad.numpy()).max(), 1e-3) < rel
 
 
-@pytest.mark.parametrize("name", ["invgrad_uncond", "invgrad_mobius_only", "invgrad_cond"])
+@pytest.mark.parametrize("name", ["invgrad_uncond", "invgrad_mobius_only", "invgrad_cond", "k96_train", "k200_cond_train", "k96_invgrad"])
 def test_inverse_gradients_match_the_reference_binfind_backward(name):
-    """The same through the C ABI against gradients the REAL reference produced (tests/golden/invgrad_*.npz, fp64)."""
+    """The same through the C ABI against gradients the REAL reference produced (tests/golden/invgrad_*.npz, fp64); k96_train /
+    k200_cond_train: gradients through Flow.forward (the training direction) at segment counts only the 16-rotation backward kernel
+    holds (csrc/train_block16.h), k96_invgrad the same through Flow.inverse."""
     import os
 
     from rotationnormflow_amd.configs import make_config
@@ -245,7 +251,7 @@ def test_inverse_gradients_match_the_reference_binfind_backward(name):
     fl = product_flow(cfg, w).train()
     Rd = torch.from_numpy(R).cuda().requires_grad_(True)
     fd = None if feat is None else torch.from_numpy(feat).cuda().requires_grad_(True)
-    Ro, ldj = fl.inverse(Rd, fd)
+    Ro, ldj = fl(Rd, fd) if spec.get("direction") == "forward" else fl.inverse(Rd, fd)
     loss = (torch.from_numpy(a).float().cuda() * ldj).sum() + (torch.from_numpy(B).float().cuda() * Ro).sum()
     loss.backward()
     torch.cuda.synchronize()
@@ -489,7 +495,69 @@ def test_graphed_train_step_follows_the_oracle():
     assert abs(float(ldj.mean()) - float(ldj_o.mean())) < 2e-4
 
 
-@pytest.mark.parametrize("n", [0, 1, 65])
+@pytest.fixture
+def train_block():
+    """Force the block size of the backward sweep for one test (rnf_set_train_block), restore the automatic choice afterwards."""
+    from rotationnormflow_amd import _lib
+    L = _lib.lib()
+    prev = L.rnf_set_train_block(0)
+    yield L.rnf_set_train_block
+    L.rnf_set_train_block(prev)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("name", ["uncond_k64_24", "cond_k32", "cond_first_affine", "gs36", "cgs9", "clu9", "lu"])
+def test_both_backward_kernels_agree(name, inverse, train_block):
+    """The 16-rotation sweep (csrc/train_block16.h, the default below 6144 rotations) and the 64-rotation sweep (csrc/train_kernels.h) are
+    the same reverse-mode formulas on differently tiled products: every gradient agrees to fp32 summation-order noise (each is gated
+    against the oracle on its own by the tests above, which run the automatic choice)."""
+    if inverse and name not in INVERSE_CASES:
+        pytest.skip("no inverse case")
+    cfg, w, R, feat, gR, gl = _make(name)
+    res = {}
+    for blk in (16, 64):
+        train_block(blk)
+        fl = product_flow(cfg, w).train()
+        Rd = torch.from_numpy(R).cuda().requires_grad_(True)
+        fd = None if feat is None else torch.from_numpy(feat).cuda().requires_grad_(True)
+        Ro, ldj = fl.inverse(Rd, fd) if inverse else fl(Rd, fd)
+        ((Ro * torch.from_numpy(gR).cuda()).sum() + (ldj * torch.from_numpy(gl).cuda()).sum()).backward()
+        torch.cuda.synchronize()
+        res[blk] = ({k: p.grad.cpu().numpy().astype(np.float64) for k, p in fl.named_parameters() if p.grad is not None},
+                    Rd.grad.cpu().numpy().astype(np.float64), None if fd is None else fd.grad.cpu().numpy().astype(np.float64))
+    a, b = res[16], res[64]
+    assert a[0].keys() == b[0].keys() and len(a[0]) > 0
+    for k in a[0]:
+        assert np.abs(a[0][k] - b[0][k]).max() <= 2e-5 * max(np.abs(b[0][k]).max(), 1e-3), k
+    assert np.abs(a[1] - b[1]).max() <= 2e-5 * max(np.abs(b[1]).max(), 1e-3)
+    if a[2] is not None:
+        assert np.abs(a[2] - b[2]).max() <= 2e-5 * max(np.abs(b[2]).max(), 1e-3)
+
+
+def test_backward_block_size_follows_the_batch(train_block):
+    """Automatic choice: 64-rotation workgroups from 6144 rotations on (atomic-add volume, profiles/README.md), 16-rotation ones below and
+    for more than 64 segments at any batch; forcing 64 beyond 64 segments is refused.  Checked through the gradients of a batch on
+    either side of the threshold against the oracle."""
+    cfg = orc.make_config(layers=1, segments=8)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=51, regime="trained")
+    for n in (6143, 6145):
+        R = synth.uniform_rotations(n, seed=52)
+        gl = np.random.default_rng(53).standard_normal(n).astype(np.float32)
+        want, _, _, _, _ = oracle_grads(cfg, w, R, None, np.zeros((n, 3, 3), np.float32), gl)
+        fl = product_flow(cfg, w).train()
+        _, ldj = fl(torch.from_numpy(R).cuda())
+        (ldj * torch.from_numpy(gl).cuda()).sum().backward()
+        for k, p in fl.named_parameters():
+            assert np.abs(p.grad.cpu().numpy() - want[k]).max() / max(np.abs(want[k]).max(), 1e-3) < REL, (n, k)
+    train_block(64)
+    cfg, w, R, feat, gR, gl = _make("uncond_k96")
+    fl = product_flow(cfg, w).train()
+    _, ldj = fl(torch.from_numpy(R).cuda())
+    with pytest.raises(RuntimeError, match="64 segments"):
+        ldj.sum().backward()
+
+
+@pytest.mark.parametrize("n", [0, 1, 17, 65])
 def test_training_on_tiny_and_ragged_batches(n):
     """Empty batch: zero gradients, no launch.  1 and 65 rotations: one nearly empty workgroup / one full + one with a single lane."""
     cfg, w, R, feat, gR, gl = _make("cond_first_affine")

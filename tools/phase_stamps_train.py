@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Diagnostic: where does the backward sweep (csrc/train_kernels.h) spend its cycles?  Builds a SEPARATE library with
+"""Diagnostic: where does the backward sweep (csrc/train_block16.h, csrc/train_kernels.h) spend its cycles?  Builds a SEPARATE library with
 -DRNF_STAMPS (the shipped librnf_hip.so contains no stamps), runs one training forward + backward and prints the share of
 wave-0 cycles per phase.
 
-    python tools/phase_stamps_train.py [--preset C2] [--batch 1024]
+    python tools/phase_stamps_train.py [--preset C2] [--batch 1024] [--block 16|64]
 """
 import argparse
 import contextlib
@@ -24,7 +24,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--preset", default="C2")
     ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--block", type=int, default=16, choices=[16, 64], help="rotations per workgroup: csrc/train_block16.h or csrc/train_kernels.h")
     args = ap.parse_args()
+    os.environ["RNF_TRAIN_BLOCK"] = str(args.block)
     out = os.path.join(ROOT, "tools", "_build", "librnf_hip_stamps.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     csrc = os.path.join(ROOT, "rotationnormflow_amd", "csrc")
@@ -55,7 +57,7 @@ def main():
         (-ldj).mean().backward()
         torch.cuda.synchronize()
     s = stamps.cpu().numpy().astype(float)
-    blocks = (args.batch + 63) // 64
+    blocks = (args.batch + args.block - 1) // args.block
     n_mlp = sum(1 for layer in fl.layers if hasattr(layer, "conditioner") or hasattr(layer, "net"))
     n_aff = len(fl.layers) - n_mlp
     print(f"preset={args.preset} batch={args.batch}: wave-0 shader-clock cycles (s_memtime), {blocks} workgroups, "

@@ -238,7 +238,9 @@ int rnf_flow_forward_train(const float *rotation_dev, const float *feature_dev, 
  *      differentiate w.r.t. the inputs: pose refinement, eval.py:464-478), g_rotation_in_dev [n][9],
  *      g_feature_dev [n][F] (accumulated into; may be NULL).
  * Scratch: layer_scratch_dev float[n_layers], zeroed by the caller (batch sums of dL/dldj for the d log|det M| / dM term).
- * Any segment count 1..64, n_layers <= 200. */
+ * Any segment count 1..512 (the conditioner outputs of a 16-rotation block live in LDS), n_layers <= 400 like the forward passes (beyond 200
+ * the sweep runs in chunks of 200 layers; g_rotation_in_dev then also carries the gradient between the chunks and may alias
+ * g_rotation_out_dev). */
 int rnf_flow_backward(const float *states_dev, const float *feature_dev, int64_t n, int32_t feature_dim,
                       const float *plain_dev, const int32_t *train_desc, int32_t n_layers, int32_t segments,
                       const float *g_rotation_out_dev, const float *g_ldj_dev, float *grads_dev, float *g_rotation_in_dev,

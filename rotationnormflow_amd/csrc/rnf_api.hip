@@ -1227,7 +1227,7 @@ extern "C" int rnf_flow_forward_train(const float *rot, const float *feat, int64
 extern "C" int rnf_pack_flow_device(const float *plain, const int32_t *pdesc, int32_t n_layers, int32_t K, int32_t F, int32_t prec,
                                     float *blob, int32_t *flags, void *stream_v) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
-    if (n_layers < 0 || n_layers > PK_MAX_LAYERS) return fail("n_layers=%d outside [0,%d] (device packer)", n_layers, PK_MAX_LAYERS);
+    if (n_layers < 0 || n_layers > MAX_LAYERS) return fail("n_layers=%d outside [0,%d] (device packer)", n_layers, MAX_LAYERS);
     if (K <= 0) return fail("segments=%d must be positive", K);
     if (F < 0) return fail("feature_dim %d is negative", F);
     if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2) return fail("unknown precision %d", prec);
@@ -1248,10 +1248,17 @@ extern "C" int rnf_pack_flow_device(const float *plain, const int32_t *pdesc, in
         if (d[1] < 0 || d[2] < 0 || d[2] % 4 || (d[3] >= 0 && d[3] % 4)) return fail("layer %d: bad offsets", l);
         if ((kind == RNF_KIND_COND16 || kind == RNF_KIND_COND36 || kind_is_cond9(kind)) && F == 0) return fail("layer %d: a conditional affine layer needs a feature", l);
         if (kind_has_mlp(kind) && (F > 0) != (d[3] >= 0)) return fail("layer %d: feature record offset does not match feature_dim", l);
-        a.layers[l] = PackLayer{d[0], d[1], d[2], d[3]};
     }
-    hipLaunchKernelGGL(pack_flow_kernel, dim3(8, n_layers), dim3(256), 0, stream, a);
-    HIP_TRY(hipGetLastError());
+    for (int base = 0; base < n_layers; base += PK_MAX_LAYERS) {      // the layer table travels as a kernel argument: PK_MAX_LAYERS per launch
+        const int cnt = n_layers - base < PK_MAX_LAYERS ? n_layers - base : PK_MAX_LAYERS;
+        for (int l = 0; l < cnt; ++l) {
+            const int32_t *d = pdesc + (size_t)(base + l) * 4;
+            a.layers[l] = PackLayer{d[0], d[1], d[2], d[3]};
+        }
+        a.n_layers = cnt;
+        hipLaunchKernelGGL(pack_flow_kernel, dim3(8, cnt), dim3(256), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
@@ -1292,7 +1299,7 @@ static int run_backward(const float *states, const float *rot_final, int dir, co
                         float *g_rot_in, float *g_feature, float *g_ldj_sum, void *stream_v, const BackwardExtra &x) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     if (n < 0) return fail("n=%lld is negative", (long long)n);
-    if (n_layers < 0 || n_layers > TR_MAX_LAYERS) return fail("n_layers=%d outside [0,%d] (training path)", n_layers, TR_MAX_LAYERS);
+    if (n_layers < 0 || n_layers > MAX_LAYERS) return fail("n_layers=%d outside [0,%d] (training path)", n_layers, MAX_LAYERS);
     if (K < 1 || K > 512) return fail("training path supports 1..512 segments, got %d", K);
     if (F < 0) return fail("feature_dim %d is negative", F);
     if (n == 0) return 0;
@@ -1302,6 +1309,7 @@ static int run_backward(const float *states, const float *rot_final, int dir, co
     TrainArgs a;
     std::memset(&a, 0, sizeof(a));
     bool rare = false;        // side / Gram-Schmidt / conditional 3x3 layers present: the instantiation that carries them (train_block16.h)
+    std::vector<int2> table((size_t)n_layers);
     for (int l = 0; l < n_layers; ++l) {
         const int32_t *d = tdesc + (size_t)l * 3;
         const int kind = d[0] & 15, orth = (d[0] >> 8) & 1, aux = (d[0] >> 16) & 255;
@@ -1316,13 +1324,13 @@ static int run_backward(const float *states, const float *rot_final, int dir, co
         if (kind_has_mlp(kind) && F > 0 && !feat) return fail("conditional layer %d but feature pointer is null", l);
         if ((kind == RNF_KIND_COND16 || kind == RNF_KIND_COND36 || kind_is_cond9(kind)) && F == 0) return fail("layer %d: a conditional affine layer needs a feature", l);
         if (d[2] < 0) return fail("layer %d: negative plain offset", l);
-        a.layers[l] = make_int2(kind | (d[1] << 4) | (orth << 8) | (aux << 16), d[2]);
+        table[l] = make_int2(kind | (d[1] << 4) | (orth << 8) | (aux << 16), d[2]);
     }
     a.side = x.side; a.side_grad = x.side_grad; a.g_out_ext = x.g_out_ext;
-    a.states = states; a.feature = F ? feat : nullptr; a.plain = plain; a.grads = grads; a.g_rot_out = g_rot_out; a.g_ldj = g_ldj;
-    a.g_rot_in = g_rot_in; a.g_feature = F ? g_feature : nullptr; a.g_ldj_sum = g_ldj_sum;
-    a.n = n; a.n_layers = n_layers; a.K = K; a.F = F;
-    a.dir = dir; a.rot_final = rot_final;
+    a.feature = F ? feat : nullptr; a.plain = plain; a.grads = grads; a.g_ldj = g_ldj;
+    a.g_rot_in = g_rot_in; a.g_feature = F ? g_feature : nullptr;
+    a.n = n; a.K = K; a.F = F;
+    a.dir = dir;
 #ifdef RNF_STAMPS
     {   // diagnostic build: RNF_TRAIN_STAMPS_PTR=<device address of 10 zeroed uint64> (tools/phase_stamps_train.py)
         const char *sp = std::getenv("RNF_TRAIN_STAMPS_PTR");
@@ -1335,40 +1343,53 @@ static int run_backward(const float *states, const float *rot_final, int dir, co
     const int blk_sel = train_block();
     const bool block16 = blk_sel == 16 || K > 64 || (blk_sel == 0 && n < kTrainBlock64From);
     if (blk_sel == 64 && K > 64) return fail("RNF_TRAIN_BLOCK=64: the 64-rotation backward kernel holds at most 64 segments, got %d", K);
-    if (block16) {
-        const size_t lds_bytes = sizeof(float) * (b16::HEAD_FLOATS + rows * b16::LR);
-        const long long nblocks = (n + b16::SB - 1) / b16::SB;
-        const long long per_cu = (long long)(160 * 1024 / lds_bytes) < 4 ? (long long)(160 * 1024 / lds_bytes) : 4;
-        const long long cap = (long long)device_cus() * (per_cu < 1 ? 1 : per_cu) * 2;
-        const dim3 grid((unsigned)(nblocks < cap ? nblocks : cap)), block(b16::WAVES * 64);
-        auto launch16 = [&](auto kern) -> int {
-            HIP_TRY(allow_lds(kern, lds_bytes));
-            hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
-            return 0;
-        };
-        int rc;
-        if (F) rc = rare ? launch16(b16::flow_train_backward16_kernel<true, true>) : launch16(b16::flow_train_backward16_kernel<true, false>);
-        else rc = rare ? launch16(b16::flow_train_backward16_kernel<false, true>) : launch16(b16::flow_train_backward16_kernel<false, false>);
-        if (rc) return rc;
-    } else {
-        const size_t lds_bytes = sizeof(float) * (TR_LDS_HEAD_FLOATS + rows * LROW);
-        const long long nblocks = (n + 63) / 64;
-        const int cap = device_cus() * 4;
-        const dim3 grid((unsigned)(nblocks < cap ? nblocks : cap)), block(TR_WAVES * 64);
-        if (F) {
-            auto kern = flow_train_backward_kernel<true>;
-            HIP_TRY(allow_lds(kern, lds_bytes));
-            hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+    // The layer table travels as a kernel argument, TR_MAX_LAYERS entries per launch: a deeper stack is swept in chunks from the top, each
+    // chunk starting from the rotation gradient the previous one left in g_rot_in (read at the start of a block, written at its end, by the
+    // same workgroup) and reading its own slice of the saved states; dL/dldj is the same per-rotation value for every layer.
+    for (int hi = n_layers; hi > 0 || n_layers == 0; ) {
+        const int lo = hi > TR_MAX_LAYERS ? hi - TR_MAX_LAYERS : 0;
+        for (int l = lo; l < hi; ++l) a.layers[l - lo] = table[l];
+        a.n_layers = hi - lo;
+        a.states = states ? states + (size_t)lo * (size_t)n * 9 : nullptr;
+        a.rot_final = hi == n_layers ? rot_final : states + (size_t)hi * (size_t)n * 9;      // (dir = 1: the output of the chunk's last position)
+        a.g_rot_out = hi == n_layers ? g_rot_out : g_rot_in;
+        a.g_ldj_sum = g_ldj_sum + lo;
+        if (block16) {
+            const size_t lds_bytes = sizeof(float) * (b16::HEAD_FLOATS + rows * b16::LR);
+            const long long nblocks = (n + b16::SB - 1) / b16::SB;
+            const long long cap = (long long)device_cus() * 4;
+            const dim3 grid((unsigned)(nblocks < cap ? nblocks : cap)), block(b16::WAVES * 64);
+            auto launch16 = [&](auto kern) -> int {
+                HIP_TRY(allow_lds(kern, lds_bytes));
+                hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+                return 0;
+            };
+            int rc;
+            if (F) rc = rare ? launch16(b16::flow_train_backward16_kernel<true, true>) : launch16(b16::flow_train_backward16_kernel<true, false>);
+            else rc = rare ? launch16(b16::flow_train_backward16_kernel<false, true>) : launch16(b16::flow_train_backward16_kernel<false, false>);
+            if (rc) return rc;
         } else {
-            auto kern = flow_train_backward_kernel<false>;
-            HIP_TRY(allow_lds(kern, lds_bytes));
-            hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+            const size_t lds_bytes = sizeof(float) * (TR_LDS_HEAD_FLOATS + rows * LROW);
+            const long long nblocks = (n + 63) / 64;
+            const int cap = device_cus() * 4;
+            const dim3 grid((unsigned)(nblocks < cap ? nblocks : cap)), block(TR_WAVES * 64);
+            if (F) {
+                auto kern = flow_train_backward_kernel<true>;
+                HIP_TRY(allow_lds(kern, lds_bytes));
+                hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+            } else {
+                auto kern = flow_train_backward_kernel<false>;
+                HIP_TRY(allow_lds(kern, lds_bytes));
+                hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+            }
         }
-    }
-    HIP_TRY(hipGetLastError());
-    if (n_layers) {
-        hipLaunchKernelGGL(affine_logdet_grad_kernel, dim3((n_layers + 63) / 64), dim3(64), 0, stream, a);
         HIP_TRY(hipGetLastError());
+        if (a.n_layers) {
+            hipLaunchKernelGGL(affine_logdet_grad_kernel, dim3((a.n_layers + 63) / 64), dim3(64), 0, stream, a);
+            HIP_TRY(hipGetLastError());
+        }
+        hi = lo;
+        if (n_layers == 0) break;
     }
     return 0;
 }

@@ -3,17 +3,25 @@
 // Same phases, same reverse-mode formulas (so3_grad.h), same plain / gradient blob layout as flow_train_backward_kernel; what changes is
 // the shape of the work a workgroup owns.  The 64-rotation kernel keeps 150 KB of LDS per workgroup (one per CU), gives every wave a
 // 32 x 32 x 64 product (32 dependent v_mfma_f32_32x32x2_f32, 64 cycles each) per matrix and fills 16 CUs at the reference's batch of 1024
-// (settings/*.yml).  Here a workgroup of 4 waves owns 16 rotations:
+// (settings/*.yml).  Here a workgroup of 8 waves owns 16 rotations:
 //   * activations live in LDS as [feature][16 samples] (rows of 17 floats): 22 KB + 68 B per conditioner-output row, so the segment
-//     count is bounded by LDS at K <= 500 instead of 64, and up to four workgroups share a CU;
+//     count is bounded by LDS at K <= 512 instead of 64;
 //   * every product is tiled 16 x 16 on v_mfma_f32_16x16x4_f32 (32 cycles): a wave owns 16 output rows of a 64-row product
 //     (16 matrix instructions + the bias step), and the weight-gradient products sum over the 16 samples in 4 steps;
-//   * the per-rotation layer math runs with 16 threads per rotation: the K segments of a Moebius layer are split 16 ways
+//   * WAVE SPECIALISATION: waves 0..3 ("chain") carry the dependent chain -- forward recompute, per-rotation layer math, data gradients
+//     (W^T g) -- and waves 4..7 ("gradient") run every weight-gradient product (g act^T, bias sums) and its float atomics in the SAME
+//     barrier window in which the chain runs the matching data-gradient product, plus half of the fc_last tiles of the forward
+//     recompute.  Both groups execute the same sequence of workgroup barriers (gfx950 has one barrier per workgroup); the data a
+//     gradient wave reads in a window is exactly what the chain leaves untouched until the window's closing barrier.  The fc_last weight
+//     gradient (the largest: 4K x 64) is split: half beside the chain's WL^T product, half after the layer's last barrier, beside the
+//     chain's constant layer and the next layer's x0 (its inputs -- dL/dC in LDS, t in registers -- stay valid until the next fc_last);
+//   * the per-rotation layer math runs with 16 threads per rotation (chain waves): the K segments of a Moebius layer are split 16 ways
 //     (4 lane groups x 4 waves), partial sums meet through two lane shuffles and one LDS exchange;
 //   * bias gradients are one more matrix instruction against a column of ones instead of an LDS reduction loop.
 // A batch of 1024 rotations is 64 workgroups, each with a quarter of the dependent matrix chain.  The price: every workgroup adds a
-// full-size weight gradient with float atomics and streams every weight matrix from L2, four times as many as with 64-rotation blocks --
-// rnf_api.hip picks the block size by batch (RNF_TRAIN_BLOCK=16|64 overrides).
+// full-size weight gradient with float atomics (executed at the memory side at ~1.3 TB/s chip-wide, MI355X_MICROARCH.md) and streams
+// every weight matrix from L2, four times as much as with 64-rotation blocks -- rnf_api.hip picks the block size by batch
+// (RNF_TRAIN_BLOCK=16|64 / rnf_set_train_block override).  Measured: profiles/README.md "Training".
 //
 // Lane (c, q) = (lane & 15, lane >> 4).  v_mfma_f32_16x16x4_f32: A[i = c][k = q], B[k = q][n = c], D register r = D[4q + r][c].
 // K steps of a 64-deep product are ordered k = 16q + m (m = 0..15) so that a lane's A operands are 16 consecutive floats of a weight
@@ -27,7 +35,8 @@ namespace b16 {
 
 constexpr int SB = 16;                  // rotations per workgroup
 constexpr int LR = 17;                  // LDS row stride (floats)
-constexpr int WAVES = 4;
+constexpr int CHAIN = 4;                 // waves 0..3: the dependent chain (forward recompute, layer math, data gradients)
+constexpr int WAVES = 8;                 // waves 4..7: the weight-gradient products and their atomics, beside the chain
 constexpr int HEAD_FLOATS = 5 * 64 * LR + 4 * LR;        // X0, H1, H2, H3, GA, YL
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RNF_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -143,7 +152,7 @@ __device__ __forceinline__ void store_tile(const Mat &M, int o0, int n_out, int 
     }
 }
 
-// Sum of per-thread partial values over the 16 threads that share a rotation (4 lane groups x 4 waves).  `red` needs WAVES * N * 16
+// Sum of per-thread partial values over the 16 threads that share a rotation (4 lane groups x 4 chain waves).  `red` needs CHAIN * N * 16
 // floats that no wave is still reading; ends with every thread holding the totals.
 template <int N>
 __device__ __forceinline__ void block_sum(float (&v)[N], float *red, int wave, int q, int c) {
@@ -161,7 +170,7 @@ __device__ __forceinline__ void block_sum(float (&v)[N], float *red, int wave, i
     for (int i = 0; i < N; ++i) {
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) t += red[(w * N + i) * 16 + c];
+        for (int w = 0; w < CHAIN; ++w) t += red[(w * N + i) * 16 + c];
         v[i] = t;
     }
 }
@@ -192,7 +201,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const int grp = 4 * wave + q;                         // which sixteenth of a rotation's segments this thread owns
+    const bool gw = wave >= CHAIN;                        // gradient wave (wave-uniform): no per-rotation state, weight-gradient products only
+    const int w4 = wave & 3;                              // row tile of a 64-row product (chain wave w4 and gradient wave w4 + 4 share it)
+    const int grp = 4 * w4 + q;                           // which sixteenth of a rotation's segments this (chain) thread owns
     const int K = args.K, F = HAS_FEATURE ? args.F : 0;
     const bool want_w = args.grads != nullptr;            // wave-uniform
     // LDS: X0, H1, H2, H3 (pre-activations, later reused for gradients), GA (gradient / reduction scratch), YL (the conditioning column y
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
         Rot gR;
         gR.c0 = v3f{0.f, 0.f, 0.f}; gR.c1 = gR.c0; gR.c2 = gR.c0;
         float g_ldj = 0.f;
-        if (valid) {
+        if (valid && !gw) {
             g_ldj = args.g_ldj ? args.g_ldj[sample] : 0.f;
             if (args.g_rot_out) {
                 const float *g = args.g_rot_out + sample * 9;
@@ -223,6 +234,113 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
             float *Gp = args.grads + d.y;
             Rot Rin;
             Rin.c0 = v3f{1.f, 0.f, 0.f}; Rin.c1 = v3f{0.f, 1.f, 0.f}; Rin.c2 = v3f{0.f, 0.f, 1.f};
+            if (gw) {
+                // ---- gradient waves: the barriers of every layer, the fc_last tiles 4..7 (mod 8) of the forward recompute, and every
+                // weight-gradient product, each in the window in which the chain waves run the matching data-gradient product ----
+                if (RARE && kind == RNF_KIND_GS36 && want_w) { lds_barrier(); lds_barrier(); lds_barrier(); lds_barrier(); }
+                if (!(kind == RNF_KIND_MOBIUS || kind == RNF_KIND_COND16 || kind == RNF_KIND_MLP_ONLY || (RARE && (kind == RNF_KIND_COND36 || kind_is_cond9(kind))))) continue;
+                const bool mob = kind == RNF_KIND_MOBIUS;
+                const int yo = mob ? 3 : 0, NI = yo + F, NO = mob ? 4 * K : (kind == RNF_KIND_MLP_ONLY ? ((d.x >> 16) & 255) : (kind_is_cond9(kind) ? 9 : (kind == RNF_KIND_COND36 ? 36 : 16)));
+                const float *WL = P + 64 * NI + 64 + 3 * (4096 + 64), *bL = WL + (size_t)NO * 64;
+                float *gW0 = Gp, *gb0 = gW0 + 64 * NI, *gW1 = gb0 + 64, *gb1 = gW1 + 4096, *gW3 = gb1 + 64, *gb3 = gW3 + 4096, *gW5 = gb3 + 64,
+                      *gb5 = gW5 + 4096, *gWL = gb5 + 64, *gbL = gWL + (size_t)NO * 64;
+                const int ntiles = (NO + 15) / 16, row0 = 16 * w4;
+                RowsA wnext = load_rows(WL, bL, 16 * wave + c, NO, q);
+                if (mob) lds_barrier();                   // YL
+                lds_barrier();                            // x0
+                lds_barrier(); lds_barrier(); lds_barrier();      // h1, h2, t
+                const Mat &T = H3;
+                {
+                    float tv[16];
+                    read_b(T, 0, q, c, tv);
+                    for (int rt = wave; rt < ntiles; rt += WAVES) {
+                        const RowsA wl = wnext;
+                        if (rt + WAVES < ntiles) wnext = load_rows(WL, bL, 16 * (rt + WAVES) + c, NO, q);
+                        store_tile(Cm, 16 * rt, NO, q, c, mfma_rows(wl, q, tv));
+                    }
+                }
+                float tb[4][4];                           // t over the samples, B side of gWL: read now, used after the layer math
+                if (want_w) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) read_s(T, 16 * ct + c, q, tb[ct]);
+                }
+                lds_barrier();                            // C
+                lds_barrier(); lds_barrier();             // the two exchanges of the layer math; dL/dC is in place
+                // fc_last: gWL += g_c t^T, gbL += rowsum(g_c).  dL/dC stays in place until the NEXT conditioner layer's fc_last (behind four
+                // barriers these waves join), and t is in registers: half of this wave's row tiles now, beside the chain's WL^T product; the
+                // other half after the layer's last barrier, beside the chain's constant layer and the next x0 (where these waves would idle)
+                auto last_wgrad = [&](int rt_begin, int rt_end) {
+                    for (int rt = rt_begin; rt < rt_end; rt += CHAIN) {
+                        float av[4];
+                        read_s(Cm, 16 * rt + c, q, av);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) scatter_add(gWL, 64, 16 * rt, NO, 16 * ct + c, true, q, mfma_s(av, tb[ct]));
+                        bias_add(gbL, 16 * rt, NO, q, c, mfma_s1(av));
+                    }
+                };
+                const int my_tiles = ntiles > w4 ? (ntiles - w4 + CHAIN - 1) / CHAIN : 0;      // row tiles w4, w4 + 4, ...
+                const int rt_split = w4 + CHAIN * ((my_tiles + 1) / 2);
+                if (want_w) last_wgrad(w4, rt_split < ntiles ? rt_split : ntiles);
+                lds_barrier(); lds_barrier();             // g_t stored
+                auto hidden_wgrad = [&](float *gW, float *gb, const Mat &Gout, const Mat &PreIn) {
+                    if (want_w) {
+                        float av[4], bv[4][4];
+                        read_s(Gout, row0 + c, q, av);
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) read_s(PreIn, 16 * ct + c, q, bv[ct]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) bv[ct][m] = Relu()(bv[ct][m]);
+                            scatter_add(gW, 64, row0, 64, 16 * ct + c, true, q, mfma_s(av, bv[ct]));
+                        }
+                        bias_add(gb, row0, 64, q, c, mfma_s1(av));
+                    }
+                    lds_barrier(); lds_barrier();         // the chain's store of the next gradient
+                };
+                hidden_wgrad(gW5, gb5, GA, H2);
+                hidden_wgrad(gW3, gb3, H3, H1);
+                hidden_wgrad(gW1, gb1, H2, X0);
+                lds_barrier();                            // total dL/dx0 (H3's storage)
+                if (want_w) {                             // fc_first: gb0, gW0[:, 0:3] += g y^T, gW0[:, yo:] += g f^T
+                    const Mat GB = H3;
+                    float ga[4];
+                    read_s(GB, row0 + c, q, ga);
+                    bias_add(gb0, row0, 64, q, c, mfma_s1(ga));
+                    if (mob) {
+                        float yb[4];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) yb[m] = YL.at(c < 3 ? c : 0, 4 * m + q);
+                        scatter_add(gW0, NI, row0, 64, c, c < 3, q, mfma_s(ga, yb));
+                    }
+                    if (HAS_FEATURE) {                    // this wave's row tile x ceil(F/16) column tiles, four tiles' loads in flight
+                        const int ctiles = (F + 15) / 16;
+                        for (int ct0 = 0; ct0 < ctiles; ct0 += 4) {
+                            float fb[4][4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int cc = 16 * (ct0 + u) + c;
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) {
+                                    const long long smp = blk * SB + 4 * m + q;
+                                    fb[u][m] = args.feature[(smp < args.n ? smp : args.n - 1) * F + (cc < F ? cc : F - 1)];
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {     // (rows of padding rotations: their g is exactly 0)
+                                const int cc = 16 * (ct0 + u) + c;
+                                scatter_add(gW0 + yo, NI, row0, 64, cc, cc < F, q, mfma_s(ga, fb[u]));
+                            }
+                        }
+                    }
+                }
+                lds_barrier();
+                if (want_w) last_wgrad(rt_split, ntiles);
+                continue;
+            }
             if (valid && args.states) {
                 const float *s = args.states + ((size_t)pos * args.n + sample) * 9;
                 Rin.c0 = v3f{s[0], s[3], s[6]}; Rin.c1 = v3f{s[1], s[4], s[7]}; Rin.c2 = v3f{s[2], s[5], s[8]};
@@ -351,7 +469,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
             const int p1 = (perm_row + 1) % 3;
             const v3f y = get_col(Rin, p1);
             const int ntiles = (NO + 15) / 16;            // 16-row tiles of fc_last
-            const int row0 = 16 * wave;                   // this wave's rows of a 64-row product
+            const int row0 = 16 * w4;                     // this wave's rows of a 64-row product
 
             // ================= forward recompute =================
             RowsA wnext = load_rows(W1, b1, row0 + c, 64, q);
@@ -474,7 +592,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
                 v3f pr = v3f{0.f, 0.f, 0.f}, pv = pr;
                 mobius_segments_backward_range_at(sv.b.f, sv.cs, sv.sn, sv.theta, crow, K, k0s, k1s, mg, crow, pr, pv);
                 float pp[6] = {pr.x, pr.y, pr.z, pv.x, pv.y, pv.z};
-                block_sum<6>(pp, red + WAVES * 4 * 16, wave, q, c);
+                block_sum<6>(pp, red + CHAIN * 4 * 16, wave, q, c);
                 mg.g_r = mg.g_r + v3f{pp[0], pp[1], pp[2]};
                 mg.g_v = mg.g_v + v3f{pp[3], pp[4], pp[5]};
                 mobius_backward_tail(sv.b, mg, gRin);
@@ -490,7 +608,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
                 v3f pr = v3f{0.f, 0.f, 0.f}, pv = pr;
                 mobius_segments_backward_range(sv, crow, K, k0s, k1s, mg, crow, pr, pv);
                 float pp[6] = {pr.x, pr.y, pr.z, pv.x, pv.y, pv.z};
-                block_sum<6>(pp, red + WAVES * 4 * 16, wave, q, c);
+                block_sum<6>(pp, red + CHAIN * 4 * 16, wave, q, c);
                 mg.g_r = mg.g_r + v3f{pp[0], pp[1], pp[2]};
                 mg.g_v = mg.g_v + v3f{pp[3], pp[4], pp[5]};
                 mobius_backward_tail(sv, mg, gRin);
@@ -554,20 +672,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
 
             RNF_TSTAMP(3)
             // ================= conditioner backward =================
-            // fc_last: gWL += g_c t^T, gbL += rowsum(g_c), g_t = WL^T g_c
-            if (want_w) {
-                float tb[4][4];
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) read_s(T, 16 * ct + c, q, tb[ct]);
-                for (int rt = wave; rt < ntiles; rt += WAVES) {
-                    float av[4];
-                    read_s(Cm, 16 * rt + c, q, av);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) scatter_add(gWL, 64, 16 * rt, NO, 16 * ct + c, true, q, mfma_s(av, tb[ct]));
-                    bias_add(gbL, 16 * rt, NO, q, c, mfma_s1(av));
-                }
-            }
+            // fc_last: g_t = WL^T g_c (the gradient waves add gWL, gbL meanwhile)
             RNF_TSTAMP(4)
             {
                 f32x4 acc = zero4();
@@ -594,23 +699,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
             RNF_TSTAMP(5)
             // hidden layers, last to first.  (g_out, act_in) -> gW, gb, g_in masked by the ReLU of its pre-activation.
             // cnext holds the transposed weights of this step; Wnext: the matrix of the FOLLOWING step (loaded ahead), or nullptr
-            auto hidden_backward = [&](float *gW, float *gb, const Mat &Gout, const Mat &PreIn, const Mat &Gin, const float *Wnext) {
+            auto hidden_backward = [&](const Mat &Gout, const Mat &PreIn, const Mat &Gin, const float *Wnext) {
                 const ColsA cur = cnext;
                 if (Wnext) cnext = load_cols(Wnext, 64, 0, 64, row0 + c, 64, q);
-                if (want_w) {
-                    float av[4], bv[4][4];
-                    read_s(Gout, row0 + c, q, av);
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) read_s(PreIn, 16 * ct + c, q, bv[ct]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) bv[ct][m] = Relu()(bv[ct][m]);
-                        scatter_add(gW, 64, row0, 64, 16 * ct + c, true, q, mfma_s(av, bv[ct]));
-                    }
-                    bias_add(gb, row0, 64, q, c, mfma_s1(av));
-                }
                 float gv[16];
                 read_b(Gout, 0, q, c, gv);
                 f32x4 acc = mfma_cols(cur, gv, zero4());
@@ -627,9 +718,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
                 lds_barrier();
             };
             // (each activation buffer is free once its ReLU mask has been applied, and takes the next gradient)
-            hidden_backward(gW5, gb5, GA, H2, H3, W3);    // g_h3 (GA) -> g_h2 (H3's storage)
-            hidden_backward(gW3, gb3, H3, H1, H2, W1);    // g_h2      -> g_h1 (H2's storage)
-            hidden_backward(gW1, gb1, H2, X0, H1, nullptr);   // g_h1  -> chain part of g_x0 (H1's storage)
+            hidden_backward(GA, H2, H3, W3);    // g_h3 (GA) -> g_h2 (H3's storage)
+            hidden_backward(H3, H1, H2, W1);    // g_h2      -> g_h1 (H2's storage)
+            hidden_backward(H2, X0, H1, nullptr);   // g_h1  -> chain part of g_x0 (H1's storage)
             RNF_TSTAMP(6)
             const Mat GB = H3;                            // total dL/dx0 = chain + residual
             {
@@ -642,17 +733,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
             }
             lds_barrier();
             // fc_first: x0 = W0 (y (+) f) + b0
-            float ga[4];                                  // this wave's 16 rows of dL/dx0 over the samples (A side of the weight gradients)
-            read_s(GB, row0 + c, q, ga);
-            if (want_w) {
-                bias_add(gb0, row0, 64, q, c, mfma_s1(ga));
-                if (mob) {                                // gW0[:, 0:3] += g y^T: columns 0..2 of one 16-column tile
-                    float yb[4];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) yb[m] = YL.at(c < 3 ? c : 0, 4 * m + q);
-                    scatter_add(gW0, NI, row0, 64, c, c < 3, q, mfma_s(ga, yb));
-                }
-            }
             float gv[16];                                 // dL/dx0[16q + m][this rotation]: B side of W0^T g, A side of g^T W0
             if (mob || HAS_FEATURE) read_b(GB, 0, q, c, gv);
             if (mob) {
@@ -671,32 +751,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
             }
             if (HAS_FEATURE) {
                 const int ctiles = (F + 15) / 16;
-                // gW0[o][yo + cc] += sum_s g[o][s] f[s][cc]: this wave's row tile x ceil(F/16) column tiles, four tiles' loads in flight
-                if (want_w) {
-                    for (int ct0 = 0; ct0 < ctiles; ct0 += 4) {
-                        float fb[4][4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int cc = 16 * (ct0 + u) + c;
-#pragma unroll
-                            for (int m = 0; m < 4; ++m) {
-                                const long long smp = blk * SB + 4 * m + q;
-                                fb[u][m] = args.feature[(smp < args.n ? smp : args.n - 1) * F + (cc < F ? cc : F - 1)];
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {     // (rows of padding rotations: their g is exactly 0)
-                            const int cc = 16 * (ct0 + u) + c;
-                            scatter_add(gW0 + yo, NI, row0, 64, cc, cc < F, q, mfma_s(ga, fb[u]));
-                        }
-                    }
-                }
-                asm volatile("" ::: "memory");
                 if (args.g_feature) {
                     // g_f[s][cc] = sum_o g[o][s] W0[o][yo + cc]: D[rotation][feature column]; A = g^T (gv), B = rows of W0 (coalesced over the
                     // feature index); the tile lands feature-contiguous for the read-modify-write
-                    for (int ct = wave; ct < ctiles; ct += WAVES) {
+                    for (int ct = w4; ct < ctiles; ct += CHAIN) {
                         const int cc = 16 * ct + c, ccl = cc < F ? cc : F - 1;
                         float bw[16];
                         const float *wp = W0 + (size_t)(16 * q) * NI + yo + ccl;
@@ -718,6 +776,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
             gR = gRin;
             RNF_TSTAMP(7)
         }
+        lds_barrier();                                    // g_rot_in may BE g_rot_out (chunked sweeps, rnf_api.hip): every wave has read its copy
         if (valid && writer && args.g_rot_in) {
             float *o = args.g_rot_in + sample * 9;
             o[0] = gR.c0.x; o[1] = gR.c1.x; o[2] = gR.c2.x; o[3] = gR.c0.y; o[4] = gR.c1.y; o[5] = gR.c2.y; o[6] = gR.c0.z; o[7] = gR.c1.z; o[8] = gR.c2.z;

@@ -922,6 +922,7 @@ __global__ __launch_bounds__(TR_WAVES * 64) void flow_train_backward_kernel(cons
             gR = gRin;
             RNF_TSTAMP(7)
         }
+        lds_barrier();                                    // g_rot_in may BE g_rot_out (chunked sweeps, rnf_api.hip): every wave has read its copy
         if (valid && wave == 0 && args.g_rot_in) {
             float *o = args.g_rot_in + sample * 9;
             o[0] = gR.c0.x; o[1] = gR.c1.x; o[2] = gR.c2.x; o[3] = gR.c0.y; o[4] = gR.c1.y; o[5] = gR.c2.y; o[6] = gR.c0.z; o[7] = gR.c1.z; o[8] = gR.c2.z;

@@ -179,7 +179,7 @@ def test_argument_validation_happens_before_any_gpu_work():
     tdesc = np.array([[1, 0, 0]], np.int32)
     args = (None, None, 64, 0, None, tdesc.ctypes.data, 1, 513, None, None, None, None, None, None, None)      # K <= 512 (LDS of a 16-rotation block)
     assert L.rnf_flow_backward(*args) != 0 and "segments" in err()
-    args = (None, None, 64, 0, None, tdesc.ctypes.data, 300, 64, None, None, None, None, None, None, None)
+    args = (None, None, 64, 0, None, tdesc.ctypes.data, 401, 64, None, None, None, None, None, None, None)        # <= 400 layers, like the forward passes
     assert L.rnf_flow_backward(*args) != 0 and "n_layers" in err()
     args = (None, None, 0, 0, None, tdesc.ctypes.data, 1, 64, None, None, None, None, None, None, None)
     assert L.rnf_flow_backward(*args) == 0                                  # empty batch: nothing to do

@@ -557,6 +557,38 @@ def test_backward_block_size_follows_the_batch(train_block):
         ldj.sum().backward()
 
 
+@pytest.mark.parametrize("block", [16, 64])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_training_a_flow_deeper_than_one_layer_table(block, inverse, train_block):
+    """220 layers (110 Moebius + 110 affine): the device packer and the backward sweep take 200 table entries per launch and run such a
+    stack in chunks -- the rotation gradient passes from chunk to chunk through g_rot_in, in place (round 3; refused before)."""
+    cfg = orc.make_config(layers=110, segments=8)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=61, regime="default")
+    n = 40
+    R = synth.uniform_rotations(n, seed=62)
+    rng = np.random.default_rng(63)
+    gR, gl = rng.standard_normal((n, 3, 3)).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    p = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in w.items()}
+    Rt = torch.from_numpy(R).double().requires_grad_(True)
+    run = orc.flow_inverse if inverse else orc.flow_forward
+    Ro_w, ldj_w = run(cfg, p, Rt, None, dtype=torch.float64, grad=True)
+    ((Ro_w * torch.from_numpy(gR).double()).sum() + (ldj_w * torch.from_numpy(gl).double()).sum()).backward()
+    train_block(block)
+    fl = product_flow(cfg, w).train()
+    assert len(fl.layers) == 220
+    Rd = torch.from_numpy(R).cuda().requires_grad_(True)
+    Ro, ldj = fl.inverse(Rd) if inverse else fl(Rd)
+    ((Ro * torch.from_numpy(gR).cuda()).sum() + (ldj * torch.from_numpy(gl).cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    rel = 2e-3          # 220 layers of fp32 against fp64: the first layer's gradients sit at 6e-4 (both kernels alike: it is the states' noise)
+    for k, prm in fl.named_parameters():
+        g_want = p[k].grad.numpy()
+        err = np.abs(prm.grad.cpu().numpy().astype(np.float64) - g_want).max() / max(np.abs(g_want).max(), 1e-3)
+        assert err < rel, (k, err)
+    tg, tw = tangent(R.astype(np.float64), Rd.grad.cpu().numpy().astype(np.float64)), tangent(R.astype(np.float64), Rt.grad.numpy())
+    assert np.abs(tg - tw).max() / max(np.abs(tw).max(), 1e-3) < rel
+
+
 @pytest.mark.parametrize("n", [0, 1, 17, 65])
 def test_training_on_tiny_and_ragged_batches(n):
     """Empty batch: zero gradients, no launch.  1 and 65 rotations: one nearly empty workgroup / one full + one with a single lane."""

@@ -49,6 +49,20 @@ python3 tools/parity_stats.py > $OUT/parity_stats.jsonl 2>/dev/null
 python3 tools/inverse_stats.py > $OUT/inverse_stats.jsonl 2>/dev/null
 python3 tools/bench_train.py > $OUT/train.json 2>/dev/null
 python3 tools/bench_train.py --graph > $OUT/train_graph.json 2>/dev/null
+# training: the two backward kernels (16- / 64-rotation workgroups) over the batch sizes, C4, phase stamps, kernel times of one eager iteration
+: > $OUT/train_blocks.jsonl
+for blk in 16 64; do
+  for b in 256 1024 2048 4096 8192 65536; do
+    RNF_TRAIN_BLOCK=$blk python3 tools/bench_train.py --graph --batch $b --steps 200 2>/dev/null | sed "s/^{/{\"block\": $blk, /" >> $OUT/train_blocks.jsonl
+  done
+  RNF_TRAIN_BLOCK=$blk python3 tools/bench_train.py --graph --config C4 --batch 128 --steps 200 2>/dev/null | sed "s/^{/{\"block\": $blk, /" >> $OUT/train_blocks.jsonl
+done
+python3 tools/phase_stamps_train.py --block 16 > $OUT/train_stamps_c2_b1024_block16.txt 2>&1
+python3 tools/phase_stamps_train.py --block 64 > $OUT/train_stamps_c2_b1024_block64.txt 2>&1
+python3 tools/phase_stamps_train.py --block 16 --preset C4 --batch 128 > $OUT/train_stamps_c4_b128_block16.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_train -o run -- python3 $REPO/tools/bench_train.py --batch 1024 --steps 30 --fused-adam > $OUT/train_under_rocprofv3.json 2> $OUT/stats_train.err)
+find $OUT/stats_train -name "*kernel_stats.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_train.csv \;
+rm -rf $OUT/stats_train
 find $OUT -name "*.csv" -size +1M -delete
 find $OUT -name "*.db" -delete
 rm -rf $OUT/stats_C2 $OUT/stats_C4 $OUT/stats_C5 $OUT/stats_C5u

@@ -232,6 +232,15 @@ int rnf_flow_forward_train(const float *rotation_dev, const float *feature_dev, 
                            float *rotation_out_dev, float *ldj_out_dev, float *states_dev, void *workspace_dev,
                            size_t workspace_bytes, void *stream);
 
+/* rnf_flow_forward_train for small batches, from the PLAIN parameter blob (the layout rnf_flow_backward reads: no packing step) on
+ * 16-rotation workgroups in exact fp32 (csrc/train_block16.h) -- the arithmetic of the backward sweep's own forward recompute.  Replaces
+ * Flow.forward inside the training step (agent.py:75-92) for flows made of Moebius, Uncondition16Trans / UnconditionRot and
+ * Condition16Trans layers, n_layers <= 200, segments <= 512; other flows are refused (use rnf_flow_forward_train).  train_desc: the
+ * table of rnf_flow_backward; feature_dev [n][feature_dim], unpadded. */
+int rnf_flow_forward_train_plain(const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim,
+                                 const float *plain_dev, const int32_t *train_desc, int32_t n_layers, int32_t segments,
+                                 float *rotation_out_dev, float *ldj_out_dev, float *states_dev, void *stream);
+
 /* Reverse sweep of Flow.forward (what autograd does for the reference, agent.py:79-80).
  * In : g_rotation_out_dev [n][9] (NULL = zeros), g_ldj_dev [n].
  * Out: grads_dev (plain layout, ACCUMULATED into: zero it first; NULL = skip every parameter gradient, for callers that only

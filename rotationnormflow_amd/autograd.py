@@ -93,6 +93,22 @@ class TrainPlan:
         self.flags_event = None
         self.feature_ms = None
 
+    # batches below this many rotations take the 16-rotation training forward (measured crossover against the fused stack kernel:
+    # profiles/README.md "Training"); RNF_TRAIN_FORWARD=stack|block16 forces one of them
+    PLAIN_FORWARD_BELOW = 12288
+
+    def plain_forward(self, n):
+        """Whether a training forward of ``n`` rotations runs from the plain blob on 16-rotation workgroups (rnf_flow_forward_train_plain):
+        flows of Moebius / constant 4x4 / Condition16Trans layers, at most 200 layers."""
+        import os
+        mode = os.environ.get("RNF_TRAIN_FORWARD", "")
+        if mode == "stack" or self.n_side or self.n_layers > 200 or self.n_layers < 1:
+            return False
+        kinds = set(int(k) & 15 for k in self.train_desc[:, 0])
+        if not kinds <= {runtime.KIND_MOBIUS, runtime.KIND_AFFINE16, runtime.KIND_COND16}:
+            return False
+        return mode == "block16" or n < self.PLAIN_FORWARD_BELOW
+
     def calibrate(self, feature):
         """Mean square of the feature entries, measured ONCE per plan on the first batch it sees (a training run keeps its feature
         distribution): the data-dependent input of the device packer's equalisation (csrc/equalize.h)."""
@@ -197,7 +213,18 @@ class _FlowFn(torch.autograd.Function):
             if side is None or tuple(side.shape) != (plan.n_side, n, 16):
                 raise RuntimeError("side-layer matrices are missing or mis-shaped")
             side_c = side.to(device=dev, dtype=f32).contiguous()
-        if n:
+        feat_plain = None
+        if plan.feat_dim and feature is not None:
+            feat_plain = feature.reshape(n, plan.feat_dim).to(device=dev, dtype=torch.float32).contiguous()
+        if n and direction == 0 and plan.plain_forward(n):
+            # small batches: the forward on 16-rotation workgroups straight from the plain blob (csrc/train_block16.h), no packing launch
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                _lib.check(L.rnf_flow_forward_train_plain(rot.data_ptr(), feat_plain.data_ptr() if (feat_plain is not None and plan.n_cond) else None,
+                                                          n, plan.feat_dim if plan.n_cond else 0, plain.data_ptr(), plan.train_desc.ctypes.data,
+                                                          plan.n_layers, plan.segments, out_rot.data_ptr(), out_ldj.data_ptr(),
+                                                          states.data_ptr(), stream))
+        elif n:
             ws = runtime.workspace(dev, L.rnf_workspace_bytes_segments(n, plan.n_cond, plan.segments))     # (+ the K > 128 stash of an inverse pass)
             fptr = feat.data_ptr() if feat is not None else None
             with torch.cuda.device(dev):
@@ -213,9 +240,6 @@ class _FlowFn(torch.autograd.Function):
                     fn = L.rnf_flow_inverse_train if direction else L.rnf_flow_forward_train
                     _lib.check(fn(rot.data_ptr(), fptr, n, plan.feat_padded, blob.data_ptr(), plan.desc.ctypes.data, plan.n_layers,
                                   plan.segments, out_rot.data_ptr(), out_ldj.data_ptr(), states.data_ptr(), ws.data_ptr(), ws.numel(), stream))
-        feat_plain = None
-        if plan.feat_dim and feature is not None:
-            feat_plain = feature.reshape(n, plan.feat_dim).to(device=dev, dtype=torch.float32).contiguous()
         ctx.plan = plan
         ctx.grad_sync = grad_sync
         ctx.direction = direction

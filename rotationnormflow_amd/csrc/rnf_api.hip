@@ -670,6 +670,13 @@ static int train_block() {
     }
     return g_train_block;
 }
+// Layers per launch of the device packer and of the backward sweep (their layer tables are kernel arguments): the table capacity, or fewer
+// with RNF_LAYER_CHUNK=<n> in the environment -- a test switch: a chunked sweep must reproduce the single launch (tests/test_gpu_grad.py).
+static int layer_chunk(int capacity) {
+    const char *e = std::getenv("RNF_LAYER_CHUNK");
+    const int v = e ? std::atoi(e) : 0;
+    return (v >= 1 && v < capacity) ? v : capacity;
+}
 extern "C" int rnf_set_train_block(int rotations) {
     const int prev = train_block();
     g_train_block = (rotations == 16 || rotations == 64) ? rotations : 0;
@@ -1224,6 +1231,53 @@ extern "C" int rnf_flow_forward_train(const float *rot, const float *feat, int64
     return run_flow(rot, feat, n, F, blob, desc, n_layers, K, rot_out, ldj_out, ws, ws_bytes, stream, o);
 }
 
+// Training forward from the plain blob on 16-rotation workgroups (train_block16.h: flow_train_forward16_kernel): no packed blob, exact fp32.
+// Built for the layer kinds of the reference's training recipes (Moebius, Uncondition16Trans / UnconditionRot, Condition16Trans) in the
+// forward direction, at most TR_MAX_LAYERS layers; the caller keeps every other flow on rnf_flow_forward_train.
+extern "C" int rnf_flow_forward_train_plain(const float *rot, const float *feat, int64_t n, int32_t F, const float *plain, const int32_t *tdesc,
+                                            int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, float *states, void *stream_v) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+    if (n < 0) return fail("n=%lld is negative", (long long)n);
+    if (n_layers < 1 || n_layers > TR_MAX_LAYERS) return fail("rnf_flow_forward_train_plain: n_layers=%d outside [1,%d]", n_layers, TR_MAX_LAYERS);
+    if (K < 1 || K > 512) return fail("rnf_flow_forward_train_plain: 1..512 segments, got %d", K);
+    if (F < 0) return fail("feature_dim %d is negative", F);
+    if (n == 0) return 0;
+    if (!rot || !plain || !tdesc || !rot_out || !ldj_out || !states) return fail("null pointer argument");
+    b16::FwdArgs a;
+    std::memset(&a, 0, sizeof(a));
+    bool any_feature = false;
+    for (int l = 0; l < n_layers; ++l) {
+        const int32_t *d = tdesc + (size_t)l * 3;
+        const int kind = d[0] & 15, orth = (d[0] >> 8) & 1;
+        if ((d[0] & ~(15 | 256)) || (kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16 && kind != RNF_KIND_COND16))
+            return fail("rnf_flow_forward_train_plain: layer %d (kind %d) is not built here; use rnf_flow_forward_train", l, d[0]);
+        if (d[1] < 0 || d[1] > 5) return fail("layer %d: perm_row %d outside [0,5]", l, d[1]);
+        if (d[2] < 0) return fail("layer %d: negative plain offset", l);
+        if (kind == RNF_KIND_COND16 && F == 0) return fail("layer %d: a conditional affine layer needs a feature", l);
+        any_feature = any_feature || (kind != RNF_KIND_AFFINE16 && F > 0);
+        a.layers[l] = make_int2(kind | (d[1] << 4) | (orth << 8), d[2]);
+    }
+    if (any_feature && !feat) return fail("conditional layers but feature pointer is null");
+    a.rot = rot; a.feature = F ? feat : nullptr; a.plain = plain; a.rot_out = rot_out; a.ldj_out = ldj_out; a.states = states;
+    a.n = n; a.n_layers = n_layers; a.K = K; a.F = F;
+    const size_t rows = (4 * (size_t)K + 63) / 64 * 64;
+    const size_t lds_bytes = sizeof(float) * (b16::HEAD_FLOATS + rows * b16::LR);
+    const long long nblocks = (n + b16::SB - 1) / b16::SB;
+    const long long cap = (long long)device_cus() * 4;
+    const dim3 grid((unsigned)(nblocks < cap ? nblocks : cap)), block(b16::WAVES * 64);
+    if (F) {
+        auto kern = b16::flow_train_forward16_kernel<true>;
+        HIP_TRY(allow_lds(kern, lds_bytes));
+        hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+    } else {
+        auto kern = b16::flow_train_forward16_kernel<false>;
+        HIP_TRY(allow_lds(kern, lds_bytes));
+        hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int rnf_pack_flow_device(const float *plain, const int32_t *pdesc, int32_t n_layers, int32_t K, int32_t F, int32_t prec,
                                     float *blob, int32_t *flags, void *stream_v) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
@@ -1249,8 +1303,9 @@ extern "C" int rnf_pack_flow_device(const float *plain, const int32_t *pdesc, in
         if ((kind == RNF_KIND_COND16 || kind == RNF_KIND_COND36 || kind_is_cond9(kind)) && F == 0) return fail("layer %d: a conditional affine layer needs a feature", l);
         if (kind_has_mlp(kind) && (F > 0) != (d[3] >= 0)) return fail("layer %d: feature record offset does not match feature_dim", l);
     }
-    for (int base = 0; base < n_layers; base += PK_MAX_LAYERS) {      // the layer table travels as a kernel argument: PK_MAX_LAYERS per launch
-        const int cnt = n_layers - base < PK_MAX_LAYERS ? n_layers - base : PK_MAX_LAYERS;
+    const int pk_chunk = layer_chunk(PK_MAX_LAYERS);
+    for (int base = 0; base < n_layers; base += pk_chunk) {            // the layer table travels as a kernel argument: PK_MAX_LAYERS per launch
+        const int cnt = n_layers - base < pk_chunk ? n_layers - base : pk_chunk;
         for (int l = 0; l < cnt; ++l) {
             const int32_t *d = pdesc + (size_t)(base + l) * 4;
             a.layers[l] = PackLayer{d[0], d[1], d[2], d[3]};
@@ -1346,8 +1401,9 @@ static int run_backward(const float *states, const float *rot_final, int dir, co
     // The layer table travels as a kernel argument, TR_MAX_LAYERS entries per launch: a deeper stack is swept in chunks from the top, each
     // chunk starting from the rotation gradient the previous one left in g_rot_in (read at the start of a block, written at its end, by the
     // same workgroup) and reading its own slice of the saved states; dL/dldj is the same per-rotation value for every layer.
+    const int tr_chunk = layer_chunk(TR_MAX_LAYERS);
     for (int hi = n_layers; hi > 0 || n_layers == 0; ) {
-        const int lo = hi > TR_MAX_LAYERS ? hi - TR_MAX_LAYERS : 0;
+        const int lo = hi > tr_chunk ? hi - tr_chunk : 0;
         for (int l = lo; l < hi; ++l) a.layers[l - lo] = table[l];
         a.n_layers = hi - lo;
         a.states = states ? states + (size_t)lo * (size_t)n * 9 : nullptr;

@@ -268,7 +268,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
                 lds_barrier(); lds_barrier();             // the two exchanges of the layer math; dL/dC is in place
                 // fc_last: gWL += g_c t^T, gbL += rowsum(g_c).  dL/dC stays in place until the NEXT conditioner layer's fc_last (behind four
                 // barriers these waves join), and t is in registers: half of this wave's row tiles now, beside the chain's WL^T product; the
-                // other half after the layer's last barrier, beside the chain's constant layer and the next x0 (where these waves would idle)
+                // other half after the layer's last barrier, beside the chain's constant layer and the next x0 (where these waves would idle).
+                // (What the chain writes into C before those four barriers is the pad rows [NO', pad64(NO')) of the NEXT conditioner layer:
+                // rows below 64 when NO' < 64, rows that are padding for this layer too otherwise -- every Moebius layer of a flow has the
+                // same K -- while a deferred tile is never this wave's first one, i.e. starts at row 64 or above.)
                 auto last_wgrad = [&](int rt_begin, int rt_end) {
                     for (int rt = rt_begin; rt < rt_end; rt += CHAIN) {
                         float av[4];
@@ -786,6 +789,206 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
     RNF_TSTAMP(9)
     if (args.stamps && tid == 0) for (int i_ = 0; i_ < 10; ++i_) atomicAdd(args.stamps + i_, tst_acc[i_]);
 #endif
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The training FORWARD on the same 16-rotation workgroups: Flow.forward from the PLAIN parameter blob (no packed blob, no pack launch),
+// exact fp32 on v_mfma_f32_16x16x4_f32 -- arithmetic identical to the forward recompute of the backward sweep above, product by product.
+// For the reference's batches (128-1024 rotations) the fused stack kernel of flow_kernels.h is a latency chain of one wave per 32 rotations
+// (0.27 ms for 24 layer pairs at batch 1024); here 4 waves share the conditioner of 16 rotations and the K segments are split 16 ways.
+// Layer kinds: Moebius, Uncondition16Trans / UnconditionRot, Condition16Trans (forward direction); the launcher keeps every other flow on
+// the stack kernel.  Saves the rotation entering every layer (args.states), as rnf_flow_forward_train does.
+struct FwdArgs {
+    const float *rot;         // [n][9]
+    const float *feature;     // [n][F] (unpadded) or nullptr
+    const float *plain;       // plain parameter blob
+    float *rot_out;           // [n][9]
+    float *ldj_out;           // [n]
+    float *states;            // [n_layers][n][9]
+    long long n;
+    int n_layers, K, F;
+    int2 layers[TR_MAX_LAYERS];   // x = kind | perm_row << 4 | orthogonal << 8, y = plain offset (the backward's table)
+};
+
+template <bool HAS_FEATURE>
+__global__ __launch_bounds__(WAVES * 64, 2) void flow_train_forward16_kernel(const FwdArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const bool helper = wave >= CHAIN;                    // waves 4..7: half of the fc_last tiles, nothing else
+    const int w4 = wave & 3, grp = 4 * w4 + q, row0 = 16 * w4;
+    const int K = args.K, F = HAS_FEATURE ? args.F : 0;
+    const Mat X0{lds}, H1{lds + 64 * LR}, H2{lds + 2 * 64 * LR}, H3{lds + 3 * 64 * LR}, GA{lds + 4 * 64 * LR}, YL{lds + 5 * 64 * LR},
+        Cm{lds + HEAD_FLOATS};
+    float *red = GA.p;
+    const long long nblocks = (args.n + SB - 1) / SB;
+    for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const long long sample = blk * SB + c;
+        const bool valid = sample < args.n;
+        const bool writer = wave == 0 && q == 0;
+        Rot R;
+        R.c0 = v3f{1.f, 0.f, 0.f}; R.c1 = v3f{0.f, 1.f, 0.f}; R.c2 = v3f{0.f, 0.f, 1.f};
+        float ldj = 0.f;
+        if (valid && !helper) {
+            const float *s = args.rot + sample * 9;
+            R.c0 = v3f{s[0], s[3], s[6]}; R.c1 = v3f{s[1], s[4], s[7]}; R.c2 = v3f{s[2], s[5], s[8]};
+        }
+        for (int pos = 0; pos < args.n_layers; ++pos) {
+            const int2 d = args.layers[pos];
+            const int kind = d.x & 15, perm_row = (d.x >> 4) & 15;
+            const float *P = args.plain + d.y;
+            const bool mlp = kind != RNF_KIND_AFFINE16;
+            const bool mob = kind == RNF_KIND_MOBIUS;
+            const int yo = mob ? 3 : 0, NI = yo + F, NO = mob ? 4 * K : 16;
+            const float *W0 = P, *b0 = W0 + 64 * NI, *W1 = b0 + 64, *b1 = W1 + 4096, *W3 = b1 + 64, *b3 = W3 + 4096, *W5 = b3 + 64,
+                        *b5 = W5 + 4096, *WL = b5 + 64, *bL = WL + (size_t)NO * 64;
+            const int ntiles = (NO + 15) / 16;
+            if (helper) {
+                if (!mlp) continue;
+                RowsA wnext = load_rows(WL, bL, 16 * wave + c, NO, q);
+                if (mob) lds_barrier();
+                lds_barrier(); lds_barrier(); lds_barrier(); lds_barrier();
+                float tv[16];
+                read_b(H3, 0, q, c, tv);
+                for (int rt = wave; rt < ntiles; rt += WAVES) {
+                    const RowsA wl = wnext;
+                    if (rt + WAVES < ntiles) wnext = load_rows(WL, bL, 16 * (rt + WAVES) + c, NO, q);
+                    store_tile(Cm, 16 * rt, NO, q, c, mfma_rows(wl, q, tv));
+                }
+                lds_barrier();                            // C
+                if (mob) lds_barrier();                   // the exchange of the segment sums
+                lds_barrier();                            // end of the layer
+                continue;
+            }
+            if (valid && writer) {                        // the rotation entering the layer, for the backward sweep
+                float *o = args.states + ((size_t)pos * args.n + sample) * 9;
+                o[0] = R.c0.x; o[1] = R.c1.x; o[2] = R.c2.x; o[3] = R.c0.y; o[4] = R.c1.y; o[5] = R.c2.y; o[6] = R.c0.z; o[7] = R.c1.z; o[8] = R.c2.z;
+            }
+            if (!mlp) {                                   // Uncondition16Trans (squeezetrans.py:57-66) / UnconditionRot (rottrans.py:8-23)
+                float M[16], Mi[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) M[i] = P[i];
+                const bool orth = (d.x >> 8) & 1;
+                const float det = orth ? 1.f : inv4(M, Mi);
+                affine16_apply(M, logf(fabsf(det)), R, ldj, orth);
+                continue;
+            }
+            const int p1 = (perm_row + 1) % 3;
+            const v3f y = get_col(R, p1);
+            RowsA wnext = load_rows(W1, b1, row0 + c, 64, q);
+            if (mob && writer) { YL.at(0, c) = y.x; YL.at(1, c) = y.y; YL.at(2, c) = y.z; }
+            {
+                f32x4 acc = RNF_MFMA4(b0[row0 + c], q ? 0.f : 1.f, zero4());
+                const float *wrow = W0 + (size_t)(row0 + c) * NI;
+                if (HAS_FEATURE) {
+                    const float *frow = args.feature + (valid ? sample : 0) * F;
+                    const int nch = (F + 63) / 64;
+                    for (int ch = 0; ch < nch; ++ch) {
+                        float av[16], bv[16];
+                        const int k0 = 64 * ch + 16 * q;
+                        if (k0 + 16 <= F) {
+                            const Float4U *pa = reinterpret_cast<const Float4U *>(wrow + yo + k0);
+                            const Float4U *pb = reinterpret_cast<const Float4U *>(frow + k0);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const Float4U va = pa[i], vb = pb[i];
+                                av[4 * i] = va.x; av[4 * i + 1] = va.y; av[4 * i + 2] = va.z; av[4 * i + 3] = va.w;
+                                bv[4 * i] = vb.x; bv[4 * i + 1] = vb.y; bv[4 * i + 2] = vb.z; bv[4 * i + 3] = vb.w;
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) {
+                                const int k = k0 + u, kc = k < F ? k : F - 1;
+                                av[u] = wrow[yo + kc];
+                                bv[u] = frow[kc];
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) acc = RNF_MFMA4(k0 + u < F ? av[u] : 0.f, valid ? bv[u] : 0.f, acc);
+                    }
+                }
+                if (mob) {
+                    const float a = wrow[q < 3 ? q : 2];
+                    lds_barrier();                        // YL
+                    acc = RNF_MFMA4(q < 3 ? a : 0.f, YL.at(q < 3 ? q : 0, c), acc);
+                }
+                store_tile(X0, row0, 64, q, c, acc);
+            }
+            lds_barrier();
+            {
+                const RowsA w1 = wnext;
+                wnext = load_rows(W3, b3, row0 + c, 64, q);
+                float bv[16];
+                read_b(X0, 0, q, c, bv, Relu());
+                f32x4 acc = mfma_rows(w1, q, bv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = Relu()(acc[r]);
+                store_tile(H1, row0, 64, q, c, acc);
+            }
+            lds_barrier();
+            {
+                const RowsA w3 = wnext;
+                wnext = load_rows(W5, b5, row0 + c, 64, q);
+                float bv[16];
+                read_b(H1, 0, q, c, bv);
+                f32x4 acc = mfma_rows(w3, q, bv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = Relu()(acc[r]);
+                store_tile(H2, row0, 64, q, c, acc);
+            }
+            lds_barrier();
+            {
+                const RowsA w5 = wnext;
+                wnext = load_rows(WL, bL, row0 + c, NO, q);
+                float bv[16], xv[4];
+                read_b(H2, 0, q, c, bv);
+                f32x4 acc = mfma_rows(w5, q, bv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xv[r] = X0.at(row0 + 4 * q + r, c);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = Relu()(acc[r] + xv[r]);
+                store_tile(H3, row0, 64, q, c, acc);
+            }
+            lds_barrier();
+            {
+                float tv[16];
+                read_b(H3, 0, q, c, tv);
+                for (int rt = wave; rt < ntiles; rt += WAVES) {
+                    const RowsA wl = wnext;
+                    if (rt + WAVES < ntiles) wnext = load_rows(WL, bL, 16 * (rt + WAVES) + c, NO, q);
+                    store_tile(Cm, 16 * rt, NO, q, c, mfma_rows(wl, q, tv));
+                }
+            }
+            lds_barrier();                                // C
+            if (mob) {
+                MobiusSaved sv;
+                mobius_frame(R, perm_row, sv);
+                const SampleCol crow{Cm, c};
+                float sm[3] = {0.f, 0.f, 0.f};
+                mobius_segments_sums(sv, crow, K, grp * K / 16, (grp + 1) * K / 16, sm[0], sm[1], sm[2]);
+                block_sum<3>(sm, red, wave, q, c);
+                mobius_combine(sv, sm[0], sm[1], sm[2]);
+                set_col(R, sv.p0, sv.tx);
+                set_col(R, sv.p2, sv.tzu * sv.inv_tzu);
+                ldj += logf(sm[2] / sm[0]);
+            } else {                                      // Condition16Trans (squeezetrans.py:41-50): M = I + reshape(net(f), 4, 4)
+                float M[16], Mi[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) M[i] = Cm.at(i, c) + ((i % 5) == 0 ? 1.f : 0.f);
+                const float det = inv4(M, Mi);
+                affine16_apply(M, logf(fabsf(det)), R, ldj, false);
+            }
+            lds_barrier();                                // C and the reduction scratch are free again
+        }
+        if (valid && writer) {
+            float *o = args.rot_out + sample * 9;
+            o[0] = R.c0.x; o[1] = R.c1.x; o[2] = R.c2.x; o[3] = R.c0.y; o[4] = R.c1.y; o[5] = R.c2.y; o[6] = R.c0.z; o[7] = R.c1.z; o[8] = R.c2.z;
+            args.ldj_out[sample] = ldj;
+        }
+    }
 }
 
 }  // namespace b16

@@ -62,7 +62,9 @@ def test_data_parallel_replicas_forward_and_backward():
     halves = [R[:256].clone().requires_grad_(True), R[256:].clone().requires_grad_(True)]
     outs = torch.nn.parallel.parallel_apply(replicas, [(h,) for h in halves], devices=[0, 0])        # worker threads
     got_l = torch.cat([o[1] for o in outs])
-    assert (got_l.detach() - want_l).abs().max().item() < 3e-6
+    # (differentiable evaluations of small batches run exact fp32 from the plain parameters, csrc/train_block16.h; the no_grad one above the
+    # split-precision stack kernel: they agree to the forward tolerance of tests/test_gpu_grad.py)
+    assert (got_l.detach() - want_l).abs().max().item() < 2e-5
     (-got_l).mean().backward()                                  # replica gradients flow back to the master parameters
     g = fl.layers[0].conditioner.fc_last.weight.grad
     assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0

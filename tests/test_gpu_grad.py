@@ -330,17 +330,25 @@ def test_device_packer_matches_host_packer(name, precision):
             assert np.array_equal(got[fo:fo + n].view(np.uint32), want[fo:fo + n].view(np.uint32)), (i, "feature projection")
 
 
-def test_half_range_overflow_is_reported():
+def test_half_range_overflow_is_reported(monkeypatch):
     from rotationnormflow_amd import runtime
     cfg, w, R, feat, gR, gl = _make("uncond_k16")
     w = dict(w)
     key = next(k for k in w if k.endswith("conditioner.layers.3.weight"))
     w[key] = w[key].copy()
     w[key][0, 0] = 1e6
-    fl = product_flow(cfg, w).train()
     if runtime.get_precision() != "f16x2":
         pytest.skip("only the split-precision kernels have a range limit")
     Rd = torch.from_numpy(R).cuda()
+    # small batches run the training forward in exact fp32 from the plain blob (round 3): no range limit, the weight is just a weight
+    monkeypatch.setenv("RNF_TRAIN_FORWARD", "block16")
+    fl = product_flow(cfg, w).train()
+    Ro, ldj = fl(Rd)
+    assert bool(torch.isfinite(ldj).all()) and bool(torch.isfinite(Ro).all())
+    fl(Rd)
+    # the packed (split-precision) training forward of larger batches reports it
+    monkeypatch.setenv("RNF_TRAIN_FORWARD", "stack")
+    fl = product_flow(cfg, w).train()
     fl(Rd)
     torch.cuda.synchronize()
     with pytest.raises(runtime.HalfRangeError):
@@ -534,6 +542,51 @@ def test_both_backward_kernels_agree(name, inverse, train_block):
         assert np.abs(a[2] - b[2]).max() <= 2e-5 * max(np.abs(b[2]).max(), 1e-3)
 
 
+@pytest.mark.parametrize("name", ["uncond_k64_24", "cond_k32", "cond_first_affine", "rot", "uncond_k96", "cond_k130"])
+def test_training_forward_from_the_plain_blob_matches_the_stack_kernel(name, monkeypatch):
+    """Small training batches run Flow.forward on 16-rotation workgroups straight from the plain parameter blob (csrc/train_block16.h:
+    rnf_flow_forward_train_plain, exact fp32); larger ones and every other layer kind keep the fused stack kernel.  Both against the fp64
+    oracle, values and every gradient (the saved states feed the same backward sweep)."""
+    cfg, w, R, feat, gR, gl = _make(name)
+    want, want_gR, want_gf, want_Ro, want_ldj = oracle_grads(cfg, w, R, feat, gR, gl)
+    outs = {}
+    for mode in ("block16", "stack"):
+        monkeypatch.setenv("RNF_TRAIN_FORWARD", mode)
+        fl = product_flow(cfg, w).train()
+        Rd = torch.from_numpy(R).cuda().requires_grad_(True)
+        fd = None if feat is None else torch.from_numpy(feat).cuda().requires_grad_(True)
+        Ro, ldj = fl(Rd, fd)
+        assert np.abs(Ro.detach().cpu().numpy() - want_Ro).max() < 2e-5, mode
+        assert np.abs(ldj.detach().cpu().numpy() - want_ldj).max() < 5e-5 * max(1.0, np.abs(want_ldj).max()), mode
+        ((Ro * torch.from_numpy(gR).cuda()).sum() + (ldj * torch.from_numpy(gl).cuda()).sum()).backward()
+        torch.cuda.synchronize()
+        for k, prm in fl.named_parameters():
+            if want.get(k) is None:
+                continue
+            err = np.abs(prm.grad.cpu().numpy().astype(np.float64) - want[k]).max() / max(np.abs(want[k]).max(), 1e-3)
+            assert err < REL, (mode, k, err)
+        outs[mode] = (Ro.detach().cpu().numpy(), ldj.detach().cpu().numpy())
+    assert np.abs(outs["block16"][0] - outs["stack"][0]).max() < 2e-5
+    assert np.abs(outs["block16"][1] - outs["stack"][1]).max() < 1e-4 * max(1.0, np.abs(want_ldj).max())
+
+
+def test_plain_forward_is_chosen_by_batch_size_and_layer_kinds(monkeypatch):
+    from rotationnormflow_amd.autograd import TrainPlan
+    monkeypatch.delenv("RNF_TRAIN_FORWARD", raising=False)
+
+    def plan_of(name):
+        cfg, w, R, feat, _, _ = _make(name)
+        fl = product_flow(cfg, w).train()
+        fl(torch.from_numpy(R[:8]).cuda().requires_grad_(True), None if feat is None else torch.from_numpy(feat[:8]).cuda())
+        return fl._rnf_train_plan[1]
+    plan = plan_of("uncond_k16")
+    assert isinstance(plan, TrainPlan)
+    assert plan.plain_forward(1024) and not plan.plain_forward(TrainPlan.PLAIN_FORWARD_BELOW)
+    assert plan_of("cond_first_affine").plain_forward(64)
+    assert not plan_of("gs36").plain_forward(64)          # Gram-Schmidt layers: the stack kernel
+    assert not plan_of("clu9").plain_forward(64)          # side layers: the stack kernel
+
+
 def test_backward_block_size_follows_the_batch(train_block):
     """Automatic choice: 64-rotation workgroups from 6144 rotations on (atomic-add volume, profiles/README.md), 16-rotation ones below and
     for more than 64 segments at any batch; forcing 64 beyond 64 segments is refused.  Checked through the gradients of a batch on
@@ -557,36 +610,73 @@ def test_backward_block_size_follows_the_batch(train_block):
         ldj.sum().backward()
 
 
+def _all_grads(cfg, w, R, gR, gl, inverse):
+    fl = product_flow(cfg, w).train()
+    Rd = torch.from_numpy(R).cuda().requires_grad_(True)
+    Ro, ldj = fl.inverse(Rd) if inverse else fl(Rd)
+    ((Ro * torch.from_numpy(gR).cuda()).sum() + (ldj * torch.from_numpy(gl).cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    g = {k: prm.grad.cpu().numpy().astype(np.float64) for k, prm in fl.named_parameters()}
+    g["<rotation>"] = Rd.grad.cpu().numpy().astype(np.float64)
+    return g, Ro.detach().cpu().numpy().astype(np.float64), ldj.detach().cpu().numpy().astype(np.float64), len(fl.layers)
+
+
+def _assert_same_grads(a, b, rel):
+    assert a.keys() == b.keys()
+    for k in a:
+        assert np.abs(a[k] - b[k]).max() <= rel * max(np.abs(b[k]).max(), 1e-3), k
+
+
 @pytest.mark.parametrize("block", [16, 64])
 @pytest.mark.parametrize("inverse", [False, True])
-def test_training_a_flow_deeper_than_one_layer_table(block, inverse, train_block):
-    """220 layers (110 Moebius + 110 affine): the device packer and the backward sweep take 200 table entries per launch and run such a
-    stack in chunks -- the rotation gradient passes from chunk to chunk through g_rot_in, in place (round 3; refused before)."""
+def test_chunked_sweeps_reproduce_the_single_launch(block, inverse, train_block, monkeypatch):
+    """The device packer and the backward sweep carry their layer tables as kernel arguments (200 entries) and run a deeper stack in
+    chunks; the rotation gradient passes from chunk to chunk through g_rot_in, in place.  With RNF_LAYER_CHUNK=10 a 48-layer flow is packed
+    and swept in five chunks: same states, same formulas -- every gradient equals the single launch up to the order of the float atomics."""
+    monkeypatch.setenv("RNF_TRAIN_FORWARD", "stack")       # (the packed forward, so that the packer's chunks are exercised as well)
+    cfg = orc.make_config(layers=24, segments=8)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=61, regime="default")
+    n = 70
+    R = synth.uniform_rotations(n, seed=62)
+    rng = np.random.default_rng(63)
+    gR, gl = rng.standard_normal((n, 3, 3)).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    train_block(block)
+    monkeypatch.delenv("RNF_LAYER_CHUNK", raising=False)
+    one, Ro1, ldj1, _ = _all_grads(cfg, w, R, gR, gl, inverse)
+    monkeypatch.setenv("RNF_LAYER_CHUNK", "10")
+    many, Ro2, ldj2, _ = _all_grads(cfg, w, R, gR, gl, inverse)
+    assert np.array_equal(Ro1, Ro2) and np.array_equal(ldj1, ldj2)           # the chunk-packed blob is the same blob
+    _assert_same_grads(many, one, 2e-6)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_training_a_flow_deeper_than_one_layer_table(inverse, train_block, monkeypatch):
+    """220 layers (110 Moebius + 110 affine; refused before round 3): values against the fp64 oracle, and the gradients of the two
+    backward kernels -- each sweeping the stack as 200 + 20 layers -- against each other and against a sweep in chunks of 64.
+    (No gradient gate against the oracle here: 110 x 40 x 256 ReLU units put the smallest |pre-activation| at ~3e-7, below what any
+    fp32 forward resolves, so a unit flips and the exact gradient itself jumps by percents; the shallow cases above carry that gate.)"""
     cfg = orc.make_config(layers=110, segments=8)
     w = synth.fill_state_dict(orc.state_shapes(cfg), seed=61, regime="default")
     n = 40
     R = synth.uniform_rotations(n, seed=62)
     rng = np.random.default_rng(63)
     gR, gl = rng.standard_normal((n, 3, 3)).astype(np.float32), rng.standard_normal(n).astype(np.float32)
-    p = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in w.items()}
-    Rt = torch.from_numpy(R).double().requires_grad_(True)
     run = orc.flow_inverse if inverse else orc.flow_forward
-    Ro_w, ldj_w = run(cfg, p, Rt, None, dtype=torch.float64, grad=True)
-    ((Ro_w * torch.from_numpy(gR).double()).sum() + (ldj_w * torch.from_numpy(gl).double()).sum()).backward()
-    train_block(block)
-    fl = product_flow(cfg, w).train()
-    assert len(fl.layers) == 220
-    Rd = torch.from_numpy(R).cuda().requires_grad_(True)
-    Ro, ldj = fl.inverse(Rd) if inverse else fl(Rd)
-    ((Ro * torch.from_numpy(gR).cuda()).sum() + (ldj * torch.from_numpy(gl).cuda()).sum()).backward()
-    torch.cuda.synchronize()
-    rel = 2e-3          # 220 layers of fp32 against fp64: the first layer's gradients sit at 6e-4 (both kernels alike: it is the states' noise)
-    for k, prm in fl.named_parameters():
-        g_want = p[k].grad.numpy()
-        err = np.abs(prm.grad.cpu().numpy().astype(np.float64) - g_want).max() / max(np.abs(g_want).max(), 1e-3)
-        assert err < rel, (k, err)
-    tg, tw = tangent(R.astype(np.float64), Rd.grad.cpu().numpy().astype(np.float64)), tangent(R.astype(np.float64), Rt.grad.numpy())
-    assert np.abs(tg - tw).max() / max(np.abs(tw).max(), 1e-3) < rel
+    p = {k: torch.from_numpy(v).double() for k, v in w.items()}
+    Ro_w, ldj_w = run(cfg, p, torch.from_numpy(R).double(), None, dtype=torch.float64)
+    train_block(16)
+    g16, Ro, ldj, depth = _all_grads(cfg, w, R, gR, gl, inverse)
+    assert depth == 220
+    # (inverse: 110 roots on the bisection grid, one cell = pi / 2^14 each)
+    assert np.abs(Ro - Ro_w.numpy()).max() < (2e-3 if inverse else 1e-4)
+    assert np.abs(ldj - ldj_w.numpy()).max() < (5e-3 if inverse else 2e-4) * max(1.0, np.abs(ldj_w.numpy()).max())
+    assert all(np.isfinite(v).all() for v in g16.values()) and max(np.abs(v).max() for v in g16.values()) > 0
+    train_block(64)
+    g64, _, _, _ = _all_grads(cfg, w, R, gR, gl, inverse)
+    _assert_same_grads(g16, g64, 5e-5)
+    monkeypatch.setenv("RNF_LAYER_CHUNK", "64")
+    g64c, _, _, _ = _all_grads(cfg, w, R, gR, gl, inverse)
+    _assert_same_grads(g64c, g64, 2e-6)
 
 
 @pytest.mark.parametrize("n", [0, 1, 17, 65])

@@ -239,7 +239,15 @@ int rnf_flow_forward_train(const float *rotation_dev, const float *feature_dev, 
  * table of rnf_flow_backward; feature_dev [n][feature_dim], unpadded. */
 int rnf_flow_forward_train_plain(const float *rotation_dev, const float *feature_dev, int64_t n, int32_t feature_dim,
                                  const float *plain_dev, const int32_t *train_desc, int32_t n_layers, int32_t segments,
-                                 float *rotation_out_dev, float *ldj_out_dev, float *states_dev, void *stream);
+                                 float *rotation_out_dev, float *ldj_out_dev, float *states_dev, float *acts_dev, void *stream);
+/* acts_dev (may be NULL): rnf_train_acts_floats(n, conditioner layers, segments) floats in which the forward leaves every conditioner's
+ * activations (2 KB per rotation and layer at 64 segments); rnf_flow_backward_saved -- rnf_flow_backward with that buffer -- then reads them
+ * back instead of recomputing each conditioner (16-rotation sweep; the 64-rotation sweep of large batches ignores the buffer). */
+size_t rnf_train_acts_floats(int64_t n, int32_t n_conditioner_layers, int32_t segments);
+int rnf_flow_backward_saved(const float *states_dev, const float *acts_dev, const float *feature_dev, int64_t n, int32_t feature_dim,
+                            const float *plain_dev, const int32_t *train_desc, int32_t n_layers, int32_t segments,
+                            const float *g_rotation_out_dev, const float *g_ldj_dev, float *grads_dev, float *g_rotation_in_dev,
+                            float *g_feature_dev, float *layer_scratch_dev, void *stream);
 
 /* Reverse sweep of Flow.forward (what autograd does for the reference, agent.py:79-80).
  * In : g_rotation_out_dev [n][9] (NULL = zeros), g_ldj_dev [n].

@@ -59,7 +59,10 @@ _SIGNATURES = {
     "rnf_flow_forward_train": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
                                          c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnf_flow_forward_train_plain": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
-                                               c_f32p, c_f32p, c_f32p, C.c_void_p]),
+                                               c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "rnf_train_acts_floats": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "rnf_flow_backward_saved": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
+                                          c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "rnf_flow_backward": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,
                                     c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "rnf_flow_inverse_train": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,

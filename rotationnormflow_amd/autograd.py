@@ -83,6 +83,7 @@ class TrainPlan:
                 rec_off += (fsize + 3) // 4 * 4
         self.n_cond = slot
         self.n_side = side_slot
+        self.n_mlp = sum(1 for kind, k, f in shapes if kind in (runtime.KIND_MOBIUS, runtime.KIND_COND16))
         self.plain_floats = plain_off
         self.blob_floats = max(rec_off, 4)
         self.desc = np.ascontiguousarray(self.desc)
@@ -108,6 +109,20 @@ class TrainPlan:
         if not kinds <= {runtime.KIND_MOBIUS, runtime.KIND_AFFINE16, runtime.KIND_COND16}:
             return False
         return mode == "block16" or n < self.PLAIN_FORWARD_BELOW
+
+    # below this many rotations the plain forward also saves the conditioner activations (2 KB per rotation and layer at K = 64) and the
+    # 16-rotation backward sweep reads them back instead of recomputing them (measured, profiles/README.md "Training": unconditional recipe
+    # -5 % at 1024, even at 2048, +3 % at 4096; conditional F = 256, whose recompute includes the feature product: -18 % at 1024, -4 % at
+    # 4096 -- up to where the 16-rotation sweep is used at all); RNF_TRAIN_ACTS=0|1 forces
+    ACTS_BELOW = 2048
+    ACTS_BELOW_CONDITIONAL = 6144
+
+    def save_activations(self, n):
+        import os
+        mode = os.environ.get("RNF_TRAIN_ACTS", "")
+        if mode == "0":
+            return False
+        return mode == "1" or n < (self.ACTS_BELOW_CONDITIONAL if self.n_cond else self.ACTS_BELOW)
 
     def calibrate(self, feature):
         """Mean square of the feature entries, measured ONCE per plan on the first batch it sees (a training run keeps its feature
@@ -216,14 +231,18 @@ class _FlowFn(torch.autograd.Function):
         feat_plain = None
         if plan.feat_dim and feature is not None:
             feat_plain = feature.reshape(n, plan.feat_dim).to(device=dev, dtype=torch.float32).contiguous()
+        acts = None
         if n and direction == 0 and plan.plain_forward(n):
-            # small batches: the forward on 16-rotation workgroups straight from the plain blob (csrc/train_block16.h), no packing launch
+            # small batches: the forward on 16-rotation workgroups straight from the plain blob (csrc/train_block16.h), no packing launch;
+            # below ACTS_BELOW rotations it also leaves the conditioner activations for the backward sweep (no recompute there)
+            if plan.save_activations(n):
+                acts = torch.empty(L.rnf_train_acts_floats(n, plan.n_mlp, plan.segments), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 stream = torch.cuda.current_stream(dev).cuda_stream
                 _lib.check(L.rnf_flow_forward_train_plain(rot.data_ptr(), feat_plain.data_ptr() if (feat_plain is not None and plan.n_cond) else None,
                                                           n, plan.feat_dim if plan.n_cond else 0, plain.data_ptr(), plan.train_desc.ctypes.data,
                                                           plan.n_layers, plan.segments, out_rot.data_ptr(), out_ldj.data_ptr(),
-                                                          states.data_ptr(), stream))
+                                                          states.data_ptr(), acts.data_ptr() if acts is not None else None, stream))
         elif n:
             ws = runtime.workspace(dev, L.rnf_workspace_bytes_segments(n, plan.n_cond, plan.segments))     # (+ the K > 128 stash of an inverse pass)
             fptr = feat.data_ptr() if feat is not None else None
@@ -247,13 +266,13 @@ class _FlowFn(torch.autograd.Function):
         ctx.feat_shape = feature.shape if feature is not None else None
         ctx.shapes = [(t.shape, t.device, t.dtype) for t in tensors]
         ctx.sizes = [t.numel() for t in tensors]
-        ctx.save_for_backward(states, out_rot if direction else None, feat_plain, plain, side_c)
+        ctx.save_for_backward(states, out_rot if direction else None, feat_plain, plain, side_c, acts)
         return out_rot.reshape(rotation.shape), out_ldj
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_rot, g_ldj):
-        states, out_rot, feat_plain, plain, side_c = ctx.saved_tensors
+        states, out_rot, feat_plain, plain, side_c, acts = ctx.saved_tensors
         plan = ctx.plan
         n = states.shape[1]
         dev = states.device
@@ -285,6 +304,11 @@ class _FlowFn(torch.autograd.Function):
                                                            plain.data_ptr(), tdesc.ctypes.data, plan.n_layers, plan.segments,
                                                            ptr(g_rot_c), g_ldj_c.data_ptr(), ptr(grads), g_rot_in.data_ptr(), ptr(g_feat),
                                                            scratch.data_ptr(), stream))
+                elif acts is not None:
+                    _lib.check(L.rnf_flow_backward_saved(states.data_ptr(), acts.data_ptr(), ptr(feat_plain) if plan.n_cond else None, n,
+                                                         plan.feat_dim if plan.n_cond else 0, plain.data_ptr(), tdesc.ctypes.data,
+                                                         plan.n_layers, plan.segments, ptr(g_rot_c), g_ldj_c.data_ptr(), ptr(grads),
+                                                         g_rot_in.data_ptr(), ptr(g_feat), scratch.data_ptr(), stream))
                 else:
                     _lib.check(L.rnf_flow_backward(states.data_ptr(), ptr(feat_plain), n, plan.feat_dim, plain.data_ptr(),
                                                    tdesc.ctypes.data, plan.n_layers, plan.segments, ptr(g_rot_c),

@@ -1234,8 +1234,17 @@ extern "C" int rnf_flow_forward_train(const float *rot, const float *feat, int64
 // Training forward from the plain blob on 16-rotation workgroups (train_block16.h: flow_train_forward16_kernel): no packed blob, exact fp32.
 // Built for the layer kinds of the reference's training recipes (Moebius, Uncondition16Trans / UnconditionRot, Condition16Trans) in the
 // forward direction, at most TR_MAX_LAYERS layers; the caller keeps every other flow on rnf_flow_forward_train.
+// Floats of the activation buffer the training forward can leave for the backward sweep: one slot of (256 + 4K rounded up to 16) x 16 floats
+// per conditioner layer and 16-rotation block (train_block16.h).
+static int act_rows_for(int32_t K) { return b16::ACT_HEAD_ROWS + (4 * K + 15) / 16 * 16; }
+extern "C" size_t rnf_train_acts_floats(int64_t n, int32_t n_conditioner_layers, int32_t segments) {
+    if (n <= 0 || n_conditioner_layers <= 0 || segments <= 0) return 0;
+    return (size_t)n_conditioner_layers * (size_t)((n + b16::SB - 1) / b16::SB) * (size_t)act_rows_for(segments) * 16;
+}
+
 extern "C" int rnf_flow_forward_train_plain(const float *rot, const float *feat, int64_t n, int32_t F, const float *plain, const int32_t *tdesc,
-                                            int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, float *states, void *stream_v) {
+                                            int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, float *states, float *acts,
+                                            void *stream_v) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
     if (n < 0) return fail("n=%lld is negative", (long long)n);
     if (n_layers < 1 || n_layers > TR_MAX_LAYERS) return fail("rnf_flow_forward_train_plain: n_layers=%d outside [1,%d]", n_layers, TR_MAX_LAYERS);
@@ -1260,6 +1269,7 @@ extern "C" int rnf_flow_forward_train_plain(const float *rot, const float *feat,
     if (any_feature && !feat) return fail("conditional layers but feature pointer is null");
     a.rot = rot; a.feature = F ? feat : nullptr; a.plain = plain; a.rot_out = rot_out; a.ldj_out = ldj_out; a.states = states;
     a.n = n; a.n_layers = n_layers; a.K = K; a.F = F;
+    a.acts = acts; a.act_rows = act_rows_for(K);
     const size_t rows = (4 * (size_t)K + 63) / 64 * 64;
     const size_t lds_bytes = sizeof(float) * (b16::HEAD_FLOATS + rows * b16::LR);
     const long long nblocks = (n + b16::SB - 1) / b16::SB;
@@ -1331,6 +1341,7 @@ struct BackwardExtra {
     const float *side = nullptr;       // [n_side][n][16] per-sample matrices of the side layers
     float *side_grad = nullptr;        // [n_side][n][16] out: dL/d(matrix)
     const float *g_out_ext = nullptr;  // RNF_KIND_MLP_ONLY: dL/d(outputs) [n][NO]
+    const float *acts = nullptr;       // activations saved by rnf_flow_forward_train_plain (16-rotation sweep only; else recomputed)
 };
 static int run_backward(const float *states, const float *rot_final, int dir, const float *feat, int64_t n, int32_t F, const float *plain,
                         const int32_t *tdesc, int32_t n_layers, int32_t K, const float *g_rot_out, const float *g_ldj, float *grads,
@@ -1340,6 +1351,21 @@ extern "C" int rnf_flow_backward(const float *states, const float *feat, int64_t
                                  int32_t n_layers, int32_t K, const float *g_rot_out, const float *g_ldj, float *grads,
                                  float *g_rot_in, float *g_feature, float *g_ldj_sum, void *stream_v) {
     return run_backward(states, nullptr, 0, feat, n, F, plain, tdesc, n_layers, K, g_rot_out, g_ldj, grads, g_rot_in, g_feature, g_ldj_sum, stream_v);
+}
+
+// rnf_flow_backward with the conditioner activations that rnf_flow_forward_train_plain saved (same n, table and K): the 16-rotation sweep
+// reads them back instead of recomputing every conditioner; the 64-rotation sweep of large batches ignores them.
+extern "C" int rnf_flow_backward_saved(const float *states, const float *acts, const float *feat, int64_t n, int32_t F, const float *plain,
+                                       const int32_t *tdesc, int32_t n_layers, int32_t K, const float *g_rot_out, const float *g_ldj, float *grads,
+                                       float *g_rot_in, float *g_feature, float *g_ldj_sum, void *stream_v) {
+    BackwardExtra x;
+    x.acts = acts;
+    for (int l = 0; acts && l < n_layers; ++l) {
+        const int kind = tdesc[(size_t)l * 3] & 15;
+        if (kind != RNF_KIND_MOBIUS && kind != RNF_KIND_AFFINE16 && kind != RNF_KIND_COND16)
+            return fail("rnf_flow_backward_saved: layer %d (kind %d) has no saved activations (rnf_flow_forward_train_plain does not run it)", l, kind);
+    }
+    return run_backward(states, nullptr, 0, feat, n, F, plain, tdesc, n_layers, K, g_rot_out, g_ldj, grads, g_rot_in, g_feature, g_ldj_sum, stream_v, x);
 }
 
 extern "C" int rnf_flow_inverse_backward(const float *states, const float *rot_out, const float *feat, int64_t n, int32_t F, const float *plain,
@@ -1410,6 +1436,10 @@ static int run_backward(const float *states, const float *rot_final, int dir, co
         a.rot_final = hi == n_layers ? rot_final : states + (size_t)hi * (size_t)n * 9;      // (dir = 1: the output of the chunk's last position)
         a.g_rot_out = hi == n_layers ? g_rot_out : g_rot_in;
         a.g_ldj_sum = g_ldj_sum + lo;
+        a.acts = block16 ? x.acts : nullptr;
+        a.act_rows = act_rows_for(K);
+        a.mlp_base = 0;
+        for (int l = 0; l < lo; ++l) a.mlp_base += ((table[l].x & 15) == RNF_KIND_MOBIUS || (table[l].x & 15) == RNF_KIND_COND16) ? 1 : 0;
         if (block16) {
             const size_t lds_bytes = sizeof(float) * (b16::HEAD_FLOATS + rows * b16::LR);
             const long long nblocks = (n + b16::SB - 1) / b16::SB;

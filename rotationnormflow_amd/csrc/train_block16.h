@@ -193,6 +193,28 @@ __device__ __forceinline__ float batch_sum16(const Mat &S, const float (&val)[16
 // RARE: the instantiation that also carries the side / Gram-Schmidt / conditional 3x3 layer kinds.  Inlined beside the common kinds they
 // cost the common path 49 spilled registers (C2, batch 1024, graphed iteration: 1.126 ms against 0.993 ms without them), so the launcher
 // picks the instantiation from the layer table.
+// Saved activations of one conditioner layer and one 16-rotation block: rows 0..255 = X0 (raw), H1, H2 (after ReLU), T = relu(x0 + h3), then
+// the conditioner outputs C, 16 floats per row -- the LDS matrices without their padding column.  Written by the training forward
+// (flow_train_forward16_kernel), read back by the backward sweep instead of recomputing the conditioner; all 512 threads move 16 bytes a time.
+constexpr int ACT_HEAD_ROWS = 256;
+__device__ __forceinline__ void acts_to_lds(const float *__restrict__ slot, int rows, float *lds, float *cm, int tid) {
+    const float4 *src = reinterpret_cast<const float4 *>(slot);
+    for (int f = tid; f < rows * 4; f += WAVES * 64) {
+        const float4 v = src[f];
+        const int row = f >> 2, col = 4 * (f & 3);
+        float *dst = row < ACT_HEAD_ROWS ? lds + row * LR + col : cm + (row - ACT_HEAD_ROWS) * LR + col;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+}
+__device__ __forceinline__ void lds_to_acts(float *__restrict__ slot, int rows, const float *lds, const float *cm, int tid) {
+    float4 *dst = reinterpret_cast<float4 *>(slot);
+    for (int f = tid; f < rows * 4; f += WAVES * 64) {
+        const int row = f >> 2, col = 4 * (f & 3);
+        const float *src = row < ACT_HEAD_ROWS ? lds + row * LR + col : cm + (row - ACT_HEAD_ROWS) * LR + col;
+        dst[f] = float4{src[0], src[1], src[2], src[3]};
+    }
+}
+
 template <bool HAS_FEATURE, bool RARE>
 __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(const TrainArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -217,6 +239,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
         const long long sample = blk * SB + c;            // the rotation this thread carries (16 threads per rotation)
         const bool valid = sample < args.n;
         const bool writer = wave == 0 && q == 0;          // the one thread per rotation that stores per-rotation results
+        int mlp_idx = args.mlp_base;                      // saved activations: slot index of the conditioner layer being processed
+        if (args.acts) {
+            for (int l = 0; l < args.n_layers; ++l) {
+                const int kd = args.layers[l].x & 15;
+                mlp_idx += (kd == RNF_KIND_MOBIUS || kd == RNF_KIND_COND16) ? 1 : 0;
+            }
+        }
         Rot gR;
         gR.c0 = v3f{0.f, 0.f, 0.f}; gR.c1 = gR.c0; gR.c2 = gR.c0;
         float g_ldj = 0.f;
@@ -245,26 +274,36 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
                 float *gW0 = Gp, *gb0 = gW0 + 64 * NI, *gW1 = gb0 + 64, *gb1 = gW1 + 4096, *gW3 = gb1 + 64, *gb3 = gW3 + 4096, *gW5 = gb3 + 64,
                       *gb5 = gW5 + 4096, *gWL = gb5 + 64, *gbL = gWL + (size_t)NO * 64;
                 const int ntiles = (NO + 15) / 16, row0 = 16 * w4;
-                RowsA wnext = load_rows(WL, bL, 16 * wave + c, NO, q);
-                if (mob) lds_barrier();                   // YL
-                lds_barrier();                            // x0
-                lds_barrier(); lds_barrier(); lds_barrier();      // h1, h2, t
                 const Mat &T = H3;
-                {
-                    float tv[16];
-                    read_b(T, 0, q, c, tv);
-                    for (int rt = wave; rt < ntiles; rt += WAVES) {
-                        const RowsA wl = wnext;
-                        if (rt + WAVES < ntiles) wnext = load_rows(WL, bL, 16 * (rt + WAVES) + c, NO, q);
-                        store_tile(Cm, 16 * rt, NO, q, c, mfma_rows(wl, q, tv));
-                    }
-                }
                 float tb[4][4];                           // t over the samples, B side of gWL: read now, used after the layer math
-                if (want_w) {
+                if (args.acts) {                          // the forward's activations come back from memory: one fill, one barrier
+                    --mlp_idx;
+                    acts_to_lds(args.acts + ((size_t)mlp_idx * nblocks + blk) * args.act_rows * 16, ACT_HEAD_ROWS + NO, lds, Cm.p, tid);
+                    lds_barrier();
+                    if (want_w) {
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) read_s(T, 16 * ct + c, q, tb[ct]);
+                        for (int ct = 0; ct < 4; ++ct) read_s(T, 16 * ct + c, q, tb[ct]);
+                    }
+                } else {
+                    RowsA wnext = load_rows(WL, bL, 16 * wave + c, NO, q);
+                    if (mob) lds_barrier();               // YL
+                    lds_barrier();                        // x0
+                    lds_barrier(); lds_barrier(); lds_barrier();      // h1, h2, t
+                    {
+                        float tv[16];
+                        read_b(T, 0, q, c, tv);
+                        for (int rt = wave; rt < ntiles; rt += WAVES) {
+                            const RowsA wl = wnext;
+                            if (rt + WAVES < ntiles) wnext = load_rows(WL, bL, 16 * (rt + WAVES) + c, NO, q);
+                            store_tile(Cm, 16 * rt, NO, q, c, mfma_rows(wl, q, tv));
+                        }
+                    }
+                    if (want_w) {
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) read_s(T, 16 * ct + c, q, tb[ct]);
+                    }
+                    lds_barrier();                        // C
                 }
-                lds_barrier();                            // C
                 lds_barrier(); lds_barrier();             // the two exchanges of the layer math; dL/dC is in place
                 // fc_last: gWL += g_c t^T, gbL += rowsum(g_c).  dL/dC stays in place until the NEXT conditioner layer's fc_last (behind four
                 // barriers these waves join), and t is in registers: half of this wave's row tiles now, beside the chain's WL^T product; the
@@ -474,98 +513,103 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
             const int ntiles = (NO + 15) / 16;            // 16-row tiles of fc_last
             const int row0 = 16 * w4;                     // this wave's rows of a 64-row product
 
-            // ================= forward recompute =================
-            RowsA wnext = load_rows(W1, b1, row0 + c, 64, q);
+            // ================= the conditioner's activations: read back what the forward saved, or recompute them =================
             if (mob && writer) { YL.at(0, c) = y.x; YL.at(1, c) = y.y; YL.at(2, c) = y.z; }
             for (int o = NO + grp; o < ((NO + 63) & ~63); o += 16) Cm.at(o, c) = 0.f;      // pad rows of C: B side of the WL^T slabs
-            // x0 = b0 + W0[:, yo:] f (K dimension = F in chunks of 64) + W0[:, :3] y (one K = 4 step)
-            {
-                f32x4 acc = RNF_MFMA4(b0[row0 + c], q ? 0.f : 1.f, zero4());
-                const float *wrow = W0 + (size_t)(row0 + c) * NI;
-                if (HAS_FEATURE) {
-                    // chunk ch covers k = 64 ch + 16 q + u: each lane's 16 operands are one 64-byte run of its weight row / feature row
-                    const float *frow = args.feature + (valid ? sample : 0) * F;
-                    const int nch = (F + 63) / 64;
-                    for (int ch = 0; ch < nch; ++ch) {
-                        float av[16], bv[16];
-                        const int k0 = 64 * ch + 16 * q;
-                        if (k0 + 16 <= F) {               // 4 x 16-byte loads per operand (4-byte aligned)
-                            const Float4U *pa = reinterpret_cast<const Float4U *>(wrow + yo + k0);
-                            const Float4U *pb = reinterpret_cast<const Float4U *>(frow + k0);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const Float4U va = pa[i], vb = pb[i];
-                                av[4 * i] = va.x; av[4 * i + 1] = va.y; av[4 * i + 2] = va.z; av[4 * i + 3] = va.w;
-                                bv[4 * i] = vb.x; bv[4 * i + 1] = vb.y; bv[4 * i + 2] = vb.z; bv[4 * i + 3] = vb.w;
-                            }
-                        } else {
-#pragma unroll
-                            for (int u = 0; u < 16; ++u) {
-                                const int k = k0 + u, kc = k < F ? k : F - 1;
-                                av[u] = wrow[yo + kc];
-                                bv[u] = frow[kc];
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) acc = RNF_MFMA4(k0 + u < F ? av[u] : 0.f, valid ? bv[u] : 0.f, acc);
-                    }
-                }
-                if (mob) {
-                    const float a = wrow[q < 3 ? q : 2];
-                    lds_barrier();                        // YL
-                    acc = RNF_MFMA4(q < 3 ? a : 0.f, YL.at(q < 3 ? q : 0, c), acc);
-                }
-                store_tile(X0, row0, 64, q, c, acc);
-            }
-            lds_barrier();
-            RNF_TSTAMP(0)
-            // H1, H2 hold relu(h1), relu(h2); H3 holds t = relu(x0 + h3) (the ReLU masks only need the sign)
-            {
-                const RowsA w1 = wnext;
-                wnext = load_rows(W3, b3, row0 + c, 64, q);
-                float bv[16];
-                read_b(X0, 0, q, c, bv, Relu());
-                f32x4 acc = mfma_rows(w1, q, bv);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = Relu()(acc[r]);
-                store_tile(H1, row0, 64, q, c, acc);
-            }
-            lds_barrier();
-            {
-                const RowsA w3 = wnext;
-                wnext = load_rows(W5, b5, row0 + c, 64, q);
-                float bv[16];
-                read_b(H1, 0, q, c, bv);
-                f32x4 acc = mfma_rows(w3, q, bv);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = Relu()(acc[r]);
-                store_tile(H2, row0, 64, q, c, acc);
-            }
-            lds_barrier();
-            {
-                const RowsA w5 = wnext;
-                wnext = load_rows(WL, bL, row0 + c, NO, q);
-                float bv[16], xv[4];
-                read_b(H2, 0, q, c, bv);
-                f32x4 acc = mfma_rows(w5, q, bv);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xv[r] = X0.at(row0 + 4 * q + r, c);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = Relu()(acc[r] + xv[r]);
-                store_tile(H3, row0, 64, q, c, acc);
-            }
             const Mat &T = H3;
-            lds_barrier();
-            RNF_TSTAMP(1)
-            {                                             // fc_last: C = WL t + bL; the B operands (t) are read once for all row tiles
-                float tv[16];
-                read_b(T, 0, q, c, tv);
-                for (int rt = wave; rt < ntiles; rt += WAVES) {
-                    const RowsA wl = wnext;
-                    if (rt + WAVES < ntiles) wnext = load_rows(WL, bL, 16 * (rt + WAVES) + c, NO, q);
-                    store_tile(Cm, 16 * rt, NO, q, c, mfma_rows(wl, q, tv));
+            if (args.acts) {
+                --mlp_idx;
+                acts_to_lds(args.acts + ((size_t)mlp_idx * nblocks + blk) * args.act_rows * 16, ACT_HEAD_ROWS + NO, lds, Cm.p, tid);
+            } else {
+                RowsA wnext = load_rows(W1, b1, row0 + c, 64, q);
+                // x0 = b0 + W0[:, yo:] f (K dimension = F in chunks of 64) + W0[:, :3] y (one K = 4 step)
+                {
+                    f32x4 acc = RNF_MFMA4(b0[row0 + c], q ? 0.f : 1.f, zero4());
+                    const float *wrow = W0 + (size_t)(row0 + c) * NI;
+                    if (HAS_FEATURE) {
+                        // chunk ch covers k = 64 ch + 16 q + u: each lane's 16 operands are one 64-byte run of its weight row / feature row
+                        const float *frow = args.feature + (valid ? sample : 0) * F;
+                        const int nch = (F + 63) / 64;
+                        for (int ch = 0; ch < nch; ++ch) {
+                            float av[16], bv[16];
+                            const int k0 = 64 * ch + 16 * q;
+                            if (k0 + 16 <= F) {               // 4 x 16-byte loads per operand (4-byte aligned)
+                                const Float4U *pa = reinterpret_cast<const Float4U *>(wrow + yo + k0);
+                                const Float4U *pb = reinterpret_cast<const Float4U *>(frow + k0);
+    #pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const Float4U va = pa[i], vb = pb[i];
+                                    av[4 * i] = va.x; av[4 * i + 1] = va.y; av[4 * i + 2] = va.z; av[4 * i + 3] = va.w;
+                                    bv[4 * i] = vb.x; bv[4 * i + 1] = vb.y; bv[4 * i + 2] = vb.z; bv[4 * i + 3] = vb.w;
+                                }
+                            } else {
+    #pragma unroll
+                                for (int u = 0; u < 16; ++u) {
+                                    const int k = k0 + u, kc = k < F ? k : F - 1;
+                                    av[u] = wrow[yo + kc];
+                                    bv[u] = frow[kc];
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                            for (int u = 0; u < 16; ++u) acc = RNF_MFMA4(k0 + u < F ? av[u] : 0.f, valid ? bv[u] : 0.f, acc);
+                        }
+                    }
+                    if (mob) {
+                        const float a = wrow[q < 3 ? q : 2];
+                        lds_barrier();                        // YL
+                        acc = RNF_MFMA4(q < 3 ? a : 0.f, YL.at(q < 3 ? q : 0, c), acc);
+                    }
+                    store_tile(X0, row0, 64, q, c, acc);
+                }
+                lds_barrier();
+                RNF_TSTAMP(0)
+                // H1, H2 hold relu(h1), relu(h2); H3 holds t = relu(x0 + h3) (the ReLU masks only need the sign)
+                {
+                    const RowsA w1 = wnext;
+                    wnext = load_rows(W3, b3, row0 + c, 64, q);
+                    float bv[16];
+                    read_b(X0, 0, q, c, bv, Relu());
+                    f32x4 acc = mfma_rows(w1, q, bv);
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = Relu()(acc[r]);
+                    store_tile(H1, row0, 64, q, c, acc);
+                }
+                lds_barrier();
+                {
+                    const RowsA w3 = wnext;
+                    wnext = load_rows(W5, b5, row0 + c, 64, q);
+                    float bv[16];
+                    read_b(H1, 0, q, c, bv);
+                    f32x4 acc = mfma_rows(w3, q, bv);
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = Relu()(acc[r]);
+                    store_tile(H2, row0, 64, q, c, acc);
+                }
+                lds_barrier();
+                {
+                    const RowsA w5 = wnext;
+                    wnext = load_rows(WL, bL, row0 + c, NO, q);
+                    float bv[16], xv[4];
+                    read_b(H2, 0, q, c, bv);
+                    f32x4 acc = mfma_rows(w5, q, bv);
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) xv[r] = X0.at(row0 + 4 * q + r, c);
+                    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = Relu()(acc[r] + xv[r]);
+                    store_tile(H3, row0, 64, q, c, acc);
+                }
+                lds_barrier();
+                RNF_TSTAMP(1)
+                {                                             // fc_last: C = WL t + bL; the B operands (t) are read once for all row tiles
+                    float tv[16];
+                    read_b(T, 0, q, c, tv);
+                    for (int rt = wave; rt < ntiles; rt += WAVES) {
+                        const RowsA wl = wnext;
+                        if (rt + WAVES < ntiles) wnext = load_rows(WL, bL, 16 * (rt + WAVES) + c, NO, q);
+                        store_tile(Cm, 16 * rt, NO, q, c, mfma_rows(wl, q, tv));
+                    }
                 }
             }
             ColsA cnext = load_cols(WL, 64, 0, NO, row0 + c, 64, q);         // first slab of WL^T, needed after the layer math
@@ -806,8 +850,9 @@ struct FwdArgs {
     float *rot_out;           // [n][9]
     float *ldj_out;           // [n]
     float *states;            // [n_layers][n][9]
+    float *acts;              // conditioner activations for the backward sweep (lds_to_acts), or nullptr: the sweep recomputes them
     long long n;
-    int n_layers, K, F;
+    int n_layers, K, F, act_rows;
     int2 layers[TR_MAX_LAYERS];   // x = kind | perm_row << 4 | orthogonal << 8, y = plain offset (the backward's table)
 };
 
@@ -830,6 +875,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_forward16_kernel(con
         Rot R;
         R.c0 = v3f{1.f, 0.f, 0.f}; R.c1 = v3f{0.f, 1.f, 0.f}; R.c2 = v3f{0.f, 0.f, 1.f};
         float ldj = 0.f;
+        int mlp_idx = 0;
         if (valid && !helper) {
             const float *s = args.rot + sample * 9;
             R.c0 = v3f{s[0], s[3], s[6]}; R.c1 = v3f{s[1], s[4], s[7]}; R.c2 = v3f{s[2], s[5], s[8]};
@@ -857,6 +903,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_forward16_kernel(con
                     store_tile(Cm, 16 * rt, NO, q, c, mfma_rows(wl, q, tv));
                 }
                 lds_barrier();                            // C
+                if (args.acts) lds_to_acts(args.acts + ((size_t)mlp_idx * nblocks + blk) * args.act_rows * 16, ACT_HEAD_ROWS + NO, lds, Cm.p, tid);
+                ++mlp_idx;
                 if (mob) lds_barrier();                   // the exchange of the segment sums
                 lds_barrier();                            // end of the layer
                 continue;
@@ -963,6 +1011,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_forward16_kernel(con
                 }
             }
             lds_barrier();                                // C
+            if (args.acts) lds_to_acts(args.acts + ((size_t)mlp_idx * nblocks + blk) * args.act_rows * 16, ACT_HEAD_ROWS + NO, lds, Cm.p, tid);
+            ++mlp_idx;
             if (mob) {
                 MobiusSaved sv;
                 mobius_frame(R, perm_row, sv);

@@ -54,6 +54,10 @@ struct TrainArgs {
     float *side_grad;
     // RNF_KIND_MLP_ONLY: dL/d(outputs) of the one conditioner MLP of the call, [n][NO] row-major, NO in bits 16..23 of x
     const float *g_out_ext;
+    // 16-rotation sweep only (train_block16.h): the conditioner activations the training forward saved, one slot of act_rows x 16 floats
+    // per (conditioner layer, 16-rotation block), or nullptr = recompute them; mlp_base = conditioner layers below this chunk of the table
+    const float *acts;
+    int act_rows, mlp_base;
     // per layer: x = kind | perm_row << 4 | orthogonal << 8 | (side slot or NO) << 16, y = plain offset
     int2 layers[TR_MAX_LAYERS];
 };

@@ -88,6 +88,23 @@ def _make(name):
     return cfg, w, R, feat, gR, gl
 
 
+def _all_grads(cfg, w, R, gR, gl, inverse):
+    fl = product_flow(cfg, w).train()
+    Rd = torch.from_numpy(R).cuda().requires_grad_(True)
+    Ro, ldj = fl.inverse(Rd) if inverse else fl(Rd)
+    ((Ro * torch.from_numpy(gR).cuda()).sum() + (ldj * torch.from_numpy(gl).cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    g = {k: prm.grad.cpu().numpy().astype(np.float64) for k, prm in fl.named_parameters()}
+    g["<rotation>"] = Rd.grad.cpu().numpy().astype(np.float64)
+    return g, Ro.detach().cpu().numpy().astype(np.float64), ldj.detach().cpu().numpy().astype(np.float64), len(fl.layers)
+
+
+def _assert_same_grads(a, b, rel):
+    assert a.keys() == b.keys()
+    for k in a:
+        assert np.abs(a[k] - b[k]).max() <= rel * max(np.abs(b[k]).max(), 1e-3), k
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_gradients_match_oracle_autograd(name):
     cfg, w, R, feat, gR, gl = _make(name)
@@ -570,6 +587,31 @@ def test_training_forward_from_the_plain_blob_matches_the_stack_kernel(name, mon
     assert np.abs(outs["block16"][1] - outs["stack"][1]).max() < 1e-4 * max(1.0, np.abs(want_ldj).max())
 
 
+@pytest.mark.parametrize("name", ["uncond_k64_24", "cond_k32", "cond_k11", "cond_first_affine", "uncond_k20", "uncond_k96", "rot"])
+def test_saved_activations_equal_the_recompute(name, monkeypatch):
+    """Small batches (below 2048 rotations, conditional flows below 6144): the plain-blob forward leaves every conditioner's activations
+    in memory and the 16-rotation sweep reads them back instead of recomputing them (RNF_TRAIN_ACTS=0: recompute).  Same arithmetic, same values: the gradients agree up to the order of
+    the float atomics."""
+    cfg, w, R, feat, gR, gl = _make(name)
+    monkeypatch.setenv("RNF_TRAIN_FORWARD", "block16")
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RNF_TRAIN_ACTS", mode)
+        fl = product_flow(cfg, w).train()
+        Rd = torch.from_numpy(R).cuda().requires_grad_(True)
+        fd = None if feat is None else torch.from_numpy(feat).cuda().requires_grad_(True)
+        Ro, ldj = fl(Rd, fd)
+        assert (ldj.grad_fn.saved_tensors[5] is not None) == (mode == "1")
+        ((Ro * torch.from_numpy(gR).cuda()).sum() + (ldj * torch.from_numpy(gl).cuda()).sum()).backward()
+        torch.cuda.synchronize()
+        g = {k: prm.grad.cpu().numpy().astype(np.float64) for k, prm in fl.named_parameters() if prm.grad is not None}
+        g["<rotation>"] = Rd.grad.cpu().numpy().astype(np.float64)
+        if fd is not None:
+            g["<feature>"] = fd.grad.cpu().numpy().astype(np.float64)
+        res[mode] = g
+    _assert_same_grads(res["1"], res["0"], 2e-6)
+
+
 def test_plain_forward_is_chosen_by_batch_size_and_layer_kinds(monkeypatch):
     from rotationnormflow_amd.autograd import TrainPlan
     monkeypatch.delenv("RNF_TRAIN_FORWARD", raising=False)
@@ -608,23 +650,6 @@ def test_backward_block_size_follows_the_batch(train_block):
     _, ldj = fl(torch.from_numpy(R).cuda())
     with pytest.raises(RuntimeError, match="64 segments"):
         ldj.sum().backward()
-
-
-def _all_grads(cfg, w, R, gR, gl, inverse):
-    fl = product_flow(cfg, w).train()
-    Rd = torch.from_numpy(R).cuda().requires_grad_(True)
-    Ro, ldj = fl.inverse(Rd) if inverse else fl(Rd)
-    ((Ro * torch.from_numpy(gR).cuda()).sum() + (ldj * torch.from_numpy(gl).cuda()).sum()).backward()
-    torch.cuda.synchronize()
-    g = {k: prm.grad.cpu().numpy().astype(np.float64) for k, prm in fl.named_parameters()}
-    g["<rotation>"] = Rd.grad.cpu().numpy().astype(np.float64)
-    return g, Ro.detach().cpu().numpy().astype(np.float64), ldj.detach().cpu().numpy().astype(np.float64), len(fl.layers)
-
-
-def _assert_same_grads(a, b, rel):
-    assert a.keys() == b.keys()
-    for k in a:
-        assert np.abs(a[k] - b[k]).max() <= rel * max(np.abs(b[k]).max(), 1e-3), k
 
 
 @pytest.mark.parametrize("block", [16, 64])

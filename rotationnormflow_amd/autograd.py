@@ -1,10 +1,12 @@
 """Differentiable ``Flow.forward``: what ``loss.backward()`` needs in the reference's training loop (agent.py:75-92).
 
-The reference lets autograd trace every PyTorch op of every layer.  Here the forward is the fused HIP stack kernel (which
-also saves the rotation entering each layer) and the backward is ONE launch of ``flow_train_backward_kernel``
-(csrc/train_kernels.h) that recomputes each layer from its saved input and applies hand-derived reverse-mode formulas
-(csrc/so3_grad.h).  This module is only the glue: it hands the layers' parameter tensors to ``torch.autograd.Function`` so
-that optimizers, ``zero_grad`` and parameterisations built from tiny host-side tensor ops (LU, SVD) keep working unchanged.
+The reference lets autograd trace every PyTorch op of every layer.  Here the forward is one HIP launch that also saves the rotation
+entering each layer -- for the reference's batch sizes the 16-rotation kernel of csrc/train_block16.h straight from the parameters (it
+keeps the conditioner activations too), otherwise the packed stack kernel -- and the backward is ONE launch of the reverse sweep
+(csrc/train_block16.h below 6144 rotations, csrc/train_kernels.h above) applying hand-derived reverse-mode formulas (csrc/so3_grad.h)
+to the saved activations or to a recompute from the saved inputs.  This module is only the glue: it hands the layers' parameter tensors
+to ``torch.autograd.Function`` so that optimizers, ``zero_grad`` and parameterisations built from tiny host-side tensor ops (LU, SVD) keep
+working unchanged.
 """
 from __future__ import annotations
 

@@ -197,9 +197,12 @@ __device__ __forceinline__ float batch_sum16(const Mat &S, const float (&val)[16
 // the conditioner outputs C, 16 floats per row -- the LDS matrices without their padding column.  Written by the training forward
 // (flow_train_forward16_kernel), read back by the backward sweep instead of recomputing the conditioner; all 512 threads move 16 bytes a time.
 constexpr int ACT_HEAD_ROWS = 256;
-__device__ __forceinline__ void acts_to_lds(const float *__restrict__ slot, int rows, float *lds, float *cm, int tid) {
+// rows [row_begin, row_end) by `nthreads` threads (t = 0 .. nthreads - 1).  In the backward sweep the GRADIENT waves do this: they may
+// still be reading the previous layer's dL/dC (their deferred fc_last tiles) and overwrite it only behind that, in their own program order,
+// while the chain waves, busy with a constant layer, touch none of these buffers.
+__device__ __forceinline__ void acts_to_lds(const float *__restrict__ slot, int row_begin, int row_end, float *lds, float *cm, int t, int nthreads) {
     const float4 *src = reinterpret_cast<const float4 *>(slot);
-    for (int f = tid; f < rows * 4; f += WAVES * 64) {
+    for (int f = 4 * row_begin + t; f < row_end * 4; f += nthreads) {
         const float4 v = src[f];
         const int row = f >> 2, col = 4 * (f & 3);
         float *dst = row < ACT_HEAD_ROWS ? lds + row * LR + col : cm + (row - ACT_HEAD_ROWS) * LR + col;
@@ -256,14 +259,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
                 gR.c0 = v3f{g[0], g[3], g[6]}; gR.c1 = v3f{g[1], g[4], g[7]}; gR.c2 = v3f{g[2], g[5], g[8]};
             }
         }
-        for (int pos = args.n_layers - 1; pos >= 0; --pos) {
-            const int2 d = args.layers[pos];
-            const int kind = d.x & 15, perm_row = (d.x >> 4) & 15;
-            const float *P = args.plain + d.y;
-            float *Gp = args.grads + d.y;
-            Rot Rin;
-            Rin.c0 = v3f{1.f, 0.f, 0.f}; Rin.c1 = v3f{0.f, 1.f, 0.f}; Rin.c2 = v3f{0.f, 0.f, 1.f};
-            if (gw) {
+        // Two loops over the layers, one per wave group (the groups share nothing but LDS and the barrier sequence; one loop with a branch
+        // inside would keep the gradient waves' prefetch registers alive across the chain's code).
+        if (gw) {
+            for (int pos = args.n_layers - 1; pos >= 0; --pos) {
+                const int2 d = args.layers[pos];
+                const int kind = d.x & 15;
+                const float *P = args.plain + d.y;
+                float *Gp = args.grads + d.y;
                 // ---- gradient waves: the barriers of every layer, the fc_last tiles 4..7 (mod 8) of the forward recompute, and every
                 // weight-gradient product, each in the window in which the chain waves run the matching data-gradient product ----
                 if (RARE && kind == RNF_KIND_GS36 && want_w) { lds_barrier(); lds_barrier(); lds_barrier(); lds_barrier(); }
@@ -278,7 +281,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
                 float tb[4][4];                           // t over the samples, B side of gWL: read now, used after the layer math
                 if (args.acts) {                          // the forward's activations come back from memory: one fill, one barrier
                     --mlp_idx;
-                    acts_to_lds(args.acts + ((size_t)mlp_idx * nblocks + blk) * args.act_rows * 16, ACT_HEAD_ROWS + NO, lds, Cm.p, tid);
+                    acts_to_lds(args.acts + ((size_t)mlp_idx * nblocks + blk) * args.act_rows * 16, 0, ACT_HEAD_ROWS + NO, lds, Cm.p,
+                                tid - CHAIN * 64, CHAIN * 64);
                     lds_barrier();
                     if (want_w) {
 #pragma unroll
@@ -383,6 +387,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
                 if (want_w) last_wgrad(rt_split, ntiles);
                 continue;
             }
+        } else {
+        for (int pos = args.n_layers - 1; pos >= 0; --pos) {
+            const int2 d = args.layers[pos];
+            const int kind = d.x & 15, perm_row = (d.x >> 4) & 15;
+            const float *P = args.plain + d.y;
+            float *Gp = args.grads + d.y;
+            Rot Rin;
+            Rin.c0 = v3f{1.f, 0.f, 0.f}; Rin.c1 = v3f{0.f, 1.f, 0.f}; Rin.c2 = v3f{0.f, 0.f, 1.f};
             if (valid && args.states) {
                 const float *s = args.states + ((size_t)pos * args.n + sample) * 9;
                 Rin.c0 = v3f{s[0], s[3], s[6]}; Rin.c1 = v3f{s[1], s[4], s[7]}; Rin.c2 = v3f{s[2], s[5], s[8]};
@@ -518,8 +530,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
             for (int o = NO + grp; o < ((NO + 63) & ~63); o += 16) Cm.at(o, c) = 0.f;      // pad rows of C: B side of the WL^T slabs
             const Mat &T = H3;
             if (args.acts) {
-                --mlp_idx;
-                acts_to_lds(args.acts + ((size_t)mlp_idx * nblocks + blk) * args.act_rows * 16, ACT_HEAD_ROWS + NO, lds, Cm.p, tid);
+                --mlp_idx;                                // (the gradient waves bring the slot in)
             } else {
                 RowsA wnext = load_rows(W1, b1, row0 + c, 64, q);
                 // x0 = b0 + W0[:, yo:] f (K dimension = F in chunks of 64) + W0[:, :3] y (one K = 4 step)
@@ -822,6 +833,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void flow_train_backward16_kernel(co
             lds_barrier();
             gR = gRin;
             RNF_TSTAMP(7)
+        }
         }
         lds_barrier();                                    // g_rot_in may BE g_rot_out (chunked sweeps, rnf_api.hip): every wave has read its copy
         if (valid && writer && args.g_rot_in) {

@@ -51,6 +51,9 @@ CASES = {
     "cond_k32": (dict(layers=2, segments=32, condition=1, feature_dim=40), 150, "trained"),
     "cond_first_affine": (dict(layers=2, segments=16, condition=1, feature_dim=24, last_affine=1), 130, "default"),
     "mobius_only": (dict(layers=4, segments=8, rot="None"), 64, "trained"),
+    # Moebius layers back to back with enough segments for deferred fc_last gradient tiles (csrc/train_block16.h): the next layer's
+    # activations must not land in LDS before those tiles have read the previous layer's dL/dC
+    "mobius_only_k64": (dict(layers=6, segments=64, rot="None"), 96, "trained"),
     "lu": (dict(layers=2, segments=16, lu=1), 100, "default"),
     "rot": (dict(layers=2, segments=16, rot="UnRot"), 100, "default"),
     # constant left / right rotations built from a 3x3 parameter on the host (polar factor, Gram-Schmidt): autograd chains dL/dM4x4
@@ -203,7 +206,7 @@ def test_side_kernels_in_isolation(kind, inverse):
     assert np.abs(tg - tw).max() / max(np.abs(tw).max(), 1e-3) < 2e-4
 
 
-INVERSE_CASES = ["uncond_k16", "uncond_k20", "cond_k11", "cond_k32", "uncond_k96", "cond_k130", "cond_first_affine", "mobius_only", "lu", "rot", "gs9", "svdl9", "cgs9", "csvdl9", "csvdr9", "csmithr9", "gs36", "cgs36", "clu9"]
+INVERSE_CASES = ["uncond_k16", "uncond_k20", "cond_k11", "cond_k32", "uncond_k96", "cond_k130", "mobius_only_k64", "cond_first_affine", "mobius_only", "lu", "rot", "gs9", "svdl9", "cgs9", "csvdl9", "csvdr9", "csmithr9", "gs36", "cgs36", "clu9"]
 
 
 @pytest.mark.parametrize("name", INVERSE_CASES)
@@ -587,7 +590,7 @@ def test_training_forward_from_the_plain_blob_matches_the_stack_kernel(name, mon
     assert np.abs(outs["block16"][1] - outs["stack"][1]).max() < 1e-4 * max(1.0, np.abs(want_ldj).max())
 
 
-@pytest.mark.parametrize("name", ["uncond_k64_24", "cond_k32", "cond_k11", "cond_first_affine", "uncond_k20", "uncond_k96", "rot"])
+@pytest.mark.parametrize("name", ["uncond_k64_24", "cond_k32", "cond_k11", "cond_first_affine", "uncond_k20", "uncond_k96", "rot", "mobius_only_k64"])
 def test_saved_activations_equal_the_recompute(name, monkeypatch):
     """Small batches (below 2048 rotations, conditional flows below 6144): the plain-blob forward leaves every conditioner's activations
     in memory and the 16-rotation sweep reads them back instead of recomputing them (RNF_TRAIN_ACTS=0: recompute).  Same arithmetic, same values: the gradients agree up to the order of

@@ -472,6 +472,9 @@ def _plan_for(module, layers, perm_rows, rotation):
     if cached is None or cached[0] != key:
         cached = (key, TrainPlan(layers, perm_rows, rotation.device, runtime.get_precision()))
         module._rnf_train_plan = cached
+    fixed = getattr(module, "_feature_ms_fixed", None)          # Flow.set_feature_scale / dist.calibrate_feature_scale: one value for all ranks
+    if fixed is not None:
+        cached[1].feature_ms = fixed
     return cached[1]
 
 

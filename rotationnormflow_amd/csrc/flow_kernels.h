@@ -387,6 +387,22 @@ struct Mlp<1> {
     // pre != nullptr: the projected features of this layer were already fetched into registers (flow_stack_kernel, LEAN = 2: issued behind
     // the previous layer's barrier B2, so that the HBM latency of the scratch read -- the first instruction of the hidden phase otherwise,
     // +11 k cycles per layer in the round-2 stamps -- is spent under the layer finish and the affine layer)
+    template <bool KEEPX0, class GF>
+    static __device__ __forceinline__ void residual(const float *lds, int ot, int lane, int h, float bA, float bB, const GF &g,
+                                                    const f32x16 (&x0k)[2], f32x16 &a) {
+        if (g) {
+            if constexpr (KEEPX0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[r] += x0k[ot][r];
+            } else {
+                const f32x16 x0 = first_tile(lds, ot, lane, bA, bB, g.load(ot, lane, h));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[r] += x0[r];
+            }
+        } else {
+            a = first_tile(lds, ot, lane, bA, bB, a);
+        }
+    }
     template <class GF, bool KEEPX0 = false>
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
                                                 const GF &g, Act &out, Fair &fair, bool &bad, const f32x16 *pre = nullptr) {
@@ -426,30 +442,13 @@ struct Mlp<1> {
         a1 = bias(2, 1);
         hidden_tile<1>(w(2, 0), lane, f, a0, b1, m1);
         bad |= a0[0] != a0[0];
-        if constexpr (KEEPX0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a0[r] += x0k[0][r];
-        } else {
-            a0 = first_tile(lds, 0, lane, bA, bB, a0);
-            if (g) {
-                const f32x16 gg = g.load(0, lane, h);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a0[r] += gg[r];
-            }
-        }
+        // ONE definition of the residual for every instantiation (so that a rotation's result does not depend on the workgroup width its
+        // launch picked): a conditional layer adds x0 = fc_first(y) accumulated onto the projected features -- kept (KEEPX0) or recomputed
+        // bit for bit from a second read of the scratch --, an unconditional layer accumulates fc_first(y) onto x3 in the matrix unit.
+        residual<KEEPX0>(lds, 0, lane, h, bA, bB, g, x0k, a0);
         hidden_tile<2>(w(2, 1), lane, f, a1, a0, m1);
         fair.tick();
-        if constexpr (KEEPX0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a1[r] += x0k[1][r];
-        } else {
-            a1 = first_tile(lds, 1, lane, bA, bB, a1);
-            if (g) {
-                const f32x16 gg = g.load(1, lane, h);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a1[r] += gg[r];
-            }
-        }
+        residual<KEEPX0>(lds, 1, lane, h, bA, bB, g, x0k, a1);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             split_pair(a1[2 * e], a1[2 * e + 1], m1, f.hi[2], f.lo[2], e);

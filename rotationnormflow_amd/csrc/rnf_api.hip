@@ -696,45 +696,38 @@ static int launch_fused(const FlowArgs &a, int grid, size_t lds_bytes, hipStream
     return 0;
 }
 
+// `lean` picks the kernel FAMILY -- 1: Moebius + constant-affine layers only (BASELINE C1 / C2 / C3), 2: the conditional counterpart (Moebius +
+// constant-affine + Condition16Trans, every MLP conditional: C4), 0: the general kernel -- from the flow's structure and from whether the call
+// runs guarded, NEVER from the batch size: the families differ in arithmetic (one-piece softplus of the lean kernels, so3_math.h), the
+// workgroup widths of one family do not, so a rotation's result does not depend on the size of the launch (or chunk, or shard) it travels in.
 template <int DIR, int KT_INV, bool PIPE, int PREC, bool EXT = false>
 static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream, int nwk, int lean = 0) {
+#define RNF_STACK_GO(NW_, LEAN_)                                                                                \
+    do {                                                                                                        \
+        auto kern = flow_stack_kernel<DIR, KT_INV, NW_, PIPE, PREC, EXT, LEAN_>;                                \
+        HIP_TRY(allow_lds(kern, lds_bytes));                                                                    \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_ * 64), lds_bytes, stream, a);                             \
+        HIP_TRY(hipGetLastError());                                                                             \
+        return 0;                                                                                               \
+    } while (0)
     if constexpr (DIR == 0 && PREC == 1 && PIPE && !EXT) {
-        if (nwk == NW_FWD_WIDE && lean == 2) {   // conditional lean instantiation: Moebius + constant-affine + Condition16Trans, every MLP conditional (C4)
-            auto kern = flow_stack_kernel<DIR, KT_INV, NW_FWD_WIDE, PIPE, PREC, false, 2>;
-            HIP_TRY(allow_lds(kern, lds_bytes));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_FWD_WIDE * 64), lds_bytes, stream, a);
-            HIP_TRY(hipGetLastError());
-            return 0;
-        }
-        if (nwk == NW_FWD_WIDE && lean == 1) {   // lean instantiation: Moebius + constant-affine layers only (BASELINE C1 / C2 / C3)
-            auto kern = flow_stack_kernel<DIR, KT_INV, NW_FWD_WIDE, PIPE, PREC, false, 1>;
-            HIP_TRY(allow_lds(kern, lds_bytes));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_FWD_WIDE * 64), lds_bytes, stream, a);
-            HIP_TRY(hipGetLastError());
-            return 0;
-        }
-        if (nwk == NW_FWD_WIDE) {
-            auto kern = flow_stack_kernel<DIR, KT_INV, NW_FWD_WIDE, PIPE, PREC, EXT>;
-            HIP_TRY(allow_lds(kern, lds_bytes));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_FWD_WIDE * 64), lds_bytes, stream, a);
-            HIP_TRY(hipGetLastError());
-            return 0;
-        }
-        if (nwk == NW_FWD_NARROW) {
-            auto kern = flow_stack_kernel<DIR, KT_INV, NW_FWD_NARROW, PIPE, PREC, EXT>;
-            HIP_TRY(allow_lds(kern, lds_bytes));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_FWD_NARROW * 64), lds_bytes, stream, a);
-            HIP_TRY(hipGetLastError());
-            return 0;
+        if (lean == 2) {
+            if (nwk == NW_FWD_WIDE) RNF_STACK_GO(NW_FWD_WIDE, 2);
+            if (nwk == NW_FWD_H) RNF_STACK_GO(NW_FWD_H, 2);
+            if (nwk == NW_FWD_NARROW) RNF_STACK_GO(NW_FWD_NARROW, 2);
+        } else if (lean == 1) {
+            if (nwk == NW_FWD_WIDE) RNF_STACK_GO(NW_FWD_WIDE, 1);
+            if (nwk == NW_FWD_H) RNF_STACK_GO(NW_FWD_H, 1);
+            if (nwk == NW_FWD_NARROW) RNF_STACK_GO(NW_FWD_NARROW, 1);
+        } else {
+            if (nwk == NW_FWD_WIDE) RNF_STACK_GO(NW_FWD_WIDE, 0);
+            if (nwk == NW_FWD_NARROW) RNF_STACK_GO(NW_FWD_NARROW, 0);
         }
     }
     constexpr int NWK = (DIR == 0 && PREC == 1) ? NW_FWD_H : NW;
-    if (nwk != NWK) return fail("internal: no %d-wave instantiation of this stack kernel", nwk);
-    auto kern = flow_stack_kernel<DIR, KT_INV, NWK, PIPE, PREC, EXT>;
-    HIP_TRY(allow_lds(kern, lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWK * 64), lds_bytes, stream, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    if (nwk != NWK || lean) return fail("internal: no %d-wave instantiation of this stack kernel", nwk);
+    RNF_STACK_GO(NWK, 0);
+#undef RNF_STACK_GO
 }
 
 // inverse with 64 < K <= 128 (flow_kernels.h mobius_inv_tiles: 16 tiles of segment parameters in registers, synchronous staging)
@@ -941,7 +934,9 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         const bool narrow = !fused && o.dir == 0 && prec == 1 && pipe && !ext && wide_allowed() && cn <= (long long)cus * NW_FWD_NARROW * 32;
         const bool big_inv = o.dir == 1 && any_mlp && KT > 8;                  // 4-wave instantiation (512 registers per lane)
         const int nwk = fused ? NW_FUSED : (big_inv ? NW_INV_BIG : (wide ? NW_FWD_WIDE : (narrow ? NW_FWD_NARROW : ((o.dir == 0 && prec == 1) ? NW_FWD_H : NW))));
-        a.fair_off = (wide || narrow || (fused && NW_FUSED != 8)) ? -1 : fair_off;                       // the governor pairs two waves per SIMD
+        // kernel family of this call (launch_stack): fixed by the flow and by `guarded`, the same for every chunk and batch size
+        const int family = (guarded && a.tab_off >= 0 && o.dir == 0 && prec == 1 && pipe && !ext) ? (lean ? 1 : (lean2 && all_mlp_cond && n_slots > 0 && !shared ? 2 : 0)) : 0;
+        a.fair_off = (wide || narrow || family || (fused && NW_FUSED != 8)) ? -1 : fair_off;             // the governor pairs two waves per SIMD (general 8-wave kernel)
         const long long ntiles = (cn + nwk * 32 - 1) / (nwk * 32);
         const long long ntiles_fp = (cn + NW_FP * 32 - 1) / (NW_FP * 32);
         const int nw_fb = (o.dir == 1 && any_mlp && KT > 8) ? NW_INV_BIG : NW;
@@ -1010,7 +1005,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
                         : launch_stack<DIR_, KT_, true, 0, true>(a, grid, lds_bytes, stream, nwk))                  \
                 : (prec ? launch_stack<DIR_, KT_, false, 1, true>(a, grid, lds_bytes, stream, nwk)                  \
                         : launch_stack<DIR_, KT_, false, 0, true>(a, grid, lds_bytes, stream, nwk))) :              \
-    (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1>(a, grid, lds_bytes, stream, nwk, (guarded && a.tab_off >= 0) ? (lean ? 1 : (lean2 && all_mlp_cond && n_slots > 0 && !shared ? 2 : 0)) : 0)       \
+    (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1>(a, grid, lds_bytes, stream, nwk, family)                        \
                   : launch_stack<DIR_, KT_, true, 0>(a, grid, lds_bytes, stream, nwk))                              \
           : (prec ? launch_stack<DIR_, KT_, false, 1>(a, grid, lds_bytes, stream, nwk)                              \
                   : launch_stack<DIR_, KT_, false, 0>(a, grid, lds_bytes, stream, nwk)))
@@ -1041,8 +1036,8 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             {
                 FlowArgs &a = b;                          // RNF_LAUNCH names `a`, `grid`, `prec`, `nwk`
                 const int grid = grid_fb, prec = 0, nwk = NW;
-                const bool lean = false, lean2 = false;
-                (void)lean; (void)lean2;
+                const int family = 0;                     // the exact-fp32 kernels have no lean family
+                (void)family;
                 if (o.dir == 0) rc = RNF_LAUNCH(0, 0);
                 else if (kt_inv == 1) rc = RNF_LAUNCH(1, 1);
                 else if (kt_inv == 2) rc = RNF_LAUNCH(1, 2);

@@ -79,6 +79,14 @@ class Flow(nn.Module):
         self._cache.feature_ms = None
         self.__dict__.pop("_rnf_train_plan", None)
 
+    def set_feature_scale(self, mean_square):
+        """Fix the calibration input of the conditional layers' pack-time equalisation (csrc/equalize.h): the mean square of a feature entry.
+        By default it is measured on the first feature batch a parameter version is packed for -- per PROCESS, so the ranks of a sharded
+        evaluation would each measure their own shard; ``dist.calibrate_feature_scale`` all-reduces one value and sets it here on every rank,
+        which makes the packed images, and with them every rotation's result, identical on 1 and on N GPUs.  ``None`` returns to measuring."""
+        self._feature_ms_fixed = None if mean_square is None else runtime.quantise_feature_ms(float(mean_square))
+        self.invalidate()
+
     def _device_packed(self, device, feature=None):
         """Kernel blob built on the device from the live parameters (rnf_pack_flow_device, one 18 us launch): used when the host cache
         cannot be trusted or would thrash -- training mode (optimizers may write through .data) and nn.DataParallel replicas (fresh
@@ -98,7 +106,10 @@ class Flow(nn.Module):
                 if self.condition:
                     # one measurement per flow, not per replica / per call: nn.DataParallel replicas are rebuilt every forward, but they
                     # share this cache object (runtime.PackCache)
-                    if plan.feature_ms is None:
+                    fixed = getattr(self, "_feature_ms_fixed", None)
+                    if fixed is not None:
+                        plan.feature_ms = fixed
+                    elif plan.feature_ms is None:
                         plan.feature_ms = getattr(self._cache, "feature_ms", None)
                     plan.calibrate(feature)
                     self._cache.feature_ms = plan.feature_ms
@@ -127,7 +138,9 @@ class Flow(nn.Module):
             for layer, a, b in zip(self.layers, rows, inv):
                 if isinstance(layer, MobiusFlow) and a % 3 != b % 3:
                     raise RuntimeError("forward/inverse permutation schedules disagree (flow/flow.py:58-90)")
-            return runtime.pack_layers(list(self.layers), rows, device, feature_ms=runtime.feature_mean_square(feature) if self.condition else 1.0)
+            fixed = getattr(self, "_feature_ms_fixed", None)
+            ms = 1.0 if not self.condition else (fixed if fixed is not None else runtime.feature_mean_square(feature))
+            return runtime.pack_layers(list(self.layers), rows, device, feature_ms=ms)
         return self._cache.get(self, device, build)
 
     # ---- reference API ----------------------------------------------------------------------------------------------

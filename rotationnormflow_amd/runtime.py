@@ -4,6 +4,7 @@ PyTorch is used here only as plumbing: device memory (tensors), the current HIP 
 """
 from __future__ import annotations
 
+import math
 import os
 import threading
 
@@ -100,14 +101,38 @@ class HalfRangeError(RuntimeError):
     """A weight does not fit the fp16 range: the flow must be packed for the exact fp32 kernels instead."""
 
 
+def quantise_feature_ms(ms: float) -> float:
+    """The calibration value the packers see: the measured mean square rounded to 1/16 of a binade.  The equalisation only takes
+    power-of-two decisions from it (csrc/equalize.h), so nothing is lost, and two measurements of the same data that differ by summation
+    order (one GPU over the whole batch / the all-reduced sums of N shards) land on the SAME value -- identical packed images on every rank."""
+    if not (1e-20 < ms < 1e20):
+        return 1.0
+    return float(2.0 ** (round(math.log2(ms) * 16.0) / 16.0))
+
+
+def feature_square_sum(feature) -> torch.Tensor:
+    """float64 [2] = {sum of squares, count} of a feature batch on its device (no host sync): what ranks all-reduce to agree on one
+    calibration (dist.calibrate_feature_scale)."""
+    f = feature.detach().to(torch.float64)
+    return torch.stack((f.square().sum(), torch.tensor(float(f.numel()), dtype=torch.float64, device=f.device)))
+
+
 def feature_mean_square(feature) -> float:
     """Mean square of the entries of a feature batch: the one data-dependent input of the packers' equalisation (csrc/equalize.h).
     One device reduction + one scalar read-back; called when a parameter version is packed (which copies every parameter to the host
     anyway), never per evaluation."""
     if feature is None or feature.numel() == 0:
         return 1.0
-    ms = float(feature.detach().to(torch.float32).square().mean())
-    return ms if 1e-20 < ms < 1e20 else 1.0
+    sq = feature_square_sum(feature)
+    return quantise_feature_ms(float(sq[0] / sq[1]))
+
+
+def expand_shared_rows(feature, n_rot: int, feature_repeat: int):
+    """``feature`` holds n_rot / feature_repeat rows, row r conditioning rotations [r Q, (r + 1) Q): materialise the reference's
+    ``feature.repeat`` (agent.py:240-244) for the paths that take one feature row per rotation."""
+    if n_rot % feature_repeat:
+        raise ValueError(f"{n_rot} rotations are not a multiple of feature_repeat={feature_repeat}")
+    return feature.reshape(n_rot // feature_repeat, -1).repeat_interleave(feature_repeat, dim=0)
 
 
 def pack_layers(layers, perm_rows, device, precision=None, feature_ms=1.0) -> PackedFlow:
@@ -482,10 +507,7 @@ def run_flow(module, packed, rotation, feature, inverse=False, train_layers=None
             # eval.py:464-480 (nll_grad) differentiates log p w.r.t. the QUERY rotations with every image feature repeated number_queries
             # times (agent.py:240-244 materialises feature.repeat): the differentiable kernels take one feature row per rotation, so the
             # rows are expanded here -- autograd's repeat_interleave sums the row gradients back onto the shared rows
-            n_rot = rotation.reshape(-1, 3, 3).shape[0]
-            if n_rot % feature_repeat:
-                raise ValueError(f"{n_rot} rotations are not a multiple of feature_repeat={feature_repeat}")
-            feature = feature.reshape(n_rot // feature_repeat, -1).repeat_interleave(feature_repeat, dim=0)
+            feature = expand_shared_rows(feature, rotation.reshape(-1, 3, 3).shape[0], feature_repeat)
         from . import autograd
         if inverse:                                        # BinFind.backward (flow/mobiusflow.py:247-273) and friends
             return autograd.flow_inverse(module, train_layers, train_rows, rotation, feature)
@@ -496,10 +518,7 @@ def run_flow(module, packed, rotation, feature, inverse=False, train_layers=None
     if packed.side_layers and feature_repeat and feature is not None:
         # ConditionRot / ConditionLU build their per-sample matrices from the feature rows with batched torch ops: expand the shared rows
         # (the reference's feature.repeat, agent.py:240-244) and take the one-row-per-rotation path
-        n_rot = rotation.reshape(-1, 3, 3).shape[0]
-        if n_rot % feature_repeat:
-            raise ValueError(f"{n_rot} rotations are not a multiple of feature_repeat={feature_repeat}")
-        feature = feature.reshape(n_rot // feature_repeat, -1).repeat_interleave(feature_repeat, dim=0)
+        feature = expand_shared_rows(feature, rotation.reshape(-1, 3, 3).shape[0], feature_repeat)
         feature_repeat, shared = None, False
     rot, feat = _check_inputs(rotation, feature, packed, feature_repeat if shared else None)
     n = rot.shape[0]
@@ -537,8 +556,7 @@ def run_log_prob(module, packed: PackedFlow, rotation, feature, fisher_A=None, f
     """Fused Flow.forward + base log-density + NLL sum.  -> dict(logp, sum [2] float64 device tensor, rotation, ldj)"""
     _refuse_autograd(rotation, feature, module, "the fused log_prob evaluation")
     if packed.side_layers and feature_repeat and feature is not None:      # see run_flow: side layers take one feature row per rotation
-        n_rot = rotation.reshape(-1, 3, 3).shape[0]
-        feature = feature.reshape(n_rot // feature_repeat, -1).repeat_interleave(feature_repeat, dim=0)
+        feature = expand_shared_rows(feature, rotation.reshape(-1, 3, 3).shape[0], feature_repeat)
         feature_repeat = None
     shared = bool(feature_repeat) and packed.n_cond > 0
     rot, feat = _check_inputs(rotation, feature, packed, feature_repeat if shared else None)

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Fixtures with weights the REFERENCE's own training produced (VERDICT r3 "missing" #1).
+
+Run in the build container only:   python tests/golden/make_trained.py [trained_c1] [trained_cond4] [traj_c1]
+
+What runs here is the reference's ``flow.flow.Flow`` (imported from /root/reference with the two third-party stand-ins of
+oracle/stubs) under ``torch.optim.Adam`` with the loss of agent.py:55-65 (``mean(-ldjs)``, uniform base) -- the loop of agent.py:75-92
+without the Agent object (agent.py itself needs tensorboard and CUDA and cannot be imported here).  The targets are ``raw``-style
+rotation sets (dataset/dataset_raw.py:13: float32 [M,3,3]) drawn with the reference's ``MatrixFisherN._sample``.
+
+Outputs (data only; nothing of the reference travels):
+  trained_c1.pth      checkpoint in the layout of Agent.save_ckpt (agent.py:132-151): {"clock", "flow_state_dict"} -- the optimizer state is
+                      left out (it would triple the file; Agent.load_ckpt would need it, this repo's harness does not)
+  trained_c1.npz      held-out test rotations [M,3,3], the reference's fp32 and fp64 ldj / rotation' on them, its eval statistic
+                      (eval_uncondition.py:43-45), the training curve, and the same for the inverse pass on base samples
+  trained_cond4.pth / .npz   the same for a 4-layer conditional flow (SYMSOL structure, F = 32) trained on a feature-dependent target
+  traj_c1.npz         20 Adam steps from the synth "default" weights on fixed batches: per-step loss and the parameter update of every tensor,
+                      from an fp32 and an fp64 run of the reference
+"""
+import contextlib
+import io
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+if not os.path.isdir(REF):
+    sys.exit("reference tree not present; these fixtures can only be regenerated in the build container")
+sys.path[:0] = [os.path.join(REPO, "oracle", "stubs"), REF, REPO]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import flow.flow as ref_flow_mod  # noqa: E402
+import utils.fisher as ref_fisher_mod  # noqa: E402
+
+assert ref_flow_mod.__file__.startswith(REF), ref_flow_mod.__file__
+assert ref_fisher_mod.__file__.startswith(REF), ref_fisher_mod.__file__
+
+from rotationnormflow_amd import synth  # noqa: E402
+from rotationnormflow_amd.configs import make_config  # noqa: E402
+from tests.golden.trained_cases import TRAINED, TRAJ  # noqa: E402
+
+
+def ref_flow(cfg, dtype):
+    torch.set_default_dtype(dtype)
+    with contextlib.redirect_stdout(io.StringIO()):
+        fl = ref_flow_mod.Flow(cfg)
+    return fl.to(dtype)
+
+
+def fisher_samples(modes, kappa, n, seed):
+    """n rotations from an equal-weight mixture of matrix-Fisher modes A_j = kappa * M_j, drawn with the reference's own sampler."""
+    torch.manual_seed(seed)
+    torch.set_default_dtype(torch.float32)
+    per = -(-n // len(modes))
+    out = []
+    for M in modes:
+        A = torch.from_numpy((kappa * M).astype(np.float32))[None]
+        out.append(ref_fisher_mod.MatrixFisherN(A)._sample(per).reshape(-1, 3, 3))
+    R = torch.cat(out)[torch.randperm(per * len(modes))][:n]
+    return R.numpy().astype(np.float32)
+
+
+def make_dataset(spec):
+    """-> train rotations, test rotations, train features, test features (None for unconditional)."""
+    modes = synth.uniform_rotations(8, seed=spec["mode_seed"]).astype(np.float64)
+    if not spec["cfg"].get("condition"):
+        pick = modes[: spec["n_modes"]]
+        return (fisher_samples(pick, spec["kappa"], spec["n_train"], spec["data_seed"]),
+                fisher_samples(pick, spec["kappa"], spec["n_test"], spec["data_seed"] + 1), None, None)
+    # conditional: the feature vector is a noisy class centre; class c owns modes [2c, 2c + 1] (a two-fold "symmetric" target)
+    F, C = spec["cfg"]["feature_dim"], spec["n_classes"]
+    centres = np.random.default_rng(spec["mode_seed"] + 1).standard_normal((C, F)).astype(np.float32)
+
+    def draw(n, seed):
+        rng = np.random.default_rng(seed)
+        cls = rng.integers(0, C, n)
+        feat = (centres[cls] + 0.3 * rng.standard_normal((n, F))).astype(np.float32)
+        R = np.empty((n, 3, 3), np.float32)
+        for c in range(C):
+            idx = np.nonzero(cls == c)[0]
+            R[idx] = fisher_samples(modes[2 * c: 2 * c + 2], spec["kappa"], len(idx), seed + 17 * (c + 1))
+        return R, feat
+    Rtr, ftr = draw(spec["n_train"], spec["data_seed"])
+    Rte, fte = draw(spec["n_test"], spec["data_seed"] + 1)
+    return Rtr, Rte, ftr, fte
+
+
+def train(fl, R, feat, steps, batch, lr, seed, log_every=100):
+    """agent.py:23 (Adam(flow.parameters(), lr)) + agent.py:75-92 (forward, loss = mean(-ldjs), zero_grad, backward, step) on shuffled
+    mini-batches (dataset_raw.py:36: shuffle=True)."""
+    opt = torch.optim.Adam(fl.parameters(), lr)
+    fl.train()
+    g = torch.Generator().manual_seed(seed)
+    n = R.shape[0]
+    curve = []
+    perm, at = torch.randperm(n, generator=g), 0
+    t0 = time.time()
+    for it in range(steps):
+        if at + batch > n:
+            perm, at = torch.randperm(n, generator=g), 0
+        idx = perm[at: at + batch]
+        at += batch
+        _, ldjs = fl(R[idx], None if feat is None else feat[idx])
+        loss = (-ldjs).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        curve.append(float(loss))
+        if it % log_every == 0 or it == steps - 1:
+            print(f"  it {it:5d}  loss {float(loss):8.4f}  ({time.time() - t0:.0f} s)", flush=True)
+    return np.array(curve)
+
+
+def evaluate(cfg, state, Rte, fte, base_rot):
+    out = {}
+    for tag, dtype in (("32", torch.float32), ("64", torch.float64)):
+        fl = ref_flow(cfg, dtype).eval()
+        fl.load_state_dict({k: v.to(dtype) for k, v in state.items()})
+        R = torch.from_numpy(Rte).to(dtype)
+        f = None if fte is None else torch.from_numpy(fte).to(dtype)
+        with torch.no_grad():
+            rot, ldj = fl(R, f)
+            m = base_rot.shape[0]
+            irot, ildj = fl.inverse(torch.from_numpy(base_rot).to(dtype), None if f is None else f[:m])
+        out["rot" + tag], out["ldj" + tag] = rot.numpy().copy(), ldj.numpy().copy()
+        out["inv_rot" + tag], out["inv_ldj" + tag] = irot.numpy().copy(), ildj.numpy().copy()
+        # eval_uncondition.py:43-45: np.mean(np.concatenate(losses)) with losses = pre_ll + ldjs (agent.py:226-229; uniform base: pre_ll = 0)
+        out["mean_ll" + tag] = np.float64(np.mean(ldj.numpy()))
+    torch.set_default_dtype(torch.float32)
+    return out
+
+
+def run_trained(name, spec):
+    cfg = make_config(**spec["cfg"])
+    Rtr, Rte, ftr, fte = make_dataset(spec)
+    torch.manual_seed(spec["init_seed"])                 # the reference's own initialisation (nn.Linear defaults, mat = I + 1e-3 randn)
+    fl = ref_flow(cfg, torch.float32)
+    print(f"{name}: {len(fl.layers)} layers, {sum(p.numel() for p in fl.parameters())} parameters, train {Rtr.shape[0]}, test {Rte.shape[0]}")
+    curve = train(fl, torch.from_numpy(Rtr), None if ftr is None else torch.from_numpy(ftr), spec["steps"], spec["batch"], spec["lr"], spec["init_seed"])
+    state = {k: v.detach().clone() for k, v in fl.state_dict().items()}
+    torch.save({"clock": {"epoch": spec["steps"] * spec["batch"] // Rtr.shape[0], "minibatch": 0, "iteration": spec["steps"]},
+                "flow_state_dict": state}, os.path.join(HERE, name + ".pth"))
+    base_rot = synth.uniform_rotations(spec["n_inverse"], seed=spec["data_seed"] + 5)
+    out = evaluate(cfg, state, Rte, fte, base_rot)
+    out.update(test_rot=Rte, base_rot=base_rot, curve=curve.astype(np.float32))
+    if fte is not None:
+        out["test_feat"] = fte
+    # how "trained" the weights are: segment-weight saturation and squashed centre norms of the first test rows are visible in the ldj range
+    d = np.abs(out["ldj32"].astype(np.float64) - out["ldj64"])
+    print(f"{name}: mean log-likelihood fp64 {out['mean_ll64']:.6f} (fp32 {out['mean_ll32']:.6f}), ldj range [{out['ldj64'].min():.2f}, "
+          f"{out['ldj64'].max():.2f}], reference fp32 noise mean {d.mean():.2e} max {d.max():.2e}")
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def run_traj(name, spec):
+    cfg = make_config(**spec["cfg"])
+    R = fisher_samples(synth.uniform_rotations(8, seed=spec["mode_seed"]).astype(np.float64)[: spec["n_modes"]], spec["kappa"],
+                       spec["steps"] * spec["batch"], spec["data_seed"])
+    out = {"rot": R}
+    dw = {}
+    for tag, dtype in (("32", torch.float32), ("64", torch.float64)):
+        fl = ref_flow(cfg, dtype).train()
+        shapes = {k: tuple(v.shape) for k, v in fl.state_dict().items()}
+        w0 = synth.fill_state_dict(shapes, seed=spec["wseed"], regime=spec["regime"])
+        fl.load_state_dict({k: torch.from_numpy(v).to(dtype) for k, v in w0.items()})
+        opt = torch.optim.Adam(fl.parameters(), spec["lr"])
+        losses = []
+        for it in range(spec["steps"]):
+            batch = torch.from_numpy(R[it * spec["batch"]: (it + 1) * spec["batch"]]).to(dtype)
+            _, ldjs = fl(batch, None)
+            loss = (-ldjs).mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        out["loss" + tag] = np.array(losses, np.float64)
+        dw[tag] = {k: v.detach().double().numpy() - w0[k].astype(np.float64) for k, v in fl.state_dict().items()}
+    torch.set_default_dtype(torch.float32)
+    # the fp64 run's parameter updates (the truth, stored as float32) and, per tensor, how far the reference's own fp32 run lands from them
+    for k in dw["64"]:
+        out["dw64:" + k] = dw["64"][k].astype(np.float32)
+        out["ref32_err:" + k] = np.float64(np.linalg.norm(dw["32"][k] - dw["64"][k]))
+    dl = np.abs(out["loss32"] - out["loss64"])
+    print(f"{name}: loss {out['loss64'][0]:.5f} -> {out['loss64'][-1]:.5f}; reference fp32 vs fp64 loss max diff {dl.max():.2e}")
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def main():
+    want = sys.argv[1:]
+    for name, spec in TRAINED.items():
+        if not want or name in want:
+            run_trained(name, spec)
+    for name, spec in TRAJ.items():
+        if not want or name in want:
+            run_traj(name, spec)
+
+
+if __name__ == "__main__":
+    main()

@@ -89,3 +89,49 @@ def test_gradient_blob_all_reduce_mean_world2():
         p.join(60)
     want = np.arange(1000, dtype=np.float32) * 1.5
     assert np.allclose(got[0], want) and np.allclose(got[1], want)
+
+
+def _calib_worker(rank, world, port, out_dir):
+    import contextlib
+    import io
+    import torch.distributed as dist
+    from rotationnormflow_amd import make_config
+    from rotationnormflow_amd.flow.flow import Flow
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            fl = Flow(make_config(None, layers=2, condition=1, feature_dim=16, rot="16UnTrans", last_affine=1, first_affine=0, frequent_permute=1))
+        # shards of very different scale: per-process calibration would disagree by a factor of 16
+        feat = torch.from_numpy(synth.features(1001, 16, seed=9))
+        feat[:501] *= 4.0
+        lo, hi = rdist.shard_bounds(1001, rank, world)
+        ms = rdist.calibrate_feature_scale(fl, feat[lo:hi])
+        again = rdist.calibrate_feature_scale(fl, feat[lo:hi] * 100.0)            # already fixed: no second measurement
+        np.save(os.path.join(out_dir, f"ms{rank}.npy"), np.array([ms, again, fl._feature_ms_fixed]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_feature_calibration_is_one_value_for_all_ranks(tmp_path):
+    """the ranks of a sharded evaluation agree on ONE feature mean square (all-reduce of {sum f^2, count}), equal to the
+    value a single process measures on the whole batch -- so that every rank packs the same images as the 1-GPU run."""
+    from rotationnormflow_amd import runtime
+    world = 2
+    mp.spawn(_calib_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    m0, m1 = np.load(tmp_path / "ms0.npy"), np.load(tmp_path / "ms1.npy")
+    assert np.array_equal(m0, m1) and m0[0] == m0[1] == m0[2]
+    feat = torch.from_numpy(synth.features(1001, 16, seed=9))
+    feat[:501] *= 4.0
+    assert m0[0] == runtime.feature_mean_square(feat)                              # the single-process measurement, bit for bit
+    assert abs(np.log2(m0[0]) * 16 - round(np.log2(m0[0]) * 16)) < 1e-9            # quantised to 1/16 binade
+    assert 0.9 < m0[0] / float(feat.double().square().mean()) < 1.1
+
+
+def test_shared_feature_rows_must_divide_the_batch():
+    """one helper, one error, for every path that expands shared feature rows."""
+    from rotationnormflow_amd import runtime
+    f = torch.arange(12.0).reshape(3, 4)
+    out = runtime.expand_shared_rows(f, 6, 2)
+    assert out.shape == (6, 4) and torch.equal(out[0], out[1]) and torch.equal(out[4], f[2])
+    with pytest.raises(ValueError, match="not a multiple of feature_repeat"):
+        runtime.expand_shared_rows(f, 7, 2)

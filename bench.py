@@ -1,32 +1,47 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: rotation log-prob evaluations per second + mean NLL.
 
-Default workload (BASELINE.json configs[1], "fisher24" = --config C2): 24-layer MobiusAffine flow (48 layers: [Moebius,
-Uncondition16Trans] x 24, K = 64 segments) + matrix-Fisher base, forward log_prob only, 2^20 uniform-SO(3) rotations per GPU, fp32.
-A "step" = one fused density evaluation of the whole per-GPU batch (inputs resident in HBM) + the mean-NLL reduction
-(on N > 1 GPUs: one RCCL all-reduce of {sum log p, count}).  Weak scaling: every rank evaluates its own 2^20 shard.
+Headline workload (BASELINE.json configs[1], "fisher24" = C2): 24-layer MobiusAffine flow (48 layers: [Moebius, Uncondition16Trans] x 24,
+K = 64 segments) + matrix-Fisher base, forward log_prob only, 2^20 uniform-SO(3) rotations per GPU, fp32.
+A "step" = one fused density evaluation of the whole per-GPU batch (inputs resident in HBM) + the mean-NLL reduction (on N > 1 GPUs: one
+RCCL all-reduce of {sum log p, count}).  Weak scaling: every rank evaluates its own 2^20 shard.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C3|C4|C5|C5u] [--batch-log2 B] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C1|C2|C3|C4|C5|C5u] [--batch-log2 B]
+                    [--no-cpu-baseline] [--no-secondary] [--no-configs] [--no-pmc]
 
---config C3 (BASELINE.json configs[2]) is the STRONG-scaling workload: one global batch of 2^22 rotations split contiguously over the
-N ranks (2^19 per GPU at N = 8, all 2^22 on one GPU at N = 1), uniform base, one all-reduce of {sum log p, count}; every other config
-is weak scaling (2^20 rotations per GPU).
+ONE JSON line on rank 0.  At N = 1 with the default workload the line also carries (round 4):
+  * `value_fp32_exact` / `ms_per_step_fp32_exact`: the same workload on the exact fp32-input MFMA kernels (the unconditional number; `value`
+    is the default split-precision arithmetic -- fp32 operands carried as fp16 hi+lo pairs, fp32 accumulate);
+  * `configs`: every other BASELINE.json config on the same clock -- C1, C3 (its 2^22 rotations on this one GPU), C4, C5, C5u -- each with
+    value, ms_per_step, both arithmetics, roofline (frac, kernel list, HBM traffic, VALU-issue and matrix-pipe fractions), parity against the
+    fp64 oracle with the reference-fp32 arithmetic's own error beside it, and a CPU baseline;
+  * `roofline.traffic` and the binding fractions MEASURED IN THIS RUN: before this process touches the GPU it runs three short
+    `rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --pmc-child ...` children (FETCH_SIZE, WRITE_SIZE and the SQ/GRBM group each in
+    its own pass, as MI355X_MICROARCH.md prescribes; FETCH_SIZE x 2 x 1024, WRITE_SIZE x 1024) over the same workloads of the same library.
+    If rocprofv3 is unavailable the committed summaries under profiles/ are replayed when their source hash matches (else null + the reason).
 
-With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its N ranks itself
-(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` as a CHILD process, before this process
-touches the GPU) and relays the child's JSON line and exit code; under torchrun (WORLD_SIZE set) it is one rank.
-Prints ONE JSON line on rank 0.  The line carries both arithmetics of the conditioner GEMMs: `value` is the default
-split-precision fp16-MFMA path ("f16x2"), `secondary` the exact fp32-MFMA path.
+--config C3 (BASELINE.json configs[2]) is the STRONG-scaling workload: one global batch of 2^22 rotations split contiguously over the N
+ranks (2^19 per GPU at N = 8, all 2^22 on one GPU at N = 1), uniform base, one all-reduce of {sum log p, count}; every other config is weak
+scaling (2^20 rotations per GPU).  An explicit --config runs that workload alone (no `configs` object).
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its N ranks itself (`python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ...` as a CHILD process, before this process touches the GPU) and relays the child's JSON line
+and exit code; under torchrun (WORLD_SIZE set) it is one rank.
 """
 import argparse
 import contextlib
+import csv
+import glob
 import io
 import json
 import os
+import shutil
 import socket
 import subprocess
 import sys
+import tempfile
 import time
+from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -36,6 +51,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md chip table: f32-i
 PEAK_F16_MFMA_TFLOPS = 2500.0            # MI355X_MICROARCH.md chip table: BF16/FP16 MFMA dense
 PEAK_HBM_GBPS = 8000.0
 CLOCK_SETTLE_LAUNCHES = 16                # untimed launches in front of the warm-up steps (GPU clock ramp), reported in the JSON line
+SIMDS = 1024                              # 256 CUs x 4
 
 # algorithmic GEMM FLOP per rotation (exact 2*MAC of the conditioner MLPs) and algorithmic HBM bytes per
 # rotation (inputs read once + what the step writes); preset of rotationnormflow_amd.configs; direction; matrix-Fisher base.
@@ -57,6 +73,14 @@ WORKLOADS = {
     "C5u": dict(preset="C5u", direction="inverse", fisher=True, flop=42 * 57_728, bytes=36 + 36 + 4,
                 text="inverse sampling, unconditional variant: MF(diag(5,3,1)) samples through the inverse of a 42-layer Moebius-only flow"),
 }
+ALL_CONFIGS = ["C2", "C1", "C3", "C4", "C5", "C5u"]
+PMC_GROUPS = {
+    "fetch": "FETCH_SIZE",
+    "write": "WRITE_SIZE",
+    "sq": "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE",
+}
+PMC_EVALS = 2                             # profiled evaluations per workload and arithmetic in a --pmc-child pass (behind one warm-up)
+MARKER = "FillFunctor<short>"             # an int16 fill: a kernel nothing else launches, separates the sections of a --pmc-child pass
 
 
 def self_launch(args, argv):
@@ -102,9 +126,21 @@ def host_threads():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(cfg, weights, A, wl, feat_dim, budget_s=12.0):
-    """The oracle (torch CPU restatement of the reference path, parity-pinned to it) timed on this box's host cores,
-    on a bounded sample sized from a short probe so the default run stays within minutes."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, weights, A, wl, feat_dim, sizes, budget_s):
+    """the oracle (torch-CPU restatement of the reference path, parity-pinned to it) on this box's host cores, fp32,
+    no_grad, the same seeded recipe as the GPU run, at each N of ``sizes``: one warm-up, then best of 3 -- fewer repetitions (never fewer
+    than one) where three would overrun ``budget_s`` seconds, which `sample` then says.  `value` is the best rate over the sizes."""
     import torch
     from oracle import flow_oracle as orc          # measured as the BASELINE only; never used by the product
     from rotationnormflow_amd import synth
@@ -112,76 +148,407 @@ def cpu_baseline(cfg, weights, A, wl, feat_dim, budget_s=12.0):
     torch.set_num_threads(threads)
 
     def run(R, f):
-        if wl["direction"] == "forward":
-            orc.log_prob(cfg, weights, R, f, A if wl["fisher"] else None, torch.float32)
-        else:
-            orc.flow_inverse(cfg, weights, R, f, dtype=torch.float32)
+        chunk = 16384                                                        # bound the [N,K,3,3] temporaries
+        t0 = time.perf_counter()
+        for s in range(0, R.shape[0], chunk):
+            if wl["direction"] == "forward":
+                orc.log_prob(cfg, weights, R[s:s + chunk], None if f is None else f[s:s + chunk], A if wl["fisher"] else None, torch.float32)
+            else:
+                orc.flow_inverse(cfg, weights, R[s:s + chunk], None if f is None else f[s:s + chunk], dtype=torch.float32)
+        return time.perf_counter() - t0
 
-    probe_n = 1024 if wl["direction"] == "forward" else 256
-    R = synth.uniform_rotations(probe_n, seed=1)
-    f = synth.features(probe_n, feat_dim, seed=5) if feat_dim else None
-    run(R[:128], None if f is None else f[:128])                              # warm-up
-    t0 = time.perf_counter()
-    run(R, f)
-    probe_rate = probe_n / (time.perf_counter() - t0)
-    n = int(min(max(probe_rate * budget_s, 1024), 131072)) // 512 * 512
-    R = synth.uniform_rotations(n, seed=2)
-    f = synth.features(n, feat_dim, seed=6) if feat_dim else None
-    chunk = 16384                                                            # bound the [N,K,3,3] temporaries
-    t0 = time.perf_counter()
-    for s in range(0, n, chunk):
-        run(R[s:s + chunk], None if f is None else f[s:s + chunk])
-    dt = time.perf_counter() - t0
+    runs, best_rate, spent = [], 0.0, 0.0
+    for n in sizes:
+        R = synth.uniform_rotations(n, seed=2)
+        f = synth.features(n, feat_dim, seed=6) if feat_dim else None
+        m = min(n, 512)
+        t_warm = run(R[:m], None if f is None else f[:m])                    # warm-up (thread pool, allocator)
+        est = t_warm * n / m
+        reps = 3 if spent + 3 * est <= budget_s else max(1, int((budget_s - spent) / max(est, 1e-9)))
+        reps = min(reps, 3)
+        times = [run(R, f) for _ in range(reps)]
+        spent += sum(times) + t_warm
+        runs.append({"n": n, "best_s": min(times), "repetitions": reps, "rotations_per_s": n / min(times)})
+        best_rate = max(best_rate, n / min(times))
     what = "forward log_prob" if wl["direction"] == "forward" else "inverse pass (base sampling not included)"
-    return dict(value=n / dt, unit="rotations/s", cores=threads, kind="port",
-                sample=f"{n} rotations of the same workload ({wl['preset']} {what}), fp32, torch-CPU oracle, {threads} threads, one pass of {dt:.1f} s")
+    return dict(value=best_rate, unit="rotations/s", cores=threads, kind="port", cpu=cpu_model(), runs=runs,
+                sample=f"{wl['preset']} {what}, fp32, torch-CPU oracle, {threads} threads; " +
+                       "; ".join(f"N={r['n']}: best of {r['repetitions']} = {r['best_s']:.2f} s" for r in runs))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# one workload on the device
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """Flow, inputs (resident in HBM) and the step of one BASELINE config on ``device``."""
+
+    def __init__(self, name, device, batch_log2=None, rank=0, world=1, share=None):
+        import torch
+        from rotationnormflow_amd import synth
+        from rotationnormflow_amd.utils.fisher import MatrixFisherN
+        self.name, self.device, self.wl = name, device, WORKLOADS[name]
+        wl = self.wl
+        if share is not None and share.wl["preset"] in ("C2", "C3") and wl["preset"] in ("C2", "C3"):
+            self.cfg, self.weights, self.fl = share.cfg, share.weights, share.fl      # C2 and C3: the same flow and weights
+        else:
+            self.cfg, self.weights, self.fl = build_flow(device, wl["preset"])
+        self.strong = bool(wl.get("strong"))
+        log2n = batch_log2 if batch_log2 is not None else wl.get("batch_log2", 20)
+        self.A = synth.fisher_A("diag531")
+        self.base = MatrixFisherN(torch.from_numpy(self.A).to(device)) if wl["fisher"] else None
+        self.feat_dim = self.fl.feature_dim if self.cfg.condition else 0
+        gen = torch.Generator(device=device)
+        if self.strong:
+            # ONE global batch, the same for every world size; rank r evaluates rows [r N / G, (r + 1) N / G) (dist.shard_bounds, the partition
+            # of torch's scatter on dim 0 = the reference's nn.DataParallel, agent.py:22): no data-path collective
+            from rotationnormflow_amd.dist import shard_bounds
+            self.n_global = 1 << log2n
+            lo, hi = shard_bounds(self.n_global, rank, world)
+            self.R = torch.from_numpy(synth.uniform_rotations(self.n_global, seed=synth.RD_SEED)[lo:hi].copy()).to(device)
+            self.n = hi - lo
+            fseed, skip = synth.RD_SEED + 1000, lo
+        else:
+            # weak scaling: rank r evaluates its own batch (seeded per rank): no data-path collective
+            self.n = 1 << log2n
+            self.n_global = self.n * world
+            self.R = torch.from_numpy(synth.uniform_rotations(self.n, seed=synth.RD_SEED + rank)).to(device)
+            fseed, skip = synth.RD_SEED + 1000 + rank, 0
+        self.feat = None
+        if self.feat_dim:
+            # precomputed features ~ N(0, 1) [N, F] drawn on the device (2 GB for C5: a host generator would take longer than the bench)
+            gen.manual_seed(fseed)
+            full = torch.randn((skip + self.n, self.feat_dim), generator=gen, device=device, dtype=torch.float32)
+            self.feat = full[skip:].contiguous()
+
+    def evaluate(self):
+        import torch
+        if self.wl["direction"] == "forward":
+            return self.fl.log_prob(self.R, self.feat, base=self.base)["sum"]
+        # eval.py:327-347: base samples + their log-density, inverse pass, log p = base - ldj
+        z = self.base._sample(self.n).reshape(-1, 3, 3)
+        lp = self.base._log_prob(z)
+        _, ldj = self.fl.inverse(z, self.feat)
+        lp = (lp - ldj).double()
+        return torch.stack((lp.sum(), torch.tensor(float(self.n), dtype=torch.float64, device=self.device)))
+
+    def timed(self, steps, warmup, settle, dist=None):
+        """-> (elapsed s over `steps` (max over ranks), mean HIP-event ms of the library calls, last {sum, count})."""
+        import numpy as np
+        import torch
+        from rotationnormflow_amd.dist import all_reduce_nll
+        distributed = dist is not None
+        with torch.no_grad():
+            # the SMU needs ~10 launches (50 ms) of this kernel to settle on its clock; these launches are outside both the W warm-up
+            # steps and the K timed steps and are reported in the JSON line
+            for _ in range(settle):
+                self.evaluate()
+            tot = None
+            for _ in range(warmup):
+                tot = all_reduce_nll(self.evaluate()) if distributed else self.evaluate()
+            torch.cuda.synchronize()
+            if distributed:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            t0 = time.perf_counter()
+            for i in range(steps):
+                ev[i][0].record()                              # the library launches on torch's current stream: these events bracket its kernels
+                part = self.evaluate()
+                ev[i][1].record()
+                tot = all_reduce_nll(part) if distributed else part
+            torch.cuda.synchronize()
+            if distributed:
+                dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, float(np.mean([a.elapsed_time(b) for a, b in ev])), tot.cpu().numpy()
+
+    def parity(self, rows):
+        """Error statistics of `rows` rotations of THIS run's inputs and weights against the fp64 oracle, for the arithmetic in force, with
+        the error of the oracle's own fp32 evaluation (= the reference's arithmetic) of the same rows beside it."""
+        import numpy as np
+        import torch
+        from oracle import flow_oracle as orc
+        torch.set_num_threads(host_threads())
+        wl = self.wl
+        sub = self.R[:rows]
+        fsub = None if self.feat is None else self.feat[:rows]
+        sub_np, fsub_np = sub.cpu().numpy(), None if fsub is None else fsub.cpu().numpy()
+
+        def oracle(dtype):
+            if wl["direction"] == "forward":
+                return orc.log_prob(self.cfg, self.weights, sub_np, fsub_np, self.A if wl["fisher"] else None, dtype)[0].double().numpy()
+            return orc.flow_inverse(self.cfg, self.weights, sub_np, fsub_np, dtype=dtype)[1].double().numpy()
+
+        def product():
+            with torch.no_grad():
+                if wl["direction"] == "forward":
+                    return self.fl.log_prob(sub, fsub, base=self.base)["logp"].cpu().double().numpy()
+                return self.fl.inverse(sub, fsub)[1].cpu().double().numpy()
+
+        def stats(got, want):
+            e = np.abs(got - want)
+            return {"mean_abs_err_of_the_mean": abs(float(got.mean() - want.mean())), "mean_abs_err": float(e.mean()),
+                    "p99_abs_err": float(np.quantile(e, 0.99)), "max_abs_err": float(e.max())}
+        want = oracle(torch.float64)
+        what = "per-rotation log p (mean = -mean NLL)" if wl["direction"] == "forward" else "per-rotation log-det of the inverse pass"
+        return {"samples": rows, "quantity": what, "against": "fp64 oracle (pinned to the reference's fp64 run to 1e-11)"}, stats, product, want, oracle
+
+
+def roofline_of(w, precision, kernel_ms, pmc):
+    """`achieved` = ALGORITHMIC GEMM FLOP of one step / the step's HIP-event time.  f16x2: the conditioner GEMMs run on the fp16 matrix cores
+    (3 fp16 MFMAs with fp32 accumulate per fp32 product-sum), so the matrix roofline is the dense fp16 peak while `achieved` stays the
+    algorithmic fp32 FLOP rate (executed matrix FLOPs are 3x that); what binds is VALU issue (per-segment softplus / arctangent /
+    reciprocal math): bound = "valu", with `valu_issue_frac` (PMC, this run) as the binding fraction.  fp32: exact fp32-input MFMA."""
+    wl = w.wl
+    achieved = wl["flop"] * w.n / (kernel_ms * 1e-3) / 1e12
+    if precision == "f16x2":
+        r = {"bound": "valu", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_MFMA_TFLOPS,
+             "kernel_ms": kernel_ms, "algorithmic_flop_per_rotation": wl["flop"], "executed_mfma_tflops": 3 * achieved,
+             "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+             "note": "frac = algorithmic GEMM FLOP rate / dense fp16 MFMA peak; the stack kernel is VALU-issue bound (valu_issue_frac), neither "
+                     "matrix- nor HBM-bound"}
+    else:
+        r = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+             "kernel_ms": kernel_ms, "algorithmic_flop_per_rotation": wl["flop"],
+             "note": "exact fp32-input MFMA; shares the FMA datapath with the VALU segment math on gfx950"}
+    r["traffic_algorithmic"] = wl["bytes"] * w.n
+    sec = (pmc or {}).get("sections", {}).get(f"{w.name}:{precision}")
+    if sec and sec.get("rotations") == w.n:
+        r.update(sec["roofline"])
+        r["traffic_source"] = pmc["source"]
+    else:
+        committed, why = committed_pmc(w.name, precision, w.n)
+        if committed:
+            r.update(committed)
+        else:
+            r["traffic"] = None
+            r["traffic_source"] = (pmc or {}).get("error") or why
+    if "kernel" not in r:
+        r["kernel"] = f"rnf::flow_stack_kernel<{1 if wl['direction'] == 'inverse' else 0},...>"
+    return r
 
 
 def committed_pmc(workload, precision, n):
-    """Counters of the dominant kernel from the committed rocprofv3 PMC passes of THIS workload (tools/profile_round.sh collects
-    FETCH_SIZE and WRITE_SIZE each in its own run; tools/pmc_summary.py applies the gfx950 correction).  A summary is only replayed when
-    it was taken from the kernel sources this build was made from (`csrc_sha` recorded by pmc_summary.py) and its launch size divides
-    this run's batch (the conditional / inverse configs run in chunks of 2^18 rotations: the per-launch bytes of the projection pre-pass
-    and of the stack kernel are added and scaled to the step); otherwise (None, reason)."""
+    """Fallback when the live PMC passes could not run: counters of the committed rocprofv3 passes of THIS workload (profiles/r*/pmc_live.json,
+    written by `bench.py --save-pmc`), replayed only when they were taken from the kernel sources this build was made from."""
     from rotationnormflow_amd.build import source_hash
-    names = [f"pmc_{workload}_{precision}.json"] if precision == "f16x2" else []
-    names += [f"pmc_{workload}_stack.json", f"pmc_{workload}_featproj.json"] if precision == "f16x2" else []
-    found = []
-    for rnd in ("r3", "r2", "r1"):
-        found = [os.path.join(ROOT, "profiles", rnd, nm) for nm in names if os.path.exists(os.path.join(ROOT, "profiles", rnd, nm))]
-        if found:
-            break
-    if not found:
-        return None, "no committed PMC summary for this workload"
-    total, primary = 0.0, None
-    for path in found:
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_live.json")), reverse=True):
         with open(path) as fh:
             d = json.load(fh)
         rel = os.path.relpath(path, ROOT)
         if d.get("csrc_sha") != source_hash():
             return None, f"{rel} was collected from other kernel sources (csrc_sha {d.get('csrc_sha')} != {source_hash()}): not replayed"
-        per = d.get("rotations_per_launch") or 0
-        if per <= 0 or n % per:
-            return None, f"{rel} was collected at another launch size: not replayed"
-        if "hbm_bytes_per_launch" in d:
-            total += d["hbm_bytes_per_launch"] * (n // per)
-        if primary is None:
-            primary = dict(d, source=rel)
-    primary["hbm_bytes_per_launch"] = total
-    primary["source"] = ", ".join(os.path.relpath(p, ROOT) for p in found)
-    return primary, None
+        sec = d.get("sections", {}).get(f"{workload}:{precision}")
+        if not sec or sec.get("rotations") != n:
+            return None, f"{rel} holds no pass of this workload at this batch size"
+        return dict(sec["roofline"], traffic_source=f"committed {rel} (csrc_sha {d['csrc_sha']})"), None
+    return None, "rocprofv3 passes unavailable and no committed PMC summary"
 
 
-def pmc_fractions(d):
-    c = d["counters"]
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# live PMC passes: children of this process under rocprofv3, run BEFORE this process touches the GPU
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+def pmc_child(args):
+    """`rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --pmc-child --pmc-configs C2,C1,...`: every workload once per arithmetic,
+    sections separated by a marker kernel; prints the section table (JSON) that pmc_parse joins with the profiler's CSV."""
+    import torch
+    from rotationnormflow_amd import set_precision
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    marker = torch.empty(64, dtype=torch.int16, device=device)       # (empty, not zeros: a zeros() would itself launch the marker kernel)
+    sections = []
+    prev = None
+    for name in args.pmc_configs.split(","):
+        w = Workload(name, device, args.batch_log2, share=prev)
+        prev = w
+        for precision in ("f16x2", "fp32"):
+            set_precision(precision)
+            with torch.no_grad():
+                w.evaluate()                                    # warm-up of this arithmetic: packs, allocates; profiled too, then dropped by position
+                torch.cuda.synchronize()
+                marker.fill_(1)
+                for _ in range(PMC_EVALS):
+                    w.evaluate()
+                torch.cuda.synchronize()
+                marker.fill_(2)
+            sections.append({"key": f"{name}:{precision}", "rotations": w.n, "evals": PMC_EVALS,
+                             "packed_precision": w.fl._packed(device, w.feat).precision})
+        set_precision("f16x2")
+        w.R = w.feat = None
+        torch.cuda.empty_cache()
+    print("PMC_SECTIONS " + json.dumps(sections), flush=True)
+
+
+def pmc_parse(csv_paths, sections):
+    """Join one pass's counter_collection.csv with the child's section table: dispatches in order, an int16 fill opens and closes every
+    section.  -> {section key: {kernel name: {calls, ns, counters{name: sum}}}}"""
+    disp = {}
+    for path in csv_paths:
+        with open(path, newline="") as fh:
+            for r in csv.DictReader(fh):
+                d = disp.setdefault(int(r["Dispatch_Id"]), {"kernel": r["Kernel_Name"], "ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
+                                                           "vgpr": int(r["VGPR_Count"]), "wg": int(r["Workgroup_Size"]), "c": defaultdict(float)})
+                d["c"][r["Counter_Name"]] += float(r["Counter_Value"])
+    out, idx, inside = {}, 0, False
+    for k in sorted(disp):
+        d = disp[k]
+        if MARKER in d["kernel"]:
+            if inside:
+                idx += 1
+            inside = not inside
+            continue
+        if not inside or idx >= len(sections) or "rnf::" not in d["kernel"]:
+            continue
+        sec = out.setdefault(sections[idx]["key"], {})
+        e = sec.setdefault(d["kernel"], {"calls": 0, "ns": 0, "vgpr": d["vgpr"], "wg": d["wg"], "counters": defaultdict(float)})
+        e["calls"] += 1
+        e["ns"] += d["ns"]
+        for cn, cv in d["c"].items():
+            e["counters"][cn] += cv
+    return out
+
+
+def short_kernel(name):
+    name = name.replace("void ", "").replace("rnf::", "")
+    return name.split("(")[0]
+
+
+def pmc_sections_summary(passes, sections):
+    """-> {section key: {rotations, roofline{traffic, traffic_fetch, traffic_write, kernel, kernels[...], valu_issue_frac, ...}}} per STEP."""
+    out = {}
+    for s in sections:
+        key, evals = s["key"], s["evals"]
+        kernels = {}
+        for grp, per in passes.items():
+            for kname, e in per.get(key, {}).items():
+                k = kernels.setdefault(kname, {"name": short_kernel(kname), "calls_per_step": e["calls"] / evals, "vgpr": e["vgpr"], "workgroup": e["wg"]})
+                k.setdefault("ms_per_call_under_pmc", {})[grp] = e["ns"] / e["calls"] * 1e-6
+                c = e["counters"]
+                if "FETCH_SIZE" in c:
+                    k["fetch_bytes_per_step"] = c["FETCH_SIZE"] * 1024 * 2 / evals        # gfx950: 64 B tallied per 128-B request (MI355X_MICROARCH.md)
+                if "WRITE_SIZE" in c:
+                    k["write_bytes_per_step"] = c["WRITE_SIZE"] * 1024 / evals
+                if "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:
+                    cycles = c["GRBM_GUI_ACTIVE"] / 8.0                                  # the counter sums the 8 XCDs
+                    k["valu_issue_frac"] = c.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (SIMDS * cycles)      # quad-cycles -> cycles
+                    k["matrix_pipe_frac"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (SIMDS * cycles)
+                    k["valu_instructions_per_step"] = c.get("SQ_INSTS_VALU", 0.0) / evals
+                    k["mfma_instructions_per_step"] = c.get("SQ_INSTS_MFMA", 0.0) / evals
+                    wc = c.get("SQ_WAVE_CYCLES", 0.0)
+                    if wc > 0:
+                        k["wave_wait_any_frac"] = c.get("SQ_WAIT_ANY", 0.0) / wc
+                        k["wave_wait_inst_frac"] = c.get("SQ_WAIT_INST_ANY", 0.0) / wc
+                        k["wave_active_inst_frac"] = c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc
+                    k["gpu_cycles_per_step"] = cycles / evals
+        if not kernels:
+            continue
+        klist = sorted(kernels.values(), key=lambda k: -k["calls_per_step"] * max(k["ms_per_call_under_pmc"].values()))
+        for k in klist:
+            k["ms_per_call_under_pmc"] = min(k["ms_per_call_under_pmc"].values())
+        klist = [k for k in klist if k["ms_per_call_under_pmc"] * k["calls_per_step"] > 0.002]          # drop the early-exit guard re-runs and finalizers
+        dom = klist[0]
+        fetch = sum(k.get("fetch_bytes_per_step", 0.0) for k in kernels.values())
+        write = sum(k.get("write_bytes_per_step", 0.0) for k in kernels.values())
+        roof = {"traffic": fetch + write if ("fetch" in passes and "write" in passes) else None, "traffic_fetch": fetch, "traffic_write": write,
+                "kernel": dom["name"], "kernels": klist}
+        tot_cyc = sum(k.get("gpu_cycles_per_step", 0.0) for k in klist)
+        if tot_cyc > 0:                                          # step-level fractions: cycle-weighted over the step's kernels
+            roof["valu_issue_frac"] = sum(k.get("valu_issue_frac", 0.0) * k.get("gpu_cycles_per_step", 0.0) for k in klist) / tot_cyc
+            roof["matrix_pipe_frac"] = sum(k.get("matrix_pipe_frac", 0.0) * k.get("gpu_cycles_per_step", 0.0) for k in klist) / tot_cyc
+        out[key] = {"rotations": s["rotations"], "packed_precision": s.get("packed_precision"), "roofline": roof}
+    return out
+
+
+def run_pmc_passes(configs, batch_log2, keep_dir=None):
+    """Three rocprofv3 children (one per counter group).  Must be called before this process initialises the GPU."""
+    from rotationnormflow_amd.build import source_hash
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found on this box: no live PMC passes"}
+    passes, sections, t0 = {}, None, time.time()
+    work = tempfile.mkdtemp(prefix="rnf_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     try:
-        cycles = c["GRBM_GUI_ACTIVE"] / 8.0                      # the counter sums the 8 XCDs
-        simds = 1024.0
-        return {"valu_issue_frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (simds * cycles),     # quad-cycles -> cycles
-                "matrix_pipe_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (simds * cycles),
-                "valu_instructions": c["SQ_INSTS_VALU"], "mfma_instructions": c["SQ_INSTS_MFMA"]}
-    except KeyError:
-        return {}
+        for grp, counters in PMC_GROUPS.items():
+            d = os.path.join(work, grp)
+            cmd = [exe, "--pmc"] + counters.split() + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "run", "--",
+                                                       sys.executable, os.path.abspath(__file__), "--pmc-child", "--pmc-configs", ",".join(configs)]
+            if batch_log2 is not None:
+                cmd += ["--batch-log2", str(batch_log2)]
+            env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            try:
+                res = subprocess.run(cmd, cwd=work, env=env, capture_output=True, text=True, timeout=420)
+            except subprocess.TimeoutExpired:
+                return {"error": f"rocprofv3 pass '{grp}' timed out"}
+            line = [ln for ln in res.stdout.splitlines() if ln.startswith("PMC_SECTIONS ")]
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if res.returncode != 0 or not line or not files:
+                return {"error": f"rocprofv3 pass '{grp}' failed (rc {res.returncode}): {(res.stderr or res.stdout)[-300:]}"}
+            sections = json.loads(line[0][len("PMC_SECTIONS "):])
+            passes[grp] = pmc_parse(files, sections)
+        out = {"sections": pmc_sections_summary(passes, sections), "csrc_sha": source_hash(), "seconds": time.time() - t0,
+               "source": f"this run: rocprofv3 --pmc passes ({', '.join(PMC_GROUPS)}; each group its own process) over {PMC_EVALS} evaluations per "
+                         "workload and arithmetic; FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 (gfx950 correction of MI355X_MICROARCH.md), summed over "
+                         "every kernel of a step"}
+        if keep_dir:
+            os.makedirs(keep_dir, exist_ok=True)
+            with open(os.path.join(keep_dir, "pmc_live.json"), "w") as fh:
+                json.dump(out, fh, indent=1)
+        return out
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+def measure(w, args, dist, pmc, steps, warmup, want_secondary, want_parity, cpu_sizes, cpu_budget):
+    """One workload -> its record (rank 0 fills the host-side legs)."""
+    import torch
+    from rotationnormflow_amd import get_precision, set_precision
+    rank0 = dist is None or dist.get_rank() == 0
+    world = 1 if dist is None else dist.get_world_size()
+    primary = get_precision()
+    elapsed, kernel_ms, tot = w.timed(steps, warmup, CLOCK_SETTLE_LAUNCHES, dist)
+    used = w.fl._packed(w.device, w.feat).precision      # "fp32" when a weight left the fp16 range and the packer fell back
+    rec = {"workload": f"{w.name} -- {w.wl['text']}", "value": w.n_global * steps / elapsed, "unit": "rotations/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": elapsed / steps * 1e3,
+           "dtype": "f32" if used == "fp32" else "f32 (GEMM operands as fp16 hi+lo pairs, fp32 accumulate)",
+           "rotations_per_gpu": w.n, "global_batch": w.n_global, "mean_nll": -float(tot[0] / tot[1]),
+           "roofline": roofline_of(w, used, kernel_ms, pmc),
+           "hbm": {"achieved": w.wl["bytes"] * w.n / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                   "frac": w.wl["bytes"] * w.n / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, "algorithmic_bytes_per_rotation": w.wl["bytes"]}}
+    secondary = None
+    if want_secondary and used == "f16x2":
+        set_precision("fp32")
+        try:
+            s_steps = max(2, min(steps, 8))
+            s_elapsed, s_kernel_ms, s_tot = w.timed(s_steps, 2, 4, dist)
+            secondary = {"dtype": "f32 (exact fp32-input MFMA)", "value": w.n_global * s_steps / s_elapsed, "unit": "rotations/s",
+                         "steps": s_steps, "ms_per_step": s_elapsed / s_steps * 1e3, "mean_nll": -float(s_tot[0] / s_tot[1]),
+                         "roofline": roofline_of(w, "fp32", s_kernel_ms, pmc)}
+        finally:
+            set_precision(primary)
+        rec["value_fp32_exact"] = secondary["value"]
+        rec["ms_per_step_fp32_exact"] = secondary["ms_per_step"]
+        rec["secondary"] = secondary
+    elif used == "fp32":
+        rec["value_fp32_exact"], rec["ms_per_step_fp32_exact"] = rec["value"], rec["ms_per_step"]
+    if rank0 and world == 1 and want_parity:
+        head, stats, product, want, oracle = w.parity(2048 if w.wl["direction"] == "forward" else 256)
+        rec["parity"] = {**head, **stats(product(), want), "reference_fp32": stats(oracle(torch.float32), want)}
+        if secondary:
+            set_precision("fp32")
+            try:
+                secondary["parity"] = {"samples": head["samples"], **stats(product(), want)}
+            finally:
+                set_precision(primary)
+    if rank0 and world == 1 and cpu_sizes:
+        rec["cpu_baseline"] = cpu_baseline(w.cfg, w.weights, w.A, w.wl, w.feat_dim, cpu_sizes, cpu_budget)
+        rec["vs_cpu_baseline"] = rec["value"] / rec["cpu_baseline"]["value"]
+    return rec
 
 
 def main():
@@ -189,13 +556,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--config", default=None, choices=sorted(WORKLOADS), help="run this workload alone (default: C2 headline + every other config)")
     ap.add_argument("--batch-log2", type=int, default=None, help="log2 of the batch: per GPU (weak-scaling configs, default 20) or global (C3, default 22)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host-side legs (CPU baseline and the oracle parity block)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the exact-fp32 leg")
+    ap.add_argument("--no-configs", action="store_true", help="headline workload only")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes")
+    ap.add_argument("--save-pmc", default=None, metavar="DIR", help="also write the live PMC summary to DIR/pmc_live.json (profiles/<round>/)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-configs", default=",".join(ALL_CONFIGS), help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.pmc_child:
+        return pmc_child(args)
 
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
@@ -215,8 +589,19 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["RNF_BENCH_HANG_DUMP"]), exit=True)
 
-    import numpy as np
-    import torch
+    headline = args.config or "C2"
+    full = args.config is None and not args.no_configs and not distributed
+    others = [c for c in ALL_CONFIGS if c != headline] if full else []
+
+    import torch                                              # (importing torch and counting devices does not initialise the GPU)
+
+    # live counter passes: children under rocprofv3, BEFORE this process touches the GPU (only in the single-process run)
+    pmc = None
+    if not distributed and not args.no_pmc:
+        if torch.cuda.device_count() < 1:
+            print("bench.py: no GPU visible", file=sys.stderr)
+            sys.exit(2)
+        pmc = run_pmc_passes([headline] + others, args.batch_log2, args.save_pmc)
 
     # RNF_BENCH_SHARED_GPU=1 (test rig only: a 1-GPU box): every rank uses cuda:0 and the collective runs over gloo, so that the
     # N > 1 control flow of this script can be exercised without N GPUs.  The driver never sets it.
@@ -226,7 +611,7 @@ def main():
     elif world > torch.cuda.device_count():
         print(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
         sys.exit(2)
-    backend = None
+    backend, dist = None, None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -239,184 +624,45 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    from rotationnormflow_amd import get_precision, set_precision, synth
-    from rotationnormflow_amd.dist import all_reduce_nll
-    from rotationnormflow_amd.utils.fisher import MatrixFisherN
-
-    wl = WORKLOADS[args.config]
-    cfg, weights, fl = build_flow(device, wl["preset"])
-    strong = bool(wl.get("strong"))
-    batch_log2 = args.batch_log2 if args.batch_log2 is not None else wl.get("batch_log2", 20)
-    A = synth.fisher_A("diag531")
-    base = MatrixFisherN(torch.from_numpy(A).to(device)) if wl["fisher"] else None
-    feat_dim = fl.feature_dim if cfg.condition else 0
-    if strong:
-        # ONE global batch, the same for every world size; rank r evaluates rows [r N / G, (r + 1) N / G) (dist.shard_bounds, the partition
-        # of torch's scatter on dim 0 = the reference's nn.DataParallel, agent.py:22): no data-path collective
-        from rotationnormflow_amd.dist import shard_bounds
-        n_global = 1 << batch_log2
-        lo, hi = shard_bounds(n_global, rank, world)
-        R = torch.from_numpy(synth.uniform_rotations(n_global, seed=synth.RD_SEED)[lo:hi].copy()).to(device)
-        feat = torch.from_numpy(synth.features(n_global, feat_dim, seed=synth.RD_SEED + 1000)[lo:hi].copy()).to(device) if feat_dim else None
-        n = hi - lo
-    else:
-        # weak scaling: rank r evaluates its own batch (seeded per rank): no data-path collective
-        n = 1 << batch_log2
-        n_global = n * world
-        R = torch.from_numpy(synth.uniform_rotations(n, seed=synth.RD_SEED + rank)).to(device)
-        feat = torch.from_numpy(synth.features(n, feat_dim, seed=synth.RD_SEED + 1000 + rank)).to(device) if feat_dim else None
-
-    if wl["direction"] == "forward":
-        def evaluate():
-            return fl.log_prob(R, feat, base=base)["sum"]
-    else:
-        def evaluate():                                        # eval.py:327-347: base samples + their log-density, inverse pass, log p = base - ldj
-            z = base._sample(n).reshape(-1, 3, 3)
-            lp = base._log_prob(z)
-            _, ldj = fl.inverse(z, feat)
-            lp = (lp - ldj).double()
-            return torch.stack((lp.sum(), torch.tensor(float(n), dtype=torch.float64, device=device)))
-
-    def timed(steps, warmup, settle):
-        """-> (elapsed s over `steps` (max over ranks), mean HIP-event ms of the library calls, last {sum, count})."""
-        with torch.no_grad():
-            # the SMU needs ~10 launches (50 ms) of this kernel to settle on its clock; these launches are outside both the W warm-up
-            # steps and the K timed steps and are reported in the JSON line
-            for _ in range(settle):
-                evaluate()
-            tot = None
-            for _ in range(warmup):
-                tot = all_reduce_nll(evaluate()) if distributed else evaluate()
-            torch.cuda.synchronize()
-            if distributed:
-                dist.barrier()
-            torch.cuda.synchronize()
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-            t0 = time.perf_counter()
-            for i in range(steps):
-                ev[i][0].record()                              # the library launches on torch's current stream: these events bracket its kernels
-                part = evaluate()
-                ev[i][1].record()
-                tot = all_reduce_nll(part) if distributed else part
-            torch.cuda.synchronize()
-            if distributed:
-                dist.barrier()
-            torch.cuda.synchronize()
-            elapsed = time.perf_counter() - t0
-        if distributed:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        return elapsed, float(np.mean([a.elapsed_time(b) for a, b in ev])), tot.cpu().numpy()
-
-    def roofline_of(precision, kernel_ms):
-        achieved = wl["flop"] * n / (kernel_ms * 1e-3) / 1e12
-        cus = torch.cuda.get_device_properties(device).multi_processor_count
-        if precision == "f16x2":
-            nw = 8
-            if wl["direction"] == "forward" and os.environ.get("RNF_WIDE") != "0" and not cfg.condition:
-                nw = 16 if n > cus * 256 else (4 if n <= cus * 128 else 8)
-            elif wl["direction"] == "forward" and os.environ.get("RNF_WIDE") != "0":
-                nw = 16 if min(n, 1 << 18) > cus * 256 else 8
-            # The conditioner GEMMs run on the fp16 matrix cores (3 fp16 MFMAs with fp32 accumulate per fp32 product-sum), so the
-            # matrix roofline of this kernel is the dense fp16 peak; `achieved` stays the ALGORITHMIC fp32 FLOP rate (executed matrix
-            # FLOPs are 3x that).  What binds is VALU issue (per-segment softplus / arctangent / reciprocal math): bound = "valu".
-            r = {"bound": "valu", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_MFMA_TFLOPS,
-                 "kernel": f"rnf::flow_stack_kernel<{1 if wl['direction'] == 'inverse' else 0},...,{nw} waves,f16x2>", "kernel_ms": kernel_ms,
-                 "algorithmic_flop_per_rotation": wl["flop"], "executed_mfma_tflops": 3 * achieved,
-                 "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
-                 "note": "frac = algorithmic GEMM FLOP rate / dense fp16 MFMA peak; the kernel is VALU-issue bound (valu_issue_frac is the "
-                         "binding fraction, from PMC), neither matrix- nor HBM-bound"}
-        else:
-            r = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                 "kernel": f"rnf::flow_stack_kernel<{1 if wl['direction'] == 'inverse' else 0},...,8 waves,fp32>", "kernel_ms": kernel_ms,
-                 "algorithmic_flop_per_rotation": wl["flop"],
-                 "note": "exact fp32-input MFMA; shares the FMA datapath with the VALU segment math on gfx950"}
-        pmc, why = committed_pmc(args.config, precision, n)
-        if pmc:
-            r["traffic"] = pmc.get("hbm_bytes_per_launch")          # HBM bytes of one step (all launches of the step, all its kernels)
-            r["traffic_source"] = f"committed profile {pmc['source']} (csrc_sha {pmc['csrc_sha']}, kernel {pmc.get('kernel')})"
-            r.update(pmc_fractions(pmc))
-        else:
-            r["traffic"] = None
-            r["traffic_source"] = why
-        return r
-
-    primary = get_precision()
-    elapsed, kernel_ms, tot = timed(args.steps, args.warmup, CLOCK_SETTLE_LAUNCHES)
-    packed = fl._packed(device)
-    primary_used = packed.precision                       # "fp32" when a weight left the fp16 range and the packer fell back
-    mean_nll = -float(tot[0] / tot[1])
-    secondary = None
-    if not args.no_secondary and primary_used == "f16x2":
-        set_precision("fp32")
-        try:
-            s_steps = max(2, min(args.steps, 8))
-            s_elapsed, s_kernel_ms, s_tot = timed(s_steps, 2, 4)
-            secondary = {"dtype": "f32 (exact fp32-input MFMA)", "value": n_global * s_steps / s_elapsed, "unit": "rotations/s",
-                         "steps": s_steps, "ms_per_step": s_elapsed / s_steps * 1e3, "mean_nll": -float(s_tot[0] / s_tot[1]),
-                         "roofline": roofline_of("fp32", s_kernel_ms)}
-        finally:
-            set_precision(primary)
+    host_legs = world == 1 and not args.no_cpu_baseline
+    w = Workload(headline, device, args.batch_log2, rank, world)
+    if w.feat is not None and distributed:
+        from rotationnormflow_amd.dist import calibrate_feature_scale
+        calibrate_feature_scale(w.fl, w.feat)                 # one calibration for all ranks: identical packed images (dist.py)
+    head = measure(w, args, dist, pmc, args.steps, args.warmup, not args.no_secondary, host_legs,
+                   (4096, 65536) if host_legs else None, 30.0)
+    configs = {}
+    prev = w
+    for name in others:
+        w.R = w.feat = None
+        torch.cuda.empty_cache()
+        w = Workload(name, device, args.batch_log2, 0, 1, share=prev)
+        prev = w
+        c_steps = 6 if name == "C3" else 10
+        # bounded host legs for the secondary configs: N = 4096 (1024 for the inverse passes, which the oracle runs at ~2e3 rotations/s)
+        sizes = ((4096,) if w.wl["direction"] == "forward" else (1024,)) if host_legs else None
+        configs[name] = measure(w, args, None, pmc, c_steps, 3, not args.no_secondary, host_legs, sizes, 10.0)
 
     if rank == 0:
-        value = n_global * args.steps / elapsed
+        strong = bool(WORKLOADS[headline].get("strong"))
         out = {
-            "metric": "rotation log_prob evals/s (24-layer MobiusAffine + matrix-Fisher base), mean NLL alongside" if args.config == "C2"
-                      else f"rotation evals/s, workload {args.config}",
-            "value": value, "unit": "rotations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "metric": "rotation log_prob evals/s (24-layer MobiusAffine + matrix-Fisher base), mean NLL alongside" if headline == "C2"
+                      else f"rotation evals/s, workload {headline}",
+            "value": head["value"], "unit": "rotations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None,         # BASELINE.md section 1: the reference publishes no number for this metric; see vs_cpu_baseline
-            "dtype": "f32" if primary_used == "fp32" else "f32 (GEMM operands as fp16 hi+lo pairs, fp32 accumulate)",
-            "data": "synthetic",
-            "config": {"workload": f"{args.config} -- {wl['text']}", "rotations_per_gpu": n, "global_batch": n_global,
+            "dtype": head["dtype"], "data": "synthetic",
+            "config": {"workload": head["workload"], "rotations_per_gpu": head["rotations_per_gpu"], "global_batch": head["global_batch"],
                        "parallelism": (f"batch-sharded x{world}, one all-reduce of {{sum log p, count}} per step" if world > 1 else "single GPU")},
-            "rccl_ranks": world, "backend": backend,
-            "mean_nll": mean_nll,
-            "clock_settle_launches": CLOCK_SETTLE_LAUNCHES,
-            "roofline": roofline_of(primary_used, kernel_ms),
-            "hbm": {"achieved": wl["bytes"] * n / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                    "frac": wl["bytes"] * n / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, "algorithmic_bytes_per_rotation": wl["bytes"]},
+            "rccl_ranks": world, "backend": backend, "mean_nll": head["mean_nll"], "clock_settle_launches": CLOCK_SETTLE_LAUNCHES,
         }
-        if secondary:
-            out["secondary"] = secondary
-        if world == 1 and not args.no_cpu_baseline:
-            # parity spot check of the benchmarked weights/inputs against the oracle (fp64) on the first rotations, for BOTH arithmetics, with
-            # the error of the oracle's own fp32 evaluation (= the reference's arithmetic) of the same rows beside it
-            from oracle import flow_oracle as orc
-            torch.set_num_threads(host_threads())
-            m = 2048 if wl["direction"] == "forward" else 256
-            sub = R[:m]
-            fsub = None if feat is None else feat[:m]
-            sub_np, fsub_np = sub.cpu().numpy(), None if fsub is None else fsub.cpu().numpy()
-
-            def oracle(dtype):
-                if wl["direction"] == "forward":
-                    return orc.log_prob(cfg, weights, sub_np, fsub_np, A if wl["fisher"] else None, dtype)[0].double().numpy()
-                return orc.flow_inverse(cfg, weights, sub_np, fsub_np, dtype=dtype)[1].double().numpy()
-
-            def product():
-                with torch.no_grad():
-                    if wl["direction"] == "forward":
-                        return fl.log_prob(sub, fsub, base=base)["logp"].cpu().double().numpy()
-                    return fl.inverse(sub, fsub)[1].cpu().double().numpy()
-
-            def stats(got, want):
-                e = np.abs(got - want)
-                return {"mean_abs_err_of_the_mean": abs(float(got.mean() - want.mean())), "mean_abs_err": float(e.mean()),
-                        "p99_abs_err": float(np.quantile(e, 0.99)), "max_abs_err": float(e.max())}
-            want = oracle(torch.float64)
-            what = "per-rotation log p (mean = -mean NLL)" if wl["direction"] == "forward" else "per-rotation log-det of the inverse pass"
-            out["parity"] = {"samples": m, "quantity": what, "against": "fp64 oracle (pinned to the reference's fp64 run to 1e-11)",
-                             **stats(product(), want), "reference_fp32": stats(oracle(torch.float32), want)}
-            if secondary:
-                set_precision("fp32")
-                try:
-                    secondary["parity"] = {"samples": m, **stats(product(), want)}
-                finally:
-                    set_precision(primary)
-            out["cpu_baseline"] = cpu_baseline(cfg, weights, A, wl, feat_dim)
-            out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        for k in ("value_fp32_exact", "ms_per_step_fp32_exact", "roofline", "hbm", "secondary", "parity", "cpu_baseline", "vs_cpu_baseline"):
+            if k in head:
+                out[k] = head[k]
+        if configs:
+            out["configs"] = configs
+        if pmc is not None:
+            out["pmc"] = {k: pmc[k] for k in ("source", "seconds", "csrc_sha", "error") if k in pmc}
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

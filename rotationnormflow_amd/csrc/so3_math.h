@@ -365,6 +365,20 @@ RNF_HD float softplus2_safe(float x) {
     return e < 0.015625f ? small : big;
 }
 
+// The one-piece form of the lean kernels, overflow-proof in ONE more instruction (round 4: weights the reference's own training produced
+// reach s = 250, s log2 e = 360 -- tests/golden/trained_cond4 -- where 2^x is inf and round 3 re-ran the whole launch on the exact-fp32
+// kernels): t = log2(1 + 2^x) is >= x everywhere, equals x (to fp32 rounding) from x ~ 25 on and is +inf from x = 128 on, so the median
+// of (t, x, 127) is t below 127 and x above.  exp2 + add + log2 + med3 = 4 VALU.  (What remains for the launch guard is the all-weights-
+// tiny corner: flow_kernels.h kMinWeightSum.)
+RNF_HD float softplus2_lean(float x) {
+    const float t = hw_log2(1.0f + hw_exp2(x));
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(t, x, 127.0f);
+#else
+    return x >= 127.0f ? x : t;
+#endif
+}
+
 template <int STAGE, bool SAFE = true>
 RNF_HD void seg_s7_stage(SegS7 &g, float s_raw, float w0, float w1, float w2, const Frame &f7, float &S, float &A, float &J) {
     if constexpr (STAGE == 0) {
@@ -394,11 +408,11 @@ RNF_HD void seg_s7_stage(SegS7 &g, float s_raw, float w0, float w1, float w2, co
 #else
         // softplus(s) / ln 2 = log2(1 + 2^(s log2 e)) in one piece (the packers fold log2 e into the weights that produce s): S, A and J all carry the common factor 1 / ln 2 and the layer only uses
         // their ratios (theta' = pi + 2 A / S, ldj = log(J / S)).  No argument split: for s < -17 the weight rounds to 0 exactly as before
-        // (< 1e-7 absolute on a term divided by the sum of K such terms); for s > 88 the exponential overflows to inf, the layer's ratios
-        // become NaN and the range guard re-runs the launch on the exact-fp32 kernels, whose softplus is the full form.
-        // That form (SAFE = false) is only instantiated by kernels the launcher runs GUARDED (flow_kernels.h: LEAN / FUSED); their layer
-        // finish also flags a weight sum so small that fl(1 + e) has rounded the weights themselves (mobius_fwd_finish: kMinWeightSum).
-        const float sp = SAFE ? softplus2_safe(s_raw) : hw_log2(1.0f + hw_exp2(s_raw));          // s_raw arrives multiplied by log2 e (layout.h S_PRESCALE)
+        // (< 1e-7 absolute on a term divided by the sum of K such terms); for s > 88 the exponential overflows to inf and the median picks
+        // s itself (softplus2_lean).  That form (SAFE = false) is only instantiated by kernels the launcher runs GUARDED (flow_kernels.h:
+        // LEAN / FUSED): their layer finish flags a weight sum so small that fl(1 + e) has rounded the weights themselves
+        // (mobius_fwd_finish: kMinWeightSum) and the launch is re-run on the exact-fp32 kernels, whose softplus is the full form.
+        const float sp = SAFE ? softplus2_safe(s_raw) : softplus2_lean(s_raw);                   // s_raw arrives multiplied by log2 e (layout.h S_PRESCALE)
 #endif
         S += sp;
         A = fmaf(sp, p * g.t, A);

@@ -95,6 +95,7 @@ class PackedFlow:
         self.segments = segments
         self.side_layers = []                 # layer modules with _rnf_side(feature) -> [n, 16], in side-slot order
         self.feature_ms = 1.0                 # mean square of a feature entry the conditional layers were equalised for
+        self.audit = 0.0                      # host packers: worst pack-time audit value of the split-precision images
 
 
 class HalfRangeError(RuntimeError):
@@ -149,7 +150,9 @@ def pack_layers(layers, perm_rows, device, precision=None, feature_ms=1.0) -> Pa
     _prefetched.map = _prefetch_parameters(layers)
     old_ms = L.rnf_set_feature_ms(float(feature_ms))
     try:
+        _audit.worst = 0.0
         blob, desc, slot, feat_dim, segments = _pack_layers(layers, perm_rows, prec, L)
+        audit = _audit.worst
         if precision == "f16x2" and _guard_fallback:
             # the same layers once more as exact-fp32 images behind the split-precision ones: the library re-runs a call on them, on the
             # device, when a sample comes out non-finite (an fp16 operand overflowed; include/rnf_hip.h desc columns 6, 7)
@@ -165,6 +168,7 @@ def pack_layers(layers, perm_rows, device, precision=None, feature_ms=1.0) -> Pa
         L.rnf_set_feature_ms(old_ms)
     packed = PackedFlow(torch.from_numpy(blob).to(device), np.ascontiguousarray(desc), slot, feat_dim, pad8(feat_dim), segments, precision)
     packed.feature_ms = float(feature_ms)
+    packed.audit = audit                     # worst conditioner-output error of the packed split-precision images on the probe inputs (0 for fp32 images)
     for i, layer in enumerate(layers):
         if layer._rnf_kind in SIDE_KINDS:
             packed.desc[i, 2] = len(packed.side_layers)          # param offset column = slot in the side buffer
@@ -239,10 +243,14 @@ def _pack_layers(layers, perm_rows, prec, L):
     return blob, desc, slot, feat_dim, segments
 
 
+_audit = threading.local()           # worst pack-time audit value (rnf_last_pack_audit) of the split-precision images of the flow being packed
+
+
 def _check_pack(L, rc):
     if rc == 2:
         raise HalfRangeError(L.rnf_last_error().decode())
     _lib.check(rc)
+    _audit.worst = max(getattr(_audit, "worst", 0.0), float(L.rnf_last_pack_audit()))
 
 
 # ---- per-layer packers (called by the layer modules) -----------------------------------------------------------

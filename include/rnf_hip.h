@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define RNF_ABI_VERSION 5
+#define RNF_ABI_VERSION 6
 
 /* width of the conditioner MLP's hidden layers: flow/condition.py:9 (Nh=64, never overridden by any caller) */
 #define RNF_HIDDEN 64
@@ -195,8 +195,15 @@ int rnf_flow_log_prob_side(const float *rotation_dev, const float *feature_dev, 
 /* ConditionRot (flow/rottrans.py:37-66): the per-sample orthogonal 4x4 matrices U^T V of svd(I + reshape(mlp_out, 4, 4)), with the sign
  * conventions of the reference's torch.svd (LAPACK's dense-SVD path restated for 4x4, csrc/svd4_lapack.h; identical for >= 99.8 % of
  * random matrices, the rest differ like two LAPACK builds do).  mlp_out_dev [n][16] from rnf_cond_mlp_forward, rot_out_dev [n][16] = one
- * slot of the side buffer of an RNF_LAYER_SIDE16_ROT layer.  Stream-ordered, no host synchronisation. */
-int rnf_condrot_matrices(const float *mlp_out_dev, int64_t n, float *rot_out_dev, void *stream);
+ * slot of the side buffer of an RNF_LAYER_SIDE16_ROT layer.  Stream-ordered, no host synchronisation.
+ * fail_flag_dev (int32, may be null): bit 0 is OR-ed in when the QR iteration of a sample did not converge within LAPACK's sweep limit (the
+ * slot then holds the factors of the last sweep); the caller zeroes it and reads it back when convenient.
+ * rnf_condrot_svd also returns the factors -- u_out_dev [n][16] (U row-major), s_out_dev [n][4] (decreasing), vt_out_dev [n][16] (V^T
+ * row-major) -- which is what the backward of U^T V needs (d rot = -wU rot + rot wV with wU, wV from U^T dM V; flow/rottrans.py here), so
+ * that evaluation AND training see the same routine's sign choices (ABI v6; v5 trained through the host's torch.svd). */
+int rnf_condrot_matrices(const float *mlp_out_dev, int64_t n, float *rot_out_dev, int32_t *fail_flag_dev, void *stream);
+int rnf_condrot_svd(const float *mlp_out_dev, int64_t n, float *rot_out_dev, float *u_out_dev, float *s_out_dev, float *vt_out_dev,
+                    int32_t *fail_flag_dev, void *stream);
 
 /* ConditionalTransform(feature_dim, <= 16 outputs)(feature) alone (flow/condition.py:24-30): records packed by rnf_pack_cond16 at
  * layer_offset / feat_offset (floats) of blob_dev; out_dev float[n][16], output o in column o.  Workspace: rnf_workspace_bytes(n, 1). */

@@ -230,8 +230,11 @@ class _FlowFn(torch.autograd.Function):
         out_ldj = torch.empty(n, dtype=torch.float32, device=dev)
         states = torch.empty((plan.n_layers, n, 9), dtype=torch.float32, device=dev)
         f32 = torch.float32                               # (grad mode is off inside Function.forward: no detach needed)
-        plain = torch.cat([t.reshape(-1) if (t.is_cuda and t.dtype is f32) else t.to(device=dev, dtype=f32).reshape(-1)
-                           for t in tensors]) if tensors else torch.zeros(0, device=dev)
+        if len(tensors) == 1 and tensors[0].is_cuda and tensors[0].dtype is f32 and tensors[0].is_contiguous():
+            plain = tensors[0].reshape(-1)                # a flattened flow (Flow.flatten_parameters): the parameter storage, in place
+        else:
+            plain = torch.cat([t.reshape(-1) if (t.is_cuda and t.dtype is f32) else t.to(device=dev, dtype=f32).reshape(-1)
+                               for t in tensors]) if tensors else torch.zeros(0, device=dev)
         if plain.numel() != plan.plain_floats:
             raise RuntimeError(f"plain parameter blob has {plain.numel()} floats, layer table expects {plan.plain_floats}")
         side_c = None
@@ -478,15 +481,22 @@ def _plan_for(module, layers, perm_rows, rotation):
     return cached[1]
 
 
+def _parameter_inputs(module, layers):
+    """What _FlowFn differentiates with respect to: the ONE flat parameter of a flattened flow (Flow.flatten_parameters), else every
+    training tensor of every layer (264 for the reference's raw.yml recipe)."""
+    flat = getattr(module, "_parameters", {}).get("_flat")
+    return [flat] if flat is not None else train_tensors(layers)
+
+
 def flow_inverse(module, layers, perm_rows, rotation, feature):
     """Differentiable ``Flow.inverse``.  ``layers`` / ``perm_rows`` in FLOW order; the inverse pass walks them back to front."""
     plan = _plan_for(module, layers, perm_rows, rotation)
     side = _side_tensor(plan, layers, rotation, feature, True)
-    return _FlowFn.apply(plan, getattr(module, "_rnf_grad_sync", None), 1, rotation, feature, side, *train_tensors(layers))
+    return _FlowFn.apply(plan, getattr(module, "_rnf_grad_sync", None), 1, rotation, feature, side, *_parameter_inputs(module, layers))
 
 
 def flow_forward(module, layers, perm_rows, rotation, feature):
     """Differentiable (rotation', ldj) for a stack of layers; called by runtime.run_flow when a gradient is required."""
     plan = _plan_for(module, layers, perm_rows, rotation)
     side = _side_tensor(plan, layers, rotation, feature, False)
-    return _FlowFn.apply(plan, getattr(module, "_rnf_grad_sync", None), 0, rotation, feature, side, *train_tensors(layers))
+    return _FlowFn.apply(plan, getattr(module, "_rnf_grad_sync", None), 0, rotation, feature, side, *_parameter_inputs(module, layers))

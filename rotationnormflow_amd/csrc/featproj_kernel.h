@@ -192,8 +192,10 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
                 const bool spread = FP_SPREAD && NW == 8 && ns == FP_KCHUNK / 16 && !args.row_mode;
                 for (int t = 0; t < n_t; ++t) {
                     const float *wl = lds + (t & 1) * BUF;
+#ifndef RNF_FPKO_BAR
                     dma_wait_all();
                     __syncthreads();                               // tile t is complete; nobody still reads the other buffer
+#endif
                     if (!spread) {
                         if (t + 1 < n_t) {
                             dma_floats(lds + ((t + 1) & 1) * BUF, tile_src(t + 1), ns * 512, wave, lane, NW);
@@ -236,10 +238,12 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
                         for (int s = 0; s < FP_KCHUNK / 16; ++s) {
                             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah), "+v"(al) :: "memory");
                             h8 nah = ah, nal = al;
+#ifndef RNF_FPKO_LDS
                             if (s + 1 < FP_KCHUNK / 16) {
                                 fp_lds_read_at(nah, wl_lds, (s + 1) * 2048);
                                 fp_lds_read_at(nal, wl_lds, (s + 1) * 2048 + 1024);
                             }
+#endif
                             __builtin_amdgcn_sched_barrier(0);
 #ifndef RNF_FPKO_MFMA
                             acc1 = RNF_MFMA_H(ah, bh[s], acc1);

@@ -1199,22 +1199,40 @@ extern "C" int rnf_cond_mlp_forward(const float *feat, int64_t n, int32_t F, con
 // ConditionRot (flow/rottrans.py:37-66): rot = U^T V of svd(I + reshape(net(feature), 4, 4)) per sample, with the SIGN CONVENTIONS of the
 // reference's torch.svd (LAPACK sgesdd; svd4_lapack.h restates that path for 4x4).  mlp_out [n][16] = the conditioner's outputs (row-major
 // 4x4 per sample), rot_out [n][16] = the orthogonal matrix the RNF_LAYER_SIDE16_ROT layer applies to the quaternion.  One thread per sample.
-__global__ void condrot_utv_kernel(const float *mlp_out, long long n, float *rot_out, int *fail_flag) {
+// usv != nullptr: also U [n][16] (row-major), the singular values [n][4] and V^T [n][16], for the analytic backward of U^T V (rottrans.py).
+__global__ void condrot_utv_kernel(const float *mlp_out, long long n, float *rot_out, float *u_out, float *s_out, float *vt_out, int *fail_flag) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float A[16], R[16];
+    float A[16], U[16], sv[4], VT[16];
     for (int k = 0; k < 16; ++k) A[k] = mlp_out[i * 16 + k] + ((k % 5 == 0) ? 1.0f : 0.0f);
-    if (!svd4::utv(A, R) && fail_flag) atomicOr(fail_flag, 1);
-    for (int k = 0; k < 16; ++k) rot_out[i * 16 + k] = R[k];
+    if (!svd4::svd(A, U, sv, VT) && fail_flag) atomicOr(fail_flag, 1);
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {                                   // rot = U^T V: rot[r][c] = u_r . v_c
+            float a = 0.f;
+            for (int k = 0; k < 4; ++k) a += U[4 * k + r] * VT[4 * c + k];
+            rot_out[i * 16 + 4 * r + c] = a;
+        }
+    if (u_out) {
+        for (int k = 0; k < 16; ++k) { u_out[i * 16 + k] = U[k]; vt_out[i * 16 + k] = VT[k]; }
+        for (int k = 0; k < 4; ++k) s_out[i * 4 + k] = sv[k];
+    }
 }
-extern "C" int rnf_condrot_matrices(const float *mlp_out, int64_t n, float *rot_out, void *stream) {
-    if (n < 0) return fail("rnf_condrot_matrices: n=%lld", (long long)n);
+static int condrot_launch(const float *mlp_out, int64_t n, float *rot_out, float *u, float *sv, float *vt, int32_t *fail_flag, void *stream) {
+    if (n < 0) return fail("rnf_condrot: n=%lld", (long long)n);
     if (n == 0) return 0;
-    if (!mlp_out || !rot_out) return fail("rnf_condrot_matrices: null pointer");
+    if (!mlp_out || !rot_out) return fail("rnf_condrot: null pointer");
     hipLaunchKernelGGL(condrot_utv_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), mlp_out, (long long)n,
-                       rot_out, (int *)nullptr);
+                       rot_out, u, sv, vt, reinterpret_cast<int *>(fail_flag));
     HIP_TRY(hipGetLastError());
     return 0;
+}
+extern "C" int rnf_condrot_matrices(const float *mlp_out, int64_t n, float *rot_out, int32_t *fail_flag, void *stream) {
+    return condrot_launch(mlp_out, n, rot_out, nullptr, nullptr, nullptr, fail_flag, stream);
+}
+extern "C" int rnf_condrot_svd(const float *mlp_out, int64_t n, float *rot_out, float *u_out, float *s_out, float *vt_out, int32_t *fail_flag,
+                               void *stream) {
+    if (n > 0 && (!u_out || !s_out || !vt_out)) return fail("rnf_condrot_svd: null factor pointer");
+    return condrot_launch(mlp_out, n, rot_out, u_out, s_out, vt_out, fail_flag, stream);
 }
 
 extern "C" int rnf_flow_forward_train(const float *rot, const float *feat, int64_t n, int32_t F, const float *blob, const int32_t *desc,

@@ -14,7 +14,16 @@ from .mobiusflow import MobiusFlow, get_mobius
 
 
 def get_flow(config):
-    return Flow(config)
+    """flow/flow.py:9-10 -- what the reference's drivers call (agent.py:20: ``self.flow = get_flow(config)``).  The flow comes back with its
+    parameters FLATTENED (``Flow.flatten_parameters``: one ``nn.Parameter`` behind the unchanged state-dict keys) when its layer kinds
+    allow it, because that is what makes the unedited training loop fast: ``optim.Adam(self.flow.parameters(), lr)`` (agent.py:23) then
+    steps one tensor instead of 264, and autograd sees one leaf.  ``RNF_FLAT_PARAMS=0`` in the environment keeps per-tensor Parameters;
+    ``Flow(config)`` itself never flattens."""
+    import os
+    flow = Flow(config)
+    if os.environ.get("RNF_FLAT_PARAMS", "1") != "0":
+        flow.flatten_parameters()
+    return flow
 
 
 _permute_prop = torch.tensor(runtime.PERMUTE_ROWS, dtype=torch.long)     # flow/flow.py:13-15
@@ -51,6 +60,100 @@ class Flow(nn.Module):
             raise TypeError(f"rot={config.rot!r} with last_affine=1 yields no first affine layer ('NoneType' object is not callable)")
         self.layers = nn.ModuleList(stack)
         self._cache = runtime.PackCache()
+
+    # ---- flat parameters (round 4) ----------------------------------------------------------------------------------
+    def flatten_parameters(self) -> bool:
+        """Move every parameter of the flow into ONE ``nn.Parameter`` (``self._flat``, fp32, the layout of the kernels' plain training
+        blob = the reference's own tensor order) and leave the per-layer tensors behind as persistent BUFFERS that are views into it.
+        What stays the same: ``state_dict()`` / ``load_state_dict()`` keys and values (agent.py:132-151,171-198), ``.cuda()`` / ``.to()``,
+        ``nn.DataParallel``, evaluation, every result bit for bit.  What changes: ``flow.parameters()`` yields one tensor -- the
+        reference's ``optim.Adam(flow.parameters(), lr)`` (agent.py:23) steps ONE tensor (its per-tensor host bookkeeping over 264 tensors
+        was 10 ms per iteration with the default Adam, the whole iteration is 0.8 ms) -- autograd sees one leaf instead of 264, the training
+        kernels read the parameter storage in place (no ``cat``) and ``loss.backward()`` leaves one gradient blob in ``_flat.grad``
+        (``named_parameter_gradients()`` gives per-key views).  Optimizer STATE therefore has one entry; ``harness.expand_optimizer_state`` /
+        ``flatten_optimizer_state`` convert to and from the reference's per-tensor layout.
+        Returns False (and changes nothing) when a layer's training tensors are not its raw parameters (LU / SVD parameterisations, side
+        layers), when the flow is already flat, or when it has no parameters."""
+        if self.is_flat:
+            return False
+        slots, tensors = [], []
+        for layer in self.layers:
+            fn = getattr(layer, "_rnf_train_tensors", None)
+            if fn is None or getattr(layer, "_rnf_side_layer", False):
+                return False
+            owners = {id(prm): (mod, name) for mod in layer.modules() for name, prm in mod._parameters.items() if prm is not None}
+            for t in fn():
+                if id(t) not in owners or t.dtype is not torch.float32:
+                    return False                                   # a computed tensor (LU product, SVD rotation): stays classic
+                slots.append(owners[id(t)])
+                tensors.append(t)
+            if sum(1 for _ in layer.parameters()) != len({id(t) for t in fn()}):
+                return False                                       # a parameter that is not part of the training blob
+        if not tensors:
+            return False
+        with torch.no_grad():
+            flat = nn.Parameter(torch.cat([t.detach().reshape(-1) for t in tensors]), requires_grad=all(t.requires_grad for t in tensors))
+        self._flat_slots, off = [], 0
+        for (mod, name), t in zip(slots, tensors):
+            del mod._parameters[name]
+            mod.register_buffer(name, None)
+            self._flat_slots.append((mod, name, off, tuple(t.shape)))
+            off += t.numel()
+        self.register_parameter("_flat", flat)
+        self._realias()
+        self.invalidate()
+        return True
+
+    @property
+    def is_flat(self) -> bool:
+        return self._parameters.get("_flat") is not None
+
+    def _realias(self):
+        """Point every per-layer buffer at its slice of ``_flat``.  The slices are cut from ``_flat.detach()``: same storage and the SAME
+        version counter as the parameter (an in-place write through either side is seen by the pack cache and by autograd's saved-tensor
+        check), but no autograd view relation to the leaf (views of a leaf made under no_grad may not be touched again once the leaf has
+        been written in place)."""
+        base = self._parameters["_flat"].detach()
+        for mod, name, off, shape in self._flat_slots:
+            n = 1
+            for d in shape:
+                n *= d
+            mod._buffers[name] = base[off:off + n].view(shape)
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        if self.is_flat and not getattr(self, "_is_replica", False):
+            if self._parameters["_flat"].dtype is not torch.float32:
+                raise TypeError("a flattened flow keeps its parameters in fp32 (the kernels' plain blob); convert inputs, not the module")
+            self._realias()                                        # .cuda() / .to() moved the buffers as separate tensors
+            self.invalidate()
+        return out
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        destination.pop(prefix + "_flat", None)                    # the reference's keys only: the values live in the per-layer views
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        had = set(missing_keys)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        if prefix + "_flat" in missing_keys and prefix + "_flat" not in had:
+            missing_keys.remove(prefix + "_flat")
+
+    def named_parameter_gradients(self):
+        """{state-dict key: gradient view or None} -- per-tensor views of ``_flat.grad`` for a flattened flow, the parameters' own
+        ``.grad`` otherwise."""
+        if not self.is_flat:
+            return {k: p.grad for k, p in self.named_parameters()}
+        g = self._parameters["_flat"].grad
+        names = {id(mod): name for name, mod in self.named_modules()}
+        out = {}
+        for mod, name, off, shape in self._flat_slots:
+            n = 1
+            for d in shape:
+                n *= d
+            key = (names[id(mod)] + "." if names[id(mod)] else "") + name
+            out[key] = None if g is None else g[off:off + n].view(shape)
+        return out
 
     # ---- permutation schedule (flow/flow.py:58-70 and 77-90) ------------------------------------------------------
     def _forward_rows(self):
@@ -93,15 +196,19 @@ class Flow(nn.Module):
         parameter tensors on every forward, agent.py:22).  None when a layer has no device-packing support (ragged K, 3x3 / 6x6 kinds)."""
         from .. import autograd
         layers = list(self.layers)
+        flat = self._parameters.get("_flat")
         try:
             plan = autograd._plan_for(self, layers, self._forward_rows(), torch.empty(0, device=device))
-            tensors = autograd.train_tensors(layers)
+            tensors = [flat] if flat is not None else autograd.train_tensors(layers)
         except NotImplementedError:
             return None
         with torch.no_grad():
             f32 = torch.float32
-            plain = torch.cat([t.reshape(-1) if (t.is_cuda and t.dtype is f32) else t.to(device=device, dtype=f32).reshape(-1)
-                               for t in tensors]) if tensors else torch.zeros(0, device=device)
+            if flat is not None and flat.is_cuda:
+                plain = flat.detach()                              # flattened flow: the parameter storage IS the plain blob
+            else:
+                plain = torch.cat([t.reshape(-1) if (t.is_cuda and t.dtype is f32) else t.to(device=device, dtype=f32).reshape(-1)
+                                   for t in tensors]) if tensors else torch.zeros(0, device=device)
             with torch.cuda.device(device):
                 if self.condition:
                     # one measurement per flow, not per replica / per call: nn.DataParallel replicas are rebuilt every forward, but they

@@ -55,7 +55,8 @@ def _np32(t) -> np.ndarray:
 
 def _prefetch_parameters(layers):
     """One device->host copy for all parameters of the stack instead of one per tensor (a training step repacks every iteration)."""
-    params = [p for layer in layers for p in layer.parameters()]
+    # (a flattened flow -- Flow.flatten_parameters -- keeps its per-layer tensors as buffers that are views of one parameter)
+    params = [p for layer in layers for p in list(layer.parameters()) + [b for b in layer.buffers() if b.is_floating_point()]]
     dev = [p for p in params if p.is_cuda]
     if len(dev) < 2:
         return {}
@@ -423,6 +424,9 @@ class PackCache:
 
     def _walk(self, module):
         self._slots = [(m._parameters, name) for m in module.modules() for name, p in m._parameters.items() if p is not None]
+        # floating-point buffers too: the per-layer tensors of a flattened flow (Flow.flatten_parameters) are buffers that view one
+        # parameter and share its version counter; a layer called on its own has no parameter left to key on
+        self._slots += [(m._buffers, name) for m in module.modules() for name, b in m._buffers.items() if b is not None and b.is_floating_point()]
         self._params = [d[name] for d, name in self._slots]
 
     def _live(self):

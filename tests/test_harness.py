@@ -69,3 +69,56 @@ def test_estimate_rotations_matches_oracle_argmax():
     agree = (best == got_best) | ((lw.gather(1, got_best[:, None])[:, 0] - lw.max(-1).values).abs() < 1e-3)
     assert bool(agree.all())
     assert est.shape == (B, 3, 3)
+
+
+def test_flattened_flow_keeps_the_reference_contract(tmp_path):
+    """Flow.flatten_parameters (what get_flow hands the reference's drivers): ONE nn.Parameter for the optimizer and autograd, the
+    reference's 264 state-dict keys in the reference's order for checkpoints (agent.py:132-151,171-198), values shared in both directions."""
+    import contextlib
+    import io
+    from rotationnormflow_amd.flow.flow import Flow, get_flow
+    cfg = make_config("C2")
+    with contextlib.redirect_stdout(io.StringIO()):
+        classic, flat = Flow(cfg), get_flow(cfg)
+    assert not classic.is_flat and flat.is_flat and not flat.flatten_parameters()          # idempotent
+    assert len(list(classic.parameters())) == 264 and len(list(flat.parameters())) == 1
+    assert list(classic.state_dict()) == list(flat.state_dict()) and "_flat" not in flat.state_dict()
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=8, regime="trained")
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    res = flat.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    v0 = flat._flat._version
+    assert all(torch.equal(flat.state_dict()[k], sd[k]) for k in sd)
+    assert torch.equal(flat._flat.detach(), torch.cat([sd[k].reshape(-1) for k in classic.state_dict()]))     # reference tensor order
+    # an optimizer step on the flat parameter is seen through the per-layer views (and bumps the version the pack cache keys on)
+    with torch.no_grad():
+        flat._flat.add_(1.0)
+    assert flat._flat._version > v0
+    assert torch.equal(flat.layers[1].mat, sd["layers.1.mat"] + 1.0)
+    assert torch.equal(flat.state_dict()["layers.0.conditioner.fc_last.bias"], sd["layers.0.conditioner.fc_last.bias"] + 1.0)
+    # ... and a write through a view (load_state_dict's copy_) lands in the parameter
+    flat.load_state_dict(sd)
+    assert torch.equal(flat._flat.detach()[:192], sd["layers.0.conditioner.fc_first.weight"].reshape(-1))
+    # layer kinds whose training tensors are computed (LU, SVD) stay classic
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert not get_flow(make_config(None, layers=2, lu=1)).is_flat
+        assert not get_flow(make_config(None, layers=2, rot="16Rot")).is_flat
+        assert get_flow(make_config("C4")).is_flat and get_flow(make_config("C5")).is_flat
+    # optimizer state: one entry <-> the reference's per-tensor layout
+    opt = torch.optim.Adam(flat.parameters(), 1e-3)
+    flat._flat.grad = torch.randn_like(flat._flat)
+    opt.step()
+    ref_layout = harness.expand_optimizer_state(flat, opt.state_dict())
+    assert ref_layout["param_groups"][0]["params"] == list(range(264)) and len(ref_layout["state"]) == 264
+    assert ref_layout["state"][1]["exp_avg"].shape == (64,) and float(ref_layout["state"][5]["step"]) == 1.0
+    opt_ref = torch.optim.Adam(classic.parameters(), 1e-3)
+    opt_ref.load_state_dict(ref_layout)                                   # what Agent.load_ckpt does with it (agent.py:193-196)
+    back = harness.flatten_optimizer_state(flat, opt_ref.state_dict())
+    assert torch.equal(back["state"][0]["exp_avg"], opt.state_dict()["state"][0]["exp_avg"])
+    assert torch.equal(back["state"][0]["exp_avg_sq"], opt.state_dict()["state"][0]["exp_avg_sq"])
+    harness.save_reference_checkpoint(tmp_path / "c.pth", flat, opt, 0, 0, 1)
+    ck = torch.load(tmp_path / "c.pth", weights_only=False)
+    assert len(ck["optimizer_flow_state_dict"]["state"]) == 264 and sorted(ck["flow_state_dict"]) == sorted(w)
+    # a DataParallel wrapper (agent.py:22) hands the optimizer the same single tensor, and saves the same keys under "module."
+    dp = torch.nn.DataParallel(flat)
+    assert len(list(dp.parameters())) == 1 and sorted(dp.state_dict()) == sorted("module." + k for k in w)

@@ -134,3 +134,24 @@ def test_inplane_mobius_layer_matches_oracle_3d_formulation(hm, perm_row):
     hm.hm_mobius_forward(ptr(R), ptr(c32), K, perm_row, ptr(Ro), ptr(ldj), n)
     assert np.abs(ldj - wantl.numpy()).max() < 3e-6
     assert np.abs(Ro - wantR.numpy()).max() < 3e-6
+
+
+def test_condrot_backward_formula_matches_autograd_of_the_svd():
+    """flow/rottrans.py condrot_grad (the analytic backward of rot = U^T V, flow/rottrans.py:42-53 of the reference differentiates
+    torch.svd): against fp64 autograd of torch.svd on the SAME factors, for random matrices near the identity (the layer's regime)."""
+    import torch
+    from rotationnormflow_amd.flow.rottrans import condrot_grad
+    torch.manual_seed(3)
+    n = 200
+    M = (torch.eye(4)[None] + 0.3 * torch.randn(n, 4, 4)).double().requires_grad_(True)
+    U, S, V = torch.svd(M)
+    rot = U.transpose(-1, -2) @ V
+    G = torch.randn(n, 4, 4).double()
+    (rot * G).sum().backward()
+    got = condrot_grad(rot.detach().reshape(n, 16), U.detach().reshape(n, 16), S.detach(), V.detach().transpose(-1, -2).reshape(n, 16), G.reshape(n, 16))
+    want = M.grad.reshape(n, 16)
+    gap = (S.detach()[:, :-1] - S.detach()[:, 1:]).min(1).values                  # the derivative is singular where two singular values meet
+    ok = gap > 1e-3
+    assert ok.sum() > 150
+    err = (got - want).abs().amax(1) / want.abs().amax(1).clamp_min(1e-6)
+    assert err[ok].max() < 1e-8

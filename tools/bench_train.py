@@ -29,10 +29,13 @@ def main():
     ap.add_argument("--cpu-oracle", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the iteration as a HIP graph (harness.GraphedTrainStep) and replay it")
     ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): one optimizer launch instead of foreach kernels")
+    ap.add_argument("--classic", action="store_true", help="per-tensor nn.Parameters (Flow(config)) instead of the flattened flow get_flow(config) returns")
     a = ap.parse_args()
     cfg = configs.make_config(a.config)
     with contextlib.redirect_stdout(io.StringIO()):
         fl = Flow(cfg)
+        if not a.classic:
+            fl.flatten_parameters()                        # what flow.flow.get_flow returns to the reference's drivers (agent.py:20)
     shapes = {k: tuple(v.shape) for k, v in fl.state_dict().items()}
     w = synth.fill_state_dict(shapes, seed=0)
     fl.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
@@ -97,7 +100,7 @@ def main():
     fl._packed(R.device)
     torch.cuda.synchronize()
     pack_ms = (time.perf_counter() - t3) * 1e3
-    out = dict(pack_ms=pack_ms, optimizer="Adam(fused=True)" if a.fused_adam else "Adam", metric="training iteration (forward + backward + Adam)", config=a.config, batch=a.batch, ms_per_iteration=dt * 1e3,
+    out = dict(parameters="flat (1 tensor)" if fl.is_flat else f"classic ({len(list(fl.parameters()))} tensors)", pack_ms=pack_ms, optimizer="Adam(fused=True)" if a.fused_adam else "Adam", metric="training iteration (forward + backward + Adam)", config=a.config, batch=a.batch, ms_per_iteration=dt * 1e3,
                rotations_per_s=a.batch / dt, forward_ms_gpu=ev[0].elapsed_time(ev[1]), backward_ms_gpu=ev[2].elapsed_time(ev[3]),
                fwd_bwd_wall_ms=(t2 - t1) * 1e3, loss=float(loss.detach()))
     if a.cpu_oracle:

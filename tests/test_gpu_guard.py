@@ -138,23 +138,23 @@ def test_side_layer_conditioner_overflow_is_reported_one_call_later():
 
 @pytest.mark.parametrize("n", [1500, 70000])
 def test_segment_weight_beyond_the_one_piece_softplus(n):
-    """softplus(s) for s = 120 (the reference's softplus returns s itself beyond its threshold of 20).  Large launches run the LEAN
-    instantiation, whose one-piece log2(1 + 2^(s log2 e)) overflows: the ratios of the layer become NaN, the guard fires and the exact-fp32
-    kernels recompute the launch.  Every other instantiation clamps the exponent and needs no re-run (so3_math.h softplus2_safe).
-    Either way the result follows the oracle."""
+    """softplus(s) for s = 120 and s = 400 (the reference's softplus returns s itself beyond its threshold of 20; weights the reference's own
+    training produced reach s = 250, tests/golden/trained_cond4).  Round 3's lean one-piece log2(1 + 2^(s log2 e)) overflowed there and the
+    whole launch was re-run on the exact-fp32 kernels; since round 4 the lean form takes the median of (log2(1 + 2^x), x, 127)
+    (so3_math.h softplus2_lean) and every launch size runs the same lean family: no re-run, the result follows the oracle."""
     cfg = make_config(layers=2, segments=16)
     w = synth.fill_state_dict(orc.state_shapes(cfg), seed=9, regime="trained")
     for k in w:
         if k.endswith("conditioner.fc_last.bias"):
             b = w[k].copy()
             b[3] = 120.0                                           # the raw weight of segment 3: softplus(120) = 120 in the reference
+            b[7] = 400.0                                           # 2^(400 log2 e) is inf in fp32
             w[k] = b
     fl = product_flow(cfg, w)
     R = torch.from_numpy(synth.uniform_rotations(n, seed=13)).cuda()
     with torch.no_grad():
         Rt, ldj = fl(R)
-    lean = n > 256 * 8 * 32                                        # rnf_api.hip: 16-wave LEAN launches once 8-wave workgroups overfill the CUs
-    assert runtime.fallback_fired(R.device) == lean
+    assert not runtime.fallback_fired(R.device)
     assert torch.isfinite(ldj).all() and torch.isfinite(Rt).all()
     m = 2000
     Rw, lw = orc.flow_forward(cfg, w, R[:m].cpu().numpy(), None, dtype=torch.float64)
@@ -164,9 +164,9 @@ def test_segment_weight_beyond_the_one_piece_softplus(n):
 
 @pytest.mark.parametrize("n", [1500, 70000])
 def test_all_segment_weights_tiny(n):
-    """Every raw segment weight at -12: softplus ~ 6e-6.  The one-piece form of the LEAN kernel would round fl(1 + e) to ~7 bits of e:
-    its layer finish flags the tiny weight SUM and the exact-fp32 kernels re-run the launch; the other instantiations switch to the series
-    of log2(1 + e) and need no re-run."""
+    """Every raw segment weight at -12: softplus ~ 6e-6.  The one-piece form of the lean kernels would round fl(1 + e) to ~7 bits of e: their
+    layer finish flags the tiny weight SUM and the exact-fp32 kernels re-run the launch -- at every launch size (round 4: the lean family is
+    chosen by the flow's structure, not by the batch size)."""
     cfg = make_config(layers=2, segments=16)
     w = synth.fill_state_dict(orc.state_shapes(cfg), seed=10, regime="trained")
     for k in w:
@@ -178,7 +178,7 @@ def test_all_segment_weights_tiny(n):
     R = torch.from_numpy(synth.uniform_rotations(n, seed=14)).cuda()
     with torch.no_grad():
         Rt, ldj = fl(R)
-    assert runtime.fallback_fired(R.device) == (n > 256 * 8 * 32)
+    assert runtime.fallback_fired(R.device)
     m = 2000
     Rw, lw = orc.flow_forward(cfg, w, R[:m].cpu().numpy(), None, dtype=torch.float64)
     err = np.abs(ldj[:m].cpu().double().numpy() - lw.numpy())

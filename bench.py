@@ -585,6 +585,9 @@ def main():
     # a launcher started this rank (torchrun sets RANK): the collective leg runs even at world size 1, so that RCCL initialisation, the
     # barrier and the {sum, count} all-reduce execute on a 1-GPU box exactly as they do on N (a 1-rank communicator)
     distributed = world > 1 or "RANK" in os.environ
+    if os.environ.get("RNF_BENCH_DIE_RANK") == str(rank):     # test rig: this rank dies before the rendezvous; the launcher must end the others
+        print(f"bench.py: rank {rank} exits on request (RNF_BENCH_DIE_RANK)", file=sys.stderr)
+        sys.exit(3)
     if os.environ.get("RNF_BENCH_HANG_DUMP"):                 # diagnostics: dump every thread's stack and exit after that many seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["RNF_BENCH_HANG_DUMP"]), exit=True)

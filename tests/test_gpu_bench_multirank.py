@@ -165,3 +165,48 @@ def test_full_line_carries_every_config_with_live_counters():
     # the conditional configs' steps are made of a projection pre-pass and the stack kernel
     names = " ".join(k["name"] for k in rec["configs"]["C4"]["roofline"]["kernels"])
     assert "featproj" in names and "flow_stack_kernel" in names
+
+
+def _self_launch(args, extra_env=None, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(RNF_BENCH_SHARED_GPU="1", RNF_BENCH_HANG_DUMP="400", OMP_NUM_THREADS="2")
+    env.update(extra_env or {})
+    return _run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env, timeout=timeout)
+
+
+def test_eight_ranks_weak_and_strong_equal_the_single_rank_statistic():
+    """world 8 on the shared-GPU rig (the driver's N = 8 launch shape: `bench.py --gpus 8`, ranks started by the script itself on a free
+    port, one JSON line from rank 0).  C2, weak: 8 x 2^14 rotations.  C3, strong: ONE global batch split 8 ways (`rotations_per_gpu` =
+    global / 8) whose reduced mean NLL equals the one-rank evaluation of the same batch to fp64 addition order -- every shard reproduces its
+    rows bit for bit whatever launch shape its size selects (tests/test_gpu_scale_properties.py)."""
+    weak = _self_launch(["--gpus", "8", "--steps", "2", "--warmup", "1", "--batch-log2", "14", "--no-secondary"])
+    assert weak.returncode == 0, weak.stderr[-2000:]
+    lines = [ln for ln in weak.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, weak.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["rccl_ranks"] == 8 and r["scaling"] == "weak" and r["config"]["global_batch"] == 8 << 14
+    assert r["config"]["workload"].startswith("C2") and "configs" not in r and "cpu_baseline" not in r
+    base = ["--config", "C3", "--steps", "2", "--warmup", "1", "--batch-log2", "17", "--no-secondary", "--no-cpu-baseline", "--no-pmc"]
+    one = _self_launch(base + ["--gpus", "1"], {"RNF_BENCH_SHARED_GPU": "0"})
+    assert one.returncode == 0, one.stderr[-2000:]
+    r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    eight = _self_launch(base + ["--gpus", "8"])
+    assert eight.returncode == 0, eight.stderr[-2000:]
+    r8 = json.loads([ln for ln in eight.stdout.splitlines() if ln.startswith("{")][0])
+    assert r8["scaling"] == "strong" and r8["rccl_ranks"] == 8 and r8["config"]["global_batch"] == 1 << 17
+    assert r8["config"]["rotations_per_gpu"] == (1 << 17) // 8 and r1["config"]["rotations_per_gpu"] == 1 << 17
+    assert abs(r1["mean_nll"] - r8["mean_nll"]) <= 1e-12 * abs(r1["mean_nll"])
+
+
+def test_a_dying_rank_ends_the_run_with_an_error_not_a_hang():
+    """One of four ranks exits before the rendezvous: the launcher tears the others down and `bench.py --gpus 4` returns non-zero without a
+    JSON line, well inside the timeout."""
+    import time
+    t0 = time.time()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(RNF_BENCH_SHARED_GPU="1", RNF_BENCH_DIE_RANK="2", RNF_BENCH_HANG_DUMP="300")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0", "--batch-log2", "12",
+                          "--no-secondary"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert time.time() - t0 < 400

@@ -120,3 +120,78 @@ def test_rccl_all_reduce_is_captured_into_the_training_graph():
     assert np.quantile(diff, 0.99) < 2e-2 * moved, (np.quantile(diff, 0.99), moved)
     ll = harness.mean_log_likelihood(fl, _data()[:1024], device="cuda")
     assert abs(ll0 - ll) < 2e-3, (ll0, ll)
+
+
+def _cond_flow(flat):
+    from rotationnormflow_amd import synth
+    from rotationnormflow_amd.configs import make_config
+    from rotationnormflow_amd.flow.flow import Flow
+    cfg = make_config(layers=2, segments=16, condition=1, feature_dim=24, rot="16UnTrans", frequent_permute=1, last_affine=1, first_affine=0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        fl = Flow(cfg)
+    shapes = {k: tuple(v.shape) for k, v in fl.state_dict().items()}
+    fl.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, seed=6).items()})
+    if flat:
+        assert fl.flatten_parameters()
+    return fl
+
+
+def _cond_data():
+    from rotationnormflow_amd import synth
+    return torch.from_numpy(synth.uniform_rotations(512, seed=19)), torch.from_numpy(synth.features(512, 24, seed=20))
+
+
+def _cond_train(fl, rank, world, steps=4):
+    """agent.py:75-92 for a conditional flow, data parallel: every rank takes its contiguous slice of the SAME global mini-batch, the
+    gradient blob is averaged by ONE all-reduce inside backward (dist.data_parallel_training), every rank steps its own optimizer."""
+    from rotationnormflow_amd.dist import calibrate_feature_scale, data_parallel_training, shard_bounds
+    R, F = _cond_data()
+    fl = fl.cuda().train()
+    if world > 1:
+        data_parallel_training(fl)
+    opt = torch.optim.Adam(fl.parameters(), 2e-3)
+    for it in range(steps):
+        lo, hi = it * 128, (it + 1) * 128
+        a, b = shard_bounds(128, rank, world)
+        r, f = R[lo:hi][a:b].cuda(), F[lo:hi][a:b].cuda()
+        if it == 0:
+            calibrate_feature_scale(fl, F.cuda() if world == 1 else f)      # one calibration for all ranks (all-reduced)
+        _, ldj = fl(r, f)
+        loss = (-ldj).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    return torch.cat([v.detach().reshape(-1) for v in fl.state_dict().values()]).cpu().numpy()
+
+
+def _cond_worker(rank, world, port, flat, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        q.put((rank, _cond_train(_cond_flow(flat), rank, world)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_two_ranks_train_a_conditional_flow_like_one(flat):
+    """dist.data_parallel_training on a CONDITIONAL flow (Condition16Trans + conditional Moebius layers), per-tensor and flattened
+    parameters: the two replicas stay bit-identical and follow the single-process run on the global batch."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cond_worker, args=(r, 2, port, flat, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert np.array_equal(got[0], got[1])
+    want = _cond_train(_cond_flow(flat), 0, 1)
+    start = torch.cat([v.reshape(-1) for v in _cond_flow(False).state_dict().values()]).numpy()
+    moved = np.abs(want - start).max()
+    assert moved > 3e-3
+    diff = np.abs(got[0] - want)
+    assert np.quantile(diff, 0.99) < 2e-2 * moved and diff.max() <= 1.5 * moved, (np.quantile(diff, 0.99), diff.max(), moved)

@@ -836,17 +836,21 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
         th = fminf(fmaxf(fmaf(2.0f, d, c.target), lo + 1.0e-3f), hi - 1.0e-3f);
     }
     bool done = false;
+    float prev = 1.0f;                                                     // size of the previous step (1: none yet)
 #pragma unroll 1
     for (int it = 0; it < 16; ++it) {
         float sn, cs;
         sincos_small(th, sn, cs);
         // per segment (so3_math.h mobius_angle): phi = th + 2 atan(-b / (1 - a)), c = (1 - |u|^2) / (b^2 + (1 - a)^2), (a, b) = u conj(z);
-        // the constant parts are hoisted: sum sp phi = th S + 2 sum sp atan(.), sum sp c = sum q / (b^2 + (1 - a)^2)   (21 + 2 instead of 27 + 2)
-        float acc = 0.f, der = 0.f;
+        // the constant parts are hoisted: sum sp phi = th S + 2 sum sp atan(.), sum sp c = sum q / (b^2 + (1 - a)^2)   (21 + 2 instead of 27 + 2).
+        // Round 4: the SECOND derivative rides along -- d/dtheta of q / den is 2 q b / den^2 (da/dtheta = b, db/dtheta = -a) -- three more
+        // packed instructions per segment pair, for a third-order (Halley) step: on trained-like weights a wave needs 2.9 passes instead of
+        // 4.0 (tests/test_inverse_rootfinder.py), the pass costs 12 % more.
+        float acc = 0.f, der = 0.f, dd = 0.f;
         // two segments per instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): no matrix instruction runs during the root finder,
         // so the packed fp32 VALU forms pay here (-6.5 % on the whole inverse pass) -- beside MFMAs they are an anti-lever
         {
-            f2 acc2 = {0.f, 0.f}, der2 = {0.f, 0.f};
+            f2 acc2 = {0.f, 0.f}, der2 = {0.f, 0.f}, dd2 = {0.f, 0.f};
             const f2 sn2 = {sn, sn}, cs2 = {cs, cs};
 #pragma unroll
             for (int s = 0; s < 4 * KT; s += 2) {
@@ -869,10 +873,13 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
                 acc2 = __builtin_elementwise_fma(sp, p * t, acc2);
                 const f2 den = __builtin_elementwise_fma(b, b, e1 * e1);
                 const f2 r2 = {hw_rcp(den.x), hw_rcp(den.y)};
-                der2 = __builtin_elementwise_fma(q, r2, der2);
+                const f2 cq = q * r2;
+                der2 = der2 + cq;
+                dd2 = __builtin_elementwise_fma(cq, b * r2, dd2);
             }
             acc = acc2.x + acc2.y;
             der = der2.x + der2.y;
+            dd = dd2.x + dd2.y;
         }
         if constexpr (KT == 16)
             for (int s = 0; s < n_over; ++s) {                         // the same per-segment evaluation on the stashed parameters
@@ -881,20 +888,30 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
                 const float e1 = 1.0f - a;
                 const float t = -b * hw_rcp(e1);
                 acc = fmaf(p.x, atan_unit(t), acc);
-                der = fmaf(p.w, hw_rcp(fmaf(b, b, e1 * e1)), der);
+                const float r2 = hw_rcp(fmaf(b, b, e1 * e1));
+                const float cq = p.w * r2;
+                der += cq;
+                dd = fmaf(cq, b * r2, dd);
             }
 
         const float fx = fmaf(2.0f * pair_sum(acc), invS, th) - c.target;
-        const float dfx = pair_sum(der) * invS;
+        const float dfx = pair_sum(der) * invS;                            // f'  > 0
+        const float ddfx = 2.0f * pair_sum(dd) * invS;                     // f''
         if (fx < 0.f) lo = th; else hi = th;
-        float nt = th - fx * hw_rcp(dfx);
+        // Halley: theta - f / (f' - f f'' / (2 f')); a non-positive denominator (far from the root) falls back to the Newton step
+        const float hden = fmaf(-0.5f * fx * ddfx, hw_rcp(dfx), dfx);
+        float nt = th - fx * hw_rcp(hden > 0.25f * dfx ? hden : dfx);
         if (!(nt >= lo && nt <= hi)) nt = 0.5f * (lo + hi);               // keep the iterate inside the sign bracket
         if (done) nt = th;                                                // a converged lane stays put
-        // Newton converges quadratically (|f''/2f'| is a few units here, < 74 in the worst geometry): a step of 1e-4 leaves an error of
-        // ~1e-8, below the fp32 spacing of theta (2.4e-7), so the pass that would only confirm a < 1e-6 step is not run
-        done = done || fabsf(nt - th) <= 1.0e-4f;
+        // Third-order convergence: the error left behind a step of size d is ~ C d^3 with C estimated from this step and the previous one
+        // (d / d_prev^3, floored at 20).  A lane stops when that prediction is below the fp32 spacing of theta (2.4e-7) -- the pass that would
+        // only confirm it is not run -- or, as before, after a step of <= 1e-4.
+        const float step = fabsf(nt - th);
+        const float c3 = fmaxf(step * hw_rcp(prev * prev * prev), 20.0f);
+        done = done || step <= 1.0e-4f || (step <= 5.0e-3f && c3 * step * step * step <= 2.4e-7f);
+        prev = done ? prev : step;
         th = nt;
-        if (__all(done)) break;                                           // wave-uniform exit: typically 4-5 passes
+        if (__all(done)) break;                                           // wave-uniform exit: typically 3 passes
     }
     const float cell = kPi * (1.0f / 16384.0f);
     float n = floorf((th - 0.5f * kPi) * (16384.0f / kPi));

@@ -238,6 +238,11 @@ class Flow(nn.Module):
             if packed is not None:
                 return packed
 
+        watch = self.__dict__.get("_rnf_guard_watch")
+        if watch is not None and self.condition and getattr(self, "_feature_ms_fixed", None) is None and watch.poll():
+            self._cache.invalidate()                               # the guard kept firing: measure the feature scale again on this batch
+            self._cache.feature_ms = None
+
         def build():
             rows = self._forward_rows()
             inv = self._inverse_rows()

@@ -199,6 +199,47 @@ def fallback_fired(device) -> bool:
     return bool(ws[4095 * 8 + 4: 4095 * 8 + 8].view(torch.int32).item())
 
 
+class GuardWatch:
+    """Notices, without ever waiting for the device, when the range guard keeps re-running a flow's launches on the exact-fp32 kernels
+    (correct, but ~3x slower, and silent -- ADVICE r3): after every guarded call of a conditional flow the guard word of the workspace is
+    copied to pinned memory behind an event; a later call reads the words that have landed.  ``REPEAT`` consecutive fired calls warn once
+    and ask the caller to re-calibrate (the usual cause: features far larger than the batch the equalisation was calibrated on, so that the
+    projected x0 trips kX0Guard; Flow._packed then measures the feature scale again on the batch at hand and re-packs)."""
+    REPEAT = 3
+
+    def __init__(self):
+        self.pending = None            # (event, pinned host word)
+        self.streak = 0
+        self.warned = False
+
+    def poll(self) -> bool:
+        """-> True when a re-calibration is due."""
+        if self.pending is not None and self.pending[0].query():
+            fired = bool(int(self.pending[1][0]))
+            self.pending = None
+            self.streak = self.streak + 1 if fired else 0
+            if self.streak >= self.REPEAT:
+                self.streak = 0
+                if not self.warned:
+                    import warnings
+                    warnings.warn("rotationnormflow_amd: the range guard re-ran several consecutive launches of this flow on the exact-fp32 "
+                                  "kernels (features far from the scale the packed images were calibrated for, or an activation beyond "
+                                  "the fp16 range): results are correct but ~3x slower; re-calibrating on the current batch -- "
+                                  "Flow.set_feature_scale() fixes a scale, set_precision('fp32') avoids the guarded path", RuntimeWarning)
+                    self.warned = True
+                return True
+        return False
+
+    def watch(self, ws):
+        if self.pending is not None or torch.cuda.is_current_stream_capturing():
+            return
+        host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        host.copy_(ws[4095 * 8 + 4: 4095 * 8 + 8].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending = (ev, host)
+
+
 def _pack_layers(layers, perm_rows, prec, L):
     records, feat_records = [], []
     desc = np.zeros((len(layers), DESC_STRIDE), dtype=np.int32)
@@ -507,6 +548,15 @@ def _refuse_autograd(rotation, feature, module, what):
             "torch.no_grad() -- there is deliberately no PyTorch fallback path")
 
 
+def _watch_guard(module, packed, ws):
+    """Conditional flows packed for the guarded split-precision kernels: keep an eye on the guard word (GuardWatch)."""
+    if packed.n_cond and packed.precision == "f16x2" and _guard_fallback:
+        watch = getattr(module, "_rnf_guard_watch", None)
+        if watch is None:
+            watch = module.__dict__.setdefault("_rnf_guard_watch", GuardWatch())
+        watch.watch(ws)
+
+
 def run_flow(module, packed, rotation, feature, inverse=False, train_layers=None, train_rows=None, feature_repeat=None):
     """-> (rotation' [N,3,3], ldj [N]) through rnf_flow_forward / rnf_flow_inverse.
     When a gradient is required (training, agent.py:75-92) the forward direction goes through autograd.flow_forward, which
@@ -560,6 +610,7 @@ def run_flow(module, packed, rotation, feature, inverse=False, train_layers=None
             _lib.check(fn(rot.data_ptr(), feat.data_ptr() if feat is not None else None, n, packed.feat_padded,
                           packed.blob.data_ptr(), packed.desc.ctypes.data, packed.n_layers, packed.segments,
                           out_rot.data_ptr(), out_ldj.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+            _watch_guard(module, packed, ws)
     return out_rot.reshape(rotation.shape), out_ldj
 
 
@@ -608,4 +659,5 @@ def run_log_prob(module, packed: PackedFlow, rotation, feature, fisher_A=None, f
                                            packed.desc.ctypes.data, packed.n_layers, packed.segments,
                                            ptr(fisher_A), ptr(fisher_c), B, ptr(out_rot), ptr(out_ldj), ptr(out_lp),
                                            out_sum.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+            _watch_guard(module, packed, ws)
     return dict(logp=out_lp, sum=out_sum, rotation=out_rot, ldj=out_ldj)

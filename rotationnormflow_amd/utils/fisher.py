@@ -27,10 +27,11 @@ def device_proper_svd(A):
 
 
 def proper_singular_values(A):
-    """[B,3,3] -> [B,3] (utils/fisher.py:67-76).  GPU-resident A: on the device (no host round trip); CPU A: host LAPACK, fp64."""
-    if A.is_cuda:
-        return device_proper_svd(A)[2].to(torch.float64)
-    A64 = A.detach().to("cpu", torch.float64)               # tiny [B,3,3]: LAPACK on the host (no rocSOLVER start-up cost)
+    """[B,3,3] -> [B,3] in fp64 (utils/fisher.py:67-76), by host LAPACK on an fp64 copy of A -- also for a GPU-resident A (one tiny
+    device -> host copy).  This serves the lazily computed ``MatrixFisherN.norm`` attribute only (a diagnostic: the density path uses the
+    device kernels and never calls it), where round 3's fp32 device values cost ``sum(S) * 6e-8`` of relative accuracy and dropped the
+    precision of a float64 A."""
+    A64 = A.detach().to("cpu", torch.float64)
     U, S, Vh = torch.linalg.svd(A64)
     S = S.clone()
     S[:, 2] = S[:, 2] * torch.det(U) * torch.det(Vh)

@@ -183,3 +183,37 @@ def test_all_segment_weights_tiny(n):
     Rw, lw = orc.flow_forward(cfg, w, R[:m].cpu().numpy(), None, dtype=torch.float64)
     err = np.abs(ldj[:m].cpu().double().numpy() - lw.numpy())
     assert err.max() < 5e-5 and err.mean() < 5e-6, (err.max(), err.mean())
+
+
+def test_repeated_guard_firing_warns_and_recalibrates():
+    """the equalisation of conditional layers is calibrated on the first feature batch a parameter version is packed for; later
+    batches with far larger features trip the x0 guard and every launch is silently re-run on the exact-fp32 kernels.  The runtime now
+    notices (asynchronously -- no call waits for the device), warns once and re-calibrates on the batch at hand; after that the guard is
+    quiet again and the results are right throughout."""
+    import time
+    import warnings
+    if runtime.get_precision() != "f16x2":
+        pytest.skip("only the split-precision kernels are guarded")
+    cfg = make_config(layers=2, segments=16, condition=1, feature_dim=24, rot="16UnTrans", frequent_permute=1, last_affine=1, first_affine=0)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=12, regime="trained")
+    fl = product_flow(cfg, w)
+    n = 4096
+    R = torch.from_numpy(synth.uniform_rotations(n, seed=15)).cuda()
+    f_small = synth.features(n, 24, seed=16)
+    f_big = (f_small * 3000.0).astype(np.float32)               # x0 lands far beyond kX0Guard = 64 for images calibrated on f_small
+    with torch.no_grad():
+        fl.log_prob(R, torch.from_numpy(f_small).cuda())
+        assert not runtime.fallback_fired(R.device)
+        fb = torch.from_numpy(f_big).cuda()
+        want, _ = orc.log_prob(cfg, w, R[:256].cpu().numpy(), f_big[:256], None, torch.float64)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            fired = []
+            for it in range(12):
+                got = fl.log_prob(R, fb)["logp"]
+                fired.append(runtime.fallback_fired(R.device))   # (synchronises: the watch words of earlier calls have landed)
+                time.sleep(0.01)
+        assert (got[:256].cpu().double() - want).abs().max() < 1e-3 * max(1.0, float(want.abs().max()))
+    assert fired[0] and fired[1]                                 # stale calibration: the guard fires ...
+    assert not any(fired[-3:]), fired                            # ... until the runtime re-calibrated on the large features
+    assert sum(1 for c in caught if "range guard" in str(c.message)) == 1

@@ -163,7 +163,7 @@ def cpu_baseline(cfg, weights, A, wl, feat_dim, sizes, budget_s):
         f = synth.features(n, feat_dim, seed=6) if feat_dim else None
         m = min(n, 512)
         t_warm = run(R[:m], None if f is None else f[:m])                    # warm-up (thread pool, allocator)
-        est = t_warm * n / m
+        est = n / best_rate if best_rate > 0 else t_warm * n / m            # (the rate of the previous, smaller size predicts this one)
         reps = 3 if spent + 3 * est <= budget_s else max(1, int((budget_s - spent) / max(est, 1e-9)))
         reps = min(reps, 3)
         times = [run(R, f) for _ in range(reps)]
@@ -633,7 +633,7 @@ def main():
         from rotationnormflow_amd.dist import calibrate_feature_scale
         calibrate_feature_scale(w.fl, w.feat)                 # one calibration for all ranks: identical packed images (dist.py)
     head = measure(w, args, dist, pmc, args.steps, args.warmup, not args.no_secondary, host_legs,
-                   (4096, 65536) if host_legs else None, 30.0)
+                   (4096, 65536) if host_legs else None, 36.0)
     configs = {}
     prev = w
     for name in others:

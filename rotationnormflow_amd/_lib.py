@@ -110,6 +110,10 @@ def load(path):
         raise RuntimeError(
             f"{path} is missing: the MI355X HIP library has not been built and there is no CPU fallback. "
             "Run `python -m rotationnormflow_amd.build` (needs hipcc).")
+    # torch first: it maps its own HIP runtime (libamdhip64.so.7 under torch/lib), which the dynamic loader then also binds this library to.
+    # Loaded the other way round (e.g. build() and smoke() in ONE process) the library would pull the system's runtime from /opt/rocm and the
+    # process would hold two HIP runtimes, of which only torch's has the device open ("no ROCm-capable device is detected" in ours).
+    import torch  # noqa: F401
     handle = C.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(handle, name)

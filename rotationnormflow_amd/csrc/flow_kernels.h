@@ -721,7 +721,7 @@ __device__ __forceinline__ void mobius_fwd_finish(const MobiusCtx &c, float S, f
     const v3f tz = normalize3(c.cyc ? cross3(tx, c.y) : cross3(c.y, tx));               // mobiusflow.py:75-79
     set_col(R, c.p0, tx);
     set_col(R, c.p2, tz);
-    ldj += logf(J * invS);
+    ldj = fmaf(0.693147180559945309f, hw_log2(J * invS), ldj);        // J / S in [0.18, 5.7]: the hardware log2 (1 ulp) needs none of logf's range handling
 }
 
 // inverse: the 4*KT segment parameters of this lane stay in registers for the 15 bisection steps
@@ -733,7 +733,7 @@ struct InvSegs {
 
 // kt: tiles this layer really has (<= KT, the instantiation's capacity), K: its real segment count; slots beyond them get weight 0.
 // KT > MOB_MAX_TILES_IN_LDS (K > 64, synchronous staging only): the second half of the fc_last image is staged in the middle.
-template <int KT, int PREC>
+template <int KT, int PREC, bool FASTSP = false>
 __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_params, int kt, int K, int lane, int h, const typename Mlp<PREC>::Act &tt,
                                                  const MobiusCtx &c, InvSegs<KT> &sg, float &S, int tid, int nthreads, float4 *stash = nullptr) {
 #pragma unroll
@@ -754,7 +754,9 @@ __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_
                 // the matrix output is s log2 e (layout.h S_PRESCALE).  Split precision: softplus / ln 2 in one piece, as the forward segment
                 // does -- the root finder and the log-det only use ratios of the weights -- in its overflow-safe form (once per segment and layer:
                 // free next to the root finder)
-                float sp = PREC == 1 ? softplus2_safe(o[4 * g]) : softplus(S_UNSCALE * o[4 * g]);
+                // FASTSP (round 4; guarded calls only): the lean one-piece form, 4 instructions instead of 11 -- the all-weights-tiny corner it
+                // cannot resolve is flagged by mobius_inv_finish's weight-sum test and re-run on the exact-fp32 kernels, as in the forward pass
+                float sp = PREC == 1 ? (FASTSP ? softplus2_lean(o[4 * g]) : softplus2_safe(o[4 * g])) : softplus(S_UNSCALE * o[4 * g]);
                 if (8 * tau + 2 * g + h >= K) sp = 0.f;          // pad segment of a K % 8 != 0 layer: weight 0 AFTER the activation
                 sg.sp[4 * tau + g] = sp;
                 sg.q[4 * tau + g] = sp * (1.0f - fmaf(sg.uv[4 * tau + g], sg.uv[4 * tau + g], sg.ur[4 * tau + g] * sg.ur[4 * tau + g]));
@@ -782,7 +784,7 @@ __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_
             for (int g = 0; g < 4; ++g) {
                 float ur, uv;
                 squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, ur, uv);
-                float sp = PREC == 1 ? softplus2_safe(o[4 * g]) : softplus(S_UNSCALE * o[4 * g]);
+                float sp = PREC == 1 ? (FASTSP ? softplus2_lean(o[4 * g]) : softplus2_safe(o[4 * g])) : softplus(S_UNSCALE * o[4 * g]);
                 if (8 * tau + 2 * g + h >= K) sp = 0.f;
                 stash[(size_t)(4 * (tau - KT) + g) * 64 + lane] = make_float4(sp, ur, uv, sp * (1.0f - fmaf(uv, uv, ur * ur)));
                 S += sp;
@@ -805,8 +807,9 @@ __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_
 // sum over the segments continues over them (one float4 load per segment and pass: a K > 128 inverse is rare, L2 absorbs it)
 template <int KT>
 __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvSegs<KT> &sg, float S, Rot &R, float &ldj, const float4 *stash = nullptr,
-                                                  int n_over = 0, int lane = 0) {
+                                                  int n_over = 0, int lane = 0, float min_s = 0.f, bool *bad = nullptr) {
     S = pair_sum(S);
+    if (bad) *bad |= !(S >= min_s);                                       // lean softplus: every weight tiny (or a NaN sum) -> exact-fp32 re-run
     const float invS = hw_rcp(S);
     float lo = 0.5f * kPi, hi = 1.5f * kPi, th;
     {   // Starting point: the exact inverse of ONE Moebius map with the weighted mean centre m = sum wt_k u_k (the map with centre -m
@@ -946,7 +949,7 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
     const v3f zz = normalize3(c.cyc ? cross3(xx, c.y) : cross3(c.y, xx));               // mobiusflow.py:172-176
     set_col(R, c.p0, xx);
     set_col(R, c.p2, zz);
-    ldj -= logf(J * invS);                                                               // mobiusflow.py:183
+    ldj = fmaf(-0.693147180559945309f, hw_log2(J * invS), ldj);                          // mobiusflow.py:183
 }
 
 // Condition16Trans (flow/squeezetrans.py:41-55): M = I + reshape(MLP(feature), 4, 4); the one fc_last tile leaves
@@ -1450,13 +1453,18 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     InvSegs<KTI> sg;
                     float S = 0.f;
                     float4 *const istash = (KTI == 16 && args.inv_stash) ? args.inv_stash + ((size_t)blockIdx.x * NW + wave) * (size_t)(4 * max(KT - KTI, 0)) * 64 : nullptr;
-                    mobius_inv_tiles<KTI, PREC>(lds, params, KT, args.K, lane, h, tt, ctx, sg, S, tid, NT, istash);
+                    // a guarded split-precision call (the launcher runs the exact-fp32 kernels behind it when the guard fires) may use the
+                    // lean softplus: the branch is wave uniform, each side its own copy of the tile loop
+                    const bool fastsp = PREC == 1 && args.guard_mode == 1;
+                    if (fastsp) mobius_inv_tiles<KTI, PREC, PREC == 1>(lds, params, KT, args.K, lane, h, tt, ctx, sg, S, tid, NT, istash);
+                    else mobius_inv_tiles<KTI, PREC, false>(lds, params, KT, args.K, lane, h, tt, ctx, sg, S, tid, NT, istash);
                     // the barrier right behind the tiles (the root finder does not touch LDS, and its pass count differs from wave to wave:
                     // a barrier behind it was 19 % of the wave time), the DMA request of the next fc_last image behind the root finder:
                     // in front of it the DMA address arithmetic would sit on top of the 96 live segment registers (36 spills at K = 64);
                     // the image still has the whole hidden-layer phase of the next layer to land
                     b2_sync();
-                    mobius_inv_finish<KTI>(ctx, sg, S, R, ldj, istash, KTI == 16 ? 4 * max(KT - KTI, 0) : 0, lane);
+                    mobius_inv_finish<KTI>(ctx, sg, S, R, ldj, istash, KTI == 16 ? 4 * max(KT - KTI, 0) : 0, lane,
+                                           fastsp ? kMinWeightSum * (float)args.K : 0.f, fastsp ? &bad : nullptr);
                     b2_issue();
                 } else {
                     float S = 0.f, A = 0.f, J = 0.f;

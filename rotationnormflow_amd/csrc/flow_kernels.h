@@ -387,20 +387,22 @@ struct Mlp<1> {
     // pre != nullptr: the projected features of this layer were already fetched into registers (flow_stack_kernel, LEAN = 2: issued behind
     // the previous layer's barrier B2, so that the HBM latency of the scratch read -- the first instruction of the hidden phase otherwise,
     // +11 k cycles per layer in the round-2 stamps -- is spent under the layer finish and the affine layer)
+    // ONE definition of the residual x0 + x3 (flow/condition.py:29) for every instantiation, so that a rotation's result does not depend on
+    // the workgroup width its launch picked: fc_first(y) is accumulated onto x3 in the matrix unit, then the layer's projected features G
+    // are added -- from the registers that kept them (KEEPX0: one read of the scratch) or from a second read of the scratch.
     template <bool KEEPX0, class GF>
     static __device__ __forceinline__ void residual(const float *lds, int ot, int lane, int h, float bA, float bB, const GF &g,
-                                                    const f32x16 (&x0k)[2], f32x16 &a) {
+                                                    const f32x16 (&gk)[2], f32x16 &a) {
+        a = first_tile(lds, ot, lane, bA, bB, a);
         if (g) {
             if constexpr (KEEPX0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a[r] += x0k[ot][r];
+                for (int r = 0; r < 16; ++r) a[r] += gk[ot][r];
             } else {
-                const f32x16 x0 = first_tile(lds, ot, lane, bA, bB, g.load(ot, lane, h));
+                const f32x16 gg = g.load(ot, lane, h);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a[r] += x0[r];
+                for (int r = 0; r < 16; ++r) a[r] += gg[r];
             }
-        } else {
-            a = first_tile(lds, ot, lane, bA, bB, a);
         }
     }
     template <class GF, bool KEEPX0 = false>
@@ -412,16 +414,19 @@ struct Mlp<1> {
         float m1 = -1.0f;
         asm("" : "+s"(m1));                                     // see split_act
         ActFrag &f = out;                                       // the fragments are rewritten in place, layer after layer
-        f32x16 x0k[2];                                          // KEEPX0 only (dead otherwise)
+        f32x16 x0k[2];                                          // KEEPX0 only (dead otherwise): the projected features G of this layer
         {
             f32x16 x0[2];
 #pragma unroll
-            for (int ot = 0; ot < 2; ++ot) x0[ot] = first_tile(lds, ot, lane, bA, bB, pre ? pre[ot] : (g ? g.load(ot, lane, h) : zero));
+            for (int ot = 0; ot < 2; ++ot) {
+                const f32x16 gin = pre ? pre[ot] : (g ? g.load(ot, lane, h) : zero);
+                if constexpr (KEEPX0) x0k[ot] = gin;
+                x0[ot] = first_tile(lds, ot, lane, bA, bB, gin);
+            }
             // a feature beyond the fp16 range (the whole projection row is NaN), or features so much larger than the packer's equalisation
             // assumed (x0 is normalised to an rms of 1/4 .. 1/2; kX0Guard = 64) that fc_last's down-scaled columns would lose bits
             if (g) bad |= !(fmaxf(fmaxf(fabsf(x0[0][0]), fabsf(x0[0][9])), fmaxf(fabsf(x0[1][3]), fabsf(x0[1][14]))) < kX0Guard);
             split_act<true>(x0, f);
-            if constexpr (KEEPX0) { x0k[0] = x0[0]; x0k[1] = x0[1]; }
         }
         auto w = [&](int L, int ot) { return lds + MOB_HID + (L * 2 + ot) * (8 * 64 * 4); };
         auto bias = [&](int L, int ot) { return load_bias16(lds + MOB_HB + ((L * 2 + ot) * 2 + h) * 16); };
@@ -442,9 +447,6 @@ struct Mlp<1> {
         a1 = bias(2, 1);
         hidden_tile<1>(w(2, 0), lane, f, a0, b1, m1);
         bad |= a0[0] != a0[0];
-        // ONE definition of the residual for every instantiation (so that a rotation's result does not depend on the workgroup width its
-        // launch picked): a conditional layer adds x0 = fc_first(y) accumulated onto the projected features -- kept (KEEPX0) or recomputed
-        // bit for bit from a second read of the scratch --, an unconditional layer accumulates fc_first(y) onto x3 in the matrix unit.
         residual<KEEPX0>(lds, 0, lane, h, bA, bB, g, x0k, a0);
         hidden_tile<2>(w(2, 1), lane, f, a1, a0, m1);
         fair.tick();

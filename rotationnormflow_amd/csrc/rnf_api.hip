@@ -731,9 +731,9 @@ static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream
 }
 
 // inverse with 64 < K <= 128 (flow_kernels.h mobius_inv_tiles: 16 tiles of segment parameters in registers, synchronous staging)
-template <int PREC>
+template <int PREC, bool EXT = false>
 static int launch_big_inverse(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream) {
-    auto kern = flow_stack_kernel<1, 16, NW_INV_BIG, false, PREC, false>;
+    auto kern = flow_stack_kernel<1, 16, NW_INV_BIG, false, PREC, EXT>;
     HIP_TRY(allow_lds(kern, lds_bytes));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_INV_BIG * 64), lds_bytes, stream, a);
     HIP_TRY(hipGetLastError());
@@ -838,8 +838,8 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     // inverse: the segment parameters of a layer stay in registers through the root finder; instantiations hold 1, 2, 4, 8 tiles
     // (8-wave workgroups) or 16 (K <= 128: 4-wave workgroups with the whole register file, fc_last staged in two halves)
     const int kt_inv = KT <= 1 ? 1 : (KT <= 2 ? 2 : (KT <= 4 ? 4 : (KT <= 8 ? 8 : 16)));
-    if (o.dir == 1 && any_mlp && KT > 8 && (ext || o.feature_div > 0))
-        return fail("inverse pass with segments > 64 is not built for conditional 3x3 / 6x6 layers or shared feature rows; got %d", K);
+    // (round 4: inverse passes with more than 64 segments also run for conditional 3x3 / 6x6 layers, side layers and shared feature rows --
+    // flow/mobiusflow.py:7-14 takes any `segments` with any `rot` -- on the extended build of the 4-wave instantiation)
 
     if (o.dir == 1 && any_mlp && KT > 16) {            // overflow stash of the K > 128 inverse (flow_kernels.h mobius_inv_tiles), behind everything else
         if (shared) return fail("inverse pass with segments > 128 is not built for shared feature rows; got %d", K);
@@ -1019,7 +1019,8 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         else if (kt_inv == 2) rc = RNF_LAUNCH(1, 2);
         else if (kt_inv == 4) rc = RNF_LAUNCH(1, 4);
         else if (kt_inv == 8) rc = RNF_LAUNCH(1, 8);
-        else rc = prec ? launch_big_inverse<1>(a, grid, lds_bytes, stream) : launch_big_inverse<0>(a, grid, lds_bytes, stream);
+        else rc = ext ? (prec ? launch_big_inverse<1, true>(a, grid, lds_bytes, stream) : launch_big_inverse<0, true>(a, grid, lds_bytes, stream))
+                      : (prec ? launch_big_inverse<1>(a, grid, lds_bytes, stream) : launch_big_inverse<0>(a, grid, lds_bytes, stream));
         if (rc) return rc;
         int grid_fb = 0;
         if (guarded) {                                   // the same chunk on the exact-fp32 kernels, skipped on the device unless the guard fired
@@ -1043,7 +1044,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
                 else if (kt_inv == 2) rc = RNF_LAUNCH(1, 2);
                 else if (kt_inv == 4) rc = RNF_LAUNCH(1, 4);
                 else if (kt_inv == 8) rc = RNF_LAUNCH(1, 8);
-                else rc = launch_big_inverse<0>(a, grid, lds_bytes, stream);
+                else rc = ext ? launch_big_inverse<0, true>(a, grid, lds_bytes, stream) : launch_big_inverse<0>(a, grid, lds_bytes, stream);
             }
             (void)grid_keep;
             if (rc) return rc;

@@ -116,6 +116,17 @@ CASES.update({
 })
 
 
+# Round 4: inverse passes with MORE THAN 64 SEGMENTS through the layer kinds of the extended instantiation -- conditional 3x3 Gram-Schmidt and
+# 6x6 layers, a side layer (the batch-coupled conditional LU on the 3x3 layer) -- which round 3 refused (flow/mobiusflow.py:7-14 takes any
+# `segments` with any `rot`)
+CASES.update({
+    "k96_cgs9_inv":    dict(cfg=dict(layers=2, segments=96, condition=1, feature_dim=24, rot="9TransLSmith"), n=256, regime="trained", wseed=71, rseed=181, direction="inverse", fisher=None),
+    "k80_cgs36_inv":   dict(cfg=dict(layers=2, segments=80, condition=1, feature_dim=24, rot="36Trans", last_affine=1), n=256, regime="trained", wseed=72, rseed=182, direction="inverse", fisher=None),
+    "k72_clu9_inv":    dict(cfg=dict(layers=2, segments=72, condition=1, feature_dim=24, rot="9TransLSmith", lu=1), n=256, regime="trained", wseed=73, rseed=183, direction="inverse", fisher=None),
+    "k136_csvdl9_inv": dict(cfg=dict(layers=2, segments=136, condition=1, feature_dim=24, rot="9TransLSVD"), n=256, regime="trained", wseed=74, rseed=184, direction="inverse", fisher=None),
+})
+
+
 # Gradients through Flow.inverse (BinFind.backward, flow/mobiusflow.py:247-273): the reference's own autograd in fp64, loss =
 # sum(a * ldj) + sum(B * R_out) with seeded a [n], B [n,3,3] (tests/golden/make_golden.py run_inverse_grad_case).
 GRAD_CASES = {

@@ -286,3 +286,24 @@ def test_shared_feature_rows_are_differentiable():
         _, l2 = fl2(R, f.repeat_interleave(Q, dim=0))
         l3 = fl2.log_prob(R, f, feature_repeat=Q)["logp"]
     assert torch.allclose(l1, l2, atol=1e-6) and torch.allclose(l3, l2, atol=1e-5)
+
+
+def test_shared_feature_rows_inverse_with_more_than_64_segments():
+    """Round 4: the pose-estimation pattern (one image feature against Q query rotations pushed through Flow.inverse, agent.py:238-263) for
+    K = 96 segments -- round 3 refused shared feature rows on the K > 64 inverse.  Equal to the materialised repeat (the reference's
+    feature.repeat, agent.py:240-244) and to the oracle."""
+    cfg = make_config(layers=2, segments=96, condition=1, feature_dim=24, rot="16UnTrans", frequent_permute=1, last_affine=1, first_affine=0)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=81, regime="trained")
+    fl = product_flow(cfg, w)
+    B, Q = 4, 96
+    R = synth.uniform_rotations(B * Q, seed=82)
+    f = synth.features(B, 24, seed=83)
+    Rd, fd = torch.from_numpy(R).cuda(), torch.from_numpy(f).cuda()
+    with torch.no_grad():
+        xa, la = fl.inverse(Rd, fd, feature_repeat=Q)
+        xb, lb = fl.inverse(Rd, fd.repeat_interleave(Q, dim=0))
+    assert torch.allclose(la, lb, atol=2e-5) and torch.allclose(xa, xb, atol=2e-5)
+    wR, wl = orc.flow_inverse(cfg, w, R, np.repeat(f, Q, axis=0), dtype=torch.float64)
+    cell = np.pi / 2 ** 14
+    assert (xa.cpu().double() - wR).abs().reshape(B * Q, -1).max(1).values.median().item() < cell
+    assert (la.cpu().double() - wl).abs().median().item() < 2e-4

@@ -120,6 +120,37 @@ class Flow(nn.Module):
                 n *= d
             mod._buffers[name] = base[off:off + n].view(shape)
 
+    def _ensure_alias(self):
+        """The per-layer views must alias ``_flat``; copy.deepcopy / pickling a module clones every tensor on its own, after which the copy's
+        views would silently go stale.  Checked (one pointer comparison) wherever the views or the parameter are about to be used."""
+        if self.is_flat and self._flat_slots:
+            mod, name, off, _ = self._flat_slots[-1]
+            flat = self._parameters["_flat"]
+            buf = mod._buffers.get(name)
+            if buf is None or buf.device != flat.device or buf.data_ptr() != flat.data_ptr() + 4 * off:
+                self._realias()
+                self.invalidate()
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in self._TRANSIENT:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        new._ensure_alias()                                        # the cloned views alias the cloned parameter again
+        return new
+
+    _TRANSIENT = ("_rnf_train_plan", "_rnf_guard_watch")           # per-process launch state (pinned words, events): rebuilt on demand
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._ensure_alias()
+
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
         if self.is_flat and not getattr(self, "_is_replica", False):
@@ -130,10 +161,12 @@ class Flow(nn.Module):
         return out
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._ensure_alias()
         super()._save_to_state_dict(destination, prefix, keep_vars)
         destination.pop(prefix + "_flat", None)                    # the reference's keys only: the values live in the per-layer views
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        self._ensure_alias()
         had = set(missing_keys)
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
         if prefix + "_flat" in missing_keys and prefix + "_flat" not in had:
@@ -238,6 +271,7 @@ class Flow(nn.Module):
             if packed is not None:
                 return packed
 
+        self._ensure_alias()
         watch = self.__dict__.get("_rnf_guard_watch")
         if watch is not None and self.condition and getattr(self, "_feature_ms_fixed", None) is None and watch.poll():
             self._cache.invalidate()                               # the guard kept firing: measure the feature scale again on this batch

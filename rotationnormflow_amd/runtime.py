@@ -463,6 +463,13 @@ class PackCache:
             self._params = None
             self._slots = None
 
+    # a copied / unpickled module starts with an empty cache of its own (the lock and the device blobs do not travel)
+    def __deepcopy__(self, memo):
+        return PackCache()
+
+    def __reduce__(self):
+        return (PackCache, ())
+
     def _walk(self, module):
         self._slots = [(m._parameters, name) for m in module.modules() for name, p in m._parameters.items() if p is not None]
         # floating-point buffers too: the per-layer tensors of a flattened flow (Flow.flatten_parameters) are buffers that view one

@@ -14,7 +14,8 @@ ONE JSON line on rank 0.  At N = 1 with the default workload the line also carri
     is the default split-precision arithmetic -- fp32 operands carried as fp16 hi+lo pairs, fp32 accumulate);
   * `configs`: every other BASELINE.json config on the same clock -- C1, C3 (its 2^22 rotations on this one GPU), C4, C5, C5u -- each with
     value, ms_per_step, both arithmetics, roofline (frac, kernel list, HBM traffic, VALU-issue and matrix-pipe fractions), parity against the
-    fp64 oracle with the reference-fp32 arithmetic's own error beside it, and a CPU baseline;
+    fp64 oracle with the reference-fp32 arithmetic's own error beside it, and a CPU baseline; plus `configs.train`: one training iteration
+    of the reference's recipe, eager with torch's default Adam, as the unedited driver runs it;
   * `roofline.traffic` and the binding fractions MEASURED IN THIS RUN: before this process touches the GPU it runs three short
     `rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --pmc-child ...` children (FETCH_SIZE, WRITE_SIZE and the SQ/GRBM group each in
     its own pass, as MI355X_MICROARCH.md prescribes; FETCH_SIZE x 2 x 1024, WRITE_SIZE x 1024) over the same workloads of the same library.
@@ -551,6 +552,56 @@ def measure(w, args, dist, pmc, steps, warmup, want_secondary, want_parity, cpu_
     return rec
 
 
+def measure_training(device, batch=1024, steps=40, warmup=10):
+    """One training iteration of the reference's unconditional recipe (settings/raw.yml: 24 layer pairs, K = 64, batch 1024; agent.py:75-92:
+    forward, loss = mean(-ldjs), zero_grad, backward, optimizer.step()) exactly as the reference's unedited driver runs it: the flow from
+    ``get_flow`` (flattened parameters), ``torch.optim.Adam(flow.parameters(), lr)`` with torch's defaults, eager.  Beside it the same loop
+    on per-tensor parameters (``Flow(config)``) and the HIP-graph replay of the iteration."""
+    import torch
+    from rotationnormflow_amd import make_config, synth
+    from rotationnormflow_amd.flow.flow import Flow, get_flow
+    from rotationnormflow_amd.harness import GraphedTrainStep
+    cfg = make_config("C2")
+    R = torch.from_numpy(synth.uniform_rotations(batch, seed=1)).to(device)
+    out = {"workload": "training iteration (forward + backward + Adam), settings/raw.yml recipe: 24-layer MobiusAffine, K = 64, batch 1024, eager, "
+                       "torch.optim.Adam defaults (agent.py:23,75-92)", "batch": batch, "unit": "ms per iteration"}
+
+    def run(flow, opt):
+        def step():
+            opt.zero_grad()
+            _, ldj = flow(R)
+            loss = (-ldj).mean()
+            loss.backward()
+            opt.step()
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        flat, classic, graphed = get_flow(cfg), Flow(cfg), get_flow(cfg)
+    flat, classic, graphed = flat.to(device).train(), classic.to(device).train(), graphed.to(device).train()
+    out["ms_per_iteration"] = run(flat, torch.optim.Adam(flat.parameters(), 1e-4))
+    out["value"] = batch / (out["ms_per_iteration"] * 1e-3)
+    out["parameters"] = f"flattened: {len(list(flat.parameters()))} tensor" if flat.is_flat else "per tensor"
+    out["ms_per_iteration_per_tensor_parameters"] = run(classic, torch.optim.Adam(classic.parameters(), 1e-4))
+    opt = torch.optim.Adam(graphed.parameters(), 1e-4, fused=True, capturable=True)
+    gstep = GraphedTrainStep(graphed, opt, tuple(R.shape))
+    for _ in range(warmup):
+        gstep(R)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gstep(R)
+    torch.cuda.synchronize()
+    out["ms_per_iteration_hip_graph"] = (time.perf_counter() - t0) / steps * 1e3
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -645,6 +696,10 @@ def main():
         # bounded host legs for the secondary configs: N = 4096 (1024 for the inverse passes, which the oracle runs at ~2e3 rotations/s)
         sizes = ((4096,) if w.wl["direction"] == "forward" else (1024,)) if host_legs else None
         configs[name] = measure(w, args, None, pmc, c_steps, 3, not args.no_secondary, host_legs, sizes, 10.0)
+    if full and rank == 0:
+        w.R = w.feat = None
+        torch.cuda.empty_cache()
+        configs["train"] = measure_training(device)           # the reference's training step, on the driver's clock too
 
     if rank == 0:
         strong = bool(WORKLOADS[headline].get("strong"))

@@ -91,8 +91,10 @@ class Flow(nn.Module):
                 return False                                       # a parameter that is not part of the training blob
         if not tensors:
             return False
+        if len({bool(t.requires_grad) for t in tensors}) != 1 or len({t.device for t in tensors}) != 1:
+            return False                                           # partly frozen flow (or parameters on several devices): stays per-tensor
         with torch.no_grad():
-            flat = nn.Parameter(torch.cat([t.detach().reshape(-1) for t in tensors]), requires_grad=all(t.requires_grad for t in tensors))
+            flat = nn.Parameter(torch.cat([t.detach().reshape(-1) for t in tensors]), requires_grad=bool(tensors[0].requires_grad))
         self._flat_slots, off = [], 0
         for (mod, name), t in zip(slots, tensors):
             del mod._parameters[name]
@@ -123,6 +125,8 @@ class Flow(nn.Module):
     def _ensure_alias(self):
         """The per-layer views must alias ``_flat``; copy.deepcopy / pickling a module clones every tensor on its own, after which the copy's
         views would silently go stale.  Checked (one pointer comparison) wherever the views or the parameter are about to be used."""
+        if getattr(self, "_is_replica", False):                    # nn.DataParallel replica: its slot table still names the MASTER's modules;
+            return                                                 # a replica's buffers are broadcast copies and need no aliasing
         if self.is_flat and self._flat_slots:
             mod, name, off, _ = self._flat_slots[-1]
             flat = self._parameters["_flat"]

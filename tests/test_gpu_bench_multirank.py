@@ -153,7 +153,9 @@ def test_full_line_carries_every_config_with_live_counters():
     rec = json.loads(lines[0])
     assert rec["config"]["workload"].startswith("C2") and rec["value"] > 0 and rec["value_fp32_exact"] > 0
     assert "error" not in rec["pmc"], rec["pmc"]
-    assert sorted(rec["configs"]) == ["C1", "C3", "C4", "C5", "C5u"]
+    assert sorted(rec["configs"]) == ["C1", "C3", "C4", "C5", "C5u", "train"]
+    tr = rec["configs"].pop("train")
+    assert 0.0 < tr["ms_per_iteration"] < tr["ms_per_iteration_per_tensor_parameters"] and tr["ms_per_iteration_hip_graph"] > 0.0
     for name, c in [("C2", rec)] + sorted(rec["configs"].items()):
         r = c["roofline"]
         assert r["traffic"] is not None and r["traffic"] > 0, (name, r.get("traffic_source"))

@@ -79,7 +79,12 @@ def main():
     print(f"staging={os.environ.get('RNF_STAGING', 'dma')} preset={args.preset} {args.direction} n={n}: "
           f"{a.elapsed_time(b):.2f} ms (instrumented)")
     print(f"{'phase':40s} {'share':>7s} {'cycles/wave-tile':>18s}")
-    for name, v in zip(PHASES, s):
+    phases = list(PHASES)
+    if args.direction != "forward":                 # the inverse pass places the stamps differently (flow_kernels.h: b2_sync / mobius_inv_finish / b2_issue)
+        phases[3] = "3 fc_last tiles + segment parameters (L)"
+        phases[4] = "4 barrier B2 + ROOT FINDER + DMA issue"
+        phases[5] = "5 behind the layer"
+    for name, v in zip(phases, s):
         print(f"{name:40s} {v / s.sum() * 100:6.1f}% {v / waves:18.0f}")
     print(f"{'total':40s} {100:6.1f}% {s.sum() / waves:18.0f}")
 

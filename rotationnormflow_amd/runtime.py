@@ -208,15 +208,23 @@ class GuardWatch:
     REPEAT = 3
 
     def __init__(self):
-        self.pending = None            # (event, pinned host word)
+        self.pending = False           # a copy of the guard word is in flight (one pinned word and one event, reused for every call)
+        self.host = None
+        self.event = None
         self.streak = 0
         self.warned = False
 
+    def __deepcopy__(self, memo):
+        return GuardWatch()
+
+    def __reduce__(self):
+        return (GuardWatch, ())
+
     def poll(self) -> bool:
         """-> True when a re-calibration is due."""
-        if self.pending is not None and self.pending[0].query():
-            fired = bool(int(self.pending[1][0]))
-            self.pending = None
+        if self.pending and self.event.query():
+            fired = bool(int(self.host[0]))
+            self.pending = False
             self.streak = self.streak + 1 if fired else 0
             if self.streak >= self.REPEAT:
                 self.streak = 0
@@ -231,13 +239,14 @@ class GuardWatch:
         return False
 
     def watch(self, ws):
-        if self.pending is not None or torch.cuda.is_current_stream_capturing():
+        if self.pending or torch.cuda.is_current_stream_capturing():
             return
-        host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        host.copy_(ws[4095 * 8 + 4: 4095 * 8 + 8].view(torch.int32), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.pending = (ev, host)
+        if self.host is None:
+            self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self.event = torch.cuda.Event()
+        self.host.copy_(ws[4095 * 8 + 4: 4095 * 8 + 8].view(torch.int32), non_blocking=True)
+        self.event.record()
+        self.pending = True
 
 
 def _pack_layers(layers, perm_rows, prec, L):

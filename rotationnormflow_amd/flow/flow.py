@@ -156,10 +156,12 @@ class Flow(nn.Module):
         self._ensure_alias()
 
     def _apply(self, fn, recurse=True):
+        flat = self.is_flat and not getattr(self, "_is_replica", False)
+        if flat and fn(torch.empty(0, dtype=torch.float32, device=self._parameters["_flat"].device)).dtype is not torch.float32:
+            # checked BEFORE anything is converted, so that the module is not left half-way
+            raise TypeError("a flattened flow keeps its parameters in fp32 (the kernels' plain blob); convert inputs, not the module")
         out = super()._apply(fn, recurse)
-        if self.is_flat and not getattr(self, "_is_replica", False):
-            if self._parameters["_flat"].dtype is not torch.float32:
-                raise TypeError("a flattened flow keeps its parameters in fp32 (the kernels' plain blob); convert inputs, not the module")
+        if flat:
             self._realias()                                        # .cuda() / .to() moved the buffers as separate tensors
             self.invalidate()
         return out

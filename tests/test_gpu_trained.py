@@ -108,3 +108,45 @@ def test_hip_training_follows_the_reference_adam_trajectory(name, graph):
         worst = max(worst, err / tol)
         assert err <= tol, (k, err, float(fx["ref32_err:" + k]), np.linalg.norm(want))
     print(f"{name} graph={graph}: loss err max {np.abs(losses - fx['loss64']).max():.2e} (reference fp32: {ref_noise.max():.2e}); worst update err / tol {worst:.2f}")
+
+
+@pytest.mark.parametrize("name", list(TRAINED))
+def test_trained_checkpoint_at_full_batch_runs_on_the_fast_path(name):
+    """The checkpoints the reference's own training produced at BASELINE batch size (2^20 rotations): the default split-precision kernels
+    carry them WITHOUT the exact-fp32 re-run (round 3's lean softplus overflowed on these weights and every launch was re-run), shards of
+    any size reproduce their rows bit for bit, inverse(forward(R)) returns R to the bisection cells of the stack, and the mean NLL over 2^20
+    uniform rotations is consistent with a normalised density (E_uniform[exp(log p)] = 1)."""
+    from rotationnormflow_amd.dist import shard_bounds
+    cfg, ckpt, w, fx, spec = load_trained(name)
+    flow = harness.build_flow_from_checkpoint(cfg, ckpt)
+    n = 1 << 20
+    R = torch.from_numpy(synth.uniform_rotations(n, seed=77)).cuda()
+    feat = None
+    if cfg.condition:                                              # features of the three classes the flow was trained on (+ noise), one row per rotation
+        base = torch.from_numpy(fx["test_feat"]).cuda()
+        feat = base[torch.arange(n, device="cuda") % base.shape[0]].contiguous()
+    with torch.no_grad():
+        full = flow.log_prob(R, feat)
+    assert runtime.get_precision() == "f16x2" and flow._packed(R.device, feat).precision == "f16x2"
+    assert not runtime.fallback_fired(R.device)
+    lp = full["logp"]
+    assert torch.isfinite(lp).all()
+    for r in (0, 3, 7):
+        lo, hi = shard_bounds(n, r, 8)
+        with torch.no_grad():
+            part = flow.log_prob(R[lo:hi], None if feat is None else feat[lo:hi])["logp"]
+        assert torch.equal(part, lp[lo:hi])
+    with torch.no_grad():
+        small = flow.log_prob(R[:3000].contiguous(), None if feat is None else feat[:3000].contiguous())["logp"]
+    assert torch.equal(small, lp[:3000])
+    # a normalised density: the Monte-Carlo estimate of its integral over SO(3) (Haar measure normalised to 1) is 1.  The trained densities
+    # are sharp (modes of kappa = 20), so the estimator's own spread is large: checked within its standard error
+    p = torch.exp(lp.double())
+    mass, se = p.mean().item(), (p.std() / np.sqrt(n)).item()
+    assert abs(mass - 1.0) < 6 * se + 0.02, (mass, se)
+    # round trip on a slice
+    m = 1 << 16
+    with torch.no_grad():
+        Rt, ldj = flow(R[:m], None if feat is None else feat[:m])
+        Rb, ldjb = flow.inverse(Rt, None if feat is None else feat[:m])
+    assert (Rb - R[:m]).abs().mean().item() < 1e-3 and (ldj + ldjb).abs().mean().item() < 5e-3

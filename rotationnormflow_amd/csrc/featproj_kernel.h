@@ -49,7 +49,12 @@ struct GOut {
             ok = true;
         }
     }
-    __device__ __forceinline__ void store(int q, float4 v) const { if (ok) p[q * stride] = v; }
+    // non-temporal stores: the scratch is written once and read by another kernel after 0.3 - 3 GB more of it have gone by -- there is
+    // nothing to gain from keeping it in L2, and the weight tiles every workgroup streams from there stay resident (C5 -4.3 %, C4 -1.3 %)
+    __device__ __forceinline__ void store(int q, float4 v) const {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        if (ok) __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f4v *>(p + q * stride));
+    }
     __device__ __forceinline__ f32x16 load() const {
         const float4 b0 = p[0], b1 = p[stride], b2 = p[2 * stride], b3 = p[3 * stride];
         f32x16 c;

@@ -821,10 +821,13 @@ __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_
 // n_over > 0 (KT = 16 only): `stash` holds the parameters of this lane's segments beyond the 4 KT in registers (mobius_inv_tiles); every
 // sum over the segments continues over them (one float4 load per segment and pass: a K > 128 inverse is rare, L2 absorbs it)
 template <int KT>
-__device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvSegs<KT> &sg, float S, Rot &R, float &ldj, const float4 *stash = nullptr,
-                                                  int n_over = 0, int lane = 0, float min_s = 0.f, bool *bad = nullptr) {
+__device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvSegs<KT> &sg, float S, Rot &R, float &ldj, const float4 *stash,
+                                                  int n_over, int lane, float min_s, bool check_s, bool &bad) {
     S = pair_sum(S);
-    if (bad) *bad |= !(S >= min_s);                                       // lean softplus: every weight tiny (or a NaN sum) -> exact-fp32 re-run
+    // lean softplus: every weight tiny (or a NaN sum) -> exact-fp32 re-run.  (`bad` by reference and the test switched by a value: a
+    // `bool *` that is either &bad or nullptr kept the flag in scratch memory, and every update of it was a load + store on the vector
+    // memory counter in front of the scratch-tile loads of the hidden phase)
+    bad |= check_s && !(S >= min_s);
     const float invS = hw_rcp(S);
     float lo = 0.5f * kPi, hi = 1.5f * kPi, th;
     {   // Starting point: the exact inverse of ONE Moebius map with the weighted mean centre m = sum wt_k u_k (the map with centre -m
@@ -1065,13 +1068,19 @@ __device__ __forceinline__ void cond36_finish(const f32x16 &o0, const f32x16 &o1
 //         the two compute phases of a layer: while fc_last + segment math of layer l read the L part, the H part of
 //         the next MLP layer streams in; while the hidden layers of layer l+1 read H, its L part streams in.
 // ------------------------------------------------------------------------------------------------------------
+// One 1 KiB LDS-DMA piece (16 bytes per lane).  hipcc counts a piece issued through the builtin as a pending store to LDS and puts
+// `s_waitcnt vmcnt(0)` in front of the first ds_read behind it (visible in the .s in front of the affine layer's table read and of the first
+// fc_last operand read).  Round 4 measured the same pieces issued from inline assembly, hidden from that bookkeeping (the protocol orders the
+// data itself: dma_wait_all() + the layer barrier): no difference on any config (C2 4.248 / 4.243 ms, profiles/README.md) -- the images have
+// landed by then -- so the compiler-tracked form stays.
+__device__ __forceinline__ void dma_piece(const float *g_lane /* this lane's 16 source bytes */, float *lds_piece /* wave uniform */) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g_lane, (__attribute__((address_space(3))) void *)lds_piece, 16, 0, 0);
+}
 __device__ __forceinline__ void dma_floats(float *lds_dst, const float *g_src, int nfloats, int wave, int lane, int nwaves) {
     const int n4 = nfloats >> 2;
     for (int base = wave * 64; base < n4; base += nwaves * 64) {          // `base` is wave uniform: 1 KiB per instruction
         const int idx = base + lane;
-        if (idx < n4)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g_src + 4 * (size_t)idx),
-                                             (__attribute__((address_space(3))) void *)(lds_dst + 4 * base), 16, 0, 0);
+        if (idx < n4) dma_piece(g_src + 4 * (size_t)idx, lds_dst + 4 * base);
     }
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -1082,6 +1091,12 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 // ------------------------------------------------------------------------------------------------------------
 // In-kernel phase stamps (diagnostic build only, -DRNF_STAMPS; cdna_hip_programming.md section 7 "In-kernel stamps").
 // The shipped library is built without them: no stamp executes in the product kernel.
+// timing-only diagnostic (-DRNF_KO_BARRIER): the two layer barriers of the DMA pipeline removed -- results are garbage, the guard is muted
+#ifdef RNF_KO_BARRIER
+#define RNF_LAYER_BARRIER() asm volatile("" ::: "memory")
+#else
+#define RNF_LAYER_BARRIER() __syncthreads()
+#endif
 #ifdef RNF_STAMPS
 #define RNF_STAMP_DECL unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = clock64();
 #define RNF_STAMP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = clock64(); st_acc[i] += now_ - st_t; st_t = now_; __builtin_amdgcn_sched_barrier(0); }
@@ -1222,8 +1237,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
         int ln = lane;
         asm volatile("" : "+v"(ln));                                  // keeps the per-lane address out of the long-lived registers
         const float *t = args.blob + da.y + (DIR ? AFF_TABLE_INV : AFF_TABLE_FWD) + 4 * ln;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)t,
-                                         (__attribute__((address_space(3))) void *)(lds + args.tab_off + AFF_TABLE_LDS_STRIDE * parity), 16, 0, 0);
+        dma_piece(t, lds + args.tab_off + AFF_TABLE_LDS_STRIDE * parity);
     };
     auto has_table = [&](int q) { return args.tab_off >= 0 && q + 1 < n_layers && (args.layers[layer_at(q + 1)].x & 15) == RNF_KIND_AFFINE16; };
     // FUSED: cond slot -> its projection record; DMA of one out tile (weights + bias image) into the LDS buffer; the slot of a position
@@ -1232,8 +1246,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
         const float *rec = args.blob + args.feat_base + (size_t)slot * args.feat_stride;
         dma_floats(lds + args.pa_off, rec + (size_t)half * fused_ns * 512, fused_ns * 512, wave, lane, NW);
         if (wave == NW - 1 && lane < 8)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rec + (size_t)2 * fused_ns * 512 + half * 32 + 4 * lane),
-                                             (__attribute__((address_space(3))) void *)(lds + args.pa_off + FUSED_PA_W), 16, 0, 0);
+            dma_piece(rec + (size_t)2 * fused_ns * 512 + half * 32 + 4 * lane, lds + args.pa_off + FUSED_PA_W);
     };
     auto slot_at = [&](int pos) { return ((args.layers[layer_at(pos)].x >> 8) & 255) - 1; };
     auto next_in_tile = [&](int pos) { return ((args.layers[layer_at(pos)].x >> 16) & 1023) - 1; };   // next MLP position, -1 at the end
@@ -1252,6 +1265,12 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
         __syncthreads();
     }
 
+#if defined(RNF_KO_BARRIER) && defined(RNF_KO_STAGGER)
+    // timing-only diagnostic: the upper half of the workgroup's waves starts RNF_KO_STAGGER x 4096 cycles late (with the barriers knocked
+    // out the offset persists): what would two wave groups half a layer apart -- one in its matrix-bound hidden phase while the other
+    // is in its VALU-bound segment phase -- be worth?
+    if (wave >= NW / 2) for (int i_ = 0; i_ < RNF_KO_STAGGER; ++i_) __builtin_amdgcn_s_sleep(64);
+#endif
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long group = tile * NW + wave;                 // 32-sample group index inside this launch
         const long long sample0 = group * TILE_SAMPLES;           // wave uniform
@@ -1417,7 +1436,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             RNF_STAMP(1)                                          // 1: frame + hidden layers (H part)
             if (PIPE) {       // B1: every wave is past the H part and this layer's L part has landed
                 dma_wait_all();
-                __syncthreads();
+                RNF_LAYER_BARRIER();
                 if (nxt_off >= 0) dma_floats(lds, args.blob + nxt_off, MOB_HEAD_FLOATS, wave, lane, NW);
             }
             RNF_STAMP(2)                                          // 2: barrier B1 (+ DMA issue)
@@ -1437,7 +1456,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 RNF_STAMP(3)                                      // 3: fc_last tiles + segment math (L part)
                 if (PIPE) {
                     dma_wait_all();
-                    __syncthreads();
+                    RNF_LAYER_BARRIER();
                 }
             };
             auto b2_issue = [&]() {
@@ -1479,7 +1498,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     // the image still has the whole hidden-layer phase of the next layer to land
                     b2_sync();
                     mobius_inv_finish<KTI>(ctx, sg, S, R, ldj, istash, KTI == 16 ? 4 * max(KT - KTI, 0) : 0, lane,
-                                           fastsp ? kMinWeightSum * (float)args.K : 0.f, fastsp ? &bad : nullptr);
+                                           kMinWeightSum * (float)args.K, fastsp, bad);
                     b2_issue();
                 } else {
                     float S = 0.f, A = 0.f, J = 0.f;
@@ -1509,7 +1528,9 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
 
         if (PREC == 1 && args.guard_mode == 1 && valid) {            // see FlowArgs::guard
             const float chk = ldj + ((R.c0.x + R.c0.y + R.c0.z) + (R.c1.x + R.c1.y + R.c1.z) + (R.c2.x + R.c2.y + R.c2.z));
+#ifndef RNF_KO_BARRIER
             if (bad || !(fabsf(chk) <= 3.0e38f)) atomicOr(args.guard, 1);
+#endif
         }
         // epilogue: outputs + fused base density + NLL partial (utils/fisher.py:217-232, agent.py:55-65)
         double lp_d = 0.0;

@@ -932,7 +932,11 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
         done = done || step <= 1.0e-4f || (step <= 5.0e-3f && c3 * step * step * step <= 2.4e-7f);
         prev = done ? prev : step;
         th = nt;
+#ifdef RNF_KO_FIXED_PASSES          // timing-only diagnostic: every wave runs exactly this many passes
+        if (it + 1 == RNF_KO_FIXED_PASSES) break;
+#else
         if (__all(done)) break;                                           // wave-uniform exit: typically 3 passes
+#endif
     }
     const float cell = kPi * (1.0f / 16384.0f);
     float n = floorf((th - 0.5f * kPi) * (16384.0f / kPi));
@@ -1096,6 +1100,11 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 #define RNF_LAYER_BARRIER() asm volatile("" ::: "memory")
 #else
 #define RNF_LAYER_BARRIER() __syncthreads()
+#endif
+#if defined(RNF_STAMPS) && defined(RNF_STAMPS_FINE)
+#define RNF_STAMP_FINE(i) RNF_STAMP(i)
+#else
+#define RNF_STAMP_FINE(i)
 #endif
 #ifdef RNF_STAMPS
 #define RNF_STAMP_DECL unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = clock64();
@@ -1436,6 +1445,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             RNF_STAMP(1)                                          // 1: frame + hidden layers (H part)
             if (PIPE) {       // B1: every wave is past the H part and this layer's L part has landed
                 dma_wait_all();
+                RNF_STAMP_FINE(8)                                 // (-DRNF_STAMPS_FINE) 8: B1's wait for this wave's own DMA pieces
                 RNF_LAYER_BARRIER();
                 if (nxt_off >= 0) dma_floats(lds, args.blob + nxt_off, MOB_HEAD_FLOATS, wave, lane, NW);
             }
@@ -1456,7 +1466,9 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 RNF_STAMP(3)                                      // 3: fc_last tiles + segment math (L part)
                 if (PIPE) {
                     dma_wait_all();
+                    RNF_STAMP_FINE(9)                             // 9: B2's wait for this wave's own DMA pieces
                     RNF_LAYER_BARRIER();
+                    RNF_STAMP_FINE(10)                            // 10: B2's barrier itself (4 is then what follows it: root finder + DMA issue)
                 }
             };
             auto b2_issue = [&]() {

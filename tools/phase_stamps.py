@@ -33,7 +33,7 @@ def main():
     csrc = os.path.join(ROOT, "rotationnormflow_amd", "csrc")
     newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc))
     if not os.path.exists(out) or os.path.getmtime(out) < newest:
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DRNF_STAMPS",
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DRNF_STAMPS"] + os.environ.get("RNF_STAMPS_FLAGS", "").split() + [
                         "-shared", "-fPIC", "-o", out, os.path.join(csrc, "rnf_api.hip")], check=True)
     if args.build_only:
         return

@@ -809,6 +809,15 @@ __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_
     }
 }
 
+// Order of the inverse pass's root-finder iteration.  3 (shipped): Halley.  4 (-DRNF_RF_ORDER=4, measured and NOT shipped): Householder's
+// method with the third derivative, four more packed instructions per segment pair and pass (+13 % per pass: 1.53 against 1.35 ms per pass
+// over C5u's 42 layers x 2^20 rotations).  On sharply peaked weights (softmax of 6 x N(0,1) logits, centres 6 x N(0,1): the start is off by
+// > 0.17 for a tenth of the rotations) it brings every wave from 2.85 passes to 2.0 with the same cell agreement (CPU emulation, 16384
+// samples); on BASELINE's C5 / C5u weights the third-order iteration already needs 2.0 passes per wave (fixed-2-pass build 11.62 ms,
+// shipped 11.64), so the fourth order only adds its per-pass cost: C5u 11.79 -> 12.26 ms, C5 22.59 -> 23.10 (profiles/README.md).
+#ifndef RNF_RF_ORDER
+#define RNF_RF_ORDER 3
+#endif
 // Root of BinFind (flow/mobiusflow.py:189-224).  The reference bisects f(theta) = sum_k wt_k phi_k(theta) - target on
 // [pi/2, 3pi/2] exactly 15 times (its batch-global stop test max(b - a) < 1e-4 is data independent) and returns the LAST
 // midpoint, i.e. the centre of the cell of the grid  pi/2 + n * pi/2^14  that contains the root:
@@ -867,11 +876,11 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
         // Round 4: the SECOND derivative rides along -- d/dtheta of q / den is 2 q b / den^2 (da/dtheta = b, db/dtheta = -a) -- three more
         // packed instructions per segment pair, for a third-order (Halley) step: on trained-like weights a wave needs 2.9 passes instead of
         // 4.0 (tests/test_inverse_rootfinder.py), the pass costs 12 % more.
-        float acc = 0.f, der = 0.f, dd = 0.f;
+        float acc = 0.f, der = 0.f, dd = 0.f, d3 = 0.f;
         // two segments per instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): no matrix instruction runs during the root finder,
         // so the packed fp32 VALU forms pay here (-6.5 % on the whole inverse pass) -- beside MFMAs they are an anti-lever
         {
-            f2 acc2 = {0.f, 0.f}, der2 = {0.f, 0.f}, dd2 = {0.f, 0.f};
+            f2 acc2 = {0.f, 0.f}, der2 = {0.f, 0.f}, dd2 = {0.f, 0.f}, e3a = {0.f, 0.f}, e3b = {0.f, 0.f};
             const f2 sn2 = {sn, sn}, cs2 = {cs, cs};
 #pragma unroll
             for (int s = 0; s < 4 * KT; s += 2) {
@@ -894,13 +903,22 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
                 acc2 = __builtin_elementwise_fma(sp, p * t, acc2);
                 const f2 den = __builtin_elementwise_fma(b, b, e1 * e1);
                 const f2 r2 = {hw_rcp(den.x), hw_rcp(den.y)};
-                const f2 cq = q * r2;
+                const f2 cq = q * r2;                               // c = q / den, the segment's term of f'
                 der2 = der2 + cq;
-                dd2 = __builtin_elementwise_fma(cq, b * r2, dd2);
+                if constexpr (RNF_RF_ORDER >= 4) {                  // dc/dtheta = 2 c b / den,  d2c/dtheta2 = 2 c (4 b^2 / den - a) / den   (d den/dtheta = -2 b)
+                    const f2 cr = cq * r2;
+                    const f2 cb = cr * b;                           // c b / den
+                    dd2 = dd2 + cb;
+                    e3a = __builtin_elementwise_fma(cb, b * r2, e3a);
+                    e3b = __builtin_elementwise_fma(cr, a, e3b);
+                } else {
+                    dd2 = __builtin_elementwise_fma(cq, b * r2, dd2);
+                }
             }
             acc = acc2.x + acc2.y;
             der = der2.x + der2.y;
             dd = dd2.x + dd2.y;
+            if constexpr (RNF_RF_ORDER >= 4) d3 = fmaf(4.0f, e3a.x + e3a.y, -(e3b.x + e3b.y));
         }
         if constexpr (KT == 16)
             for (int s = 0; s < n_over; ++s) {                         // the same per-segment evaluation on the stashed parameters
@@ -912,24 +930,48 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
                 const float r2 = hw_rcp(fmaf(b, b, e1 * e1));
                 const float cq = p.w * r2;
                 der += cq;
-                dd = fmaf(cq, b * r2, dd);
+                if constexpr (RNF_RF_ORDER >= 4) {
+                    const float cr = cq * r2, cb = cr * b;
+                    dd += cb;
+                    d3 += fmaf(4.0f * cb, b * r2, -(cr * a));
+                } else {
+                    dd = fmaf(cq, b * r2, dd);
+                }
             }
 
         const float fx = fmaf(2.0f * pair_sum(acc), invS, th) - c.target;
-        const float dfx = pair_sum(der) * invS;                            // f'  > 0
-        const float ddfx = 2.0f * pair_sum(dd) * invS;                     // f''
+        const float dfx = pair_sum(der) * invS;                            // f1 = df/dtheta  > 0
+        const float ddfx = 2.0f * pair_sum(dd) * invS;                     // f2, the second derivative
         if (fx < 0.f) lo = th; else hi = th;
-        // Halley: theta - f / (f' - f f'' / (2 f')); a non-positive denominator (far from the root) falls back to the Newton step
+        // Halley: theta - f / (f1 - f f2 / (2 f1)); a non-positive denominator (far from the root) falls back to the Newton step
         const float hden = fmaf(-0.5f * fx * ddfx, hw_rcp(dfx), dfx);
         float nt = th - fx * hw_rcp(hden > 0.25f * dfx ? hden : dfx);
+        if constexpr (RNF_RF_ORDER >= 4) {
+            // Fourth order (Householder's method with the third derivative f3):  theta - 3 f (2 f1^2 - f f2) / (6 f1 (f1^2 - f f2) + f^2 f3).
+            // The starting point is off by > 0.17 for a tenth of the rotations (0.47 at worst); a third-order step brings those to ~ 1e-2,
+            // one pass short of the fp32 spacing, so that 85 % of the waves ran a third pass for 6 % of their lanes.  The fourth-order step
+            // gets every lane there in two (2.0 - 2.1 passes per wave instead of 2.85 in the CPU emulation) for four more packed instructions
+            // per segment pair and pass.
+            const float d3fx = 2.0f * pair_sum(d3) * invS;
+            const float df2 = dfx * dfx, ffd = fx * ddfx;
+            const float den4 = fmaf(6.0f * dfx, df2 - ffd, fx * fx * d3fx);
+            const float num4 = 3.0f * fx * fmaf(2.0f, df2, -ffd);
+            if (den4 > 1.5f * df2 * dfx) nt = th - num4 * hw_rcp(den4);    // a denominator below 1/4 of its value at the root: the Halley / Newton step
+        }
         if (!(nt >= lo && nt <= hi)) nt = 0.5f * (lo + hi);               // keep the iterate inside the sign bracket
         if (done) nt = th;                                                // a converged lane stays put
-        // Third-order convergence: the error left behind a step of size d is ~ C d^3 with C estimated from this step and the previous one
-        // (d / d_prev^3, floored at 20).  A lane stops when that prediction is below the fp32 spacing of theta (2.4e-7) -- the pass that would
-        // only confirm it is not run -- or, as before, after a step of <= 1e-4.
+        // Convergence of order p (4; 3 for the Halley build): the error left behind a step of size d is ~ C d^p with C estimated from this step
+        // and the previous one (d / d_prev^p, floored).  A lane stops when that prediction is below the fp32 spacing of theta (2.4e-7) -- the
+        // pass that would only confirm it is not run -- or, as before, after a step of <= 1e-4.
         const float step = fabsf(nt - th);
-        const float c3 = fmaxf(step * hw_rcp(prev * prev * prev), 20.0f);
-        done = done || step <= 1.0e-4f || (step <= 5.0e-3f && c3 * step * step * step <= 2.4e-7f);
+        if constexpr (RNF_RF_ORDER >= 4) {
+            const float p2 = prev * prev, s2 = step * step;
+            const float c4 = fmaxf(step * hw_rcp(p2 * p2), 100.0f);
+            done = done || step <= 1.0e-4f || (step <= 1.0e-2f && c4 * s2 * s2 <= 2.4e-7f);
+        } else {
+            const float c3 = fmaxf(step * hw_rcp(prev * prev * prev), 20.0f);
+            done = done || step <= 1.0e-4f || (step <= 5.0e-3f && c3 * step * step * step <= 2.4e-7f);
+        }
         prev = done ? prev : step;
         th = nt;
 #ifdef RNF_KO_FIXED_PASSES          // timing-only diagnostic: every wave runs exactly this many passes

@@ -505,17 +505,28 @@ def run_pmc_passes(configs, batch_log2, keep_dir=None):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------------
-def measure(w, args, dist, pmc, steps, warmup, want_secondary, want_parity, cpu_sizes, cpu_budget):
-    """One workload -> its record (rank 0 fills the host-side legs)."""
+def measure(w, args, dist, pmc, steps, warmup, want_secondary, want_parity, cpu_sizes, cpu_budget, blocks=1):
+    """One workload -> its record (rank 0 fills the host-side legs).  blocks: the K timed steps are measured this many times and the
+    fastest block is kept.  The headline leg (`value`) is ALWAYS one block, as the bench contract says; the `configs` entries and the
+    exact-fp32 legs use two (one sweep of round 4 caught a leg whose eight launches ran at half clock: 8.7 ms per step for a kernel that
+    takes 4.7 before and after)."""
     import torch
     from rotationnormflow_amd import get_precision, set_precision
     rank0 = dist is None or dist.get_rank() == 0
     world = 1 if dist is None else dist.get_world_size()
     primary = get_precision()
-    elapsed, kernel_ms, tot = w.timed(steps, warmup, CLOCK_SETTLE_LAUNCHES, dist)
+
+    def timed(n_steps, n_warmup, settle, n_blocks):
+        best = w.timed(n_steps, n_warmup, settle, dist)
+        for _ in range(n_blocks - 1):
+            again = w.timed(n_steps, 0, 0, dist)
+            if again[0] < best[0]:
+                best = again
+        return best
+    elapsed, kernel_ms, tot = timed(steps, warmup, CLOCK_SETTLE_LAUNCHES, blocks)
     used = w.fl._packed(w.device, w.feat).precision      # "fp32" when a weight left the fp16 range and the packer fell back
     rec = {"workload": f"{w.name} -- {w.wl['text']}", "value": w.n_global * steps / elapsed, "unit": "rotations/s", "steps": steps, "warmup": warmup,
-           "ms_per_step": elapsed / steps * 1e3,
+           "timed_blocks": blocks, "ms_per_step": elapsed / steps * 1e3,
            "dtype": "f32" if used == "fp32" else "f32 (GEMM operands as fp16 hi+lo pairs, fp32 accumulate)",
            "rotations_per_gpu": w.n, "global_batch": w.n_global, "mean_nll": -float(tot[0] / tot[1]),
            "roofline": roofline_of(w, used, kernel_ms, pmc),
@@ -526,9 +537,9 @@ def measure(w, args, dist, pmc, steps, warmup, want_secondary, want_parity, cpu_
         set_precision("fp32")
         try:
             s_steps = max(2, min(steps, 8))
-            s_elapsed, s_kernel_ms, s_tot = w.timed(s_steps, 2, 4, dist)
+            s_elapsed, s_kernel_ms, s_tot = timed(s_steps, 2, 4, 2)
             secondary = {"dtype": "f32 (exact fp32-input MFMA)", "value": w.n_global * s_steps / s_elapsed, "unit": "rotations/s",
-                         "steps": s_steps, "ms_per_step": s_elapsed / s_steps * 1e3, "mean_nll": -float(s_tot[0] / s_tot[1]),
+                         "steps": s_steps, "timed_blocks": 2, "ms_per_step": s_elapsed / s_steps * 1e3, "mean_nll": -float(s_tot[0] / s_tot[1]),
                          "roofline": roofline_of(w, "fp32", s_kernel_ms, pmc)}
         finally:
             set_precision(primary)
@@ -695,7 +706,7 @@ def main():
         c_steps = 6 if name == "C3" else 10
         # bounded host legs for the secondary configs: N = 4096 (1024 for the inverse passes, which the oracle runs at ~2e3 rotations/s)
         sizes = ((4096,) if w.wl["direction"] == "forward" else (1024,)) if host_legs else None
-        configs[name] = measure(w, args, None, pmc, c_steps, 3, not args.no_secondary, host_legs, sizes, 10.0)
+        configs[name] = measure(w, args, None, pmc, c_steps, 3, not args.no_secondary, host_legs, sizes, 10.0, blocks=2)
     if full and rank == 0:
         w.R = w.feat = None
         torch.cuda.empty_cache()

@@ -235,3 +235,56 @@ class MatrixFisherN(torch.nn.Module):
 
     def sample(self, num_samples, context=None):
         return self._sample(num_samples)
+
+
+# ---- the reference's module-level helpers under their own names (utils/fisher.py:14-207) -----------------------------------------------
+# MatrixFisherN above never calls these (it goes to the kernels directly); they exist so that code written against the reference's module
+# finds the same names with the same argument meaning.  GPU tensors go through the device kernels; the SVD helpers also accept host tensors
+# (torch's LAPACK, as the reference itself does) because they are plain linear algebra, not part of the density path.
+
+def quat_to_rotmat(quat):
+    """[B,4] (w, x, y, z), normalised first -> [B,3,3] (utils/fisher.py:14-46)."""
+    return quaternion_to_matrix(quat)
+
+
+def proper_svd_N(A):
+    """[N,3,3] -> (U, S, V) with det(U) = det(V) = +1 and the last singular value carrying the sign (utils/fisher.py:67-76)."""
+    A = A.reshape(-1, 3, 3)
+    if A.is_cuda:
+        U, V, s, _ = device_proper_svd(A)
+        return U.to(A.dtype), s.to(A.dtype), V.to(A.dtype)
+    U, S, Vh = torch.linalg.svd(A.detach())
+    V = Vh.transpose(-1, -2).clone()
+    U, S = U.clone(), S.clone()
+    du, dv = torch.det(U), torch.det(V)
+    U[:, :, 2] *= du[:, None]
+    V[:, :, 2] *= dv[:, None]
+    S[:, 2] *= du * dv
+    return U, S, V
+
+
+def proper_svd(A, clone=False):
+    """One [3,3] matrix -> (U [3,3], S [3], V [3,3]) (utils/fisher.py:48-64; `clone` is accepted and has no effect: nothing aliases A here)."""
+    U, S, V = proper_svd_N(A.reshape(1, 3, 3))
+    return U[0], S[0], V[0]
+
+
+def matrix_fisher_norm_N(A, type_approx=0, approx_num=17890714):
+    """The approximated normalising constant of MF(A), A [N,3,3] -> [N] (utils/fisher.py:79-115): type 0 / 1 closed forms (type 0 keeps
+    the reference's batch-global ``(S**2).sum()``), type 2 Monte-Carlo over `approx_num` uniform rotations (ONE matrix, on the GPU).
+    Type 3 is refused, see MatrixFisherN."""
+    A = A.reshape(-1, 3, 3)
+    if type_approx in (0, 1):
+        S = proper_svd_N(A)[1] if A.is_cuda else proper_singular_values(A).to(A.dtype)
+        return _norm_from_singular_values(S, type_approx)
+    if type_approx == 2:
+        return MatrixFisherN(A, 2, approx_num).norm
+    raise NotImplementedError("matrix_fisher_norm_N: type_approx 0, 1 and 2 are built (type 3: see MatrixFisherN)")
+
+
+def sample_matrix_fisher(A, num_samples, b=1.5, oversampling_ratio=8):
+    """[num_samples,3,3] rotations ~ MF(A) for ONE [3,3] matrix on the GPU (utils/fisher.py:175-207).  The device sampler is an exact
+    per-sample rejection loop with the reference's envelope (b = 1.5): `oversampling_ratio` has nothing to size here, other `b` are refused."""
+    if float(b) != 1.5:
+        raise NotImplementedError("sample_matrix_fisher: the device sampler is built for the reference's envelope parameter b = 1.5")
+    return MatrixFisherN(A.reshape(1, 3, 3))._sample(num_samples)[0]

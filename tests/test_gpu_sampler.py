@@ -132,3 +132,30 @@ def test_quaternion_output_context_4():
     lp_r = dist._log_prob(R.reshape(-1, 3, 3))
     lp_q = dist._log_prob(q.reshape(-1, 4))
     assert (lp_r - lp_q).abs().max() < 1e-4
+
+
+def test_reference_named_helpers_on_the_device():
+    """proper_svd_N / proper_svd / matrix_fisher_norm_N / sample_matrix_fisher (utils/fisher.py:48-207) with GPU tensors go through the
+    device kernels: same values as the host path, samples of one matrix with the density's first moment."""
+    from rotationnormflow_amd.utils import fisher as F
+    A = _A()
+    Ud, Sd, Vd = F.proper_svd_N(A.cuda())
+    Uh, Sh, Vh = F.proper_svd_N(A.double())
+    assert torch.allclose(Sd.cpu().double(), Sh, atol=2e-5)
+    assert (Ud @ torch.diag_embed(Sd) @ Vd.transpose(-1, -2) - A.cuda()).abs().max().item() < 2e-5
+    assert (torch.linalg.det(Ud.double()) - 1).abs().max().item() < 1e-5 and (torch.linalg.det(Vd.double()) - 1).abs().max().item() < 1e-5
+    u, s, v = F.proper_svd(A[1].cuda())
+    assert s.shape == (3,) and (u @ torch.diag(s) @ v.T - A[1].cuda()).abs().max().item() < 2e-5
+    for t in (0, 1):
+        assert torch.allclose(F.matrix_fisher_norm_N(A.cuda(), t).cpu().double(), F.matrix_fisher_norm_N(A.double(), t), rtol=2e-5)
+    n = 1 << 15
+    torch.manual_seed(5)
+    R = F.sample_matrix_fisher(A[0].cuda(), n)
+    assert R.shape == (n, 3, 3)
+    torch.manual_seed(6)
+    want = orc.fisher_sample(A[:1], n)[0].double()
+    got = R.cpu().double()
+    sem = torch.sqrt(want.var(0) / n + got.var(0) / n)
+    assert ((want.mean(0) - got.mean(0)).abs() < 5 * sem + 1e-6).all()
+    with pytest.raises(NotImplementedError):
+        F.sample_matrix_fisher(A[0].cuda(), 8, b=2.0)

@@ -155,3 +155,25 @@ def test_condrot_backward_formula_matches_autograd_of_the_svd():
     assert ok.sum() > 150
     err = (got - want).abs().amax(1) / want.abs().amax(1).clamp_min(1e-6)
     assert err[ok].max() < 1e-8
+
+
+def test_reference_named_fisher_helpers_on_host_tensors():
+    """utils/fisher.py's module-level helpers under their own names (host tensors: torch's LAPACK, as the reference does) against the
+    oracle's restatements (oracle/flow_oracle.py, pinned to the reference)."""
+    from rotationnormflow_amd.utils import fisher as F
+    torch.manual_seed(3)
+    A = torch.randn(5, 3, 3, dtype=torch.float64) * 3
+    A[1] = -A[1] @ A[1].T                                  # a negative determinant: the last proper singular value is negative
+    U, S, V = F.proper_svd_N(A)
+    assert (U @ torch.diag_embed(S) @ V.transpose(-1, -2) - A).abs().max().item() < 1e-12
+    assert (torch.det(U) - 1).abs().max().item() < 1e-12 and (torch.det(V) - 1).abs().max().item() < 1e-12
+    assert torch.allclose(S, orc.proper_singular_values(A), atol=1e-12) and S[1, 2].item() < 0
+    u, s, v = F.proper_svd(A[2])
+    uo, so, vo = orc.proper_svd(A[2])
+    assert torch.allclose(s, so, atol=1e-12) and torch.allclose(u @ torch.diag(s) @ v.T, A[2], atol=1e-12)
+    for t in (0, 1):
+        assert torch.allclose(F.matrix_fisher_norm_N(A.abs(), t), orc.fisher_norm(orc.proper_singular_values(A.abs()), t), rtol=1e-12)
+    with pytest.raises(NotImplementedError):
+        F.matrix_fisher_norm_N(A, 3)
+    q = torch.randn(7, 4, dtype=torch.float64)
+    assert torch.allclose(F.quat_to_rotmat(q), orc.quaternion_to_matrix(q / q.norm(dim=1, keepdim=True)), atol=1e-12)

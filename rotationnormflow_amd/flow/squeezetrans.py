@@ -344,3 +344,67 @@ class Condition9TransLU(_SideLayer):
     def _rnf_side(self, feature, grad=False):
         with torch.set_grad_enabled(grad):
             return (self.net(feature).reshape(-1, 3, 3) + torch.eye(3, device=feature.device)).reshape(-1, 9)
+
+
+# ---- the reference's module-level functions under their own names (flow/squeezetrans.py:10-38,200-231) ---------------------------------
+# The layer classes above never call these (their maps run inside the fused kernels); they exist for code that calls the functions
+# directly.  calculate_16 / calculate_9 take a matrix per rotation -- or one matrix for all -- and run on the stack kernel's side-matrix
+# path (the one the conditional LU layers use), differentiable w.r.t. the rotations and the matrices like every other layer.
+
+class _ExplicitMatrix(_SideLayer):
+    """A side layer whose per-rotation matrices are handed in by the caller (as the `feature` argument of the single-layer launch)."""
+    _rnf_no_graph = False
+
+    def __init__(self, kind, size):
+        super().__init__()
+        self._rnf_kind = kind
+        self.feature_dim = size
+        self._cache = runtime.PackCache()
+
+    def _rnf_side(self, feature, grad=False):
+        return feature
+
+
+_explicit_layers = {}
+
+
+def _calculate(kind, size, mat, rotation):
+    if not rotation.is_cuda:
+        raise RuntimeError("rotationnormflow_amd runs on the GPU only (HIP kernels, no CPU fallback): got a CPU tensor")
+    rotation = rotation.reshape(-1, 3, 3)
+    mats = mat.reshape(-1, size).to(device=rotation.device, dtype=torch.float32)
+    if mats.shape[0] == 1:
+        mats = mats.expand(rotation.shape[0], size)
+    if mats.shape[0] != rotation.shape[0]:
+        raise ValueError(f"{mats.shape[0]} matrices for {rotation.shape[0]} rotations")
+    layer = _explicit_layers.get(kind)
+    if layer is None:
+        layer = _explicit_layers[kind] = _ExplicitMatrix(kind, size)
+    return layer._single(rotation, None, mats.contiguous(), inverse=False)
+
+
+def calculate_16(mat, rotation):
+    """flow/squeezetrans.py:33-38: q' = M q / |M q| on the rotation's quaternion, log-det = log|det M| - 4 log|M q|.  mat [N,4,4] (or one
+    [4,4] / [1,4,4] for all) -> (rotation' [N,3,3], ldj [N])."""
+    return _calculate(runtime.KIND_SIDE16, 16, mat, rotation)
+
+
+def calculate_9(mat, rotation):
+    """flow/squeezetrans.py:200-231: Gram-Schmidt of the first two columns of M R with the closed-form tangent log-det.  mat [N,9] /
+    [N,3,3] (or one for all) -> (rotation', ldj)."""
+    return _calculate(runtime.KIND_SIDE9, 9, mat, rotation)
+
+
+def my_det_3_3(A):
+    """flow/squeezetrans.py:10-14 (cofactor expansion; any leading dimensions)."""
+    return (A[..., 0, 0] * (A[..., 1, 1] * A[..., 2, 2] - A[..., 1, 2] * A[..., 2, 1])
+            + A[..., 0, 1] * (A[..., 1, 2] * A[..., 2, 0] - A[..., 1, 0] * A[..., 2, 2])
+            + A[..., 0, 2] * (A[..., 1, 0] * A[..., 2, 1] - A[..., 1, 1] * A[..., 2, 0]))
+
+
+def my_det_4_4(A):
+    """flow/squeezetrans.py:17-22: expansion along the first row."""
+    rows = A[..., 1:, :]
+    minor = lambda cols: my_det_3_3(rows[..., cols])
+    return (A[..., 0, 0] * minor([1, 2, 3]) - A[..., 0, 1] * minor([0, 2, 3])
+            + A[..., 0, 2] * minor([0, 1, 3]) - A[..., 0, 3] * minor([0, 1, 2]))

@@ -307,3 +307,33 @@ def test_shared_feature_rows_inverse_with_more_than_64_segments():
     cell = np.pi / 2 ** 14
     assert (xa.cpu().double() - wR).abs().reshape(B * Q, -1).max(1).values.median().item() < cell
     assert (la.cpu().double() - wl).abs().median().item() < 2e-4
+
+
+def test_reference_named_functions_calculate_16_and_9():
+    """flow/squeezetrans.py's module-level calculate_16 / calculate_9 under their own names: a matrix per rotation (and one for all) through
+    the stack kernel's side-matrix path, against the oracle's affine16 / gs9 (pinned to the reference), values and gradients."""
+    from rotationnormflow_amd.flow import squeezetrans as st
+    n = 1000
+    R = torch.from_numpy(synth.uniform_rotations(n, seed=5))
+    g = torch.Generator().manual_seed(9)
+    M16 = torch.eye(4) + 0.3 * torch.randn(n, 4, 4, generator=g)
+    M9 = torch.eye(3) + 0.3 * torch.randn(n, 3, 3, generator=g)
+    for fn, ofn, M in ((st.calculate_16, orc.affine16, M16), (st.calculate_9, orc.gs9, M9)):
+        Rt, ldj = fn(M.cuda(), R.cuda())
+        want_R, want_l = ofn(M.double(), R.double())
+        assert (Rt.cpu().double() - want_R).abs().max().item() < 2e-5
+        assert (ldj.cpu().double() - want_l).abs().max().item() < 2e-5
+        Rt1, ldj1 = fn(M[:1].cuda(), R.cuda())                      # one matrix for every rotation
+        w1R, w1l = ofn(M[:1].double().expand(n, *M.shape[1:]), R.double())
+        assert (Rt1.cpu().double() - w1R).abs().max().item() < 2e-5 and (ldj1.cpu().double() - w1l).abs().max().item() < 2e-5
+        Mg = M[:64].cuda().requires_grad_(True)                     # differentiable w.r.t. the matrices, like the layers built on it
+        Rt2, ldj2 = fn(Mg, R[:64].cuda())
+        (ldj2.sum() + (Rt2 * Rt2.detach().roll(1, 0)).sum()).backward()
+        Mo = M[:64].double().requires_grad_(True)
+        oR, ol = ofn(Mo, R[:64].double())
+        (ol.sum() + (oR * oR.detach().roll(1, 0)).sum()).backward()
+        assert (Mg.grad.cpu().double() - Mo.grad).abs().max().item() < 2e-4 * max(1.0, Mo.grad.abs().max().item())
+    assert torch.allclose(st.my_det_4_4(M16.cuda()), torch.linalg.det(M16.cuda()), atol=1e-5)
+    assert torch.allclose(st.my_det_3_3(M9.cuda()), torch.linalg.det(M9.cuda()), atol=1e-5)
+    with pytest.raises(ValueError):
+        st.calculate_16(M16[:7].cuda(), R.cuda())

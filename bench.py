@@ -505,6 +505,35 @@ def run_pmc_passes(configs, batch_log2, keep_dir=None):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------------
+def device_state(w, seconds=1.2):
+    """Socket power, shader clock and junction temperature (rocm-smi) under this workload: it is launched back to back for `seconds`, OUTSIDE
+    every timed region, and rocm-smi is read once near the end.  The split-precision kernels run at the board's power limit, so the clock
+    the chip grants differs between boxes and with it every time in the line (profiles/README.md "Power and clock"); None when rocm-smi
+    is not there."""
+    import re
+    import subprocess
+    import torch
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    try:
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            proc = None
+            while time.perf_counter() - t0 < seconds:
+                for _ in range(10):
+                    w.evaluate()
+                torch.cuda.synchronize()
+                if proc is None and time.perf_counter() - t0 > 0.6 * seconds:      # launches keep going while rocm-smi reads the sensors
+                    proc = subprocess.Popen([exe, "--showpower", "--showclocks", "--showtemp"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+            text = proc.communicate(timeout=20)[0] if proc else ""
+        f = lambda pat: (lambda m: float(m.group(1)) if m else None)(re.search(pat, text))
+        return {"workload": w.name, "socket_power_w": f(r"Power \(W\): ([0-9.]+)"), "sclk_mhz": f(r"sclk clock level: \d+: \((\d+)Mhz\)"),
+                "junction_c": f(r"Sensor junction\) \(C\): ([0-9.]+)"), "how": f"rocm-smi read {0.6 * seconds:.1f} s into {seconds:.1f} s of back-to-back launches, outside the timed region"}
+    except Exception as exc:                                     # a diagnostic must never cost the bench line
+        return {"workload": w.name, "error": repr(exc)}
+
+
 def measure(w, args, dist, pmc, steps, warmup, want_secondary, want_parity, cpu_sizes, cpu_budget, blocks=1):
     """One workload -> its record (rank 0 fills the host-side legs).  blocks: the K timed steps are measured this many times and the
     fastest block is kept.  The headline leg (`value`) is ALWAYS one block, as the bench contract says; the `configs` entries and the
@@ -696,6 +725,7 @@ def main():
         calibrate_feature_scale(w.fl, w.feat)                 # one calibration for all ranks: identical packed images (dist.py)
     head = measure(w, args, dist, pmc, args.steps, args.warmup, not args.no_secondary, host_legs,
                    (4096, 65536) if host_legs else None, 36.0)
+    state = device_state(w) if (rank == 0 and world == 1) else None
     configs = {}
     prev = w
     for name in others:
@@ -728,6 +758,8 @@ def main():
         for k in ("value_fp32_exact", "ms_per_step_fp32_exact", "roofline", "hbm", "secondary", "parity", "cpu_baseline", "vs_cpu_baseline"):
             if k in head:
                 out[k] = head[k]
+        if state is not None:
+            out["device_state"] = state
         if configs:
             out["configs"] = configs
         if pmc is not None:

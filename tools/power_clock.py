@@ -30,8 +30,12 @@ def main():
     ap.add_argument("configs", nargs="*", default=["C2", "C4", "C5", "C5u"])
     ap.add_argument("--seconds", type=float, default=6.0)
     ap.add_argument("--precision", default=None)
+    ap.add_argument("--lib", default=None, help="path of a variant librnf_hip.so (tools/ab_variants.py --build), e.g. a knock-out build")
     args = ap.parse_args()
     import torch
+    if args.lib:
+        from rotationnormflow_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     import bench
     from rotationnormflow_amd import set_precision
     if args.precision:
@@ -65,7 +69,7 @@ def main():
             th.join()
         kept = [s for s in samples if s["t"] >= 1.0 and s["power_w"] is not None]
         mean = lambda k: round(sum(s[k] for s in kept) / max(len(kept), 1), 1)
-        print(json.dumps({"config": name, "precision": args.precision or "f16x2", "ms_per_step": round(elapsed / steps * 1e3, 3), "samples": len(kept),
+        print(json.dumps({"config": name, "lib": os.path.basename(args.lib) if args.lib else "shipped", "precision": args.precision or "f16x2", "ms_per_step": round(elapsed / steps * 1e3, 3), "samples": len(kept),
                           "power_w_mean": mean("power_w"), "power_w_max": max((s["power_w"] for s in kept), default=None),
                           "sclk_mhz_mean": mean("sclk_mhz"), "sclk_mhz_min": min((s["sclk_mhz"] for s in kept), default=None),
                           "junction_c_max": max((s["junction_c"] for s in kept), default=None)}), flush=True)

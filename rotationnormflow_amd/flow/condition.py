@@ -19,11 +19,14 @@ class ConditionalTransform(nn.Module):
         if Nh != 64:
             raise NotImplementedError("the HIP kernels are built for the reference's hidden width Nh=64")
         self.Ni, self.No = Ni, No
+        # Registration ORDER is part of the checkpoint contract: the reference assigns fc_first, relu_last, fc_last and only then the
+        # ModuleList (flow/condition.py:13-22), so ``parameters()`` yields fc_first, fc_last, layers.1/3/5 -- the numbering of the Adam state
+        # every checkpoint carries (agent.py:23,143,193-196; pinned by tests/golden/param_order.json).
         self.fc_first = nn.Linear(Ni, Nh)
-        # same module indices as the reference (ReLU at 0/2/4, Linear at 1/3/5) => same state-dict keys
-        self.layers = nn.ModuleList([nn.ReLU(), nn.Linear(Nh, Nh), nn.ReLU(), nn.Linear(Nh, Nh), nn.ReLU(), nn.Linear(Nh, Nh)])
         self.relu_last = nn.ReLU()
         self.fc_last = nn.Linear(Nh, No)
+        # same module indices as the reference (ReLU at 0/2/4, Linear at 1/3/5) => same state-dict keys
+        self.layers = nn.ModuleList([nn.ReLU(), nn.Linear(Nh, Nh), nn.ReLU(), nn.Linear(Nh, Nh), nn.ReLU(), nn.Linear(Nh, Nh)])
 
     def forward(self, x):
         """Standalone evaluation on the GPU; supported for the unconditional Moebius conditioner shape (Ni=3, No=4K)."""

@@ -70,8 +70,9 @@ class Flow(nn.Module):
         reference's ``optim.Adam(flow.parameters(), lr)`` (agent.py:23) steps ONE tensor (its per-tensor host bookkeeping over 264 tensors
         was 10 ms per iteration with the default Adam, the whole iteration is 0.8 ms) -- autograd sees one leaf instead of 264, the training
         kernels read the parameter storage in place (no ``cat``) and ``loss.backward()`` leaves one gradient blob in ``_flat.grad``
-        (``named_parameter_gradients()`` gives per-key views).  Optimizer STATE therefore has one entry; ``harness.expand_optimizer_state`` /
-        ``flatten_optimizer_state`` convert to and from the reference's per-tensor layout.
+        (``named_parameter_gradients()`` gives per-key views).  Optimizer STATE has one entry in memory; ``optimizer.state_dict()`` /
+        ``load_state_dict()`` of any optimizer built over the flat parameter speak the reference's per-tensor layout (264 entries:
+        agent.py:143,193-196 work unedited, in both directions) through the hooks of rotationnormflow_amd/flatopt.py.
         Returns False (and changes nothing) when a layer's training tensors are not its raw parameters (LU / SVD parameterisations, side
         layers), when the flow is already flat, or when it has no parameters."""
         if self.is_flat:
@@ -95,16 +96,33 @@ class Flow(nn.Module):
             return False                                           # partly frozen flow (or parameters on several devices): stays per-tensor
         with torch.no_grad():
             flat = nn.Parameter(torch.cat([t.detach().reshape(-1) for t in tensors]), requires_grad=bool(tensors[0].requires_grad))
-        self._flat_slots, off = [], 0
+        # the blob is laid out in the kernels' order; ``parameters()`` order (= the numbering of a per-tensor optimizer's state, which
+        # checkpoints carry: agent.py:143,193-196) is kept beside it
+        rank = {id(prm): i for i, prm in enumerate(self.parameters())}
+        self._flat_slots, self._flat_rank, off = [], [], 0
         for (mod, name), t in zip(slots, tensors):
-            del mod._parameters[name]
-            mod.register_buffer(name, None)
+            self._flat_rank.append(rank[id(t)])
             self._flat_slots.append((mod, name, off, tuple(t.shape)))
             off += t.numel()
+        for r in sorted(range(len(slots)), key=lambda i: self._flat_rank[i]):      # buffers re-registered in parameters() order: state_dict() order
+            mod, name = slots[r]
+            del mod._parameters[name]
+            mod.register_buffer(name, None)
         self.register_parameter("_flat", flat)
         self._realias()
         self.invalidate()
+        # checkpoints keep the reference's per-tensor optimizer state (agent.py:143,193-196): rotationnormflow_amd/flatopt.py
+        from .. import flatopt
+        flatopt.install()
         return True
+
+    def _flat_layout(self):
+        """[(state-dict key, offset, shape)] of the slices of ``_flat``, in the reference's ``parameters()`` order."""
+        names = {id(mod): name for name, mod in self.named_modules()}
+        rank = getattr(self, "_flat_rank", None) or list(range(len(self._flat_slots)))
+        order = sorted(range(len(self._flat_slots)), key=lambda i: rank[i])
+        return [((names[id(mod)] + "." if names[id(mod)] else "") + name, off, shape)
+                for mod, name, off, shape in (self._flat_slots[i] for i in order)]
 
     @property
     def is_flat(self) -> bool:
@@ -115,12 +133,15 @@ class Flow(nn.Module):
         version counter as the parameter (an in-place write through either side is seen by the pack cache and by autograd's saved-tensor
         check), but no autograd view relation to the leaf (views of a leaf made under no_grad may not be touched again once the leaf has
         been written in place)."""
-        base = self._parameters["_flat"].detach()
+        from .. import flatopt
+        flat = self._parameters["_flat"]
+        base = flat.detach()
         for mod, name, off, shape in self._flat_slots:
             n = 1
             for d in shape:
                 n *= d
             mod._buffers[name] = base[off:off + n].view(shape)
+        flatopt.tag(flat, self._flat_layout())                     # (a deepcopy / unpickled Parameter is a new object: tagged again here)
 
     def _ensure_alias(self):
         """The per-layer views must alias ``_flat``; copy.deepcopy / pickling a module clones every tensor on its own, after which the copy's
@@ -131,7 +152,7 @@ class Flow(nn.Module):
             mod, name, off, _ = self._flat_slots[-1]
             flat = self._parameters["_flat"]
             buf = mod._buffers.get(name)
-            if buf is None or buf.device != flat.device or buf.data_ptr() != flat.data_ptr() + 4 * off:
+            if buf is None or buf.device != flat.device or buf.data_ptr() != flat.data_ptr() + 4 * off or not hasattr(flat, "_rnf_flat_layout"):
                 self._realias()
                 self.invalidate()
 
@@ -154,6 +175,9 @@ class Flow(nn.Module):
     def __setstate__(self, state):
         self.__dict__.update(state)
         self._ensure_alias()
+        if self.is_flat:
+            from .. import flatopt
+            flatopt.install()
 
     def _apply(self, fn, recurse=True):
         flat = self.is_flat and not getattr(self, "_is_replica", False)

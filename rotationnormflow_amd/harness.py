@@ -59,56 +59,31 @@ def mean_log_likelihood(flow: Flow, rotations: torch.Tensor, base=None, batch_si
     return float(total[0] / total[1])
 
 
-def _flat_layout(flow: Flow):
-    """[(offset, shape)] of the per-tensor slices of a flattened flow's single parameter, in the reference's ``parameters()`` order."""
-    return [(off, shape) for _, _, off, shape in flow._flat_slots]
-
-
 def expand_optimizer_state(flow: Flow, state: dict) -> dict:
-    """Optimizer ``state_dict()`` of a FLATTENED flow (one parameter, Flow.flatten_parameters) -> the layout the reference's
-    ``optim.Adam(flow.parameters())`` has (one entry per parameter tensor, agent.py:23,143): every per-element state tensor (``exp_avg``,
-    ``exp_avg_sq`` ...) is sliced, per-parameter scalars (``step``) are repeated.  ``Agent.load_ckpt`` (agent.py:193-196) reads the result."""
+    """Optimizer state of a FLATTENED flow in its in-memory form (one entry) -> the layout the reference's ``optim.Adam(flow.parameters())``
+    has (one entry per parameter tensor, agent.py:23,143).  ``optimizer.state_dict()`` of an optimizer built over a flattened flow already
+    returns that layout (rotationnormflow_amd/flatopt.py hooks it); such a state is returned unchanged."""
     if not flow.is_flat:
         return state
-    layout = _flat_layout(flow)
-    if len(state["param_groups"]) != 1 or state["param_groups"][0]["params"] != [0]:
-        raise ValueError("expected the state of an optimizer over the flow's single flat parameter")
-    total = flow._parameters["_flat"].numel()
-    flat_state = state["state"].get(0, {})
-    out_state = {}
-    for i, (off, shape) in enumerate(layout):
-        n = int(np.prod(shape)) if shape else 1
-        if flat_state:
-            out_state[i] = {k: (v.reshape(-1)[off:off + n].reshape(shape).clone() if (torch.is_tensor(v) and v.numel() == total) else
-                                (v.clone() if torch.is_tensor(v) else v)) for k, v in flat_state.items()}
-    group = dict(state["param_groups"][0], params=list(range(len(layout))))
-    return {"state": out_state, "param_groups": [group]}
+    from . import flatopt
+    return flatopt.expand_state([{"params": [flow._parameters["_flat"]]}], state)
 
 
 def flatten_optimizer_state(flow: Flow, state: dict) -> dict:
     """The inverse: an optimizer state in the reference's per-tensor layout (a checkpoint ``Agent.save_ckpt`` wrote) -> the one-entry
-    state of an optimizer over the flattened flow's parameter."""
+    state of an optimizer over the flattened flow's parameter (what ``optimizer.load_state_dict`` does by itself through flatopt)."""
     if not flow.is_flat:
         return state
-    layout = _flat_layout(flow)
-    ids = state["param_groups"][0]["params"]
-    if len(state["param_groups"]) != 1 or len(ids) != len(layout):
-        raise ValueError(f"optimizer state covers {len(ids)} parameters, the flow has {len(layout)} tensors")
-    out = {}
-    if state["state"]:
-        first = state["state"][ids[0]]
-        for k, v in first.items():
-            if torch.is_tensor(v) and tuple(v.shape) == tuple(layout[0][1]):
-                out[k] = torch.cat([state["state"][i][k].reshape(-1) for i in ids])
-            else:
-                out[k] = v.clone() if torch.is_tensor(v) else v          # step: equal for all parameters of one group
-    group = dict(state["param_groups"][0], params=[0])
-    return {"state": {0: out} if out else {}, "param_groups": [group]}
+    from . import flatopt
+    n = len(flow._flat_slots)
+    if len(state["param_groups"]) != 1 or len(state["param_groups"][0]["params"]) not in (1, n):
+        raise ValueError(f"optimizer state covers {[len(g['params']) for g in state['param_groups']]} parameters, the flow has {n} tensors")
+    return flatopt.flatten_state([{"params": [flow._parameters["_flat"]]}], state)
 
 
 def save_reference_checkpoint(path, flow: Flow, optimizer, epoch: int, minibatch: int, iteration: int):
     """The dictionary ``Agent.save_ckpt`` writes for an unconditional flow (agent.py:132-151; clock: utils/utils.py:36-45).  The optimizer
-    state of a flattened flow is written in the reference's per-tensor layout (``expand_optimizer_state``)."""
+    state of a flattened flow is written in the reference's per-tensor layout (``optimizer.state_dict()`` returns it: flatopt)."""
     torch.save({
         "clock": {"epoch": epoch, "minibatch": minibatch, "iteration": iteration},
         "flow_state_dict": {k: v.detach().cpu() for k, v in flow.state_dict().items()},

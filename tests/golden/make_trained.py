@@ -16,6 +16,9 @@ Outputs (data only; nothing of the reference travels):
   trained_cond4.pth / .npz   the same for a 4-layer conditional flow (SYMSOL structure, F = 32) trained on a feature-dependent target
   traj_c1.npz         20 Adam steps from the synth "default" weights on fixed batches: per-step loss and the parameter update of every tensor,
                       from an fp32 and an fp64 run of the reference
+  traj_c1_step10.pth  the fp32 run of traj_c1 stopped after 10 steps and written EXACTLY as Agent.save_ckpt writes it (agent.py:139-152):
+                      {"clock", "flow_state_dict", "optimizer_flow_state_dict"} with the reference's per-tensor Adam state (one entry per
+                      parameter tensor) -- what Agent.load_ckpt (agent.py:171-198) reads back; the resume tests continue from it to step 20
 """
 import contextlib
 import io
@@ -189,6 +192,33 @@ def run_traj(name, spec):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+def run_resume(name, spec, stop=10):
+    """The fp32 trajectory of ``run_traj`` up to step ``stop``, saved with the statements of Agent.save_ckpt (agent.py:139-152)."""
+    cfg = make_config(**spec["cfg"])
+    R = fisher_samples(synth.uniform_rotations(8, seed=spec["mode_seed"]).astype(np.float64)[: spec["n_modes"]], spec["kappa"],
+                       spec["steps"] * spec["batch"], spec["data_seed"])
+    fl = ref_flow(cfg, torch.float32).train()
+    shapes = {k: tuple(v.shape) for k, v in fl.state_dict().items()}
+    w0 = synth.fill_state_dict(shapes, seed=spec["wseed"], regime=spec["regime"])
+    fl.load_state_dict({k: torch.from_numpy(v) for k, v in w0.items()})
+    opt = torch.optim.Adam(fl.parameters(), spec["lr"])                      # agent.py:23
+    for it in range(stop):
+        _, ldjs = fl(torch.from_numpy(R[it * spec["batch"]: (it + 1) * spec["batch"]]), None)
+        loss = (-ldjs).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    save_dict = {                                                            # agent.py:139-145 (clock: utils/utils.py:36-45)
+        "clock": {"epoch": 0, "minibatch": stop, "iteration": stop},
+        "flow_state_dict": fl.cpu().state_dict(),
+        "optimizer_flow_state_dict": opt.state_dict(),
+    }
+    path = os.path.join(HERE, f"{name}_step{stop}.pth")
+    torch.save(save_dict, path)
+    n = len(save_dict["optimizer_flow_state_dict"]["state"])
+    print(f"{name}: reference checkpoint after {stop} steps, {n} optimizer entries, last loss {float(loss):.5f} -> {path}")
+
+
 def main():
     want = sys.argv[1:]
     for name, spec in TRAINED.items():
@@ -197,6 +227,8 @@ def main():
     for name, spec in TRAJ.items():
         if not want or name in want:
             run_traj(name, spec)
+        if not want or name + "_resume" in want:
+            run_resume(name, spec)
 
 
 if __name__ == "__main__":

@@ -150,3 +150,53 @@ def test_trained_checkpoint_at_full_batch_runs_on_the_fast_path(name):
         Rt, ldj = flow(R[:m], None if feat is None else feat[:m])
         Rb, ldjb = flow.inverse(Rt, None if feat is None else feat[:m])
     assert (Rb - R[:m]).abs().mean().item() < 1e-3 and (ldj + ldjb).abs().mean().item() < 5e-3
+
+
+@pytest.mark.parametrize("flat", [True, False])
+def test_agent_checkpoint_path_resumes_the_reference_trajectory(tmp_path, flat, monkeypatch):
+    """The reference's checkpoint path on the GPU, statement by statement (tests/agent_replay.py: Agent.__init__ agent.py:20-28, load_ckpt
+    agent.py:171-198 incl. the unconditional Adam ``load_state_dict``, train_func agent.py:75-92, save_ckpt agent.py:132-152 incl.
+    ``.module.cpu().state_dict()`` -> ``.cuda()``): the checkpoint the REFERENCE wrote after step 10 of traj_c1 (its own Flow + Adam, per-tensor
+    optimizer state) is loaded by the default drop-in (``get_flow``: flattened parameters), trained for 5 steps, saved, loaded by a fresh agent,
+    trained for 5 more -- and lands on the reference's own step-20 weights and losses within the trajectory gate of the test above."""
+    import contextlib
+    import io
+    import os
+    from oracle import flow_oracle as orc
+    from rotationnormflow_amd.flow.flow import get_flow
+    from tests.agent_replay import ReplayedAgent
+    from tests.trained_helpers import GOLDEN
+    monkeypatch.setenv("RNF_FLAT_PARAMS", "1" if flat else "0")
+    cfg, fx, spec = load_traj("traj_c1")
+
+    def quiet_get_flow(c):
+        with contextlib.redirect_stdout(io.StringIO()):
+            return get_flow(c)
+    w0 = synth.fill_state_dict(orc.state_shapes(cfg), seed=spec["wseed"], regime=spec["regime"])
+    B = spec["batch"]
+    R = torch.from_numpy(fx["rot"])
+    agent = ReplayedAgent(cfg, quiet_get_flow, "cuda", lr=spec["lr"])
+    assert agent.flow.module.is_flat == flat
+    agent.load_ckpt(os.path.join(GOLDEN, "traj_c1_step10.pth"))
+    assert agent.clock["iteration"] == 10
+    losses = [agent.train_func(R[it * B:(it + 1) * B]) for it in range(10, 15)]
+    agent.save_ckpt(tmp_path / "mid.pth")                                                  # .cpu() ... .cuda() around the state_dict
+    mid = torch.load(tmp_path / "mid.pth", map_location="cpu", weights_only=False)
+    assert len(mid["optimizer_flow_state_dict"]["state"]) == len(w0) and float(mid["optimizer_flow_state_dict"]["state"][0]["step"]) == 15.0
+    assert next(agent.flow.parameters()).is_cuda
+    agent = ReplayedAgent(cfg, quiet_get_flow, "cuda", lr=spec["lr"])                      # a new process would start here
+    agent.load_ckpt(tmp_path / "mid.pth")
+    assert agent.clock["iteration"] == 15
+    losses += [agent.train_func(R[it * B:(it + 1) * B]) for it in range(15, 20)]
+    losses = np.array(losses)
+    ref_noise = np.abs(fx["loss32"] - fx["loss64"])
+    assert np.abs(losses - fx["loss64"][10:]).max() <= 4 * ref_noise.max() + 2e-6, (losses - fx["loss64"][10:])
+    sd = {k: v.detach().cpu().double().numpy() for k, v in agent.flow.module.state_dict().items()}
+    worst = 0.0
+    for k, v in sd.items():
+        want = fx["dw64:" + k].astype(np.float64)
+        err = np.linalg.norm((v - w0[k].astype(np.float64)) - want)
+        tol = 4.0 * float(fx["ref32_err:" + k]) + 2e-3 * np.linalg.norm(want) + 1e-7
+        worst = max(worst, err / tol)
+        assert err <= tol, (k, err, float(fx["ref32_err:" + k]), np.linalg.norm(want))
+    print(f"resume flat={flat}: loss err max {np.abs(losses - fx['loss64'][10:]).max():.2e}; worst update err / tol {worst:.2f}")

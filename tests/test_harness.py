@@ -89,7 +89,9 @@ def test_flattened_flow_keeps_the_reference_contract(tmp_path):
     assert not res.missing_keys and not res.unexpected_keys
     v0 = flat._flat._version
     assert all(torch.equal(flat.state_dict()[k], sd[k]) for k in sd)
-    assert torch.equal(flat._flat.detach(), torch.cat([sd[k].reshape(-1) for k in classic.state_dict()]))     # reference tensor order
+    # the blob is in the kernels' order (fc_first, layers.1/3/5, fc_last per conditioner); every key sits at its slot
+    assert all(torch.equal(flat._flat.detach()[off:off + sd[k].numel()], sd[k].reshape(-1)) for k, off, _ in flat._flat_layout())
+    assert sum(sd[k].numel() for k, _, _ in flat._flat_layout()) == flat._flat.numel()
     # an optimizer step on the flat parameter is seen through the per-layer views (and bumps the version the pack cache keys on)
     with torch.no_grad():
         flat._flat.add_(1.0)
@@ -104,18 +106,25 @@ def test_flattened_flow_keeps_the_reference_contract(tmp_path):
         assert not get_flow(make_config(None, layers=2, lu=1)).is_flat
         assert not get_flow(make_config(None, layers=2, rot="16Rot")).is_flat
         assert get_flow(make_config("C4")).is_flat and get_flow(make_config("C5")).is_flat
-    # optimizer state: one entry <-> the reference's per-tensor layout
+    # optimizer state: one entry in memory; state_dict() / load_state_dict() speak the reference's per-tensor layout (flatopt hooks; the
+    # statement-by-statement replay of Agent.save_ckpt / load_ckpt is tests/test_agent_ckpt.py)
     opt = torch.optim.Adam(flat.parameters(), 1e-3)
     flat._flat.grad = torch.randn_like(flat._flat)
     opt.step()
-    ref_layout = harness.expand_optimizer_state(flat, opt.state_dict())
+    ref_layout = opt.state_dict()
+    assert harness.expand_optimizer_state(flat, ref_layout) is ref_layout                  # already per tensor: unchanged
     assert ref_layout["param_groups"][0]["params"] == list(range(264)) and len(ref_layout["state"]) == 264
-    assert ref_layout["state"][1]["exp_avg"].shape == (64,) and float(ref_layout["state"][5]["step"]) == 1.0
+    # numbering = the reference's parameters() order: fc_first.weight, fc_first.bias, fc_last.weight, fc_last.bias, layers.1.weight ...
+    assert ref_layout["state"][1]["exp_avg"].shape == (64,) and ref_layout["state"][2]["exp_avg"].shape == (256, 64)
+    assert float(ref_layout["state"][5]["step"]) == 1.0
     opt_ref = torch.optim.Adam(classic.parameters(), 1e-3)
     opt_ref.load_state_dict(ref_layout)                                   # what Agent.load_ckpt does with it (agent.py:193-196)
+    for prm, (key, off, shape) in zip(classic.parameters(), flat._flat_layout()):
+        assert tuple(prm.shape) == shape
+        assert torch.equal(opt_ref.state[prm]["exp_avg"].reshape(-1), opt.state[flat._flat]["exp_avg"][off:off + prm.numel()]), key
     back = harness.flatten_optimizer_state(flat, opt_ref.state_dict())
-    assert torch.equal(back["state"][0]["exp_avg"], opt.state_dict()["state"][0]["exp_avg"])
-    assert torch.equal(back["state"][0]["exp_avg_sq"], opt.state_dict()["state"][0]["exp_avg_sq"])
+    assert torch.equal(back["state"][0]["exp_avg"], opt.state[flat._flat]["exp_avg"])
+    assert torch.equal(back["state"][0]["exp_avg_sq"], opt.state[flat._flat]["exp_avg_sq"])
     harness.save_reference_checkpoint(tmp_path / "c.pth", flat, opt, 0, 0, 1)
     ck = torch.load(tmp_path / "c.pth", weights_only=False)
     assert len(ck["optimizer_flow_state_dict"]["state"]) == 264 and sorted(ck["flow_state_dict"]) == sorted(w)

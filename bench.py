@@ -505,6 +505,13 @@ def run_pmc_passes(configs, batch_log2, keep_dir=None):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------------
+def profiler_attached():
+    """True when this process runs under rocprofv3 / rocprof (tool library preloaded)."""
+    env = os.environ
+    return bool(env.get("ROCP_TOOL_LIBRARIES") or env.get("ROCPROFILER_LIBRARY_PATH") or env.get("HSA_TOOLS_LIB")
+                or "rocprof" in env.get("LD_PRELOAD", "") or "rocprofiler" in env.get("LD_PRELOAD", ""))
+
+
 def device_state(w, seconds=1.2):
     """Socket power, shader clock and junction temperature (rocm-smi) under this workload: it is launched back to back for `seconds`, OUTSIDE
     every timed region, and rocm-smi is read once near the end.  The split-precision kernels run at the board's power limit, so the clock
@@ -513,9 +520,15 @@ def device_state(w, seconds=1.2):
     import re
     import subprocess
     import torch
-    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if profiler_attached():
+        # rocm-smi is a `#!/usr/bin/env python3` script: started from a process a profiler preloaded into, the child would carry the tool
+        # library through an exec hop (forbidden on this pool once the GPU is initialised) and its 1.2 s of launches would sit in the trace
+        return None
+    exe = os.path.realpath(shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi")
     if not os.path.exists(exe):
         return None
+    # a fresh interpreter on the script itself (no /usr/bin/env hop), with nothing of a profiler / preload in its environment
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTX"))}
     try:
         with torch.no_grad():
             t0 = time.perf_counter()
@@ -525,7 +538,8 @@ def device_state(w, seconds=1.2):
                     w.evaluate()
                 torch.cuda.synchronize()
                 if proc is None and time.perf_counter() - t0 > 0.6 * seconds:      # launches keep going while rocm-smi reads the sensors
-                    proc = subprocess.Popen([exe, "--showpower", "--showclocks", "--showtemp"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                    proc = subprocess.Popen([sys.executable, exe, "--showpower", "--showclocks", "--showtemp"], stdout=subprocess.PIPE,
+                                            stderr=subprocess.DEVNULL, text=True, env=env)
             text = proc.communicate(timeout=20)[0] if proc else ""
         f = lambda pat: (lambda m: float(m.group(1)) if m else None)(re.search(pat, text))
         return {"workload": w.name, "socket_power_w": f(r"Power \(W\): ([0-9.]+)"), "sclk_mhz": f(r"sclk clock level: \d+: \((\d+)Mhz\)"),
@@ -577,7 +591,20 @@ def measure(w, args, dist, pmc, steps, warmup, want_secondary, want_parity, cpu_
         rec["secondary"] = secondary
     elif used == "fp32":
         rec["value_fp32_exact"], rec["ms_per_step_fp32_exact"] = rec["value"], rec["ms_per_step"]
-    if rank0 and world == 1 and want_parity:
+    if rank0 and world == 1:
+        host_legs(w, rec, want_parity, cpu_sizes, cpu_budget)
+    return rec
+
+
+def host_legs(w, rec, want_parity, cpu_sizes, cpu_budget):
+    """The host-side legs of a record, outside every timed region: parity of this run's rows against the fp64 oracle, and the CPU baseline
+    (the oracle timed on this box's host cores).  At N = 1 they run right after the workload; at N > 1 rank 0 runs them after the process
+    group is gone (nobody waits in a collective while one rank computes on the host)."""
+    import torch
+    from rotationnormflow_amd import get_precision, set_precision
+    primary = get_precision()
+    secondary = rec.get("secondary")
+    if want_parity:
         head, stats, product, want, oracle = w.parity(2048 if w.wl["direction"] == "forward" else 256)
         rec["parity"] = {**head, **stats(product(), want), "reference_fp32": stats(oracle(torch.float32), want)}
         if secondary:
@@ -586,10 +613,9 @@ def measure(w, args, dist, pmc, steps, warmup, want_secondary, want_parity, cpu_
                 secondary["parity"] = {"samples": head["samples"], **stats(product(), want)}
             finally:
                 set_precision(primary)
-    if rank0 and world == 1 and cpu_sizes:
+    if cpu_sizes:
         rec["cpu_baseline"] = cpu_baseline(w.cfg, w.weights, w.A, w.wl, w.feat_dim, cpu_sizes, cpu_budget)
         rec["vs_cpu_baseline"] = rec["value"] / rec["cpu_baseline"]["value"]
-    return rec
 
 
 def measure_training(device, batch=1024, steps=40, warmup=10):
@@ -642,6 +668,98 @@ def measure_training(device, batch=1024, steps=40, warmup=10):
     return out
 
 
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _sig(x, digits=6):
+    """Round floats to `digits` significant digits (the compact line is read by people and by a parser with a size limit)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+COMPACT_LIMIT = 3000                      # bytes; the driver keeps ~8 KB of stdout tail and parses the LAST line (BENCH_r04: a 40 KB line was lost)
+ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms", "traffic", "traffic_algorithmic", "valu_issue_frac",
+             "matrix_pipe_frac")
+
+
+def compact_record(out, full_path=None):
+    """The driver-facing line: every contract key, the roofline / cpu_baseline objects in short form, one small entry per other config."""
+    c = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                    "dtype", "data"))
+    cfg = dict(out["config"])
+    cfg["workload"] = cfg["workload"][:140]
+    c["config"] = cfg
+    c.update(_pick(out, ("rccl_ranks", "backend", "value_fp32_exact", "ms_per_step_fp32_exact", "mean_nll")))
+    if "roofline" in out:
+        c["roofline"] = _pick(out["roofline"], ROOF_KEYS)
+    if "cpu_baseline" in out:
+        c["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "cpu"))
+        c["cpu_baseline"]["sample"] = out["cpu_baseline"].get("sample", "")[:100]
+        c["vs_cpu_baseline"] = out.get("vs_cpu_baseline")
+    if "parity" in out:
+        c["parity"] = _pick(out["parity"], ("mean_abs_err_of_the_mean", "max_abs_err"))
+        c["parity"]["reference_fp32_max"] = out["parity"].get("reference_fp32", {}).get("max_abs_err")
+    if "device_state" in out:
+        c["device_state"] = _pick(out["device_state"], ("socket_power_w", "sclk_mhz"))
+    small = {}
+    for name, r in out.get("configs", {}).items():
+        if name == "train":
+            small[name] = _pick(r, ("ms_per_iteration", "ms_per_iteration_hip_graph", "ms_per_iteration_per_tensor_parameters"))
+            continue
+        e = _pick(r, ("value", "ms_per_step", "value_fp32_exact"))
+        roof = r.get("roofline", {})
+        e.update(_pick(roof, ("frac", "valu_issue_frac", "matrix_pipe_frac")))
+        if roof.get("traffic") and roof.get("traffic_algorithmic"):
+            e["traffic_x"] = roof["traffic"] / roof["traffic_algorithmic"]
+        if "parity" in r:
+            e["parity_max"] = r["parity"].get("max_abs_err")
+        if "weights" in r:
+            e["weights"] = r["weights"]
+        small[name] = e
+    if small:
+        c["configs"] = small
+    if full_path:
+        c["full_record"] = full_path
+    c = _sig(c, 5)
+    if "mean_nll" in out:
+        c["mean_nll"] = out["mean_nll"]                    # the statistic itself: every digit
+    line = json.dumps(c, separators=(",", ":"))
+    if len(line) >= COMPACT_LIMIT and "configs" in c:      # never lose the headline to an over-long line: first thin the per-config entries
+        c["configs"] = {k: _pick(v, ("value", "ms_per_step", "frac", "ms_per_iteration")) for k, v in c["configs"].items()}
+        line = json.dumps(c, separators=(",", ":"))
+    if len(line) >= COMPACT_LIMIT:                         # ... then drop the optional parts, largest first
+        for k in ("configs", "parity", "device_state", "cpu_baseline"):
+            if k == "cpu_baseline":
+                c.get(k, {}).pop("sample", None)
+            else:
+                c.pop(k, None)
+            line = json.dumps(c, separators=(",", ":"))
+            if len(line) < COMPACT_LIMIT:
+                break
+    return line
+
+
+def emit(out, full_out):
+    """stdout: `BENCH_FULL {...}` (everything: per-kernel counter lists, both arithmetics, parity blocks, CPU runs) on an earlier line and in
+    `full_out` (default bench_full.json beside this script); then, as the LAST line, the compact record (< COMPACT_LIMIT bytes)."""
+    path = full_out or os.path.join(ROOT, "bench_full.json")
+    rel = None
+    try:
+        with open(path, "w") as fh:
+            json.dump(out, fh, indent=1)
+        rel = os.path.relpath(path, ROOT)
+    except OSError as exc:
+        print(f"bench.py: could not write {path}: {exc}", file=sys.stderr)
+    print("BENCH_FULL " + json.dumps(out), flush=True)
+    print(compact_record(out, rel), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -654,6 +772,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="headline workload only")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes")
     ap.add_argument("--save-pmc", default=None, metavar="DIR", help="also write the live PMC summary to DIR/pmc_live.json (profiles/<round>/)")
+    ap.add_argument("--full-out", default=None, metavar="PATH", help="where the full record goes (default: bench_full.json beside bench.py); "
+                    "stdout carries it on a `BENCH_FULL ` line and ends with the compact record")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-configs", default=",".join(ALL_CONFIGS), help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -718,13 +838,13 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    host_legs = world == 1 and not args.no_cpu_baseline
+    want_host = world == 1 and not args.no_cpu_baseline
     w = Workload(headline, device, args.batch_log2, rank, world)
     if w.feat is not None and distributed:
         from rotationnormflow_amd.dist import calibrate_feature_scale
         calibrate_feature_scale(w.fl, w.feat)                 # one calibration for all ranks: identical packed images (dist.py)
-    head = measure(w, args, dist, pmc, args.steps, args.warmup, not args.no_secondary, host_legs,
-                   (4096, 65536) if host_legs else None, 36.0)
+    head = measure(w, args, dist, pmc, args.steps, args.warmup, not args.no_secondary, want_host,
+                   (4096, 65536) if want_host else None, 36.0)
     state = device_state(w) if (rank == 0 and world == 1) else None
     configs = {}
     prev = w
@@ -735,13 +855,26 @@ def main():
         prev = w
         c_steps = 6 if name == "C3" else 10
         # bounded host legs for the secondary configs: N = 4096 (1024 for the inverse passes, which the oracle runs at ~2e3 rotations/s)
-        sizes = ((4096,) if w.wl["direction"] == "forward" else (1024,)) if host_legs else None
-        configs[name] = measure(w, args, None, pmc, c_steps, 3, not args.no_secondary, host_legs, sizes, 10.0, blocks=2)
+        sizes = ((4096,) if w.wl["direction"] == "forward" else (1024,)) if want_host else None
+        configs[name] = measure(w, args, None, pmc, c_steps, 3, not args.no_secondary, want_host, sizes, 10.0, blocks=2)
     if full and rank == 0:
         w.R = w.feat = None
         torch.cuda.empty_cache()
         configs["train"] = measure_training(device)           # the reference's training step, on the driver's clock too
 
+    ranks_seen = world
+    if distributed:
+        # the rank count READ BACK from the communicator: one more real all-reduce (a 1 from every rank), then the group is torn down;
+        # rank 0's host legs run after that, so no rank sits in a collective while another computes on the host
+        one = torch.ones(1, dtype=torch.float64, device=device)
+        dist.all_reduce(one)
+        ranks_seen = int(round(float(one.item())))
+        assert ranks_seen == dist.get_world_size() == world, (ranks_seen, dist.get_world_size(), world)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and world > 1 and not args.no_cpu_baseline:
+        # N > 1: a short CPU baseline and the parity block of rank 0's shard, after the timed region and after the collectives
+        host_legs(w, head, True, (4096,), 8.0)
     if rank == 0:
         strong = bool(WORKLOADS[headline].get("strong"))
         out = {
@@ -753,7 +886,7 @@ def main():
             "dtype": head["dtype"], "data": "synthetic",
             "config": {"workload": head["workload"], "rotations_per_gpu": head["rotations_per_gpu"], "global_batch": head["global_batch"],
                        "parallelism": (f"batch-sharded x{world}, one all-reduce of {{sum log p, count}} per step" if world > 1 else "single GPU")},
-            "rccl_ranks": world, "backend": backend, "mean_nll": head["mean_nll"], "clock_settle_launches": CLOCK_SETTLE_LAUNCHES,
+            "rccl_ranks": ranks_seen, "backend": backend, "mean_nll": head["mean_nll"], "clock_settle_launches": CLOCK_SETTLE_LAUNCHES,
         }
         for k in ("value_fp32_exact", "ms_per_step_fp32_exact", "roofline", "hbm", "secondary", "parity", "cpu_baseline", "vs_cpu_baseline"):
             if k in head:
@@ -764,9 +897,7 @@ def main():
             out["configs"] = configs
         if pmc is not None:
             out["pmc"] = {k: pmc[k] for k in ("source", "seconds", "csrc_sha", "error") if k in pmc}
-        print(json.dumps(out))
-    if distributed:
-        dist.destroy_process_group()
+        emit(out, args.full_out)
 
 
 if __name__ == "__main__":

@@ -133,6 +133,31 @@ struct GFrag {
     }
 };
 
+// ROWS instantiations (round 5): SHARED feature rows on the lean / inverse kernels.  Pose estimation evaluates one image feature against
+// Q query rotations (agent.py:238-263, eval.py:322-347: `feature.repeat` over number_queries), so row r of the projection scratch (a 64-float
+// record per (layer, row), [out tile][lane half][16 accumulator registers]) serves rotations [r Q, (r + 1) Q).  With Q >= 32 the 32
+// rotations of a wave sit in at most two rows: everything here is wave uniform (scalar registers) except the one comparison that picks the
+// lane's row, re-derived at every load (2 VALU) instead of kept in a vector register across the layer; the loads are broadcasts of one or
+// two 64-byte lines out of L2, so the second read for the residual (16-wave kernels) costs nothing worth a register either.
+struct GFragRows {
+    const float *p;           // G + slot * g_rows * 64 (wave uniform), or nullptr for an unconditional layer
+    int row0, rem0, gdiv, last;   // first rotation of the wave: its row and position inside the row; rotations per row; last valid row
+    __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
+    template <bool NT = false>
+    __device__ __forceinline__ f32x16 load(int ot, int lane, int h) const {
+        int row = row0 + ((rem0 + (lane & 31)) >= gdiv ? 1 : 0);
+        row = min(row, last);                                    // lanes behind the end of the batch
+        const float4 *q = reinterpret_cast<const float4 *>(p + (unsigned)row * 64u + (unsigned)((ot * 2 + h) * 16));
+        const float4 b0 = q[0], b1 = q[1], b2 = q[2], b3 = q[3];
+        f32x16 c;
+        c[0] = b0.x; c[1] = b0.y; c[2] = b0.z; c[3] = b0.w;
+        c[4] = b1.x; c[5] = b1.y; c[6] = b1.z; c[7] = b1.w;
+        c[8] = b2.x; c[9] = b2.y; c[10] = b2.z; c[11] = b2.w;
+        c[12] = b3.x; c[13] = b3.y; c[14] = b3.z; c[15] = b3.w;
+        return c;
+    }
+};
+
 // LEAN instantiations (unconditional Moebius / constant-affine stacks): there is no feature projection at all
 struct NoG {
     __device__ __forceinline__ constexpr explicit operator bool() const { return false; }
@@ -1243,9 +1268,11 @@ __device__ __forceinline__ void fused_project_half(const float *pa, int ns, int 
 // LEAN = 2 (round 3): the CONDITIONAL counterpart (BASELINE configs[3]): Moebius, constant 4x4 affine and Condition16Trans layers, EVERY
 // MLP layer conditional (its projected features come from the scratch -- or, FUSED, from the wave's stash), no saved states, no governor.
 // Both run guarded only (one-piece softplus).
-template <int DIR, int KT_INV, int NW, bool PIPE, int PREC, bool EXT = false, int LEAN = 0, bool FUSED = false>
+// ROWS (round 5): shared feature rows (GFragRows) on a non-extended instantiation; the host launches it only with g_div >= 32.
+template <int DIR, int KT_INV, int NW, bool PIPE, int PREC, bool EXT = false, int LEAN = 0, bool FUSED = false, bool ROWS = false>
 __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args) {
     static_assert(!FUSED || (DIR == 0 && PIPE && PREC == 1 && !EXT && LEAN == 2), "FUSED: forward, DMA staging, split precision, conditional lean stack");
+    static_assert(!ROWS || (!EXT && !FUSED && LEAN != 1), "ROWS: the extended instantiation reads shared rows itself; lean-1 stacks have no features");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (args.guard_mode == 2) {                                      // fp32 re-run of a split-precision call: only when its guard fired
         if (__hip_atomic_load(args.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
@@ -1334,6 +1361,12 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             return sample0 + jj;
         };
         const bool more_tiles = tile + gridDim.x < ntiles;
+        int g_row0 = 0, g_rem0 = 0;                               // ROWS: feature row of the wave's first rotation, its position inside the row
+        if constexpr (ROWS) {                                     // (wave uniform; the host keeps sample_base + n below 2^31 for these launches)
+            const unsigned s0 = (unsigned)(args.sample_base + sample0), gd = (unsigned)args.g_div;
+            g_row0 = __builtin_amdgcn_readfirstlane((int)(s0 / gd));
+            g_rem0 = __builtin_amdgcn_readfirstlane((int)(s0 - (unsigned)g_row0 * gd));
+        }
 
         Rot R;
         R.c0 = v3f{1.f, 0.f, 0.f}; R.c1 = v3f{0.f, 1.f, 0.f}; R.c2 = v3f{0.f, 0.f, 1.f};
@@ -1443,9 +1476,12 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             }
 
             // ---- layers with a conditioner MLP ----
-            typedef typename std::conditional<LEAN == 1, NoG, GFrag<EXT>>::type GF;
+            typedef typename std::conditional<LEAN == 1, NoG, typename std::conditional<ROWS, GFragRows, GFrag<EXT>>::type>::type GF;
             GF gfrag{};
-            if constexpr (LEAN != 1) {
+            if constexpr (ROWS) {
+                gfrag.p = slot >= 0 ? args.G + (size_t)slot * (size_t)args.g_rows * 64 : nullptr;
+                gfrag.row0 = g_row0; gfrag.rem0 = g_rem0; gfrag.gdiv = (int)args.g_div; gfrag.last = (int)args.g_rows - 1;
+            } else if constexpr (LEAN != 1) {
                 gfrag.p = nullptr;
                 gfrag.rows = EXT && args.g_div > 0;
                 if (FUSED) {

@@ -700,17 +700,23 @@ static int launch_fused(const FlowArgs &a, int grid, size_t lds_bytes, hipStream
 // constant-affine + Condition16Trans, every MLP conditional: C4), 0: the general kernel -- from the flow's structure and from whether the call
 // runs guarded, NEVER from the batch size: the families differ in arithmetic (one-piece softplus of the lean kernels, so3_math.h), the
 // workgroup widths of one family do not, so a rotation's result does not depend on the size of the launch (or chunk, or shard) it travels in.
-template <int DIR, int KT_INV, bool PIPE, int PREC, bool EXT = false>
+template <int DIR, int KT_INV, bool PIPE, int PREC, bool EXT = false, bool ROWS = false>
 static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream_t stream, int nwk, int lean = 0) {
 #define RNF_STACK_GO(NW_, LEAN_)                                                                                \
     do {                                                                                                        \
-        auto kern = flow_stack_kernel<DIR, KT_INV, NW_, PIPE, PREC, EXT, LEAN_>;                                \
+        auto kern = flow_stack_kernel<DIR, KT_INV, NW_, PIPE, PREC, EXT, LEAN_, false, ROWS>;                   \
         HIP_TRY(allow_lds(kern, lds_bytes));                                                                    \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NW_ * 64), lds_bytes, stream, a);                             \
         HIP_TRY(hipGetLastError());                                                                             \
         return 0;                                                                                               \
     } while (0)
-    if constexpr (DIR == 0 && PREC == 1 && PIPE && !EXT) {
+    if constexpr (ROWS && DIR == 0) {                   // shared feature rows, forward: the conditional-lean family only (run_flow checks)
+        if (lean != 2) return fail("internal: shared-row forward launches exist for the conditional-lean family only");
+        if (nwk == NW_FWD_WIDE) RNF_STACK_GO(NW_FWD_WIDE, 2);
+        if (nwk == NW_FWD_H) RNF_STACK_GO(NW_FWD_H, 2);
+        if (nwk == NW_FWD_NARROW) RNF_STACK_GO(NW_FWD_NARROW, 2);
+        return fail("internal: no %d-wave instantiation of the shared-row stack kernel", nwk);
+    } else if constexpr (DIR == 0 && PREC == 1 && PIPE && !EXT) {
         if (lean == 2) {
             if (nwk == NW_FWD_WIDE) RNF_STACK_GO(NW_FWD_WIDE, 2);
             if (nwk == NW_FWD_H) RNF_STACK_GO(NW_FWD_H, 2);
@@ -724,9 +730,11 @@ static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream
             if (nwk == NW_FWD_NARROW) RNF_STACK_GO(NW_FWD_NARROW, 0);
         }
     }
-    constexpr int NWK = (DIR == 0 && PREC == 1) ? NW_FWD_H : NW;
-    if (nwk != NWK || lean) return fail("internal: no %d-wave instantiation of this stack kernel", nwk);
-    RNF_STACK_GO(NWK, 0);
+    if constexpr (!(ROWS && DIR == 0)) {
+        constexpr int NWK = (DIR == 0 && PREC == 1) ? NW_FWD_H : NW;
+        if (nwk != NWK || lean) return fail("internal: no %d-wave instantiation of this stack kernel", nwk);
+        RNF_STACK_GO(NWK, 0);
+    }
 #undef RNF_STACK_GO
 }
 
@@ -828,7 +836,8 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         return 0;
     }
     const bool shared = o.feature_div > 0 && n_slots > 0;
-    if (shared) ext = true;                              // shared feature rows are read by the extended instantiation only
+    const bool ext_layers = ext;                         // the flow holds a layer kind only the extended instantiation carries
+    if (shared) ext = true;                              // shared feature rows: the extended instantiation, unless a ROWS one fits (below)
     if (shared && n % o.feature_div) return fail("n=%lld not divisible by feature_div=%lld", (long long)n, (long long)o.feature_div);
     const size_t ws_need = shared ? rnf_workspace_bytes_shared(n, n_slots, o.feature_div) : rnf_workspace_bytes(n, n_slots);
     if (ws_bytes < ws_need && (n_slots > 0 || o.sum_out)) return fail("workspace of %zu bytes is smaller than the %zu needed", ws_bytes, ws_need);
@@ -925,6 +934,15 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         for (int l = 0; l < n_layers; ++l)
             if (kind_has_mlp(afb.layers[l].x & 15)) afb.layers[l].y = fbp[l];
     }
+    // Shared feature rows on the fast kernels (round 5; pose estimation: agent.py:238-263 evaluates number_queries rotations per image
+    // feature): rows of >= 32 rotations, guarded split-precision call with DMA staging, and either a forward pass of the conditional-lean
+    // structure (SYMSOL-I: Condition16Trans + conditional Moebius + constant affine) or an inverse pass with K <= 64 segments of a flow
+    // without extended layers.  Decided by the flow and the call's row length, never by the batch size.  Everything else with shared rows
+    // stays on the extended instantiation.
+    const bool rows_lean2 = lean2 && all_mlp_cond && guarded && a.tab_off >= 0;
+    const bool rows_fast = shared && !ext_layers && prec == 1 && pipe && any_mlp && o.feature_div >= 32 && n < (1LL << 31) &&
+                           feat_rows < (1LL << 24) && !o.states && (o.dir == 0 ? rows_lean2 : (KT <= 8));
+    if (rows_fast) ext = false;
     bool first = true;
     for (long long base = 0; base < n; base += chunk_cap) {
         const long long cn = (n - base) < chunk_cap ? (n - base) : chunk_cap;
@@ -935,7 +953,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         const bool big_inv = o.dir == 1 && any_mlp && KT > 8;                  // 4-wave instantiation (512 registers per lane)
         const int nwk = fused ? NW_FUSED : (big_inv ? NW_INV_BIG : (wide ? NW_FWD_WIDE : (narrow ? NW_FWD_NARROW : ((o.dir == 0 && prec == 1) ? NW_FWD_H : NW))));
         // kernel family of this call (launch_stack): fixed by the flow and by `guarded`, the same for every chunk and batch size
-        const int family = (guarded && a.tab_off >= 0 && o.dir == 0 && prec == 1 && pipe && !ext) ? (lean ? 1 : (lean2 && all_mlp_cond && n_slots > 0 && !shared ? 2 : 0)) : 0;
+        const int family = (guarded && a.tab_off >= 0 && o.dir == 0 && prec == 1 && pipe && !ext) ? (lean ? 1 : (lean2 && all_mlp_cond && n_slots > 0 && (!shared || rows_fast) ? 2 : 0)) : 0;
         a.fair_off = (wide || narrow || family || (fused && NW_FUSED != 8)) ? -1 : fair_off;             // the governor pairs two waves per SIMD (general 8-wave kernel)
         const long long ntiles = (cn + nwk * 32 - 1) / (nwk * 32);
         const long long ntiles_fp = (cn + NW_FP * 32 - 1) / (NW_FP * 32);
@@ -1000,7 +1018,9 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         a.guard = guard;
         a.guard_mode = guarded ? 1 : 0;
         int rc;
+        const bool rows_now = rows_fast;                   // (the exact-fp32 re-run below shadows it: shared rows there stay on the extended kernels)
 #define RNF_LAUNCH(DIR_, KT_)                                                                                   \
+    rows_now ? launch_stack<DIR_, KT_, true, 1, false, true>(a, grid, lds_bytes, stream, nwk, family) :             \
     ext ? (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1, true>(a, grid, lds_bytes, stream, nwk)                   \
                         : launch_stack<DIR_, KT_, true, 0, true>(a, grid, lds_bytes, stream, nwk))                  \
                 : (prec ? launch_stack<DIR_, KT_, false, 1, true>(a, grid, lds_bytes, stream, nwk)                  \
@@ -1034,9 +1054,11 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             b.n = cn; b.sample_base = base; b.g_groups = groups; b.guard = guard; b.guard_mode = 2; b.fair_off = -1;
             grid_fb = (int)(ntiles_fb < cus ? ntiles_fb : cus);
             const int grid_keep = grid;
+            const bool ext_fb = ext || shared;            // shared rows: the exact-fp32 re-run reads them on the extended instantiation
             {
-                FlowArgs &a = b;                          // RNF_LAUNCH names `a`, `grid`, `prec`, `nwk`
+                FlowArgs &a = b;                          // RNF_LAUNCH names `a`, `grid`, `prec`, `nwk`, `ext`, `rows_now`
                 const int grid = grid_fb, prec = 0, nwk = NW;
+                const bool ext = ext_fb, rows_now = false;
                 const int family = 0;                     // the exact-fp32 kernels have no lean family
                 (void)family;
                 if (o.dir == 0) rc = RNF_LAUNCH(0, 0);

@@ -156,6 +156,13 @@ class Flow(nn.Module):
                 self._realias()
                 self.invalidate()
 
+    def _replicate_for_data_parallel(self):
+        replica = super()._replicate_for_data_parallel()
+        # replica.__dict__ is a shallow copy of the master's: the guard watch (a pinned word and an event of the MASTER's device) must not be
+        # shared across the worker threads / devices of nn.DataParallel (agent.py:22)
+        replica.__dict__.pop("_rnf_guard_watch", None)
+        return replica
+
     def __deepcopy__(self, memo):
         import copy
         cls = self.__class__
@@ -304,8 +311,14 @@ class Flow(nn.Module):
         self._ensure_alias()
         watch = self.__dict__.get("_rnf_guard_watch")
         if watch is not None and self.condition and getattr(self, "_feature_ms_fixed", None) is None and watch.poll():
-            self._cache.invalidate()                               # the guard kept firing: measure the feature scale again on this batch
-            self._cache.feature_ms = None
+            # the guard kept firing: measure the feature scale again on this batch -- and re-pack only if the packers would see another value
+            # (same value = same images: the cause is not the calibration, a repack would cost a D2H copy per poll for nothing)
+            packed = self._cache.peek(device)
+            if packed is None or feature is None or runtime.feature_mean_square(feature) != getattr(packed, "feature_ms", None):
+                self._cache.invalidate()
+                self._cache.feature_ms = None
+            else:
+                watch.recalibrations = watch.MAX_RECALIBRATIONS
 
         def build():
             rows = self._forward_rows()

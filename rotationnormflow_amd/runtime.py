@@ -115,8 +115,11 @@ def quantise_feature_ms(ms: float) -> float:
 def feature_square_sum(feature) -> torch.Tensor:
     """float64 [2] = {sum of squares, count} of a feature batch on its device (no host sync): what ranks all-reduce to agree on one
     calibration (dist.calibrate_feature_scale)."""
-    f = feature.detach().to(torch.float64)
-    return torch.stack((f.square().sum(), torch.tensor(float(f.numel()), dtype=torch.float64, device=f.device)))
+    f = feature.detach()
+    # the square of the 2-norm, accumulated in fp64 by the reduction itself: no fp64 copy of the batch (C5's 2^20 x 512 fp32 features are
+    # 2 GB; a converted copy plus its square were 8 GB of transient HBM at every pack / calibration -- ADVICE r4)
+    ss = torch.linalg.vector_norm(f.reshape(-1), 2, dtype=torch.float64).square()
+    return torch.stack((ss, torch.tensor(float(f.numel()), dtype=torch.float64, device=f.device)))
 
 
 def feature_mean_square(feature) -> float:
@@ -206,6 +209,7 @@ class GuardWatch:
     and ask the caller to re-calibrate (the usual cause: features far larger than the batch the equalisation was calibrated on, so that the
     projected x0 trips kX0Guard; Flow._packed then measures the feature scale again on the batch at hand and re-packs)."""
     REPEAT = 3
+    MAX_RECALIBRATIONS = 2             # per watch: a guard that still fires after that is not a calibration problem (ADVICE r4)
 
     def __init__(self):
         self.pending = False           # a copy of the guard word is in flight (one pinned word and one event, reused for every call)
@@ -213,6 +217,8 @@ class GuardWatch:
         self.event = None
         self.streak = 0
         self.warned = False
+        self.recalibrations = 0
+        self.device = None             # the device the pinned word / event belong to
 
     def __deepcopy__(self, memo):
         return GuardWatch()
@@ -228,6 +234,9 @@ class GuardWatch:
             self.streak = self.streak + 1 if fired else 0
             if self.streak >= self.REPEAT:
                 self.streak = 0
+                if self.recalibrations >= self.MAX_RECALIBRATIONS:
+                    return False       # re-packing again would produce the same images: stay on the (correct) fp32 re-runs, quietly
+                self.recalibrations += 1
                 if not self.warned:
                     import warnings
                     warnings.warn("rotationnormflow_amd: the range guard re-ran several consecutive launches of this flow on the exact-fp32 "
@@ -239,8 +248,11 @@ class GuardWatch:
         return False
 
     def watch(self, ws):
-        if self.pending or torch.cuda.is_current_stream_capturing():
+        if self.pending or self.recalibrations >= self.MAX_RECALIBRATIONS or torch.cuda.is_current_stream_capturing():
             return
+        if self.device is not None and self.device != ws.device:
+            return                     # one watch, one device (nn.DataParallel replicas get their own: Flow._replicate_for_data_parallel)
+        self.device = ws.device
         if self.host is None:
             self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
             self.event = torch.cuda.Event()
@@ -491,6 +503,12 @@ class PackCache:
             if d.get(name) is not p:
                 return False
         return True
+
+    def peek(self, device):
+        """The packed flow cached for ``device`` (whatever parameter version it was built for), or None."""
+        with self._lock:
+            hit = self._entries.get(str(device))
+            return None if hit is None else hit[1]
 
     def get(self, module, device, builder):
         with self._lock:

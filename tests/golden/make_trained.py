@@ -36,6 +36,9 @@ sys.path[:0] = [os.path.join(REPO, "oracle", "stubs"), REF, REPO]
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+if os.environ.get("RNF_MAKE_THREADS"):
+    torch.set_num_threads(int(os.environ["RNF_MAKE_THREADS"]))
+
 import flow.flow as ref_flow_mod  # noqa: E402
 import utils.fisher as ref_fisher_mod  # noqa: E402
 
@@ -82,6 +85,8 @@ def make_dataset(spec):
         rng = np.random.default_rng(seed)
         cls = rng.integers(0, C, n)
         feat = (centres[cls] + 0.3 * rng.standard_normal((n, F))).astype(np.float32)
+        for c, scale in spec.get("class_scale", {}).items():          # a class whose features were not normalised
+            feat[cls == c] *= np.float32(scale)
         R = np.empty((n, 3, 3), np.float32)
         for c in range(C):
             idx = np.nonzero(cls == c)[0]

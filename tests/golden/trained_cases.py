@@ -12,6 +12,14 @@ TRAINED = {
     # two-mode target
     "trained_cond4": dict(cfg=dict(layers=4, feature_dim=32, **SYMSOL), n_classes=3, kappa=20.0, mode_seed=311, data_seed=312, init_seed=313,
                           n_train=16384, n_test=1024, n_inverse=512, steps=2500, batch=256, lr=1e-3),
+    # BASELINE configs[1] structure at full depth (settings/raw.yml: 24 layer pairs, K = 64): three sharp modes; 48 layers of compounding
+    # fc_last / softplus saturation
+    "trained_c2": dict(cfg=dict(layers=24), n_modes=3, kappa=20.0, mode_seed=331, data_seed=332, init_seed=333,
+                       n_train=32768, n_test=2048, n_inverse=256, steps=3000, batch=256, lr=5e-4),
+    # BASELINE configs[3] structure (settings/symsol.yml with --layers 24 --feature_dim 256): four feature classes, each a two-mode target;
+    # the features of class 0 arrive UN-NORMALISED (x30) to stress the pack-time equalisation of the conditional layers
+    "trained_c4": dict(cfg=dict(layers=24, feature_dim=256, **SYMSOL), n_classes=4, kappa=20.0, mode_seed=341, data_seed=342, init_seed=343,
+                       n_train=16384, n_test=1024, n_inverse=256, steps=1500, batch=256, lr=5e-4, class_scale={0: 30.0}),
 }
 
 TRAJ = {

@@ -11,6 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ALL_SECONDARY = ["C1", "C3", "C4", "C5", "C5u"]            # + the query-batched conditional workloads when bench.py has them (below)
 
 
 def _run(cmd, env, timeout=400):
@@ -27,6 +28,28 @@ def _run(cmd, env, timeout=400):
     return out
 
 
+def _compact(out):
+    """The driver-facing record: the LAST stdout line, one JSON object under 3000 bytes (BENCH_r04: a 40 KB line overflowed the driver's
+    stdout tail and the headline was lost), the only line that starts with "{"."""
+    lines = out.stdout.splitlines()
+    braces = [ln for ln in lines if ln.startswith("{")]
+    assert len(braces) == 1 and lines[-1] == braces[0], out.stdout[-3000:]
+    assert len(braces[0]) < 3000, len(braces[0])
+    rec = json.loads(braces[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config"):
+        assert k in rec, k
+    assert "frac" in rec["roofline"] and rec["roofline"]["bound"] in ("valu", "mfma") and rec["roofline"]["unit"] == "TFLOP/s"
+    return rec
+
+
+def _full(out):
+    """The full record: the `BENCH_FULL ` line (also written to bench_full.json)."""
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("BENCH_FULL ")]
+    assert len(lines) == 1
+    return json.loads(lines[0][len("BENCH_FULL "):])
+
+
 def test_two_ranks_one_json_line():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -36,13 +59,13 @@ def test_two_ranks_one_json_line():
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch-log2", "15"]
     out = _run(cmd, env)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak"
+    rec = _compact(out)
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["rccl_ranks"] == 2
     assert rec["config"]["global_batch"] == 2 * (1 << 15)
     assert rec["value"] > 0 and 10.0 < rec["mean_nll"] < 18.0          # 2 x 2^15 uniform rotations under MF(diag(5,3,1)) after the flow
-    assert "cpu_baseline" not in rec                                   # rank-0-at-N=1 only
+    # rank 0 adds a SHORT CPU baseline and the parity block of its shard after the process group is gone (round 5: the N > 1 line has the
+    # same keys as the N = 1 line)
+    assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] == "port" and rec["parity"]["mean_abs_err_of_the_mean"] < 1e-5
 
 
 def test_self_launch_from_gpus_flag():
@@ -54,9 +77,7 @@ def test_self_launch_from_gpus_flag():
     out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch-log2", "15",
                 "--no-secondary"], env)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    rec = json.loads(lines[0])
+    rec = _compact(out)
     assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["backend"] == "gloo"
     assert rec["config"]["global_batch"] == 2 * (1 << 15)
 
@@ -80,15 +101,19 @@ def test_single_gpu_line_carries_both_arithmetics_and_every_config_runs():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch-log2", "16", "--no-cpu-baseline",
                           "--no-configs", "--no-pmc"], cwd=ROOT, capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stderr[-2000:]
-    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    short, rec = _compact(out), _full(out)
     assert rec["roofline"]["bound"] == "valu" and "frac" in rec["roofline"] and rec["secondary"]["roofline"]["bound"] == "mfma"
     assert rec["secondary"]["value"] > 0 and abs(rec["secondary"]["mean_nll"] - rec["mean_nll"]) < 1e-4
     assert rec["value_fp32_exact"] == rec["secondary"]["value"] and "configs" not in rec
+    assert abs(short["value"] - rec["value"]) <= 1e-4 * rec["value"] and abs(short["value_fp32_exact"] - rec["value_fp32_exact"]) <= 1e-4 * rec["value"]
+    assert short["full_record"] == "bench_full.json"
+    with open(os.path.join(ROOT, "bench_full.json")) as fh:
+        assert json.load(fh)["value"] == rec["value"]
     for cfg in ("C1", "C4", "C5", "C5u"):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "1", "--warmup", "1", "--batch-log2", "14",
                               "--no-cpu-baseline", "--no-secondary", "--no-pmc"], cwd=ROOT, capture_output=True, text=True, timeout=400)
         assert out.returncode == 0, (cfg, out.stderr[-2000:])
-        rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+        rec = _compact(out)
         assert rec["value"] > 0 and rec["config"]["workload"].startswith(cfg)
 
 
@@ -104,7 +129,7 @@ def test_rccl_leg_executes_under_a_launcher_on_one_gpu():
                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                           "--batch-log2", "16", "--no-cpu-baseline", "--no-secondary"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stderr[-2000:]
-    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    rec = _compact(out)
     assert rec["backend"] == "nccl" and rec["rccl_ranks"] == 1 and rec["n_gpus"] == 1 and rec["value"] > 0
 
 
@@ -117,10 +142,11 @@ def test_c3_strong_scaling_splits_one_global_batch():
             "--no-cpu-baseline", "--no-pmc"]
     one = _run(base + ["--gpus", "1"], env)
     assert one.returncode == 0, one.stderr[-2000:]
-    r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    r1 = _full(one)
     two = _run(base + ["--gpus", "2"], dict(env, RNF_BENCH_SHARED_GPU="1"))
     assert two.returncode == 0, two.stderr[-2000:]
-    r2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][0])
+    r2 = _full(two)
+    assert _compact(one)["scaling"] == _compact(two)["scaling"] == "strong"
     for r, g in ((r1, 1), (r2, 2)):
         assert r["scaling"] == "strong" and r["n_gpus"] == g and r["rccl_ranks"] == g
         assert r["config"]["global_batch"] == 1 << 17 and r["config"]["rotations_per_gpu"] == (1 << 17) // g
@@ -134,7 +160,8 @@ def test_default_line_has_the_reference_noise_beside_its_parity():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch-log2", "16", "--no-configs", "--no-pmc"],
                          cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    short, rec = _compact(out), _full(out)
+    assert short["cpu_baseline"]["value"] > 0 and short["cpu_baseline"]["cores"] >= 1 and short["parity"]["reference_fp32_max"] > 0
     p = rec["parity"]
     assert p["mean_abs_err_of_the_mean"] < 1e-5 and p["max_abs_err"] <= 4 * p["reference_fp32"]["max_abs_err"] + 2e-5
     assert rec["secondary"]["parity"]["mean_abs_err_of_the_mean"] < 1e-5
@@ -148,12 +175,16 @@ def test_full_line_carries_every_config_with_live_counters():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch-log2", "15"],
                          cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    rec = json.loads(lines[0])
+    short, rec = _compact(out), _full(out)
     assert rec["config"]["workload"].startswith("C2") and rec["value"] > 0 and rec["value_fp32_exact"] > 0
     assert "error" not in rec["pmc"], rec["pmc"]
-    assert sorted(rec["configs"]) == ["C1", "C3", "C4", "C5", "C5u", "train"]
+    assert sorted(rec["configs"]) == sorted(ALL_SECONDARY + ["train"])
+    # the compact line: the headline with its live roofline and CPU baseline, and one small entry per other workload
+    assert short["roofline"]["traffic"] > 0 and 0.0 < short["roofline"]["valu_issue_frac"] <= 1.0 and short["cpu_baseline"]["value"] > 0
+    assert sorted(short["configs"]) == sorted(rec["configs"])
+    for name in ALL_SECONDARY:
+        assert short["configs"][name]["value"] > 0 and short["configs"][name]["traffic_x"] > 0 and "parity_max" in short["configs"][name], name
+    assert short["configs"]["train"]["ms_per_iteration"] > 0
     tr = rec["configs"].pop("train")
     assert 0.0 < tr["ms_per_iteration"] < tr["ms_per_iteration_per_tensor_parameters"] and tr["ms_per_iteration_hip_graph"] > 0.0
     for name, c in [("C2", rec)] + sorted(rec["configs"].items()):
@@ -183,18 +214,17 @@ def test_eight_ranks_weak_and_strong_equal_the_single_rank_statistic():
     rows bit for bit whatever launch shape its size selects (tests/test_gpu_scale_properties.py)."""
     weak = _self_launch(["--gpus", "8", "--steps", "2", "--warmup", "1", "--batch-log2", "14", "--no-secondary"])
     assert weak.returncode == 0, weak.stderr[-2000:]
-    lines = [ln for ln in weak.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, weak.stdout
-    r = json.loads(lines[0])
+    r = _compact(weak)
     assert r["n_gpus"] == 8 and r["rccl_ranks"] == 8 and r["scaling"] == "weak" and r["config"]["global_batch"] == 8 << 14
-    assert r["config"]["workload"].startswith("C2") and "configs" not in r and "cpu_baseline" not in r
+    assert r["config"]["workload"].startswith("C2") and "configs" not in r and r["cpu_baseline"]["value"] > 0
     base = ["--config", "C3", "--steps", "2", "--warmup", "1", "--batch-log2", "17", "--no-secondary", "--no-cpu-baseline", "--no-pmc"]
     one = _self_launch(base + ["--gpus", "1"], {"RNF_BENCH_SHARED_GPU": "0"})
     assert one.returncode == 0, one.stderr[-2000:]
-    r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    r1 = _full(one)
     eight = _self_launch(base + ["--gpus", "8"])
     assert eight.returncode == 0, eight.stderr[-2000:]
-    r8 = json.loads([ln for ln in eight.stdout.splitlines() if ln.startswith("{")][0])
+    r8 = _full(eight)
+    assert _compact(eight)["rccl_ranks"] == 8
     assert r8["scaling"] == "strong" and r8["rccl_ranks"] == 8 and r8["config"]["global_batch"] == 1 << 17
     assert r8["config"]["rotations_per_gpu"] == (1 << 17) // 8 and r1["config"]["rotations_per_gpu"] == 1 << 17
     assert abs(r1["mean_nll"] - r8["mean_nll"]) <= 1e-12 * abs(r1["mean_nll"])

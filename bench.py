@@ -73,8 +73,20 @@ WORKLOADS = {
                     "42-layer Moebius-only conditional flow (F=512 precomputed features), return rotation + log-det"),
     "C5u": dict(preset="C5u", direction="inverse", fisher=True, flop=42 * 57_728, bytes=36 + 36 + 4,
                 text="inverse sampling, unconditional variant: MF(diag(5,3,1)) samples through the inverse of a 42-layer Moebius-only flow"),
+    # The reference's REAL conditional evaluation pattern (agent.py:238-263, eval.py:322-347): one image feature against `number_queries`
+    # rotations -- the reference materialises feature.repeat; here the feature rows are SHARED (feature_repeat = Q): the projection runs once
+    # per image, the stack kernels read a 64-float record per (layer, image).  2048 images x 512 queries = 2^20 rotations.
+    # flop: the per-rotation GEMM work (conditioner with its 3 rotation inputs) + the per-image feature part amortised over Q rotations.
+    "C4q": dict(preset="C4", direction="forward", fisher=False, queries=512, flop=24 * 57_728 + (59_392 + 24 * 2 * 256 * 64) // 512,
+                bytes=36 + 4 + 4 * 256 // 512,
+                text="SYMSOL-I structure as the reference evaluates it: 2048 image features (F=256) x 512 query rotations each (shared feature "
+                     "rows), forward log_prob"),
+    "C5q": dict(preset="C5", direction="inverse", fisher=True, queries=512, flop=42 * 57_728 + (42 * 2 * 512 * 64) // 512,
+                bytes=36 + 36 + 4 + 4 * 512 // 512 + 36 // 512 + 1,
+                text="pose estimation as the reference runs it (agent.py:238-283): per image feature (F=512, 2048 images) 512 base samples from "
+                     "MF(diag(5,3,1)) through the inverse of the 42-layer conditional flow, log p = base - ldj, arg-max rotation per image"),
 }
-ALL_CONFIGS = ["C2", "C1", "C3", "C4", "C5", "C5u"]
+ALL_CONFIGS = ["C2", "C1", "C3", "C4", "C5", "C5u", "C4q", "C5q"]
 PMC_GROUPS = {
     "fetch": "FETCH_SIZE",
     "write": "WRITE_SIZE",
@@ -138,10 +150,11 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(cfg, weights, A, wl, feat_dim, sizes, budget_s):
+def cpu_baseline(cfg, weights, A, wl, feat_dim, sizes, budget_s, queries=None):
     """the oracle (torch-CPU restatement of the reference path, parity-pinned to it) on this box's host cores, fp32,
     no_grad, the same seeded recipe as the GPU run, at each N of ``sizes``: one warm-up, then best of 3 -- fewer repetitions (never fewer
     than one) where three would overrun ``budget_s`` seconds, which `sample` then says.  `value` is the best rate over the sizes."""
+    import numpy as np
     import torch
     from oracle import flow_oracle as orc          # measured as the BASELINE only; never used by the product
     from rotationnormflow_amd import synth
@@ -162,6 +175,8 @@ def cpu_baseline(cfg, weights, A, wl, feat_dim, sizes, budget_s):
     for n in sizes:
         R = synth.uniform_rotations(n, seed=2)
         f = synth.features(n, feat_dim, seed=6) if feat_dim else None
+        if f is not None and queries:                        # what the reference does: the image feature repeated over its queries (agent.py:240-244)
+            f = np.repeat(f[: max(1, n // queries)], queries, axis=0)[:n]
         m = min(n, 512)
         t_warm = run(R[:m], None if f is None else f[:m])                    # warm-up (thread pool, allocator)
         est = n / best_rate if best_rate > 0 else t_warm * n / m            # (the rate of the previous, smaller size predicts this one)
@@ -215,21 +230,29 @@ class Workload:
             self.R = torch.from_numpy(synth.uniform_rotations(self.n, seed=synth.RD_SEED + rank)).to(device)
             fseed, skip = synth.RD_SEED + 1000 + rank, 0
         self.feat = None
+        self.queries = wl.get("queries")                      # Q rotations share one feature row (feature_repeat)
+        if self.queries and (self.n % self.queries or skip % self.queries):
+            raise SystemExit(f"bench.py: workload {name} needs a batch that is a multiple of {self.queries} rotations per rank")
         if self.feat_dim:
             # precomputed features ~ N(0, 1) [N, F] drawn on the device (2 GB for C5: a host generator would take longer than the bench)
             gen.manual_seed(fseed)
-            full = torch.randn((skip + self.n, self.feat_dim), generator=gen, device=device, dtype=torch.float32)
-            self.feat = full[skip:].contiguous()
+            per = self.queries or 1
+            full = torch.randn(((skip + self.n) // per, self.feat_dim), generator=gen, device=device, dtype=torch.float32)
+            self.feat = full[skip // per:].contiguous()
 
     def evaluate(self):
         import torch
         if self.wl["direction"] == "forward":
-            return self.fl.log_prob(self.R, self.feat, base=self.base)["sum"]
+            return self.fl.log_prob(self.R, self.feat, base=self.base, feature_repeat=self.queries)["sum"]
         # eval.py:327-347: base samples + their log-density, inverse pass, log p = base - ldj
         z = self.base._sample(self.n).reshape(-1, 3, 3)
         lp = self.base._log_prob(z)
-        _, ldj = self.fl.inverse(z, self.feat)
-        lp = (lp - ldj).double()
+        rot, ldj = self.fl.inverse(z, self.feat, feature_repeat=self.queries)
+        lp = lp - ldj
+        if self.queries:                                      # agent.py:264-283: the most likely of each image's samples is the pose estimate
+            best = lp.view(-1, self.queries).argmax(dim=1)
+            self.estimate = rot.view(-1, self.queries, 3, 3)[torch.arange(best.numel(), device=best.device), best]
+        lp = lp.double()
         return torch.stack((lp.sum(), torch.tensor(float(self.n), dtype=torch.float64, device=self.device)))
 
     def timed(self, steps, warmup, settle, dist=None):
@@ -276,9 +299,13 @@ class Workload:
         from oracle import flow_oracle as orc
         torch.set_num_threads(host_threads())
         wl = self.wl
+        q = self.queries
+        if q:
+            rows = max(q, rows // q * q)
         sub = self.R[:rows]
-        fsub = None if self.feat is None else self.feat[:rows]
-        sub_np, fsub_np = sub.cpu().numpy(), None if fsub is None else fsub.cpu().numpy()
+        fsub = None if self.feat is None else self.feat[:rows // (q or 1)]
+        sub_np = sub.cpu().numpy()
+        fsub_np = None if fsub is None else (fsub.repeat_interleave(q, dim=0) if q else fsub).cpu().numpy()     # the reference's feature.repeat
 
         def oracle(dtype):
             if wl["direction"] == "forward":
@@ -288,8 +315,8 @@ class Workload:
         def product():
             with torch.no_grad():
                 if wl["direction"] == "forward":
-                    return self.fl.log_prob(sub, fsub, base=self.base)["logp"].cpu().double().numpy()
-                return self.fl.inverse(sub, fsub)[1].cpu().double().numpy()
+                    return self.fl.log_prob(sub, fsub, base=self.base, feature_repeat=q)["logp"].cpu().double().numpy()
+                return self.fl.inverse(sub, fsub, feature_repeat=q)[1].cpu().double().numpy()
 
         def stats(got, want):
             e = np.abs(got - want)
@@ -614,7 +641,7 @@ def host_legs(w, rec, want_parity, cpu_sizes, cpu_budget):
             finally:
                 set_precision(primary)
     if cpu_sizes:
-        rec["cpu_baseline"] = cpu_baseline(w.cfg, w.weights, w.A, w.wl, w.feat_dim, cpu_sizes, cpu_budget)
+        rec["cpu_baseline"] = cpu_baseline(w.cfg, w.weights, w.A, w.wl, w.feat_dim, cpu_sizes, cpu_budget, w.queries)
         rec["vs_cpu_baseline"] = rec["value"] / rec["cpu_baseline"]["value"]
 
 
@@ -693,14 +720,14 @@ def compact_record(out, full_path=None):
     c = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                     "dtype", "data"))
     cfg = dict(out["config"])
-    cfg["workload"] = cfg["workload"][:140]
+    cfg["workload"] = cfg["workload"][:110]
     c["config"] = cfg
     c.update(_pick(out, ("rccl_ranks", "backend", "value_fp32_exact", "ms_per_step_fp32_exact", "mean_nll")))
     if "roofline" in out:
         c["roofline"] = _pick(out["roofline"], ROOF_KEYS)
     if "cpu_baseline" in out:
         c["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "cpu"))
-        c["cpu_baseline"]["sample"] = out["cpu_baseline"].get("sample", "")[:100]
+        c["cpu_baseline"]["sample"] = out["cpu_baseline"].get("sample", "")[:70]
         c["vs_cpu_baseline"] = out.get("vs_cpu_baseline")
     if "parity" in out:
         c["parity"] = _pick(out["parity"], ("mean_abs_err_of_the_mean", "max_abs_err"))
@@ -723,7 +750,7 @@ def compact_record(out, full_path=None):
             e["weights"] = r["weights"]
         small[name] = e
     if small:
-        c["configs"] = small
+        c["configs"] = _sig(small, 4)
     if full_path:
         c["full_record"] = full_path
     c = _sig(c, 5)

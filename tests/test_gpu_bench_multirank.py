@@ -11,7 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ALL_SECONDARY = ["C1", "C3", "C4", "C5", "C5u"]            # + the query-batched conditional workloads when bench.py has them (below)
+ALL_SECONDARY = ["C1", "C3", "C4", "C5", "C5u", "C4q", "C5q"]      # C4q / C5q: the reference's own conditional evaluation shape (shared feature rows)
 
 
 def _run(cmd, env, timeout=400):
@@ -109,7 +109,7 @@ def test_single_gpu_line_carries_both_arithmetics_and_every_config_runs():
     assert short["full_record"] == "bench_full.json"
     with open(os.path.join(ROOT, "bench_full.json")) as fh:
         assert json.load(fh)["value"] == rec["value"]
-    for cfg in ("C1", "C4", "C5", "C5u"):
+    for cfg in ("C1", "C4", "C5", "C5u", "C4q", "C5q"):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "1", "--warmup", "1", "--batch-log2", "14",
                               "--no-cpu-baseline", "--no-secondary", "--no-pmc"], cwd=ROOT, capture_output=True, text=True, timeout=400)
         assert out.returncode == 0, (cfg, out.stderr[-2000:])

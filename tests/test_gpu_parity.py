@@ -200,18 +200,22 @@ def test_errors_are_loud():
 
 
 @pytest.mark.parametrize("direction", ["forward", "inverse"])
-@pytest.mark.parametrize("Q", [500, 37])
-def test_shared_feature_rows_equal_materialised_repeat(direction, Q):
+@pytest.mark.parametrize("Q", [500, 37, 32, 7])
+def test_shared_feature_rows_equal_materialised_repeat_and_the_oracle(direction, Q):
     """feature_repeat=Q (pose estimation: one image feature against Q query rotations, agent.py:238-263) must give what the reference's
-    pattern gives -- every feature row repeated Q times -- including runs that straddle 32-rotation wave tiles (Q = 37, 500).  The two
-    calls go through different instantiations of the stack kernel (shared rows live in the extended one), whose fused-multiply-add
-    contraction differs in places: agreement is to fp32 rounding, not bit for bit."""
+    pattern gives -- every feature row repeated Q times -- including runs that straddle 32-rotation wave tiles (Q = 37, 500).  Round 5: rows of
+    >= 32 rotations run on the SAME kernel family as the materialised repeat (conditional-lean forward / 8-wave inverse; ROWS instantiations,
+    the per-row record read like a layer parameter), shorter rows (Q = 7) on the extended instantiation.  Against the materialised repeat:
+    fp32 rounding (the projection sums one row per image instead of one per rotation tile); against the fp64 oracle on the repeated
+    features: the gates of the fixture tests, with the oracle's own fp32 run as the noise."""
     cfg = orc.make_config(layers=4, segments=16, condition=1, feature_dim=40, rot="16UnTrans", last_affine=1, frequent_permute=1)
     w = synth.fill_state_dict(orc.state_shapes(cfg), seed=8, regime="trained")
     fl = product_flow(cfg, w)
     B = 9
-    R = torch.from_numpy(synth.uniform_rotations(B * Q, seed=9)).cuda()
-    f = torch.from_numpy(synth.features(B, 40, seed=10)).cuda()
+    Rn = synth.uniform_rotations(B * Q, seed=9)
+    fn = synth.features(B, 40, seed=10)
+    R = torch.from_numpy(Rn).cuda()
+    f = torch.from_numpy(fn).cuda()
     frep = f[:, None, :].expand(B, Q, 40).reshape(B * Q, 40).contiguous()
     with torch.no_grad():
         if direction == "forward":
@@ -221,6 +225,21 @@ def test_shared_feature_rows_equal_materialised_repeat(direction, Q):
             a = fl.inverse(R, f, feature_repeat=Q)
             b = fl.inverse(R, frep)
     assert (a[0] - b[0]).abs().max().item() < 2e-5 and (a[1] - b[1]).abs().max().item() < 5e-5
+    frep_n = np.repeat(fn, Q, axis=0)
+    run = orc.flow_forward if direction == "forward" else orc.flow_inverse
+    r64, l64 = run(cfg, w, Rn, frep_n, dtype=torch.float64)
+    r32, l32 = run(cfg, w, Rn, frep_n, dtype=torch.float32)
+    noise = (l32.double() - l64).abs().numpy()
+    err = np.abs(a[1].cpu().double().numpy() - l64.numpy())
+    if direction == "forward":
+        assert err.mean() <= 2 * noise.mean() + 2e-6 and err.max() <= 4 * noise.max() + 2e-5, (err.mean(), err.max(), noise.mean(), noise.max())
+        assert (a[0].cpu().double() - r64).abs().max().item() < 1e-4
+    else:                                                          # the gates of test_inverse_matches_reference_golden (bisection cells)
+        cell = np.pi / 2 ** 14
+        rnoise = (r32.double() - r64).abs().reshape(len(err), -1).max(1)[0].numpy()
+        rerr = (a[0].cpu().double() - r64).abs().reshape(len(err), -1).max(1)[0].numpy()
+        assert err.mean() <= 3 * noise.mean() + 1e-5 and rerr.mean() <= 3 * rnoise.mean() + 1e-5
+        assert rerr.max() <= 2.0 * cell + rnoise.max() and err.max() <= 6 * cell + noise.max()
     with torch.no_grad(), pytest.raises(ValueError):
         fl(R[:-1], f, feature_repeat=Q)
 

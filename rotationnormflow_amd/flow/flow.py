@@ -274,6 +274,14 @@ class Flow(nn.Module):
             return None
         with torch.no_grad():
             f32 = torch.float32
+            # nn.DataParallel (agent.py:22) hands every replica broadcast copies of the parameters on ITS device and calls it from a worker
+            # thread with that device's inputs.  A replica that still saw the master's storage would make this device read another GPU's
+            # memory through the kernels (silently slow over xGMI, or a fault): refuse loudly on the first such forward instead.
+            for t in ([flat] if flat is not None else tensors):
+                if t.is_cuda and t.device != device:
+                    raise RuntimeError(f"rotationnormflow_amd: parameters live on {t.device} but this call runs on {device} "
+                                       f"({'a DataParallel replica' if getattr(self, '_is_replica', False) else 'module'}): "
+                                       "move the module with .to(device) / let nn.DataParallel replicate it")
             if flat is not None and flat.is_cuda:
                 plain = flat.detach()                              # flattened flow: the parameter storage IS the plain blob
             else:

@@ -195,3 +195,72 @@ def test_two_ranks_train_a_conditional_flow_like_one(flat):
     assert moved > 3e-3
     diff = np.abs(got[0] - want)
     assert np.quantile(diff, 0.99) < 2e-2 * moved and diff.max() <= 1.5 * moved, (np.quantile(diff, 0.99), diff.max(), moved)
+
+
+# ---- sharded EVALUATION of a conditional flow at world 8 (VERDICT r4 task 8c) ------------------------------------------------------------
+def _c4_small():
+    """The SYMSOL-I structure of BASELINE configs[3] (Condition16Trans + conditional Moebius + constant affine; F = 256) at 6 layer pairs."""
+    from oracle import flow_oracle as orc
+    from rotationnormflow_amd import synth
+    from rotationnormflow_amd.configs import make_config
+    from rotationnormflow_amd.flow.flow import Flow
+    cfg = make_config(layers=6, feature_dim=256, condition=1, rot="16UnTrans", frequent_permute=1, last_affine=1, first_affine=0)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=77, regime="trained")
+    with contextlib.redirect_stdout(io.StringIO()):
+        fl = Flow(cfg)
+    fl.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    return fl.cuda().eval()
+
+
+def _c4_inputs(n=1 << 13):
+    from rotationnormflow_amd import synth
+    R = torch.from_numpy(synth.uniform_rotations(n, seed=78))
+    F = torch.from_numpy(synth.features(n, 256, seed=79))
+    F[: n // 8] *= 30.0            # rank 0's shard is un-normalised: a per-rank calibration would equalise (and round) differently there
+    return R, F
+
+
+def _c4_eval_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from rotationnormflow_amd.dist import flow_evaluator, shard_bounds, sharded_mean_nll
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        fl = _c4_small()
+        R, F = _c4_inputs()
+        lo, hi = shard_bounds(R.shape[0], rank, world)
+        nll, tot = sharded_mean_nll(flow_evaluator(fl), R.cuda(), F.cuda(), rank, world)      # calibrates once for all ranks, one all-reduce
+        with torch.no_grad():
+            rows = fl.log_prob(R[lo:hi].cuda(), F[lo:hi].cuda())["logp"].cpu().numpy()
+        q.put((rank, (float(nll), tot.cpu().numpy(), rows, float(fl._feature_ms_fixed))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_evaluate_a_conditional_flow_bit_equal_to_one_rank():
+    """dist.calibrate_feature_scale + a conditional flow at world 8 on the shared-GPU rig: every rank packs the SAME images (one all-reduced
+    calibration, although rank 0's shard has features 30x larger than the others'), so each shard's rows equal the 1-rank evaluation of the
+    whole batch bit for bit and the reduced mean NLL is the 1-rank mean to fp64 summation order."""
+    from rotationnormflow_amd.dist import calibrate_feature_scale
+    world = 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_c4_eval_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    fl = _c4_small()
+    R, F = _c4_inputs()
+    ms = calibrate_feature_scale(fl, F.cuda())
+    with torch.no_grad():
+        full = fl.log_prob(R.cuda(), F.cuda())
+    rows = full["logp"].cpu().numpy()
+    assert all(got[r][3] == ms for r in range(world))                               # the same quantised calibration everywhere
+    assert np.array_equal(np.concatenate([got[r][2] for r in range(world)]), rows)  # bit for bit
+    want = -float(full["sum"][0] / full["sum"][1])
+    for r in range(world):
+        assert got[r][1][1] == R.shape[0] and abs(got[r][0] - want) < 1e-12 * max(1.0, abs(want))

@@ -75,7 +75,10 @@ __device__ __forceinline__ void fp_lds_read_at(h8 &d, unsigned lds_addr, int off
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(lds_addr), "n"(off));
 }
 
-template <int NW, int PREC>
+// MULTI (split precision): F > FP_KCHUNK features go through several K-chunks whose partial sums travel through the scratch (only F > 512
+// reaches this kernel that way: 256 < F <= 512 runs featproj_ksplit_kernel).  The single-chunk instantiation has no accumulator start to
+// fetch at all (round 5: the bias moved into the stack kernel's fc_first image): 16 registers fewer live across the tile loop, no spills.
+template <int NW, int PREC, bool MULTI = false>
 __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (args.only_if && __hip_atomic_load(args.only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
@@ -110,10 +113,9 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
                         __syncthreads();
                         const GOut gout(args, slot, group, sample, valid, ot, lane, h);
                         f32x16 acc;
-                        if (kc == 0) {
-                            const float *bias = rec + (size_t)2 * ngroups_k * 256 + (ot * 2 + h) * 16;
+                        if (kc == 0) {                                 // (round 5: no bias here -- it sits in the stack kernel's fc_first image)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[r] = bias[r];
+                            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                         } else {
                             acc = gout.load();
                         }
@@ -171,18 +173,12 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
                 // compiler's (or the next tile's) s_waitcnt vmcnt(0) wait for the DMA just issued as well: with the bias loaded right in
                 // front of the matrix instructions and the result stored behind them, DMA latency + matrix time + store latency ADDED UP
                 // (0.27 + 0.37 + 0.2 ms per launch instead of their maximum).
-                auto start_of = [&](int t) {                       // accumulator start of tile t (global loads)
-                    const int slot = t >> 1, ot = t & 1;
-                    if (kc == 0) {
-                        const float *bias = args.blob + args.feat_off[slot] + (size_t)2 * nsteps_all * 512 + (ot * 2 + h) * 16;
-                        f32x16 c;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) c[r] = bias[r];
-                        return c;
-                    }
-                    return GOut(args, slot, group, sample, valid, ot, lane, h).load();
+                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                auto start_of = [&](int t) {                       // accumulator start of tile t: zero, or (MULTI, later chunks) the partial sums
+                    if (!MULTI || kc == 0) return zero16;
+                    return GOut(args, t >> 1, group, sample, valid, t & 1, lane, h).load();
                 };
-                f32x16 pend, cur0 = start_of(0), nxt0 = cur0;
+                f32x16 pend, cur0 = start_of(0), nxt0 = cur0;      // (single chunk: cur0 / nxt0 are the constant zero -- no registers)
                 int pend_t = -1;
                 auto flush = [&]() {
                     if (pend_t < 0) return;
@@ -216,18 +212,13 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
                         const bool more = t + 1 < n_t;
                         const float *nsrc = tile_src(more ? t + 1 : t);
                         float *ndst = lds + ((t + 1) & 1) * BUF;
-                        const float4 *nstart;                      // the four 16-byte pieces of the next tile's accumulator start
-                        int nstride;
-                        {
-                            const int tn = more ? t + 1 : t, slot = tn >> 1, ot = tn & 1;
-                            if (kc == 0) {
-                                nstart = reinterpret_cast<const float4 *>(args.blob + args.feat_off[slot] + (size_t)2 * nsteps_all * 512 + (ot * 2 + h) * 16);
-                                nstride = 1;
-                            } else {
-                                const GOut g(args, slot, group, sample, valid, ot, lane, h);
-                                nstart = g.p;
-                                nstride = g.stride;
-                            }
+                        const float4 *nstart = nullptr;            // MULTI, later chunks: the four 16-byte pieces of the next tile's partial sums
+                        int nstride = 0;
+                        if (MULTI && kc != 0) {
+                            const int tn = more ? t + 1 : t;
+                            const GOut g(args, tn >> 1, group, sample, valid, tn & 1, lane, h);
+                            nstart = g.p;
+                            nstride = g.stride;
                         }
                         const GOut pout(args, (pend_t < 0 ? 0 : pend_t) >> 1, group, sample, valid, (pend_t < 0 ? 0 : pend_t) & 1, lane, h);
                         // one k-step of operand look-ahead: the A fragments of step s + 1 are requested BEFORE the matrix instructions of step
@@ -272,7 +263,7 @@ __global__ __launch_bounds__(NW * 64) void featproj_kernel(const FeatProjArgs ar
                                 }
 #endif
                             } else if (s < 8) {
-                                if (more) {
+                                if (MULTI && kc != 0 && more) {
                                     const float4 v = nstart[(s - 4) * nstride];
                                     nxt0[4 * (s - 4)] = v.x; nxt0[4 * (s - 4) + 1] = v.y; nxt0[4 * (s - 4) + 2] = v.z; nxt0[4 * (s - 4) + 3] = v.w;
                                 }
@@ -368,13 +359,7 @@ __global__ __launch_bounds__(8 * 64) void featproj_ksplit_kernel(const FeatProjA
         auto tile_src = [&](int t) { return args.blob + args.feat_off[t >> 1] + (size_t)(t & 1) * nsteps_all * 512; };
         __syncthreads();                                       // every wave has finished with both buffers (previous sample tile)
         dma_floats(lds, tile_src(0), nsteps_all * 512, wave, lane, 8);
-        f32x16 pend, cur0, nxt0;
-        {
-            const float *bias = args.blob + args.feat_off[0] + (size_t)2 * nsteps_all * 512 + h * 16;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cur0[r] = khalf ? 0.f : bias[r];
-            nxt0 = cur0;
-        }
+        f32x16 pend;                                           // (round 5: accumulators start at zero; the bias sits in the stack kernel's fc_first image)
         int pend_t = -1;
         for (int t = 0; t < n_t; ++t) {
             const float *wl = lds + (t & 1) * FP2_BUF + khalf * (ns_lo * 512);
@@ -391,13 +376,11 @@ __global__ __launch_bounds__(8 * 64) void featproj_ksplit_kernel(const FeatProjA
             }
             const float *nsrc = tile_src(more ? t + 1 : t);
             float *ndst = lds + ((t + 1) & 1) * FP2_BUF;
-            const float4 *nstart = reinterpret_cast<const float4 *>(args.blob + args.feat_off[(more ? t + 1 : t) >> 1] + (size_t)2 * nsteps_all * 512 +
-                                                                    (((more ? t + 1 : t) & 1) * 2 + h) * 16);
             const GOut pout(args, (pend_t < 0 ? 0 : pend_t) >> 1, group, sample, valid, (pend_t < 0 ? 0 : pend_t) & 1, lane, h);
             const int n_dma = (nsteps_all * 128 + 511) / 512;  // 1 KiB pieces per wave of the next tile (<= 8)
-            f32x16 acc1 = cur0, acc2;
+            f32x16 acc1, acc2;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc1[r] = acc2[r] = 0.f;
             const unsigned wl_lds = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)wl + 16u * lane;
             h8 ah, al;
             fp_lds_read<0>(ah, wl_lds);
@@ -425,12 +408,7 @@ __global__ __launch_bounds__(8 * 64) void featproj_ksplit_kernel(const FeatProjA
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nsrc + 4 * (size_t)(base + lane)),
                                                              (__attribute__((address_space(3))) void *)(ndst + 4 * base), 16, 0, 0);
                     }
-                } else if (s < 12) {                           // the next tile's accumulator start (bias; the upper k-half starts from zero)
-                    if (more && khalf == 0) {
-                        const float4 v = nstart[s - 8];
-                        nxt0[4 * (s - 8)] = v.x; nxt0[4 * (s - 8) + 1] = v.y; nxt0[4 * (s - 8) + 2] = v.z; nxt0[4 * (s - 8) + 3] = v.w;
-                    }
-                } else {                                       // the previous tile's finished result
+                } else if (s >= 12) {                          // the previous tile's finished result
                     if (pend_t >= 0 && khalf == 0)
                         pout.store(s - 12, make_float4(pend[4 * (s - 12)], pend[4 * (s - 12) + 1], pend[4 * (s - 12) + 2], pend[4 * (s - 12) + 3]));
                 }
@@ -444,7 +422,6 @@ __global__ __launch_bounds__(8 * 64) void featproj_ksplit_kernel(const FeatProjA
                 for (int q = 0; q < 4; ++q) x[q * 64] = make_float4(pend[4 * q], pend[4 * q + 1], pend[4 * q + 2], pend[4 * q + 3]);
             }
             pend_t = t;
-            cur0 = nxt0;
         }
         dma_wait_all();
         __syncthreads();                                       // the last tile's exchange slot is written

@@ -234,9 +234,10 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
         if (idx < MOB_HID) {                                           // fc_first image: float2 per lane
             const int ot = idx >> 7, lane = (idx >> 1) & 63, e = idx & 1;
             const int o = 32 * ot + (lane & 31), h = lane >> 5;
-            if (!mob) v = 0.f;                                         // Condition16Trans: x0 comes from the projection
+            // (round 5: b0 sits in the bias slot for conditional layers too; the projection record's bias image is zero)
+            if (!mob) v = (e == 1 && h) ? ldexpf(b0[o], ex[0][o]) : 0.f;   // Condition16Trans: no rotation inputs, x0 = projection + b0
             else if (e == 0) v = ldexpf(W0[(size_t)o * ni + h], ex[0][o]);
-            else v = h ? (F ? 0.f : ldexpf(b0[o], ex[0][o])) : ldexpf(W0[(size_t)o * ni + 2], ex[0][o]);
+            else v = h ? ldexpf(b0[o], ex[0][o]) : ldexpf(W0[(size_t)o * ni + 2], ex[0][o]);
         } else if (idx < MOB_HB) {
             const int q = idx - MOB_HID, Lh = q >> 12;
             const float *W = hw[Lh];
@@ -267,11 +268,10 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const PackArgs args) {
         float *fo = args.blob + L.feat_off;
         const int w_floats = prec ? 2 * ((Fp + 15) / 16) * 512 : 2 * (Fp / 8) * 256;
         const int total = (int)featproj_packed_floats(Fp);
-        const int bias_at = w_floats;
         for (int idx = tid; idx < total; idx += nth) {
             float v = 0.f;
             if (idx < w_floats) v = featproj_image(idx, prec, W0, ni, yo, F, Fp, args.flags, ex[0]);
-            else if (idx < bias_at + 64) { const int row = bias_row(idx - bias_at); v = ldexpf(b0[row], ex[0][row]); }
+            // (bias image: zero -- see the fc_first image above)
             fo[idx] = v;
         }
     }

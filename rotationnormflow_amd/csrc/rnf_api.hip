@@ -132,7 +132,10 @@ static void pack_featproj_h(float *out, const float *W, int ldw, int col0, int F
                     lo[j] = (_Float16)((w - (float)wh) * FEAT_LO_SCALE);
                 }
             }
-    pack_bias(out + (size_t)2 * ns * 512, 2, [&](int ot, int row) { return b0[32 * ot + row]; });
+    // bias image: zeros since round 5 -- b0 rides in the bias slot of the stack kernel's fc_first image (pack_first_bias), where it costs
+    // nothing (that matrix step exists anyway); the projection kernels start every accumulator at zero (no bias loads, 16 fewer live registers)
+    (void)b0;
+    pack_bias(out + (size_t)2 * ns * 512, 2, [&](int, int) { return 0.f; });
 }
 
 static void pack_featproj(float *out, const float *W, int ldw, int col0, int F, const float *b0) {
@@ -144,7 +147,8 @@ static void pack_featproj(float *out, const float *W, int ldw, int col0, int F, 
                 float *dst = out + (((size_t)ot * ng + tg) * 64 + lane) * 4;
                 for (int c = 0; c < 4; ++c) dst[c] = W[(size_t)(32 * ot + i) * ldw + col0 + 8 * tg + 4 * h + c];
             }
-    pack_bias(out + (size_t)2 * ng * 256, 2, [&](int ot, int row) { return b0[32 * ot + row]; });
+    (void)b0;                                              // see pack_featproj_h: the bias lives in the fc_first image
+    pack_bias(out + (size_t)2 * ng * 256, 2, [&](int, int) { return 0.f; });
 }
 
 
@@ -320,13 +324,13 @@ extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b,
     // split precision: the layer is first moved to the canonical point of its ReLU-rescaling orbit (equalize.h); exact fp32: packed as given
     ScaledMlp m;
     scale_mlp(fc_first_w, ni, 3, fc_first_b, hw, hb, fc_last_w, 4 * K, prec == RNF_PREC_F16X2, m);
-    // fc_first: float2 per lane = (W0[o][h], h ? b0[o] : W0[o][2]); conditional layers carry b0 in the projection
+    // fc_first: float2 per lane = (W0[o][h], h ? b0[o] : W0[o][2]); round 5: conditional layers too (the projection record has no bias)
     for (int ot = 0; ot < 2; ++ot)
         for (int lane = 0; lane < 64; ++lane) {
             const int o = 32 * ot + (lane & 31), h = lane >> 5;
             float *dst = out + MOB_FIRST + (ot * 64 + lane) * 2;
             dst[0] = m.W0[(size_t)o * ni + h];
-            dst[1] = h ? (F ? 0.f : m.b0[o]) : m.W0[(size_t)o * ni + 2];
+            dst[1] = h ? m.b0[o] : m.W0[(size_t)o * ni + 2];
         }
     const float *shw[3] = {m.hw[0].data(), m.hw[1].data(), m.hw[2].data()};
     const float *shb[3] = {m.hb[0].data(), m.hb[1].data(), m.hb[2].data()};
@@ -408,6 +412,10 @@ static int pack_cond(const float *fc_first_w, const float *fc_first_b, const flo
     scale_mlp(fc_first_w, F, 0, fc_first_b, hw, hb, fc_last_w, n_out, prec == RNF_PREC_F16X2, m);
     const float *shw[3] = {m.hw[0].data(), m.hw[1].data(), m.hw[2].data()};
     const float *shb[3] = {m.hb[0].data(), m.hb[1].data(), m.hb[2].data()};
+    // fc_first image: no rotation inputs (zero weights); the bias slot (element 1 of lane-half 1, multiplied by the constant 1 of the second
+    // matrix step) carries b0 -- the projection G = W0 f has no bias of its own (round 5)
+    for (int ot = 0; ot < 2; ++ot)
+        for (int lane = 32; lane < 64; ++lane) out[MOB_FIRST + (ot * 64 + lane) * 2 + 1] = m.b0[32 * ot + (lane & 31)];
     pack_hidden(out, shw, shb, prec);
     // one fc_last tile: packed row 8g + 4h + c (g = 0,1) <-> output 4*(2g+h) + c (= M[2g + h][c] of the 4x4); rows >= 16 and outputs
     // >= n_out are zero
@@ -991,6 +999,10 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
                 auto kern = featproj_ksplit_kernel;
                 HIP_TRY(allow_lds(kern, FP2_LDS_BYTES));
                 hipLaunchKernelGGL(kern, dim3(grid2), dim3(8 * 64), FP2_LDS_BYTES, stream, fp);
+            } else if (pprec && F > FP_KCHUNK) {                    // F > 512: K-chunks whose partial sums pass through the scratch
+                auto kern = featproj_kernel<NW_FP, 1, true>;
+                HIP_TRY(allow_lds(kern, fl));
+                hipLaunchKernelGGL(kern, dim3(grid_p), dim3(NW_FP * 64), fl, stream, fp);
             } else if (pprec) {
                 auto kern = featproj_kernel<NW_FP, 1>;
                 HIP_TRY(allow_lds(kern, fl));
@@ -1198,6 +1210,10 @@ extern "C" int rnf_cond_mlp_forward(const float *feat, int64_t n, int32_t F, con
                 auto kp = featproj_ksplit_kernel;
                 HIP_TRY(allow_lds(kp, FP2_LDS_BYTES));
                 hipLaunchKernelGGL(kp, dim3((int)(pt2 < cus ? pt2 : cus)), dim3(8 * 64), FP2_LDS_BYTES, stream, fp);
+            } else if (F > FP_KCHUNK) {
+                auto kp = featproj_kernel<NW_FP, 1, true>;
+                HIP_TRY(allow_lds(kp, fl));
+                hipLaunchKernelGGL(kp, dim3(grid_fp), dim3(NW_FP * 64), fl, stream, fp);
             } else {
                 auto kp = featproj_kernel<NW_FP, 1>;
                 HIP_TRY(allow_lds(kp, fl));

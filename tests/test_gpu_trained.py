@@ -46,6 +46,15 @@ def test_trained_checkpoint_eval_statistic_forward_and_inverse(name, precision):
     noise = np.abs(fx["ldj32"].astype(np.float64) - fx["ldj64"])
     err = np.abs(ldj - fx["ldj64"])
     assert err.mean() <= 2 * noise.mean() + 2e-6 and err.max() <= 4 * noise.max() + 2e-5          # the gates of tests/test_gpu_parity.py
+    # ... and their per-sample form (see test_forward_matches_reference_golden for what an independent fp32 evaluation can meet)
+    per = np.maximum(1e-5, 2 * noise)
+    frac, excess = float(np.mean(err <= per)), float(np.max(err - per))
+    p99_32, p99_ref = float(np.quantile(np.abs(ldj - fx["ldj32"].astype(np.float64)), 0.99)), float(np.quantile(noise, 0.99))
+    print(f"{name} [{precision}]: per-sample pass {frac:.4f}, worst excess {excess:.1e}, p99 vs ref32 {p99_32:.1e} (reference's own {p99_ref:.1e})")
+    if precision == "f16x2":
+        assert frac >= 0.985 and excess <= noise.max() + 1e-5 and p99_32 <= p99_ref + 1e-5, (frac, excess, p99_32, p99_ref)
+    else:
+        assert frac >= 0.88 and excess <= 2 * noise.max() + 1e-5 and p99_32 <= 1.5 * p99_ref + 1e-5, (frac, excess, p99_32, p99_ref)
     rnoise = np.abs(fx["rot32"].astype(np.float64) - fx["rot64"]).max()
     assert np.abs(Rt - fx["rot64"]).max() <= 4 * rnoise + 1e-5
     # inverse pass on base samples (agent.py:238-263), in bisection cells
@@ -149,7 +158,22 @@ def test_trained_checkpoint_at_full_batch_runs_on_the_fast_path(name):
     with torch.no_grad():
         Rt, ldj = flow(R[:m], None if feat is None else feat[:m])
         Rb, ldjb = flow.inverse(Rt, None if feat is None else feat[:m])
-    assert (Rb - R[:m]).abs().mean().item() < 1e-3 and (ldj + ldjb).abs().mean().item() < 5e-3
+    # The inverse lands on the reference's bisection grid (cells of pi / 2^15 per layer) and the layers behind a cell stretch it by their
+    # Jacobians -- uniform rotations are far from the modes these densities were trained on, where the stretch is largest -- so the gate is
+    # the REFERENCE's own round trip (the oracle in fp32 arithmetic, forward then inverse) on the first rows, not a constant: 8-layer flows
+    # sit at 2e-4, the 24-layer SYMSOL structure at 1.7e-3.
+    from oracle import flow_oracle as orc
+    k = 256
+    Rk = R[:k].cpu().numpy()
+    fk = None if feat is None else feat[:k].cpu().numpy()
+    oR, ol = orc.flow_forward(cfg, w, Rk, fk, dtype=torch.float32)
+    oRb, olb = orc.flow_inverse(cfg, w, oR.numpy(), fk, dtype=torch.float32)
+    ref_rt = (oRb - torch.from_numpy(Rk)).abs().mean().item()
+    ref_ld = (ol + olb).abs().mean().item()
+    got_rt, got_ld = (Rb[:k] - R[:k]).abs().mean().item(), (ldj[:k] + ldjb[:k]).abs().mean().item()
+    print(f"{name}: round trip {got_rt:.2e} (reference arithmetic {ref_rt:.2e}), log-det {got_ld:.2e} ({ref_ld:.2e}); all 2^16 rows {(Rb - R[:m]).abs().mean().item():.2e}")
+    assert got_rt <= 2.0 * ref_rt + 1e-4 and got_ld <= 2.0 * ref_ld + 5e-4, (got_rt, ref_rt, got_ld, ref_ld)
+    assert (Rb - R[:m]).abs().mean().item() <= 3.0 * ref_rt + 2e-4 and (ldj + ldjb).abs().mean().item() <= 3.0 * ref_ld + 1e-3
 
 
 @pytest.mark.parametrize("flat", [True, False])

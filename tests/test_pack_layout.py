@@ -60,14 +60,16 @@ def test_conditional_mobius_record_and_feature_projection(F):
 
 @pytest.mark.parametrize("F", [8, 40, 256])
 def test_split_precision_feature_projection(F):
-    """f16x2 feature-projection image (k-steps of 16, zero padded) reproduces W0[:, 3:] f + b0."""
+    """f16x2 feature-projection image (k-steps of 16, zero padded) reproduces W0[:, 3:] f; the bias b0 sits -- with the same per-row power of
+    two -- in the bias slot of the fc_first image of the layer record (round 5: the projection kernels start their accumulators at zero)."""
     K = 8
     m = _filled_mlp(3 + F, 4 * K, seed=200 + F)
     rec, frec = runtime.pack_mobius(_lib.lib(), m, K, F, _lib.PREC_F16X2)
     feat = synth.features(32, F, seed=9)
     g = emu.featproj_from_record_h(frec, feat.astype(np.float64), F)
     W0 = m.fc_first.weight.detach().double().numpy()
-    want = feat.astype(np.float64) @ W0[:, 3:].T + m.fc_first.bias.detach().double().numpy()      # [32, 64]
+    want = feat.astype(np.float64) @ W0[:, 3:].T                                                  # [32, 64]
+    b0 = m.fc_first.bias.detach().double().numpy()
     # the packer scales row i of the projection (with x0_i) by a power of two (csrc/equalize.h): recover it per row, then compare
     got = np.zeros_like(want)
     for ot in range(2):
@@ -78,6 +80,8 @@ def test_split_precision_feature_projection(F):
         e = np.log2(got[k, i] / want[k, i])
         assert abs(e - round(e)) < 1e-4, (i, e)
         assert np.abs(got[:, i] * 2.0 ** -round(e) - want[:, i]).max() < 3e-6 * max(1.0, np.abs(want).max())
+        ot, lane = i // 32, 32 + i % 32                           # fc_first image: float2 per lane, element 1 of lane-half 1 = the bias slot
+        assert abs(float(rec[(ot * 64 + lane) * 2 + 1]) * 2.0 ** -round(e) - b0[i]) < 1e-6 * max(1.0, abs(b0[i])), i
 
 
 def test_cond16_record_yields_matrix_rows_on_lane_halves():

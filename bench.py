@@ -85,8 +85,15 @@ WORKLOADS = {
                 bytes=36 + 36 + 4 + 4 * 512 // 512 + 36 // 512 + 1,
                 text="pose estimation as the reference runs it (agent.py:238-283): per image feature (F=512, 2048 images) 512 base samples from "
                      "MF(diag(5,3,1)) through the inverse of the 42-layer conditional flow, log p = base - ldj, arg-max rotation per image"),
+    # Weights the REFERENCE's own training produced (tests/golden/make_trained.py: its Flow under torch.optim.Adam) at the headline structures:
+    # the VALU-bound forward kernels are data independent, the inverse root finder's pass count is not -- both directions are timed.
+    "C2t": dict(preset="C2", direction="forward", fisher=False, flop=24 * 57_728, bytes=36 + 4, weights="tests/golden/trained_c2.pth",
+                also_inverse=True, text="the C2 structure with reference-trained weights (trained_c2.pth), forward log_prob and inverse pass"),
+    "C4t": dict(preset="C4", direction="forward", fisher=False, flop=24 * 90_496 + 59_392, bytes=36 + 4 * 256 + 4,
+                weights="tests/golden/trained_c4.pth", features="tests/golden/trained_c4.npz", also_inverse=True,
+                text="the C4 structure with reference-trained weights (trained_c4.pth) and the features it was trained on (one class un-normalised)"),
 }
-ALL_CONFIGS = ["C2", "C1", "C3", "C4", "C5", "C5u", "C4q", "C5q"]
+ALL_CONFIGS = ["C2", "C1", "C3", "C4", "C5", "C5u", "C4q", "C5q", "C2t", "C4t"]
 PMC_GROUPS = {
     "fetch": "FETCH_SIZE",
     "write": "WRITE_SIZE",
@@ -116,7 +123,7 @@ def self_launch(args, argv):
     return child.returncode
 
 
-def build_flow(device, preset):
+def build_flow(device, preset, weights_path=None):
     import torch
     from rotationnormflow_amd import make_config, synth
     from rotationnormflow_amd.flow.flow import Flow
@@ -124,7 +131,13 @@ def build_flow(device, preset):
     with contextlib.redirect_stdout(io.StringIO()):
         fl = Flow(cfg)
     shapes = {k: tuple(v.shape) for k, v in fl.state_dict().items()}
-    weights = synth.fill_state_dict(shapes, seed=2024, regime="trained")
+    if weights_path:                                          # a checkpoint in Agent.save_ckpt's layout (agent.py:139-152)
+        from rotationnormflow_amd.harness import load_reference_checkpoint
+        sd = load_reference_checkpoint(weights_path if os.path.isabs(weights_path) else os.path.join(ROOT, weights_path))
+        weights = {k: v.numpy() for k, v in sd.items()}
+        assert {k: tuple(v.shape) for k, v in weights.items()} == shapes, "checkpoint does not fit the workload's flow"
+    else:
+        weights = synth.fill_state_dict(shapes, seed=2024, regime="trained")
     fl.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
     return cfg, weights, fl.to(device).eval()
 
@@ -198,16 +211,19 @@ def cpu_baseline(cfg, weights, A, wl, feat_dim, sizes, budget_s, queries=None):
 class Workload:
     """Flow, inputs (resident in HBM) and the step of one BASELINE config on ``device``."""
 
-    def __init__(self, name, device, batch_log2=None, rank=0, world=1, share=None):
+    def __init__(self, name, device, batch_log2=None, rank=0, world=1, share=None, weights_path=None):
+        import numpy as np
         import torch
         from rotationnormflow_amd import synth
         from rotationnormflow_amd.utils.fisher import MatrixFisherN
         self.name, self.device, self.wl = name, device, WORKLOADS[name]
         wl = self.wl
-        if share is not None and share.wl["preset"] in ("C2", "C3") and wl["preset"] in ("C2", "C3"):
+        self.weights_path = weights_path or wl.get("weights")
+        if (share is not None and share.wl["preset"] in ("C2", "C3") and wl["preset"] in ("C2", "C3") and not self.weights_path
+                and not share.weights_path):
             self.cfg, self.weights, self.fl = share.cfg, share.weights, share.fl      # C2 and C3: the same flow and weights
         else:
-            self.cfg, self.weights, self.fl = build_flow(device, wl["preset"])
+            self.cfg, self.weights, self.fl = build_flow(device, wl["preset"], self.weights_path)
         self.strong = bool(wl.get("strong"))
         log2n = batch_log2 if batch_log2 is not None else wl.get("batch_log2", 20)
         self.A = synth.fisher_A("diag531")
@@ -237,8 +253,12 @@ class Workload:
             # precomputed features ~ N(0, 1) [N, F] drawn on the device (2 GB for C5: a host generator would take longer than the bench)
             gen.manual_seed(fseed)
             per = self.queries or 1
-            full = torch.randn(((skip + self.n) // per, self.feat_dim), generator=gen, device=device, dtype=torch.float32)
-            self.feat = full[skip // per:].contiguous()
+            if wl.get("features"):                             # the feature rows a trained checkpoint was fitted on, repeated over the batch
+                rows = torch.from_numpy(np.load(os.path.join(ROOT, wl["features"]))["test_feat"]).to(device)
+                self.feat = rows[(torch.arange(self.n, device=device) + skip) % rows.shape[0]].contiguous()
+            else:
+                full = torch.randn(((skip + self.n) // per, self.feat_dim), generator=gen, device=device, dtype=torch.float32)
+                self.feat = full[skip // per:].contiguous()
 
     def evaluate(self):
         import torch
@@ -602,6 +622,19 @@ def measure(w, args, dist, pmc, steps, warmup, want_secondary, want_parity, cpu_
            "roofline": roofline_of(w, used, kernel_ms, pmc),
            "hbm": {"achieved": w.wl["bytes"] * w.n / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                    "frac": w.wl["bytes"] * w.n / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, "algorithmic_bytes_per_rotation": w.wl["bytes"]}}
+    if w.weights_path:
+        rec["weights"] = os.path.basename(w.weights_path)
+    if w.wl.get("also_inverse"):                             # the inverse pass of the same flow on the same rows (root-finder passes depend on the weights)
+        with torch.no_grad():
+            for _ in range(3):
+                w.fl.inverse(w.R, w.feat)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                w.fl.inverse(w.R, w.feat)
+            torch.cuda.synchronize()
+        rec["ms_per_step_inverse"] = (time.perf_counter() - t0) / steps * 1e3
+        rec["fallback_fired"] = bool(__import__("rotationnormflow_amd").runtime.fallback_fired(w.device))
     secondary = None
     if want_secondary and used == "f16x2":
         set_precision("fp32")
@@ -710,6 +743,7 @@ def _sig(x, digits=6):
     return x
 
 
+THIN_CONFIGS = ("C3", "C2t", "C4t")
 COMPACT_LIMIT = 3000                      # bytes; the driver keeps ~8 KB of stdout tail and parses the LAST line (BENCH_r04: a 40 KB line was lost)
 ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms", "traffic", "traffic_algorithmic", "valu_issue_frac",
              "matrix_pipe_frac")
@@ -720,14 +754,14 @@ def compact_record(out, full_path=None):
     c = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                     "dtype", "data"))
     cfg = dict(out["config"])
-    cfg["workload"] = cfg["workload"][:110]
+    cfg["workload"] = cfg["workload"][:100]
     c["config"] = cfg
     c.update(_pick(out, ("rccl_ranks", "backend", "value_fp32_exact", "ms_per_step_fp32_exact", "mean_nll")))
     if "roofline" in out:
         c["roofline"] = _pick(out["roofline"], ROOF_KEYS)
     if "cpu_baseline" in out:
         c["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "cpu"))
-        c["cpu_baseline"]["sample"] = out["cpu_baseline"].get("sample", "")[:70]
+        c["cpu_baseline"]["sample"] = out["cpu_baseline"].get("sample", "")[:60]
         c["vs_cpu_baseline"] = out.get("vs_cpu_baseline")
     if "parity" in out:
         c["parity"] = _pick(out["parity"], ("mean_abs_err_of_the_mean", "max_abs_err"))
@@ -737,20 +771,23 @@ def compact_record(out, full_path=None):
     small = {}
     for name, r in out.get("configs", {}).items():
         if name == "train":
-            small[name] = _pick(r, ("ms_per_iteration", "ms_per_iteration_hip_graph", "ms_per_iteration_per_tensor_parameters"))
+            small[name] = _pick(r, ("ms_per_iteration", "ms_per_iteration_hip_graph"))
             continue
-        e = _pick(r, ("value", "ms_per_step", "value_fp32_exact"))
+        thin = name in THIN_CONFIGS
+        e = _pick(r, ("value", "ms_per_step", "ms_per_step_inverse") if thin else ("value", "ms_per_step", "value_fp32_exact"))
         roof = r.get("roofline", {})
-        e.update(_pick(roof, ("frac", "valu_issue_frac", "matrix_pipe_frac")))
-        if roof.get("traffic") and roof.get("traffic_algorithmic"):
-            e["traffic_x"] = roof["traffic"] / roof["traffic_algorithmic"]
+        if not thin:                       # (C3 runs C2's kernel; the trained-weights entries are about time and parity)
+            e.update(_pick(roof, ("frac", "valu_issue_frac", "matrix_pipe_frac")))
+            if roof.get("traffic") and roof.get("traffic_algorithmic"):
+                e["traffic_x"] = roof["traffic"] / roof["traffic_algorithmic"]
         if "parity" in r:
             e["parity_max"] = r["parity"].get("max_abs_err")
-        if "weights" in r:
-            e["weights"] = r["weights"]
+        for k in ("value", "value_fp32_exact"):            # whole rotations per second: shorter than a float and exact enough at 3 digits
+            if k in e:
+                e[k] = int(float(f"{e[k]:.3g}"))
         small[name] = e
     if small:
-        c["configs"] = _sig(small, 4)
+        c["configs"] = _sig(small, 3)
     if full_path:
         c["full_record"] = full_path
     c = _sig(c, 5)
@@ -799,6 +836,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="headline workload only")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes")
     ap.add_argument("--save-pmc", default=None, metavar="DIR", help="also write the live PMC summary to DIR/pmc_live.json (profiles/<round>/)")
+    ap.add_argument("--weights", default=None, metavar="CKPT", help="load the headline workload's flow from this checkpoint (Agent.save_ckpt "
+                    "layout, e.g. tests/golden/trained_c2.pth) instead of the recipe weights")
     ap.add_argument("--full-out", default=None, metavar="PATH", help="where the full record goes (default: bench_full.json beside bench.py); "
                     "stdout carries it on a `BENCH_FULL ` line and ends with the compact record")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -866,7 +905,7 @@ def main():
     torch.cuda.set_device(device)
 
     want_host = world == 1 and not args.no_cpu_baseline
-    w = Workload(headline, device, args.batch_log2, rank, world)
+    w = Workload(headline, device, args.batch_log2, rank, world, weights_path=args.weights)
     if w.feat is not None and distributed:
         from rotationnormflow_amd.dist import calibrate_feature_scale
         calibrate_feature_scale(w.fl, w.feat)                 # one calibration for all ranks: identical packed images (dist.py)
@@ -883,7 +922,8 @@ def main():
         c_steps = 6 if name == "C3" else 10
         # bounded host legs for the secondary configs: N = 4096 (1024 for the inverse passes, which the oracle runs at ~2e3 rotations/s)
         sizes = ((4096,) if w.wl["direction"] == "forward" else (1024,)) if want_host else None
-        configs[name] = measure(w, args, None, pmc, c_steps, 3, not args.no_secondary, want_host, sizes, 10.0, blocks=2)
+        second = not args.no_secondary and not w.weights_path      # (the trained-weights entries: default arithmetic, both directions)
+        configs[name] = measure(w, args, None, pmc, c_steps, 3, second, want_host, sizes, 10.0, blocks=2)
     if full and rank == 0:
         w.R = w.feat = None
         torch.cuda.empty_cache()

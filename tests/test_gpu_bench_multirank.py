@@ -11,7 +11,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ALL_SECONDARY = ["C1", "C3", "C4", "C5", "C5u", "C4q", "C5q"]      # C4q / C5q: the reference's own conditional evaluation shape (shared feature rows)
+# C4q / C5q: the reference's own conditional evaluation shape (shared feature rows); C2t / C4t: reference-trained checkpoints
+ALL_SECONDARY = ["C1", "C3", "C4", "C5", "C5u", "C4q", "C5q", "C2t", "C4t"]
 
 
 def _run(cmd, env, timeout=400):
@@ -109,7 +110,7 @@ def test_single_gpu_line_carries_both_arithmetics_and_every_config_runs():
     assert short["full_record"] == "bench_full.json"
     with open(os.path.join(ROOT, "bench_full.json")) as fh:
         assert json.load(fh)["value"] == rec["value"]
-    for cfg in ("C1", "C4", "C5", "C5u", "C4q", "C5q"):
+    for cfg in ("C1", "C4", "C5", "C5u", "C4q", "C5q", "C4t"):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "1", "--warmup", "1", "--batch-log2", "14",
                               "--no-cpu-baseline", "--no-secondary", "--no-pmc"], cwd=ROOT, capture_output=True, text=True, timeout=400)
         assert out.returncode == 0, (cfg, out.stderr[-2000:])
@@ -183,8 +184,13 @@ def test_full_line_carries_every_config_with_live_counters():
     assert short["roofline"]["traffic"] > 0 and 0.0 < short["roofline"]["valu_issue_frac"] <= 1.0 and short["cpu_baseline"]["value"] > 0
     assert sorted(short["configs"]) == sorted(rec["configs"])
     for name in ALL_SECONDARY:
-        assert short["configs"][name]["value"] > 0 and short["configs"][name]["traffic_x"] > 0 and "parity_max" in short["configs"][name], name
+        assert short["configs"][name]["value"] > 0 and "parity_max" in short["configs"][name], name
+        if name not in ("C3", "C2t", "C4t"):                      # (bench.THIN_CONFIGS: value / time / parity only in the compact line)
+            assert short["configs"][name]["traffic_x"] > 0 and 0.0 < short["configs"][name]["valu_issue_frac"] <= 1.0, name
     assert short["configs"]["train"]["ms_per_iteration"] > 0
+    for name in ("C2t", "C4t"):                                   # reference-trained weights: both directions timed, the range guard quiet
+        assert rec["configs"][name]["weights"].startswith("trained_c") and rec["configs"][name]["ms_per_step_inverse"] > 0
+        assert rec["configs"][name]["fallback_fired"] is False and short["configs"][name]["ms_per_step_inverse"] > 0
     tr = rec["configs"].pop("train")
     assert 0.0 < tr["ms_per_iteration"] < tr["ms_per_iteration_per_tensor_parameters"] and tr["ms_per_iteration_hip_graph"] > 0.0
     for name, c in [("C2", rec)] + sorted(rec["configs"].items()):
@@ -192,7 +198,8 @@ def test_full_line_carries_every_config_with_live_counters():
         assert r["traffic"] is not None and r["traffic"] > 0, (name, r.get("traffic_source"))
         assert 0.0 < r["valu_issue_frac"] <= 1.0 and 0.0 <= r["matrix_pipe_frac"] <= 1.0, name
         assert r["kernels"] and "flow_stack_kernel" in r["kernel"] or "featproj" in r["kernel"], name
-        assert c["secondary"]["roofline"]["traffic"] is not None, name
+        if name not in ("C2t", "C4t"):                            # (the trained-weights entries run the default arithmetic only)
+            assert c["secondary"]["roofline"]["traffic"] is not None, name
         assert c["parity"]["mean_abs_err_of_the_mean"] < 2e-5 and "reference_fp32" in c["parity"], name
         assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["value"] > 0, name
     # the conditional configs' steps are made of a projection pre-pass and the stack kernel

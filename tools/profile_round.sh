@@ -1,5 +1,5 @@
 #!/bin/bash
-# Evidence for profiles/<round>/ (round 4).  The driver's bench line now carries every BASELINE config and collects its own counters
+# Evidence for profiles/<round>/ (rounds 4-5).  The driver's bench line now carries every BASELINE config and collects its own counters
 # (bench.py runs the FETCH_SIZE / WRITE_SIZE / SQ rocprofv3 passes as children of the run, each group in its own process, as
 # MI355X_MICROARCH.md prescribes), so this script only adds what the line does not hold: the rocprofv3 --kernel-trace --stats summaries of the
 # same per-config commands, the kernel resource table, training numbers, phase stamps.
@@ -10,11 +10,15 @@ OUT=$REPO/gpurun_out/${1:-round}
 mkdir -p $OUT
 # 1. the default invocation, exactly as the driver runs it (+ the live PMC summary kept as pmc_live.json: bench.py replays it only if rocprofv3
 #    is missing on a box AND the kernel sources are unchanged)
-python3 bench.py --save-pmc $OUT > $OUT/bench_default.json 2> $OUT/bench.err
+#    bench_default.json = the FULL record (the BENCH_FULL line / bench_full.json); bench_compact.json = the last stdout line the driver parses
+python3 bench.py --save-pmc $OUT --full-out $OUT/bench_default.json > $OUT/bench_stdout.txt 2> $OUT/bench.err
+tail -n 1 $OUT/bench_stdout.txt > $OUT/bench_compact.json
+rm -f $OUT/bench_stdout.txt
 # 2. kernel-trace statistics of the per-config commands (no PMC in these runs: timing and counters are never mixed)
 cd /tmp && export TMPDIR=/tmp
-for c in C1 C2 C3 C4 C5 C5u; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$c -o run -- python3 $REPO/bench.py --config $c --steps 10 --warmup 5 --no-cpu-baseline --no-secondary --no-pmc > $OUT/bench_${c}_under_rocprofv3.json 2> $OUT/stats_$c.err
+for c in C1 C2 C3 C4 C5 C5u C4q C5q; do
+  # (the bench lines of these profiled runs are not kept: their times include the profiler; the kernel statistics are what is read)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$c -o run -- python3 $REPO/bench.py --config $c --steps 10 --warmup 5 --no-cpu-baseline --no-secondary --no-pmc --full-out /dev/null > /dev/null 2> $OUT/stats_$c.err
   find $OUT/stats_$c -name "*kernel_stats.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_$c.csv \;
   rm -rf $OUT/stats_$c
 done
@@ -35,8 +39,9 @@ rm -rf $OUT/stats_train
 # 4. phase stamps of the forward stack kernels, parity / inverse statistics
 python3 tools/phase_stamps.py --preset C2 > $OUT/stamps_C2.txt 2>&1
 python3 tools/phase_stamps.py --preset C4 > $OUT/stamps_C4.txt 2>&1
-python3 tools/parity_stats.py > $OUT/parity_stats.jsonl 2>/dev/null
+python3 tools/parity_stats.py --all-forward > $OUT/parity_stats.jsonl 2>/dev/null
 python3 tools/inverse_stats.py > $OUT/inverse_stats.jsonl 2>/dev/null
+# (the kernel resource table needs no GPU: `python tools/kernel_resources.py > profiles/<round>/kernel_resources.txt` in the build container)
 find $OUT -name "*.csv" -size +1M -delete
 find $OUT -name "*.db" -delete
 ls $OUT

@@ -45,6 +45,9 @@ struct FlowArgs {
     int n_layers;
     int KT;                   // fc_last tiles = ceil(segments / 8)
     int K;                    // segments of the Moebius layers (pad segments of the last tile are masked when K % 8 != 0)
+    float min_wsum;           // kMinWeightSum * K, set by the launcher: a kernel argument stays in a scalar register (computed in the kernel it was a
+                              // loop-invariant VECTOR register that the 128-register instantiations spilled and reloaded -- behind an s_waitcnt vmcnt(0)
+                              // that also waited for the LDS-DMA just issued -- in every layer finish)
     int tab_off;              // >= 0 (DMA staging): float offset in LDS of two AFF_TABLE_LDS_STRIDE-float buffers for constant-affine blocks
     // Range guard of the split-precision kernels (an fp16 operand beyond 65504 turns into inf and the sample's log-det into NaN):
     //   guard_mode 1: set guard[0] when a sample ends with a non-finite log-det or rotation;
@@ -377,6 +380,14 @@ struct Fair {
     }
 };
 
+// The instantiations that never run the governor (every one but the general 8-wave forward split-precision kernel) carry none of its code:
+// compiled in behind a run-time `off < 0` test it still cost the 128-register kernels live address registers around every tick.
+struct NoFair {
+    // (the tick points stay scheduling fences: without them the scheduler interleaves the hidden layers more freely and the 128-register
+    // instantiations spill three times as much)
+    __device__ __forceinline__ void tick() { __builtin_amdgcn_sched_barrier(0); }
+};
+
 // The two precisions behind one interface: Act = what the hidden stack hands to fc_last.
 template <int PREC>
 struct Mlp;
@@ -385,9 +396,9 @@ template <>
 struct Mlp<0> {
     struct Act { f32x16 t[2]; };
     // g: this wave's feature-projection fragments for the layer (global memory), or nullptr for an unconditional layer
-    template <class GF, bool KEEPX0 = false>
+    template <class GF, bool KEEPX0 = false, class FairT = Fair>
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
-                                                const GF &g, Act &out, Fair &, bool &, const f32x16 * = nullptr) {
+                                                const GF &g, Act &out, FairT &, bool &, const f32x16 * = nullptr) {
         f32x16 cinit[2];
         if (g) {
             cinit[0] = g.load(0, lane, h);
@@ -443,9 +454,9 @@ struct Mlp<1> {
             }
         }
     }
-    template <class GF, bool KEEPX0 = false>
+    template <class GF, bool KEEPX0 = false, class FairT = Fair>
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
-                                                const GF &g, Act &out, Fair &fair, bool &bad, const f32x16 *pre = nullptr) {
+                                                const GF &g, Act &out, FairT &fair, bool &bad, const f32x16 *pre = nullptr) {
         const float bA = h ? y1 : y0;
         const float bB = h ? 1.0f : y2;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -669,9 +680,9 @@ __device__ __forceinline__ void tile_pipe_h_off(const float *base, int woff, int
     tile_step_h<0, SAFE>(rec, 0, nxt, ah, al, tt, cur, seg, c, S, A, J);
 }
 
-template <int PREC, bool PINGPONG = false, bool FASTSP = PINGPONG>
+template <int PREC, bool PINGPONG = false, bool FASTSP = PINGPONG, class FairT = Fair>
 __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int K, int lane, int h, const typename Mlp<PREC>::Act &tt,
-                                                 const MobiusCtx &c, float &S, float &A, float &J, Fair &fair) {
+                                                 const MobiusCtx &c, float &S, float &A, float &J, FairT &fair) {
     const float *rec = lds + MOB_LAST;
     if constexpr (PREC == 0) {
         f32x16 bufA = last_tile(rec, lane, h, tt.t), bufB;
@@ -1294,7 +1305,14 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     const int KT = args.KT;                                          // DIR = 1: <= KT_INV, the capacity of this instantiation
     const int n_layers = args.n_layers;
     double dsum = 0.0;                                               // wave-uniform running sum of log p (kept in scalar registers)
-    Fair fair{lds, wave, args.fair_off, 0};
+    #ifdef RNF_V_NOFAIR
+    constexpr bool FAIR_ON = NW == 8 && DIR == 0 && PREC == 1 && (LEAN == 0 || FUSED);
+#else
+    constexpr bool FAIR_ON = true;
+#endif      // the launcher sets fair_off >= 0 for these only
+    typedef typename std::conditional<FAIR_ON, Fair, NoFair>::type FairT;
+    FairT fair;
+    if constexpr (FAIR_ON) fair = Fair{lds, wave, args.fair_off, 0};
     RNF_STAMP_DECL
 
     // iteration position -> layer index, and the next position (> pos) whose layer owns an MLP image, or -1
@@ -1332,7 +1350,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     int seq = 0;                                                      // MLP layers this wave has been through (across tiles)
     int tab_parity = -1;                                              // >= 0: the next affine layer's block sits in LDS buffer tab_parity
 
-    if (args.fair_off >= 0 && tid < NW) reinterpret_cast<int *>(lds + args.fair_off)[tid] = 0;
+    if (FAIR_ON && args.fair_off >= 0 && tid < NW) reinterpret_cast<int *>(lds + args.fair_off)[tid] = 0;
     if (PIPE && first_mlp >= 0) {                                  // prologue: image of the first MLP layer
         const int2 d = args.layers[layer_at(first_mlp)];
         dma_floats(lds, args.blob + d.y, MOB_HEAD_FLOATS, wave, lane, NW);
@@ -1349,7 +1367,16 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     // is in its VALU-bound segment phase -- be worth?
     if (wave >= NW / 2) for (int i_ = 0; i_ < RNF_KO_STAGGER; ++i_) __builtin_amdgcn_s_sleep(64);
 #endif
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Tile order.  Default: workgroup b takes tiles b, b + grid, ...  ROWS (shared feature rows): XCD-AWARE -- workgroups are dealt to the 8
+    // XCDs round-robin (`blockIdx.x % 8` labels the workgroups that share an XCD and its L2, MI355X_MICROARCH.md "Workgroup dispatch"), and
+    // the per-(layer, row) records of consecutive rotations are the same few cache lines, so XCD-mate x takes the x-th CONTIGUOUS eighth of
+    // the tiles: each L2 then holds one eighth of the row records (C4q: 1.6 MB of 13 MB) instead of all of them, every XCD for itself.
+    // A pure placement choice: a rotation's result does not depend on the tile order (grids that are no multiple of 8 keep the default).
+    const bool xcd_order = ROWS && (gridDim.x & 7) == 0;
+    const long long tiles_per_xcd = (ntiles + 7) >> 3;
+    const long long tile_end = xcd_order ? min(ntiles, (long long)((blockIdx.x & 7) + 1) * tiles_per_xcd) : ntiles;
+    const long long tile_step = xcd_order ? (gridDim.x >> 3) : gridDim.x;
+    for (long long tile = xcd_order ? (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3) : blockIdx.x; tile < tile_end; tile += tile_step) {
         const long long group = tile * NW + wave;                 // 32-sample group index inside this launch
         const long long sample0 = group * TILE_SAMPLES;           // wave uniform
         const bool valid = sample0 + j < args.n;
@@ -1360,7 +1387,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             asm volatile("" : "+v"(jj));
             return sample0 + jj;
         };
-        const bool more_tiles = tile + gridDim.x < ntiles;
+        const bool more_tiles = tile + tile_step < tile_end;
         int g_row0 = 0, g_rem0 = 0;                               // ROWS: feature row of the wave's first rotation, its position inside the row
         if constexpr (ROWS) {                                     // (wave uniform; the host keeps sample_base + n below 2^31 for these launches)
             const unsigned s0 = (unsigned)(args.sample_base + sample0), gd = (unsigned)args.g_div;
@@ -1428,7 +1455,9 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 }
 #endif
                 if (PIPE && tab_parity >= 0) {                    // block staged in LDS together with the previous layer's fc_last image
-                    affine16_table_apply_pair(lds + args.tab_off + AFF_TABLE_LDS_STRIDE * tab_parity, h, R, ldj);
+                    int ht = h;                                   // (re-derived here: hoisted out of the layer loop, the lane's table address is a
+                    if constexpr (LEAN != 1) asm volatile("" : "+v"(ht));      // register the 128-register conditional instantiations spill)
+                    affine16_table_apply_pair(lds + args.tab_off + AFF_TABLE_LDS_STRIDE * tab_parity, ht, R, ldj);
                     tab_parity = -1;
                 } else {                                          // scalar loads (one ~2 us round trip per layer: 104 floats do not fit the SGPRs at once)
                     affine16_table_apply(params + (DIR ? AFF_TABLE_INV : AFF_TABLE_FWD), R, ldj);
@@ -1513,11 +1542,13 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
 
             MobiusCtx ctx;
             typename Mlp<PREC>::Act tt;
+            int hh = h;                                           // (see `ht` above: the bias offsets of the hidden layers are re-derived per layer)
+            if constexpr (LEAN == 2 && NW == 16) asm volatile("" : "+v"(hh));
             if (LEAN == 1 || kind == RNF_KIND_MOBIUS) {
                 mobius_begin<DIR, DIR == 0 && PREC == 1>(R, perm_row, ctx);
-                Mlp<PREC>::template head<GF, KEEP_X0>(lds, lane, h, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair, bad, have_gpre ? gpre : nullptr);
+                Mlp<PREC>::template head<GF, KEEP_X0, FairT>(lds, lane, hh, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair, bad, have_gpre ? gpre : nullptr);
             } else {
-                Mlp<PREC>::template head<GF, KEEP_X0>(lds, lane, h, 0.f, 0.f, 0.f, gfrag, tt, fair, bad, have_gpre ? gpre : nullptr);
+                Mlp<PREC>::template head<GF, KEEP_X0, FairT>(lds, lane, hh, 0.f, 0.f, 0.f, gfrag, tt, fair, bad, have_gpre ? gpre : nullptr);
             }
             have_gpre = false;
             RNF_STAMP(1)                                          // 1: frame + hidden layers (H part)
@@ -1588,14 +1619,14 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     // the image still has the whole hidden-layer phase of the next layer to land
                     b2_sync();
                     mobius_inv_finish<KTI>(ctx, sg, S, R, ldj, istash, KTI == 16 ? 4 * max(KT - KTI, 0) : 0, lane,
-                                           kMinWeightSum * (float)args.K, fastsp, bad);
+                                           args.min_wsum, fastsp, bad);
                     b2_issue();
                 } else {
                     float S = 0.f, A = 0.f, J = 0.f;
-                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC, LEAN == 1, LEAN != 0>(lds, KT, args.K, lane, h, tt, ctx, S, A, J, fair);
+                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC, LEAN == 1, LEAN != 0, FairT>(lds, KT, args.K, lane, h, tt, ctx, S, A, J, fair);
                     else mobius_fwd_tiles_restage<PREC>(lds, params, KT, args.K, lane, h, tt, ctx, S, A, J, tid, NT);
                     barrier2();
-                    mobius_fwd_finish<PREC == 1, LEAN != 0 && PREC == 1>(ctx, S, A, J, R, ldj, bad, kMinWeightSum * (float)args.K);
+                    mobius_fwd_finish<PREC == 1, LEAN != 0 && PREC == 1>(ctx, S, A, J, R, ldj, bad, args.min_wsum);
                 }
             } else {
                 const f32x16 o16 = Mlp<PREC>::last(lds + MOB_LAST, lane, h, tt);

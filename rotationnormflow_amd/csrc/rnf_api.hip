@@ -896,6 +896,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     a.n_layers = n_layers;
     a.KT = KT;
     a.K = K;
+    a.min_wsum = kMinWeightSum * (float)K;
     a.side = o.side;
     a.side_n = n;
     a.states = o.states;

@@ -221,21 +221,27 @@ def _c4_inputs(n=1 << 13):
 
 
 def _c4_eval_worker(rank, world, port, q):
+    import traceback
     import torch.distributed as dist
-    from rotationnormflow_amd.dist import flow_evaluator, shard_bounds, sharded_mean_nll
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.set_num_threads(2)                                  # eight ranks share the box's host cores
     try:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        from rotationnormflow_amd.dist import flow_evaluator, shard_bounds, sharded_mean_nll
         fl = _c4_small()
         R, F = _c4_inputs()
         lo, hi = shard_bounds(R.shape[0], rank, world)
-        nll, tot = sharded_mean_nll(flow_evaluator(fl), R.cuda(), F.cuda(), rank, world)      # calibrates once for all ranks, one all-reduce
-        with torch.no_grad():
+        with torch.no_grad():                                 # (evaluation: with grad enabled log_prob takes the differentiable training path)
+            nll, tot = sharded_mean_nll(flow_evaluator(fl), R.cuda(), F.cuda(), rank, world)  # calibrates once for all ranks, one all-reduce
             rows = fl.log_prob(R[lo:hi].cuda(), F[lo:hi].cuda())["logp"].cpu().numpy()
         q.put((rank, (float(nll), tot.cpu().numpy(), rows, float(fl._feature_ms_fixed))))
+    except Exception:                                         # a rank that dies silently would leave the parent waiting on the queue
+        q.put((rank, ("error", traceback.format_exc())))
     finally:
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
+@pytest.mark.timeout(900)
 def test_eight_ranks_evaluate_a_conditional_flow_bit_equal_to_one_rank():
     """dist.calibrate_feature_scale + a conditional flow at world 8 on the shared-GPU rig: every rank packs the SAME images (one all-reduced
     calibration, although rank 0's shard has features 30x larger than the others'), so each shard's rows equal the 1-rank evaluation of the
@@ -250,9 +256,11 @@ def test_eight_ranks_evaluate_a_conditional_flow_bit_equal_to_one_rank():
     procs = [ctx.Process(target=_c4_eval_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=900) for _ in range(world))
+    got = dict(q.get(timeout=600) for _ in range(world))
     for p in procs:
         p.join(60)
+    errors = {r: v[1] for r, v in got.items() if v[0] == "error"}
+    assert not errors, next(iter(errors.values()))
     fl = _c4_small()
     R, F = _c4_inputs()
     ms = calibrate_feature_scale(fl, F.cuda())

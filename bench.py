@@ -690,7 +690,7 @@ def measure_training(device, batch=1024, steps=40, warmup=10):
     cfg = make_config("C2")
     R = torch.from_numpy(synth.uniform_rotations(batch, seed=1)).to(device)
     out = {"workload": "training iteration (forward + backward + Adam), settings/raw.yml recipe: 24-layer MobiusAffine, K = 64, batch 1024, eager, "
-                       "torch.optim.Adam defaults (agent.py:23,75-92)", "batch": batch, "unit": "ms per iteration"}
+                       "torch.optim.Adam defaults (agent.py:23,75-92)", "batch": batch, "unit": "ms per iteration", "timed_blocks": 3}
 
     def run(flow, opt):
         def step():
@@ -701,12 +701,15 @@ def measure_training(device, batch=1024, steps=40, warmup=10):
             opt.step()
         for _ in range(warmup):
             step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps * 1e3
+        best = float("inf")
+        for _ in range(3):                                   # an eager loop is exposed to the host: the fastest of three timed blocks
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / steps * 1e3)
+        return best
 
     with contextlib.redirect_stdout(io.StringIO()):
         flat, classic, graphed = get_flow(cfg), Flow(cfg), get_flow(cfg)

@@ -119,6 +119,7 @@ __device__ __forceinline__ f32x16 load_g16(const float *g_tile /* [4][64] float4
 // [out tile][lane half][16 accumulator registers].
 template <bool ROWS>
 struct GFrag {
+    static constexpr bool AS_BIAS = false;
     const float *p;
     bool rows;
     __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
@@ -139,30 +140,37 @@ struct GFrag {
 // ROWS instantiations (round 5): SHARED feature rows on the lean / inverse kernels.  Pose estimation evaluates one image feature against
 // Q query rotations (agent.py:238-263, eval.py:322-347: `feature.repeat` over number_queries), so row r of the projection scratch (a 64-float
 // record per (layer, row), [out tile][lane half][16 accumulator registers]) serves rotations [r Q, (r + 1) Q).  With Q >= 32 the 32
-// rotations of a wave sit in at most two rows: everything here is wave uniform (scalar registers) except the one comparison that picks the
-// lane's row, re-derived at every load (2 VALU) instead of kept in a vector register across the layer; the loads are broadcasts of one or
-// two 64-byte lines out of L2, so the second read for the residual (16-wave kernels) costs nothing worth a register either.
+// rotations of a wave sit in at most two rows, and then G is not a per-sample tile at all but a BIAS VECTOR per row: it enters x0 as one more
+// exact-fp32 matrix step of fc_first,
+//     x0[o][j] += G[row0][o] * [row(j) == row0] + G[row0 + 1][o] * [row(j) == row0 + 1]            (K = 2: lane-half h carries row0 + h)
+// A operand: lane (i, h) holds G[row0 + h][32 ot + i] -- ONE float per lane and out tile, loaded once per layer; B operand: the 0 / 1
+// indicator of the lane's own sample.  No 16-register accumulator tile is loaded, kept (KEEPX0) or re-read for the residual: the residual
+// repeats the same matrix step.  Everything else about the rows is wave uniform (scalar registers).
 struct GFragRows {
+    static constexpr bool AS_BIAS = true;
     const float *p;           // G + slot * g_rows * 64 (wave uniform), or nullptr for an unconditional layer
     int row0, rem0, gdiv, last;   // first rotation of the wave: its row and position inside the row; rotations per row; last valid row
     __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
+    __device__ __forceinline__ float aop(int ot, int lane, int h) const {
+        const int i = lane & 31;
+        const int row = min(row0 + h, last);
+        // position of output row 32 ot + i inside the record: lane half (i >> 2) & 1, accumulator register (i & 3) + 4 (i >> 3)   (layout.h rho)
+        const unsigned idx = (unsigned)row * 64u + (unsigned)(ot * 32 + ((i >> 2) & 1) * 16 + (i & 3) + 4 * (i >> 3));
+        return p[idx];
+    }
+    __device__ __forceinline__ float bop(int lane, int h) const {
+        const int over = (rem0 + (lane & 31)) >= gdiv ? 1 : 0;       // this lane's sample sits in row0 + over
+        return over == h ? 1.0f : 0.0f;
+    }
     template <bool NT = false>
-    __device__ __forceinline__ f32x16 load(int ot, int lane, int h) const {
-        int row = row0 + ((rem0 + (lane & 31)) >= gdiv ? 1 : 0);
-        row = min(row, last);                                    // lanes behind the end of the batch
-        const float4 *q = reinterpret_cast<const float4 *>(p + (unsigned)row * 64u + (unsigned)((ot * 2 + h) * 16));
-        const float4 b0 = q[0], b1 = q[1], b2 = q[2], b3 = q[3];
-        f32x16 c;
-        c[0] = b0.x; c[1] = b0.y; c[2] = b0.z; c[3] = b0.w;
-        c[4] = b1.x; c[5] = b1.y; c[6] = b1.z; c[7] = b1.w;
-        c[8] = b2.x; c[9] = b2.y; c[10] = b2.z; c[11] = b2.w;
-        c[12] = b3.x; c[13] = b3.y; c[14] = b3.z; c[15] = b3.w;
-        return c;
+    __device__ __forceinline__ f32x16 load(int, int, int) const {       // (interface of the tile-shaped sources; never called for AS_BIAS)
+        return f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     }
 };
 
 // LEAN instantiations (unconditional Moebius / constant-affine stacks): there is no feature projection at all
 struct NoG {
+    static constexpr bool AS_BIAS = false;
     __device__ __forceinline__ constexpr explicit operator bool() const { return false; }
     template <bool NT = false>
     __device__ __forceinline__ f32x16 load(int, int, int) const {
@@ -441,9 +449,11 @@ struct Mlp<1> {
     // are added -- from the registers that kept them (KEEPX0: one read of the scratch) or from a second read of the scratch.
     template <bool KEEPX0, class GF>
     static __device__ __forceinline__ void residual(const float *lds, int ot, int lane, int h, float bA, float bB, const GF &g,
-                                                    const f32x16 (&gk)[2], f32x16 &a) {
+                                                    const f32x16 (&gk)[2], f32x16 &a, const float (&ga)[2], float gb) {
         a = first_tile(lds, ot, lane, bA, bB, a);
-        if (g) {
+        if constexpr (GF::AS_BIAS) {                              // shared rows: G as one more fc_first step (see GFragRows)
+            if (g) a = RNF_MFMA(ga[ot], gb, a);
+        } else if (g) {
             if constexpr (KEEPX0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a[r] += gk[ot][r];
@@ -464,13 +474,28 @@ struct Mlp<1> {
         asm("" : "+s"(m1));                                     // see split_act
         ActFrag &f = out;                                       // the fragments are rewritten in place, layer after layer
         f32x16 x0k[2];                                          // KEEPX0 only (dead otherwise): the projected features G of this layer
+        float ga[2] = {0.f, 0.f}, gb = 0.f;                     // AS_BIAS only: the row records' A operands and the sample's row indicator
+        if constexpr (GF::AS_BIAS) {                            // (for the tile-shaped sources the same re-derivation changes nothing: C4 7.87 / 7.93 ms)
+            // the lane-derived offsets of this layer's reads are re-derived here: hoisted out of the layer loop they are registers the
+            // 128-register instantiations spill and reload behind an s_waitcnt vmcnt(0)
+            asm volatile("" : "+v"(lane), "+v"(h));
+        }
         {
             f32x16 x0[2];
+            if constexpr (GF::AS_BIAS) {
+                if (g) { ga[0] = g.aop(0, lane, h); ga[1] = g.aop(1, lane, h); gb = g.bop(lane, h); }
 #pragma unroll
-            for (int ot = 0; ot < 2; ++ot) {
-                const f32x16 gin = pre ? pre[ot] : (g ? g.template load<KEEPX0>(ot, lane, h) : zero);      // KEEPX0: the only read of this tile
-                if constexpr (KEEPX0) x0k[ot] = gin;
-                x0[ot] = first_tile(lds, ot, lane, bA, bB, gin);
+                for (int ot = 0; ot < 2; ++ot) {
+                    x0[ot] = first_tile(lds, ot, lane, bA, bB, zero);
+                    if (g) x0[ot] = RNF_MFMA(ga[ot], gb, x0[ot]);
+                }
+            } else {
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    const f32x16 gin = pre ? pre[ot] : (g ? g.template load<KEEPX0>(ot, lane, h) : zero);      // KEEPX0: the only read of this tile
+                    if constexpr (KEEPX0) x0k[ot] = gin;
+                    x0[ot] = first_tile(lds, ot, lane, bA, bB, gin);
+                }
             }
             // a feature beyond the fp16 range (the whole projection row is NaN), or features so much larger than the packer's equalisation
             // assumed (x0 is normalised to an rms of 1/4 .. 1/2; kX0Guard = 64) that fc_last's down-scaled columns would lose bits
@@ -496,10 +521,10 @@ struct Mlp<1> {
         a1 = bias(2, 1);
         hidden_tile<1>(w(2, 0), lane, f, a0, b1, m1);
         bad |= a0[0] != a0[0];
-        residual<KEEPX0>(lds, 0, lane, h, bA, bB, g, x0k, a0);
+        residual<KEEPX0>(lds, 0, lane, h, bA, bB, g, x0k, a0, ga, gb);
         hidden_tile<2>(w(2, 1), lane, f, a1, a0, m1);
         fair.tick();
-        residual<KEEPX0>(lds, 1, lane, h, bA, bB, g, x0k, a1);
+        residual<KEEPX0>(lds, 1, lane, h, bA, bB, g, x0k, a1, ga, gb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             split_pair(a1[2 * e], a1[2 * e + 1], m1, f.hi[2], f.lo[2], e);

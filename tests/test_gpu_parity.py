@@ -227,9 +227,9 @@ def test_shared_feature_rows_equal_materialised_repeat_and_the_oracle(direction,
     """feature_repeat=Q (pose estimation: one image feature against Q query rotations, agent.py:238-263) must give what the reference's
     pattern gives -- every feature row repeated Q times -- including runs that straddle 32-rotation wave tiles (Q = 37, 500).  Round 5: rows of
     >= 32 rotations run on the SAME kernel family as the materialised repeat (conditional-lean forward / 8-wave inverse; ROWS instantiations,
-    the per-row record read like a layer parameter), shorter rows (Q = 7) on the extended instantiation.  Against the materialised repeat:
-    fp32 rounding (the projection sums one row per image instead of one per rotation tile); against the fp64 oracle on the repeated
-    features: the gates of the fixture tests, with the oracle's own fp32 run as the noise."""
+    the per-row record enters x0 as one more exact-fp32 fc_first matrix step), shorter rows (Q = 7) on the extended instantiation.  Against the
+    materialised repeat: fp32 rounding (forward; the inverse in bisection cells); against the fp64 oracle on the repeated features: the
+    gates of the fixture tests, with the oracle's own fp32 run as the noise."""
     cfg = orc.make_config(layers=4, segments=16, condition=1, feature_dim=40, rot="16UnTrans", last_affine=1, frequent_permute=1)
     w = synth.fill_state_dict(orc.state_shapes(cfg), seed=8, regime="trained")
     fl = product_flow(cfg, w)
@@ -246,7 +246,15 @@ def test_shared_feature_rows_equal_materialised_repeat_and_the_oracle(direction,
         else:
             a = fl.inverse(R, f, feature_repeat=Q)
             b = fl.inverse(R, frep)
-    assert (a[0] - b[0]).abs().max().item() < 2e-5 and (a[1] - b[1]).abs().max().item() < 5e-5
+    dR, dl = (a[0] - b[0]).abs().reshape(B * Q, -1).max(1)[0], (a[1] - b[1]).abs()
+    if direction == "forward":
+        assert dR.max().item() < 2e-5 and dl.max().item() < 5e-5
+    else:
+        # the inverse lands on the bisection grid (cells of pi / 2^14): the row form adds G to x0 in another order than the tile form (one more
+        # fc_first matrix step instead of the accumulator start), and a root within rounding of a cell boundary may take the other cell
+        cell = np.pi / 2 ** 14
+        assert dR.max().item() <= 2.0 * cell and dl.max().item() <= 6 * cell and (dR > 0.5 * cell).float().mean().item() <= 0.01
+        assert dR.median().item() < 2e-6 and dl.median().item() < 5e-6
     frep_n = np.repeat(fn, Q, axis=0)
     run = orc.flow_forward if direction == "forward" else orc.flow_inverse
     r64, l64 = run(cfg, w, Rn, frep_n, dtype=torch.float64)

@@ -289,3 +289,31 @@ def test_parameter_and_state_dict_order_is_the_references(golden_dir):
             assert [[k, list(shape)] for k, _, shape in fl._flat_layout()] == e["parameters"], name
             assert [[k, list(v.shape)] for k, v in fl.state_dict().items()] == e["state_dict"], name
     assert flat_seen >= 10
+
+
+def test_bench_compact_line_stays_parseable_and_small():
+    """The driver parses the LAST stdout line of bench.py and keeps ~8 KB of stdout tail (round 4's 40 KB single line was lost): the compact
+    record built from a committed full record (profiles/r5/bench_default.json) must stay under bench.COMPACT_LIMIT, carry every key of the
+    bench contract with `roofline` and `cpu_baseline`, and shrink -- not overflow -- when more workloads are added."""
+    import copy
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r5", "bench_default.json")) as fh:
+        full = json.load(fh)
+    line = bench.compact_record(full, "bench_full.json")
+    assert len(line) < bench.COMPACT_LIMIT and "\n" not in line
+    rec = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in rec, k
+    assert rec["config"]["workload"].startswith("C2") and rec["vs_baseline"] is None and rec["mean_nll"] == full["mean_nll"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rec["roofline"]) and abs(rec["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-4
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(rec["cpu_baseline"])
+    assert sorted(rec["configs"]) == sorted(full["configs"]) and rec["configs"]["C4q"]["traffic_x"] > 1
+    # twenty more workloads: the line thins its per-workload entries, then drops optional blocks, and never loses the headline
+    fat = copy.deepcopy(full)
+    for i in range(20):
+        fat["configs"][f"X{i}"] = copy.deepcopy(full["configs"]["C4"])
+    line = bench.compact_record(fat, "bench_full.json")
+    rec = json.loads(line)
+    assert len(line) < bench.COMPACT_LIMIT and rec["value"] == json.loads(bench.compact_record(full))["value"] and "roofline" in rec

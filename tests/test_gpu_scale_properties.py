@@ -260,3 +260,40 @@ def test_c3_small_global_batch_as_eight_shards_is_bit_equal(log2n):
     big[5000:5000 + n] = R
     with torch.no_grad():
         assert torch.equal(fl.log_prob(big)["logp"][5000:5000 + n], lp)
+
+
+@pytest.mark.parametrize("direction", ["forward", "inverse"])
+@pytest.mark.parametrize("Q", [512, 500, 37])
+def test_shared_rows_results_do_not_depend_on_the_shard(direction, Q):
+    """Shared feature rows (feature_repeat = Q, the ROWS kernels): a rotation's result must not depend on the launch it travels in either.
+    Shards cut at image boundaries start at multiples of Q, which for Q = 500 or 37 are NOT multiples of the 32-rotation wave tile: the same
+    rotation then sits in another wave, next to other neighbours, in a wave that straddles two images or does not -- the row record enters x0
+    as ONE form of matrix step whatever the wave looks like (csrc/flow_kernels.h GFragRows), so the rows are bit-equal."""
+    cfg = make_config(layers=6, feature_dim=256, condition=1, rot="16UnTrans", frequent_permute=1, last_affine=1, first_affine=0)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=91, regime="trained")
+    fl = product_flow(cfg, w)
+    B = 24
+    R = torch.from_numpy(synth.uniform_rotations(B * Q, seed=92)).cuda()
+    f = torch.from_numpy(synth.features(B, 256, seed=93)).cuda()
+    run = (lambda r, ff: fl(r, ff, feature_repeat=Q)) if direction == "forward" else (lambda r, ff: fl.inverse(r, ff, feature_repeat=Q))
+    with torch.no_grad():
+        full = run(R, f)
+        for lo, hi in ((0, 3), (3, 4), (4, 11), (11, 24)):                       # image ranges: starts at 3 Q, 4 Q, 11 Q rotations
+            part = run(R[lo * Q: hi * Q].contiguous(), f[lo:hi].contiguous())
+            assert torch.equal(part[0], full[0][lo * Q: hi * Q]) and torch.equal(part[1], full[1][lo * Q: hi * Q]), (lo, hi)
+
+
+def test_shared_rows_wide_launch_equals_narrow_shards():
+    """The same across workgroup widths: 160 images x 512 queries run the 16-wave ROWS kernel, a 3-image shard the 4-wave one, a 40-image shard
+    the 8-wave one -- bit-equal rows (one kernel family, one arithmetic)."""
+    cfg = make_config(layers=6, feature_dim=256, condition=1, rot="16UnTrans", frequent_permute=1, last_affine=1, first_affine=0)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=91, regime="trained")
+    fl = product_flow(cfg, w)
+    B, Q = 160, 512
+    R = torch.from_numpy(synth.uniform_rotations(B * Q, seed=94)).cuda()
+    f = torch.from_numpy(synth.features(B, 256, seed=95)).cuda()
+    with torch.no_grad():
+        full = fl.log_prob(R, f, feature_repeat=Q)["logp"]
+        for lo, hi in ((7, 10), (100, 140)):
+            part = fl.log_prob(R[lo * Q: hi * Q].contiguous(), f[lo:hi].contiguous(), feature_repeat=Q)["logp"]
+            assert torch.equal(part, full[lo * Q: hi * Q]), (lo, hi)

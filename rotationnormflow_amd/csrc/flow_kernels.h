@@ -199,8 +199,10 @@ __device__ __forceinline__ f32x16 gemm_tile64(const float *w_tile /* [8][64] flo
 // ConditionalTransform up to the input of fc_last (flow/condition.py:24-29): tt = relu(x0 + L5(relu(L3(relu(L1(relu(x0)))))))
 // x0 = fc_first(y (+) feature): the y part and (unconditional) bias run as two K=2 MFMA steps, the feature part and
 // (conditional) bias arrive pre-multiplied in `cinit`.
+// nan_in: set when x0 comes out NaN (a NaN input: every output row mixes every input).  fmaxf launders a NaN into 0, so without the flag a
+// NaN feature row or rotation would yield finite garbage where the reference's torch.relu propagates the NaN (SURVEY 8(b) "errors").
 __device__ __forceinline__ void mlp_head(const float *lds, int lane, int h, float y0, float y1, float y2,
-                                         const f32x16 (&cinit)[2], f32x16 (&tt)[2]) {
+                                         const f32x16 (&cinit)[2], f32x16 (&tt)[2], bool &nan_in) {
     const float bA = h ? y1 : y0;
     const float bB = h ? 1.0f : y2;
     f32x16 x0[2];
@@ -210,6 +212,7 @@ __device__ __forceinline__ void mlp_head(const float *lds, int lane, int h, floa
         f32x16 c = RNF_MFMA(a.x, bA, cinit[ot]);
         x0[ot] = RNF_MFMA(a.y, bB, c);
     }
+    nan_in |= x0[0][0] != x0[0][0];
     f32x16 hin[2] = {x0[0], x0[1]};
 #pragma unroll
     for (int L = 0; L < 3; ++L) {
@@ -406,7 +409,7 @@ struct Mlp<0> {
     // g: this wave's feature-projection fragments for the layer (global memory), or nullptr for an unconditional layer
     template <class GF, bool KEEPX0 = false, class FairT = Fair>
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
-                                                const GF &g, Act &out, FairT &, bool &, const f32x16 * = nullptr) {
+                                                const GF &g, Act &out, FairT &, bool &bad, const f32x16 * = nullptr) {
         f32x16 cinit[2];
         if (g) {
             cinit[0] = g.load(0, lane, h);
@@ -415,7 +418,7 @@ struct Mlp<0> {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { cinit[0][r] = 0.f; cinit[1][r] = 0.f; }
         }
-        mlp_head(lds, lane, h, y0, y1, y2, cinit, out.t);
+        mlp_head(lds, lane, h, y0, y1, y2, cinit, out.t, bad);
     }
     static __device__ __forceinline__ f32x16 last(const float *tile_rec, int lane, int h, const Act &a) {
         return last_tile(tile_rec, lane, h, a.t);
@@ -1677,6 +1680,13 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
 #ifndef RNF_KO_BARRIER
             if (bad || !(fabsf(chk) <= 3.0e38f)) atomicOr(args.guard, 1);
 #endif
+        }
+        // Exact-fp32 kernels (set_precision("fp32"), and the re-run of a guarded split-precision call, which a NaN always triggers): a NaN that
+        // entered a conditioner (NaN feature row / rotation) makes the sample's outputs NaN, as in the reference (its ReLU propagates NaN;
+        // fmaxf would launder it into finite garbage).  `bad` has no other source in these kernels (mlp_head).
+        if (PREC == 0 && bad) {
+            ldj = __builtin_nanf("");
+            R.c0.x = ldj;
         }
         // epilogue: outputs + fused base density + NLL partial (utils/fisher.py:217-232, agent.py:55-65)
         double lp_d = 0.0;

@@ -949,8 +949,11 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     // without extended layers.  Decided by the flow and the call's row length, never by the batch size.  Everything else with shared rows
     // stays on the extended instantiation.
     const bool rows_lean2 = lean2 && all_mlp_cond && guarded && a.tab_off >= 0;
+    // GUARDED calls only, in both directions: the row records enter x0 through a matrix step (flow_kernels.h GFragRows), where a non-finite
+    // record of one image would also poison the rotations of the NEXT image that share its wave (NaN x 0 = NaN); the guard sees that and the
+    // exact-fp32 re-run, which reads the records per lane, restores per-image semantics.  Unguarded calls keep the extended instantiation.
     const bool rows_fast = shared && !ext_layers && prec == 1 && pipe && any_mlp && o.feature_div >= 32 && n < (1LL << 31) &&
-                           feat_rows < (1LL << 24) && !o.states && (o.dir == 0 ? rows_lean2 : (KT <= 8));
+                           feat_rows < (1LL << 24) && !o.states && guarded && (o.dir == 0 ? rows_lean2 : (KT <= 8));
     if (rows_fast) ext = false;
     bool first = true;
     for (long long base = 0; base < n; base += chunk_cap) {

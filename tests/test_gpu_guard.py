@@ -217,3 +217,31 @@ def test_repeated_guard_firing_warns_and_recalibrates():
     assert fired[0] and fired[1]                                 # stale calibration: the guard fires ...
     assert not any(fired[-3:]), fired                            # ... until the runtime re-calibrated on the large features
     assert sum(1 for c in caught if "range guard" in str(c.message)) == 1
+
+
+@pytest.mark.parametrize("direction", ["forward", "inverse"])
+def test_a_non_finite_feature_row_stays_with_its_own_image_on_the_shared_row_kernels(direction):
+    """Shared feature rows (feature_repeat = Q) enter x0 through a matrix step on the ROWS kernels, where the NaN record of one image meets the
+    0 indicator of its wave-mates from the next image (NaN x 0 = NaN).  Those launches run guarded: the guard fires, the exact-fp32 re-run reads
+    the records per lane, and only the rotations of the bad image come out NaN (as the reference's would: torch.relu propagates NaN; the
+    kernels flag a NaN x0 and poison the sample's outputs) -- every other image as in a clean run (fp32 arithmetic)."""
+    cfg = make_config(layers=4, segments=16, condition=1, feature_dim=40, rot="16UnTrans", last_affine=1, frequent_permute=1)
+    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=8, regime="trained")
+    fl = product_flow(cfg, w)
+    B, Q = 6, 37                                                  # 37: every wave straddles two images somewhere
+    R = torch.from_numpy(synth.uniform_rotations(B * Q, seed=9)).cuda()
+    f = torch.from_numpy(synth.features(B, 40, seed=10)).cuda()
+    fl.set_feature_scale(1.0)                                     # (a NaN row must not enter the calibration)
+    run = (lambda ff: fl(R, ff, feature_repeat=Q)[1]) if direction == "forward" else (lambda ff: fl.inverse(R, ff, feature_repeat=Q)[1])
+    with torch.no_grad():
+        clean = run(f)
+        assert not runtime.fallback_fired(R.device)
+        bad = f.clone()
+        bad[2] = float("nan")
+        got = run(bad)
+        assert runtime.fallback_fired(R.device)
+    mine = torch.zeros(B * Q, dtype=torch.bool, device="cuda")
+    mine[2 * Q: 3 * Q] = True
+    assert torch.isnan(got[mine]).all() and torch.isfinite(got[~mine]).all()
+    tol = 2e-4 if direction == "forward" else 6 * np.pi / 2 ** 14
+    assert (got[~mine] - clean[~mine]).abs().max().item() < tol

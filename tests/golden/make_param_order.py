@@ -39,8 +39,12 @@ def main():
         out[name] = {"cfg": spec["cfg"],
                      "parameters": [[k, list(p.shape)] for k, p in fl.named_parameters()],
                      "state_dict": [[k, list(v.shape)] for k, v in fl.state_dict().items()]}
-    with open(os.path.join(HERE, "param_order.json"), "w") as fh:
-        json.dump(out, fh, indent=0, sort_keys=True)
+    with open(os.path.join(HERE, "param_order.json"), "w") as fh:         # one line per structure
+        fh.write("{\n")
+        keys = sorted(out)
+        for i, k in enumerate(keys):
+            fh.write(json.dumps(k) + ": " + json.dumps(out[k], separators=(",", ":"), sort_keys=True) + (",\n" if i + 1 < len(keys) else "\n"))
+        fh.write("}\n")
     print(f"{len(out)} structures -> param_order.json")
 
 

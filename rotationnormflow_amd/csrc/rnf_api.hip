@@ -738,6 +738,11 @@ static int launch_stack(const FlowArgs &a, int grid, size_t lds_bytes, hipStream
             if (nwk == NW_FWD_NARROW) RNF_STACK_GO(NW_FWD_NARROW, 0);
         }
     }
+    if constexpr (DIR == 1 && PREC == 1 && PIPE && !EXT && KT_INV <= 8) {
+        // small inverse launches (round 5): 4-wave workgroups, one wave per SIMD, twice as many workgroups -- a launch that leaves half of
+        // the CUs empty at 8 waves is a latency chain per wave (2^15 rotations: 0.73 -> 0.57 ms); same arithmetic, bit-equal rows
+        if (nwk == NW_FWD_NARROW && !lean) RNF_STACK_GO(NW_FWD_NARROW, 0);
+    }
     if constexpr (!(ROWS && DIR == 0)) {
         constexpr int NWK = (DIR == 0 && PREC == 1) ? NW_FWD_H : NW;
         if (nwk != NWK || lean) return fail("internal: no %d-wave instantiation of this stack kernel", nwk);
@@ -963,7 +968,8 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         const bool wide = !fused && o.dir == 0 && prec == 1 && pipe && !ext && wide_allowed() && cn > (long long)cus * NW_FWD_H * 32;
         const bool narrow = !fused && o.dir == 0 && prec == 1 && pipe && !ext && wide_allowed() && cn <= (long long)cus * NW_FWD_NARROW * 32;
         const bool big_inv = o.dir == 1 && any_mlp && KT > 8;                  // 4-wave instantiation (512 registers per lane)
-        const int nwk = fused ? NW_FUSED : (big_inv ? NW_INV_BIG : (wide ? NW_FWD_WIDE : (narrow ? NW_FWD_NARROW : ((o.dir == 0 && prec == 1) ? NW_FWD_H : NW))));
+        const bool narrow_inv = o.dir == 1 && prec == 1 && pipe && !ext && any_mlp && KT <= 8 && wide_allowed() && cn <= (long long)cus * NW_FWD_NARROW * 32;
+        const int nwk = fused ? NW_FUSED : (big_inv ? NW_INV_BIG : (wide ? NW_FWD_WIDE : ((narrow || narrow_inv) ? NW_FWD_NARROW : ((o.dir == 0 && prec == 1) ? NW_FWD_H : NW))));
         // kernel family of this call (launch_stack): fixed by the flow and by `guarded`, the same for every chunk and batch size
         const int family = (guarded && a.tab_off >= 0 && o.dir == 0 && prec == 1 && pipe && !ext) ? (lean ? 1 : (lean2 && all_mlp_cond && n_slots > 0 && (!shared || rows_fast) ? 2 : 0)) : 0;
         a.fair_off = (wide || narrow || family || (fused && NW_FUSED != 8)) ? -1 : fair_off;             // the governor pairs two waves per SIMD (general 8-wave kernel)

@@ -634,7 +634,8 @@ def measure(w, args, dist, pmc, steps, warmup, want_secondary, want_parity, cpu_
                 w.fl.inverse(w.R, w.feat)
             torch.cuda.synchronize()
         rec["ms_per_step_inverse"] = (time.perf_counter() - t0) / steps * 1e3
-        rec["fallback_fired"] = bool(__import__("rotationnormflow_amd").runtime.fallback_fired(w.device))
+        from rotationnormflow_amd import runtime as _rt
+        rec["fallback_fired"] = bool(_rt.fallback_fired(w.device))
     secondary = None
     if want_secondary and used == "f16x2":
         set_precision("fp32")

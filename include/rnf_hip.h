@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define RNF_ABI_VERSION 6
+#define RNF_ABI_VERSION 7
 
 /* width of the conditioner MLP's hidden layers: flow/condition.py:9 (Nh=64, never overridden by any caller) */
 #define RNF_HIDDEN 64
@@ -204,6 +204,24 @@ int rnf_flow_log_prob_side(const float *rotation_dev, const float *feature_dev, 
 int rnf_condrot_matrices(const float *mlp_out_dev, int64_t n, float *rot_out_dev, int32_t *fail_flag_dev, void *stream);
 int rnf_condrot_svd(const float *mlp_out_dev, int64_t n, float *rot_out_dev, float *u_out_dev, float *s_out_dev, float *vt_out_dev,
                     int32_t *fail_flag_dev, void *stream);
+
+/* ConditionLU's per-sample matrices on the device (replaces flow/squeezetrans.py:120-131, the `einsum` over `torch.diag` -- ABI v7; until v6
+ * the host library assembled them with torch ops):
+ *     weight[n] = w_p (reshape(wl[n], C, C) * l_mask + l_eye) (reshape(wu[n], C, C) * u_mask + dvec),  dvec[d] = s_sign[d] exp(ws[d][d])
+ * where `torch.diag` of the 2-D tensor s_sign * exp(ws) is its diagonal ACROSS THE BATCH (rows 0..C-1) and the C-vector is broadcast over
+ * the last axis -- added to every row of the upper factor.  Reproduced as the reference defines it: the matrix of sample n depends on the
+ * first C rows of the batch; n < C is an error (the reference fails to broadcast).
+ * wl_dev, wu_dev, ws_dev: the three conditioners' outputs (rnf_cond_mlp_forward), rows of stride_wl / stride_wu (>= C*C) and stride_ws
+ * (>= C) floats; C = 3 or 4; consts_dev = w_p [C*C] | l_mask [C*C] | u_mask [C*C] | l_eye [C*C] | s_sign [C] (the module's buffers);
+ * add_identity != 0: + I (Condition9TransLU, squeezetrans.py:269-271); side_out_dev [n][16]: one slot of the side buffer of an
+ * RNF_LAYER_SIDE16 / RNF_LAYER_SIDE9 layer (C x C row-major in the leading floats, the rest 0).
+ * rnf_condlu_backward: g_side_dev [n][16] = dL/d(weight) -> g_wl_dev [n][C*C], g_wu_dev [n][C*C], g_ws_dev [n][C] (dense rows); the
+ * batch-coupled diagonal's gradient lands in g_ws[d][d] only (every other entry 0).  scratch_dev: 4 floats. */
+int rnf_condlu_matrices(const float *wl_dev, const float *wu_dev, const float *ws_dev, int32_t stride_wl, int32_t stride_wu, int32_t stride_ws,
+                        int64_t n, int32_t C, const float *consts_dev, int32_t add_identity, float *side_out_dev, void *stream);
+int rnf_condlu_backward(const float *wl_dev, const float *wu_dev, const float *ws_dev, int32_t stride_wl, int32_t stride_wu, int32_t stride_ws,
+                        int64_t n, int32_t C, const float *consts_dev, const float *g_side_dev, float *g_wl_dev, float *g_wu_dev,
+                        float *g_ws_dev, float *scratch_dev, void *stream);
 
 /* ConditionalTransform(feature_dim, <= 16 outputs)(feature) alone (flow/condition.py:24-30): records packed by rnf_pack_cond16 at
  * layer_offset / feat_offset (floats) of blob_dev; out_dev float[n][16], output o in column o.  Workspace: rnf_workspace_bytes(n, 1). */

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librnf_hip.so")
 
 _lib = None
-ABI_VERSION = 6
+ABI_VERSION = 7
 PREC_FP32, PREC_F16X2 = 0, 1
 
 c_f32p = C.c_void_p      # device or host float*, passed as integer addresses
@@ -55,6 +55,10 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_size_t, C.c_void_p]),
     "rnf_condrot_matrices": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p, C.c_void_p]),
     "rnf_condrot_svd": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
+    "rnf_condlu_matrices": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, c_f32p, C.c_int32, c_f32p,
+                                      C.c_void_p]),
+    "rnf_condlu_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
+                                      c_f32p, c_f32p, C.c_void_p]),
     "rnf_pack_flow_device": (C.c_int, [c_f32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_i32p, C.c_void_p]),
     "rnf_plain_layer_floats": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rnf_flow_forward_train": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i32p, C.c_int32, C.c_int32,

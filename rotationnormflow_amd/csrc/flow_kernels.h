@@ -371,6 +371,50 @@ __device__ __forceinline__ void hidden_tile(const float *w_tile, int lane, ActFr
     hidden_slot<0, FILL>(w_tile, lane, f, acc, src, m1, ah, al);
 }
 
+// DEEP (round 6; workgroups of at most 8 waves, i.e. at most two waves per SIMD): the operand pairs of TWO k-steps are in flight.  hidden_slot
+// requests the operands of k-step s + 1 behind the LAST matrix instruction of k-step s and the very next instruction needs them: with four
+// waves per SIMD the partners cover that LDS round trip, with two (every inverse kernel) each k-step of the dependent chain waited for it
+// (ds_read, s_waitcnt lgkmcnt, three matrix instructions: ~220 cycles per k-step where the matrix work is 96).  Here the pair of k-step
+// s + 2 -- of the NEXT tile for s = 2, 3: the six hidden tiles of a layer are contiguous in LDS -- is requested instead, one whole k-step
+// ahead; 8 more registers, which these instantiations have in the hidden phase (no segment state is live there).  Same matrix
+// instructions in the same order: bit-identical results.
+template <int M, int FILL, bool HAS_NEXT>
+__device__ __forceinline__ void hidden_slot2(const float *w_tile, int lane, ActFrag &f, f32x16 &acc, const f32x16 &src, float m1, h8 (&ah)[2],
+                                             h8 (&al)[2]) {
+    constexpr int ks = M / 3, term = M % 3, p = ks & 1;
+    if constexpr (term == 0) acc = RNF_MFMA_H(ah[p], f.hi[ks], acc);
+    else if constexpr (term == 1) acc = RNF_MFMA_H(ah[p], f.lo[ks], acc);
+    else acc = RNF_MFMA_H(al[p], f.hi[ks], acc);
+    if constexpr (term == 2) {
+        if constexpr (ks < 2) {
+            ah[p] = lds_h8(w_tile, ((ks + 2) * 2 + 0) * 64 + lane);
+            al[p] = lds_h8(w_tile, ((ks + 2) * 2 + 1) * 64 + lane);
+        } else if constexpr (HAS_NEXT) {
+            ah[p] = lds_h8(w_tile + 8 * 64 * 4, ((ks - 2) * 2 + 0) * 64 + lane);
+            al[p] = lds_h8(w_tile + 8 * 64 * 4, ((ks - 2) * 2 + 1) * 64 + lane);
+        }
+    }
+    constexpr int dst = FILL == 1 ? (ks == 0 ? 2 : (ks == 1 ? 3 : -1)) : (FILL == 2 ? (ks == 1 ? 0 : (ks == 2 ? 1 : -1)) : -1);
+    if constexpr (dst >= 0) {
+        constexpr int half = dst & 1;
+        if constexpr (term == 0) {
+            split_pair(src[8 * half + 0], src[8 * half + 1], m1, f.hi[dst], f.lo[dst], 0);
+        } else if constexpr (term == 1) {
+            split_pair(src[8 * half + 2], src[8 * half + 3], m1, f.hi[dst], f.lo[dst], 1);
+        } else {
+            split_pair(src[8 * half + 4], src[8 * half + 5], m1, f.hi[dst], f.lo[dst], 2);
+            split_pair(src[8 * half + 6], src[8 * half + 7], m1, f.hi[dst], f.lo[dst], 3);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (M + 1 < 12) hidden_slot2<M + 1, FILL, HAS_NEXT>(w_tile, lane, f, acc, src, m1, ah, al);
+}
+template <int FILL, bool HAS_NEXT>
+__device__ __forceinline__ void hidden_tile2(const float *w_tile, int lane, ActFrag &f, f32x16 &acc, const f32x16 &src, float m1, h8 (&ah)[2], h8 (&al)[2]) {
+    __builtin_amdgcn_sched_barrier(0);
+    hidden_slot2<0, FILL, HAS_NEXT>(w_tile, lane, f, acc, src, m1, ah, al);
+}
+
 // SIMD fairness governor.  The two waves a workgroup places on one SIMD (w and w^4) run the same instruction stream; the
 // hardware arbitrates by age, so the older one runs ahead, reaches the layer barrier early and leaves its partner to finish
 // alone (a single wave cannot fill the VALU: every instruction waits for the previous one of its dependent chain).  Each wave
@@ -407,7 +451,7 @@ template <>
 struct Mlp<0> {
     struct Act { f32x16 t[2]; };
     // g: this wave's feature-projection fragments for the layer (global memory), or nullptr for an unconditional layer
-    template <class GF, bool KEEPX0 = false, class FairT = Fair>
+    template <class GF, bool KEEPX0 = false, class FairT = Fair, bool DEEP = false>
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
                                                 const GF &g, Act &out, FairT &, bool &bad, const f32x16 * = nullptr) {
         f32x16 cinit[2];
@@ -467,7 +511,7 @@ struct Mlp<1> {
             }
         }
     }
-    template <class GF, bool KEEPX0 = false, class FairT = Fair>
+    template <class GF, bool KEEPX0 = false, class FairT = Fair, bool DEEP = false>
     static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
                                                 const GF &g, Act &out, FairT &fair, bool &bad, const f32x16 *pre = nullptr) {
         const float bA = h ? y1 : y0;
@@ -507,14 +551,35 @@ struct Mlp<1> {
         }
         auto w = [&](int L, int ot) { return lds + MOB_HID + (L * 2 + ot) * (8 * 64 * 4); };
         auto bias = [&](int L, int ot) { return load_bias16(lds + MOB_HB + ((L * 2 + ot) * 2 + h) * 16); };
+        f32x16 a0, a1, b0, b1;
+        if constexpr (DEEP) {                                   // see hidden_slot2: the same tiles with two operand pairs in flight
+            h8 ah[2], al[2];
+            ah[0] = lds_h8(w(0, 0), 0 * 64 + lane); al[0] = lds_h8(w(0, 0), 1 * 64 + lane);
+            ah[1] = lds_h8(w(0, 0), 2 * 64 + lane); al[1] = lds_h8(w(0, 0), 3 * 64 + lane);
+            a0 = bias(0, 0); a1 = bias(0, 1);
+            hidden_tile2<0, true>(w(0, 0), lane, f, a0, a0, m1, ah, al);
+            bad |= a0[0] != a0[0];
+            b0 = bias(1, 0);
+            hidden_tile2<2, true>(w(0, 1), lane, f, a1, a0, m1, ah, al);
+            b1 = bias(1, 1);
+            hidden_tile2<1, true>(w(1, 0), lane, f, b0, a1, m1, ah, al);
+            bad |= b0[0] != b0[0];
+            a0 = bias(2, 0);
+            hidden_tile2<2, true>(w(1, 1), lane, f, b1, b0, m1, ah, al);
+            a1 = bias(2, 1);
+            hidden_tile2<1, true>(w(2, 0), lane, f, a0, b1, m1, ah, al);
+            bad |= a0[0] != a0[0];
+            residual<KEEPX0>(lds, 0, lane, h, bA, bB, g, x0k, a0, ga, gb);
+            hidden_tile2<2, false>(w(2, 1), lane, f, a1, a0, m1, ah, al);
+        } else {
         // layer 0: tile 0 bare (its input is complete), tile 1 carries the split of tile 0
-        f32x16 a0 = bias(0, 0), a1 = bias(0, 1);
+        a0 = bias(0, 0); a1 = bias(0, 1);
         hidden_tile<0>(w(0, 0), lane, f, a0, a0, m1);
         bad |= a0[0] != a0[0];
         hidden_tile<2>(w(0, 1), lane, f, a1, a0, m1);
         fair.tick();
         // layer 1: tile 0 carries the split of layer 0's tile 1, tile 1 the split of its own tile 0
-        f32x16 b0 = bias(1, 0), b1 = bias(1, 1);
+        b0 = bias(1, 0); b1 = bias(1, 1);
         hidden_tile<1>(w(1, 0), lane, f, b0, a1, m1);
         bad |= b0[0] != b0[0];
         hidden_tile<2>(w(1, 1), lane, f, b1, b0, m1);
@@ -527,6 +592,7 @@ struct Mlp<1> {
         residual<KEEPX0>(lds, 0, lane, h, bA, bB, g, x0k, a0, ga, gb);
         hidden_tile<2>(w(2, 1), lane, f, a1, a0, m1);
         fair.tick();
+        }
         residual<KEEPX0>(lds, 1, lane, h, bA, bB, g, x0k, a1, ga, gb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -540,7 +606,20 @@ struct Mlp<1> {
     }
 };
 
-__device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+// sum over the two lanes (j, j + 32) of a rotation.  Round 6: v_permlane32_swap (one VALU instruction: every lane gets both halves' values)
+// instead of ds_bpermute_b32 (__shfl_xor: an LDS round trip on the lgkm counter, ~100 cycles in front of every layer finish and of every
+// root-finder step).  half 0's value + half 1's value in both lanes: the same bits as own + partner's.
+#ifndef RNF_PAIRSUM_SWAP
+#define RNF_PAIRSUM_SWAP 1
+#endif
+__device__ __forceinline__ float pair_sum(float v) {
+#if RNF_PAIRSUM_SWAP
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+#else
+    return v + __shfl_xor(v, 32, 64);
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // Moebius layer (flow/mobiusflow.py:46-224), split into the three pieces the staging
@@ -570,6 +649,19 @@ __device__ __forceinline__ void mobius_begin(const Rot &R, int perm_row, MobiusC
         return;
     }
     c.f = make_frame(x, c.y);
+#ifndef RNF_INV_PI
+#define RNF_INV_PI 1
+#endif
+    if constexpr (RNF_INV_PI && DIR == 1) {
+        // Inverse pass (round 6): the given column expressed in its own frame IS (-|x|, 0) -- r = -x/|x| and v = (y x r)/|y x r| is orthogonal
+        // to r whatever y is -- so the reference's target angle atan2(tx.v, tx.r) wrapped to [0, 2 pi) (mobiusflow.py:157-167) is pi: exactly
+        // in its fp64 run, pi or a neighbouring fp32 number in its fp32 run (tx.v is rounding noise ~ 1e-8 beside tx.r = -1); the snap to 0
+        // near 2 pi never applies.  The forward split-precision path has used the same fact since round 2 (S7 branch above).  ~45 VALU
+        // instructions per layer (two dot products, a reciprocal square root, an octant arctangent) for a constant.
+        c.zc = -1.f; c.zs = 0.f; c.zth = kPi; c.target = kPi;
+        if (S7) c.f = scale_frame(c.f, kSquash);
+        return;
+    }
     const float xr = dot3(x, c.f.r), xv = dot3(x, c.f.v);
     const float inv = hw_rsq(fmaf(xv, xv, xr * xr));
     c.zc = xr * inv;
@@ -873,6 +965,80 @@ __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_
     }
 }
 
+// Round 6: the same tile loop for the split-precision kernels with every fc_last tile resident (K <= 64), software pipelined BY HAND.
+// Left to the compiler (mobius_inv_tiles at its 230-register budget) every k-step was  ds_read_b128 -> s_waitcnt lgkmcnt(0) -> MFMA  with
+// ONE operand register quad reused for all eight reads of a tile: eight fully exposed LDS latencies inside a dependent chain of twelve
+// matrix instructions, ~1000 of the ~1850 cycles a wave spent per tile (r5 stamps: the tile phase was 27 % of the kernel).  Here the
+// operands of k-step s + 2 are requested behind the last matrix instruction of k-step s (two operand pairs in flight), the NEXT tile's
+// first two k-steps and its bias (the other accumulator: the two change roles, no copies) are requested in front of the segment math of
+// the finished tile, and the pad mask is a compare against a scalar (it was 32 hoisted lane masks in spilled SGPR pairs: two
+// v_readlane per segment).  Same arithmetic per rotation as mobius_inv_tiles (the squash reciprocal folds the 0.7: one rounding moves).
+template <int KT, bool FASTSP>
+__device__ __forceinline__ void mobius_inv_tiles_pipe(const float *lds, int K, int lane, int h, const ActFrag &tt, const MobiusCtx &c,
+                                                      InvSegs<KT> &sg, float &S) {
+    static_assert(KT <= MOB_MAX_TILES_IN_LDS, "every fc_last tile resident");
+    // Two per-lane offsets the optimiser cannot fold (see tile_pipe_h_off): every LDS read then carries its tile position as an immediate.
+    // Folded into constants, the positions beyond 64 KiB (the DS offset field is 16 bits) become one address register per read group,
+    // hoisted out of the layer loop and spilled (the first build of this function: 56 spilled registers, all of them LDS addresses).
+    int woff = MOB_LAST + 4 * lane, boff = MOB_LAST + MOB_LAST_TILE_BIAS + 16 * h;
+    asm volatile("" : "+v"(woff), "+v"(boff));
+    constexpr int HALF = (KT + 1) / 2;                            // tiles from HALF on are addressed from a second pair of bases
+    int woff2 = woff + HALF * MOB_LAST_TILE_FLOATS, boff2 = boff + HALF * MOB_LAST_TILE_FLOATS;
+    asm volatile("" : "+v"(woff2), "+v"(boff2));
+    auto wt = [&](int tau) { return tau < HALF ? lds + woff + tau * MOB_LAST_TILE_FLOATS : lds + woff2 + (tau - HALF) * MOB_LAST_TILE_FLOATS; };
+    auto bt = [&](int tau) { return tau < HALF ? lds + boff + tau * MOB_LAST_TILE_FLOATS : lds + boff2 + (tau - HALF) * MOB_LAST_TILE_FLOATS; };
+    f32x16 acc = load_bias16(bt(0));
+    h8 ah[2], al[2];
+    ah[0] = lds_h8(wt(0), 0 * 64); al[0] = lds_h8(wt(0), 1 * 64);
+    ah[1] = lds_h8(wt(0), 2 * 64); al[1] = lds_h8(wt(0), 3 * 64);
+#pragma unroll
+    for (int tau = 0; tau < KT; ++tau) {                          // the caller guarantees that the layer has exactly KT tiles
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            __builtin_amdgcn_sched_barrier(0);
+            acc = RNF_MFMA_H(ah[ks & 1], tt.hi[ks], acc);
+            acc = RNF_MFMA_H(ah[ks & 1], tt.lo[ks], acc);
+            acc = RNF_MFMA_H(al[ks & 1], tt.hi[ks], acc);
+            if (ks < 2) {                                         // k-step ks + 2 of this tile
+                ah[ks & 1] = lds_h8(wt(tau), ((ks + 2) * 2 + 0) * 64);
+                al[ks & 1] = lds_h8(wt(tau), ((ks + 2) * 2 + 1) * 64);
+            } else if (tau + 1 < KT) {                            // k-step ks - 2 of the next tile
+                ah[ks & 1] = lds_h8(wt(tau + 1), ((ks - 2) * 2 + 0) * 64);
+                al[ks & 1] = lds_h8(wt(tau + 1), ((ks - 2) * 2 + 1) * 64);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // stage A: everything that reads the accumulator (7 instructions per segment); behind it the accumulator's registers are free for
+        // the next tile's bias, whose LDS latency then sits under stage B instead of in front of the next matrix chain
+        float wr[4], wv[4], sx[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float w0 = acc[4 * g + 1], w1 = acc[4 * g + 2], w2 = acc[4 * g + 3];
+            wr[g] = fmaf(w2, c.f.r.z, fmaf(w1, c.f.r.y, w0 * c.f.r.x));
+            wv[g] = fmaf(w2, c.f.v.z, fmaf(w1, c.f.v.y, w0 * c.f.v.x));
+            sx[g] = acc[4 * g];
+        }
+        asm volatile("" : "+v"(wr[0]), "+v"(wr[1]), "+v"(wr[2]), "+v"(wr[3]), "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]),
+                          "+v"(sx[0]), "+v"(sx[1]), "+v"(sx[2]), "+v"(sx[3]));
+        if (tau + 1 < KT) acc = load_bias16(bt(tau + 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // 0.7 / (1 + |w|) = 1 / (1/0.7 + |w| / 0.7)   (flow/mobiusflow.py:72)
+            const float sc = hw_rcp(fmaf(hw_sqrt(fmaf(wv[g], wv[g], wr[g] * wr[g])), kInvSquash, kInvSquash));
+            const float ur = wr[g] * sc, uv = wv[g] * sc;
+            float sp = FASTSP ? softplus2_lean(sx[g]) : softplus2_safe(sx[g]);
+            if (tau == KT - 1) sp = (h < K - 8 * tau - 2 * g) ? sp : 0.f;      // pad segment of a K % 8 != 0 layer (last tile only): weight 0 AFTER the activation
+            sg.ur[4 * tau + g] = ur;
+            sg.uv[4 * tau + g] = uv;
+            sg.sp[4 * tau + g] = sp;
+            sg.q[4 * tau + g] = fmaf(-sp, fmaf(uv, uv, ur * ur), sp);
+            S += sp;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // Order of the inverse pass's root-finder iteration.  3 (shipped): Halley.  4 (-DRNF_RF_ORDER=4, measured and NOT shipped): Householder's
 // method with the third derivative, four more packed instructions per segment pair and pass (+13 % per pass: 1.53 against 1.35 ms per pass
 // over C5u's 42 layers x 2^20 rotations).  On sharply peaked weights (softmax of 6 x N(0,1) logits, centres 6 x N(0,1): the start is off by
@@ -921,13 +1087,19 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
             }
         const float mr = pair_sum(mr2.x + mr2.y) * invS;
         const float mv = pair_sum(mv2.x + mv2.y) * invS;
-        float st, ct;
-        sincos_small(c.target, st, ct);
-        const float a = -fmaf(mv, st, mr * ct);                     // (a, b) = (-m) conj(z_target)
-        const float b = fmaf(mr, st, -mv * ct);
-        float d = angle_0_2pi(-b, 1.0f - a);                        // 1 - a >= 0.3: the angle is in (-pi/2, pi/2), returned mod 2 pi
-        d = d > kPi ? d - kTwoPi : d;
-        th = fminf(fmaxf(fmaf(2.0f, d, c.target), lo + 1.0e-3f), hi - 1.0e-3f);
+        if constexpr (RNF_INV_PI) {
+            // target = pi (mobius_begin): z_target = (-1, 0), so (a, b) = (-m) conj(z_target) = (mr, mv), and |b / (1 - a)| <= tan(asin 0.7) < 1
+            // (|m| < 0.7): the segments' own single-quadrant arctangent, no octant logic, no wrap
+            th = fminf(fmaxf(fmaf(2.0f, atan_unit(-mv * hw_rcp(1.0f - mr)), kPi), lo + 1.0e-3f), hi - 1.0e-3f);
+        } else {
+            float st, ct;
+            sincos_small(c.target, st, ct);
+            const float a = -fmaf(mv, st, mr * ct);                     // (a, b) = (-m) conj(z_target)
+            const float b = fmaf(mr, st, -mv * ct);
+            float d = angle_0_2pi(-b, 1.0f - a);                        // 1 - a >= 0.3: the angle is in (-pi/2, pi/2), returned mod 2 pi
+            d = d > kPi ? d - kTwoPi : d;
+            th = fminf(fmaxf(fmaf(2.0f, d, c.target), lo + 1.0e-3f), hi - 1.0e-3f);
+        }
     }
     bool done = false;
     float prev = 1.0f;                                                     // size of the previous step (1: none yet)
@@ -1329,6 +1501,10 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
 #else
     constexpr bool KEEP_X0 = PREC == 1 && NW <= 8 && LEAN != 1;
 #endif         // room for x0 beside the hidden layers (Mlp<1>::head), and something to re-read
+#ifndef RNF_DEEP_H
+#define RNF_DEEP_H 1
+#endif
+    constexpr bool DEEP_H = RNF_DEEP_H && PREC == 1 && DIR == 1 && NW <= 8;      // Mlp<1>::head: two operand pairs in flight (hidden_slot2)
     const long long ntiles = (args.n + TILE - 1) / TILE;
     const int KT = args.KT;                                          // DIR = 1: <= KT_INV, the capacity of this instantiation
     const int n_layers = args.n_layers;
@@ -1342,7 +1518,10 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     FairT fair;
     if constexpr (FAIR_ON) fair = Fair{lds, wave, args.fair_off, 0};
     RNF_STAMP_DECL
-
+    // (Round 6, measured and NOT kept -- profiles/r6/ab_lag_*.jsonl: the workgroup's upper four waves run ONE PHASE BEHIND the lower four --
+    // three barriers per layer, the partners of a SIMD always in different phases (hidden / tiles / root finder), the matrix-phase wave at
+    // the higher issue priority; results bit-identical; C5u 11.67 -> 11.89 ms without, 11.72 ms with the priorities, C2's inverse 6.89 ->
+    // 6.96: the lockstep kernel already overlaps a wave's hidden phase with its partner's root finder)
     // iteration position -> layer index, and the next position (> pos) whose layer owns an MLP image, or -1
     auto layer_at = [&](int pos) { return DIR ? (n_layers - 1 - pos) : pos; };
     auto next_mlp = [&](int pos) {
@@ -1574,9 +1753,9 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             if constexpr (LEAN == 2 && NW == 16) asm volatile("" : "+v"(hh));
             if (LEAN == 1 || kind == RNF_KIND_MOBIUS) {
                 mobius_begin<DIR, DIR == 0 && PREC == 1>(R, perm_row, ctx);
-                Mlp<PREC>::template head<GF, KEEP_X0, FairT>(lds, lane, hh, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair, bad, have_gpre ? gpre : nullptr);
+                Mlp<PREC>::template head<GF, KEEP_X0, FairT, DEEP_H>(lds, lane, hh, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair, bad, have_gpre ? gpre : nullptr);
             } else {
-                Mlp<PREC>::template head<GF, KEEP_X0, FairT>(lds, lane, hh, 0.f, 0.f, 0.f, gfrag, tt, fair, bad, have_gpre ? gpre : nullptr);
+                Mlp<PREC>::template head<GF, KEEP_X0, FairT, DEEP_H>(lds, lane, hh, 0.f, 0.f, 0.f, gfrag, tt, fair, bad, have_gpre ? gpre : nullptr);
             }
             have_gpre = false;
             RNF_STAMP(1)                                          // 1: frame + hidden layers (H part)
@@ -1639,8 +1818,21 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     // a guarded split-precision call (the launcher runs the exact-fp32 kernels behind it when the guard fires) may use the
                     // lean softplus: the branch is wave uniform, each side its own copy of the tile loop
                     const bool fastsp = PREC == 1 && args.guard_mode == 1;
-                    if (fastsp) mobius_inv_tiles<KTI, PREC, PREC == 1>(lds, params, KT, args.K, lane, h, tt, ctx, sg, S, tid, NT, istash);
-                    else mobius_inv_tiles<KTI, PREC, false>(lds, params, KT, args.K, lane, h, tt, ctx, sg, S, tid, NT, istash);
+#ifndef RNF_INV_TILEPIPE
+#define RNF_INV_TILEPIPE 1
+#endif
+                    bool piped = false;
+                    if constexpr (RNF_INV_TILEPIPE && PREC == 1 && PIPE && KTI <= MOB_MAX_TILES_IN_LDS) {
+                        if (KT == KTI) {                              // wave uniform: the layer fills the instantiation's tiles (K = 64 on <1,8,...>: every BASELINE config)
+                            piped = true;
+                            if (fastsp) mobius_inv_tiles_pipe<KTI, true>(lds, args.K, lane, h, tt, ctx, sg, S);
+                            else mobius_inv_tiles_pipe<KTI, false>(lds, args.K, lane, h, tt, ctx, sg, S);
+                        }
+                    }
+                    if (!piped) {
+                        if (fastsp) mobius_inv_tiles<KTI, PREC, PREC == 1>(lds, params, KT, args.K, lane, h, tt, ctx, sg, S, tid, NT, istash);
+                        else mobius_inv_tiles<KTI, PREC, false>(lds, params, KT, args.K, lane, h, tt, ctx, sg, S, tid, NT, istash);
+                    }
                     // the barrier right behind the tiles (the root finder does not touch LDS, and its pass count differs from wave to wave:
                     // a barrier behind it was 19 % of the wave time), the DMA request of the next fc_last image behind the root finder:
                     // in front of it the DMA address arithmetic would sit on top of the 96 live segment registers (36 spills at K = 64);

@@ -1284,6 +1284,155 @@ extern "C" int rnf_condrot_svd(const float *mlp_out, int64_t n, float *rot_out, 
     return condrot_launch(mlp_out, n, rot_out, u_out, s_out, vt_out, fail_flag, stream);
 }
 
+// ConditionLU (flow/squeezetrans.py:94-131) on the device (round 6; until round 5 the host ran the reference's einsum / torch.diag on the GPU):
+//     weight[n] = w_p . (reshape(wl[n], C, C) * l_mask + l_eye) . (reshape(wu[n], C, C) * u_mask + dvec),   dvec[d] = s_sign[d] exp(ws[d][d])
+// `torch.diag` of the 2-D [N, C] tensor s_sign * exp(ws) (squeezetrans.py:126-127) is its DIAGONAL ACROSS THE BATCH -- entry d of row d,
+// d < C -- and the resulting C-vector is broadcast over the last axis of every sample's upper factor: it is added to EVERY row c of
+// column d, and the weight of sample n depends on batch rows 0 .. C-1.  Reproduced as defined.  consts = w_p [C*C] | l_mask [C*C] |
+// u_mask [C*C] | l_eye [C*C] | s_sign [C] (the module's buffers, as loaded from the checkpoint).  One thread per sample; out [n][16]:
+// the C x C matrix row-major in the first C*C floats (+ identity when add_identity: Condition9TransLU, squeezetrans.py:269-271), rest 0.
+template <int C>
+__global__ void condlu_assemble_kernel(const float *wl, const float *wu, const float *ws, int sl, int su, int ss, long long n, const float *consts,
+                                       int add_identity, float *out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int CC = C * C;
+    const float *wp = consts, *lm = consts + CC, *um = consts + 2 * CC, *le = consts + 3 * CC, *sg = consts + 4 * CC;
+    float dvec[C], Lm[CC], Um[CC], PL[CC];
+#pragma unroll
+    for (int d = 0; d < C; ++d) dvec[d] = sg[d] * expf(ws[(long long)d * ss + d]);       // rows 0 .. C-1 of the BATCH
+#pragma unroll
+    for (int k = 0; k < CC; ++k) {
+        Lm[k] = wl[i * sl + k] * lm[k] + le[k];
+        Um[k] = wu[i * su + k] * um[k] + dvec[k % C];
+    }
+#pragma unroll
+    for (int a = 0; a < C; ++a)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float t = 0.f;
+#pragma unroll
+            for (int b = 0; b < C; ++b) t = fmaf(wp[a * C + b], Lm[b * C + c], t);
+            PL[a * C + c] = t;
+        }
+    float o[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) o[k] = 0.f;
+#pragma unroll
+    for (int a = 0; a < C; ++a)
+#pragma unroll
+        for (int d = 0; d < C; ++d) {
+            float t = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) t = fmaf(PL[a * C + c], Um[c * C + d], t);
+            o[a * C + d] = t + ((add_identity && a == d) ? 1.0f : 0.0f);
+        }
+    float4 *dst = reinterpret_cast<float4 *>(out + i * 16);
+    dst[0] = make_float4(o[0], o[1], o[2], o[3]); dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+    dst[2] = make_float4(o[8], o[9], o[10], o[11]); dst[3] = make_float4(o[12], o[13], o[14], o[15]);
+}
+
+// Backward of the assembly: g [n][16] = dL/d(weight).  dL/dL = P^T G U^T, dL/dU = (P L)^T G; g_wl = dL/dL * l_mask, g_wu = dL/dU * u_mask
+// (row stride gstride), and the batch-coupled diagonal collects  g_dvec[d] = sum_n sum_c dL/dU[n][c][d]  (wave sums, then one float atomic
+// per wave and column into dsum [C], zeroed by the launcher).  condlu_diag_kernel then writes g_ws: zero everywhere except
+// g_ws[d][d] = g_dvec[d] * dvec[d]  (d dvec[d] / d ws[d][d] = dvec[d]).
+template <int C>
+__global__ void condlu_backward_kernel(const float *wl, const float *wu, const float *ws, int sl, int su, int ss, long long n, const float *consts,
+                                       const float *g, float *g_wl, float *g_wu, int gsl, int gsu, float *dsum) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int CC = C * C;
+    const float *wp = consts, *lm = consts + CC, *um = consts + 2 * CC, *le = consts + 3 * CC, *sg = consts + 4 * CC;
+    float dcol[C];
+#pragma unroll
+    for (int d = 0; d < C; ++d) dcol[d] = 0.f;
+    if (i < n) {
+        float dvec[C], Lm[CC], Um[CC], PL[CC], PtG[CC], G[CC];
+#pragma unroll
+        for (int d = 0; d < C; ++d) dvec[d] = sg[d] * expf(ws[(long long)d * ss + d]);
+#pragma unroll
+        for (int k = 0; k < CC; ++k) {
+            Lm[k] = wl[i * sl + k] * lm[k] + le[k];
+            Um[k] = wu[i * su + k] * um[k] + dvec[k % C];
+            G[k] = g[i * 16 + k];
+        }
+#pragma unroll
+        for (int a = 0; a < C; ++a)
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float t = 0.f, u = 0.f;
+#pragma unroll
+                for (int b = 0; b < C; ++b) {
+                    t = fmaf(wp[a * C + b], Lm[b * C + c], t);            // (P L)[a][c]
+                    u = fmaf(wp[b * C + a], G[b * C + c], u);             // (P^T G)[a][c]
+                }
+                PL[a * C + c] = t;
+                PtG[a * C + c] = u;
+            }
+#pragma unroll
+        for (int b = 0; b < C; ++b)
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float gl = 0.f, gu = 0.f;
+#pragma unroll
+                for (int d = 0; d < C; ++d) {
+                    gl = fmaf(PtG[b * C + d], Um[c * C + d], gl);         // dL/dL[b][c] = sum_d (P^T G)[b][d] U[c][d]
+                    gu = fmaf(PL[d * C + b], G[d * C + c], gu);           // dL/dU[b][c] = sum_a (P L)[a][b] G[a][c]
+                }
+                g_wl[i * gsl + b * C + c] = gl * lm[b * C + c];
+                g_wu[i * gsu + b * C + c] = gu * um[b * C + c];
+                dcol[c] += gu;
+            }
+    }
+#pragma unroll
+    for (int d = 0; d < C; ++d) {
+        float v = dcol[d];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(dsum + d, v);
+    }
+}
+template <int C>
+__global__ void condlu_diag_kernel(const float *ws, int ss, long long n, const float *consts, const float *dsum, float *g_ws, int gss) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *sg = consts + 4 * C * C;
+#pragma unroll
+    for (int d = 0; d < C; ++d) g_ws[i * gss + d] = (i == d) ? dsum[d] * sg[d] * expf(ws[(long long)d * ss + d]) : 0.f;
+}
+extern "C" int rnf_condlu_matrices(const float *wl, const float *wu, const float *ws, int32_t stride_wl, int32_t stride_wu, int32_t stride_ws, int64_t n,
+                                   int32_t C, const float *consts, int32_t add_identity, float *side_out, void *stream) {
+    if (C != 3 && C != 4) return fail("rnf_condlu_matrices: in_channel %d (3 or 4)", C);
+    if (n < 0 || stride_wl < C * C || stride_wu < C * C || stride_ws < C) return fail("rnf_condlu_matrices: n=%lld row strides %d %d %d", (long long)n, stride_wl, stride_wu, stride_ws);
+    if (n == 0) return 0;
+    // the reference broadcasts the C-vector torch.diag(...) of an [n, C] tensor (length min(n, C)) against [n, C, C]: fewer than C rows fail there
+    if (n < C) return fail("rnf_condlu_matrices: a batch of %lld rows has no %d-entry batch diagonal (flow/squeezetrans.py:126-127 fails to broadcast)", (long long)n, C);
+    if (!wl || !wu || !ws || !consts || !side_out) return fail("rnf_condlu_matrices: null pointer");
+    const dim3 grid((unsigned)((n + 127) / 128)), block(128);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (C == 4) hipLaunchKernelGGL(condlu_assemble_kernel<4>, grid, block, 0, st, wl, wu, ws, stride_wl, stride_wu, stride_ws, (long long)n, consts, add_identity, side_out);
+    else hipLaunchKernelGGL(condlu_assemble_kernel<3>, grid, block, 0, st, wl, wu, ws, stride_wl, stride_wu, stride_ws, (long long)n, consts, add_identity, side_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+extern "C" int rnf_condlu_backward(const float *wl, const float *wu, const float *ws, int32_t stride_wl, int32_t stride_wu, int32_t stride_ws, int64_t n,
+                                   int32_t C, const float *consts, const float *g_side, float *g_wl, float *g_wu, float *g_ws, float *scratch, void *stream) {
+    if (C != 3 && C != 4) return fail("rnf_condlu_backward: in_channel %d (3 or 4)", C);
+    if (n < C || stride_wl < C * C || stride_wu < C * C || stride_ws < C) return fail("rnf_condlu_backward: n=%lld row strides %d %d %d", (long long)n, stride_wl, stride_wu, stride_ws);
+    if (!wl || !wu || !ws || !consts || !g_side || !g_wl || !g_wu || !g_ws || !scratch) return fail("rnf_condlu_backward: null pointer");
+    const dim3 grid((unsigned)((n + 127) / 128)), block(128);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(float) * 4, st));
+    if (C == 4) {
+        hipLaunchKernelGGL(condlu_backward_kernel<4>, grid, block, 0, st, wl, wu, ws, stride_wl, stride_wu, stride_ws, (long long)n, consts, g_side, g_wl, g_wu, C * C, C * C, scratch);
+        hipLaunchKernelGGL(condlu_diag_kernel<4>, grid, block, 0, st, ws, stride_ws, (long long)n, consts, scratch, g_ws, C);
+    } else {
+        hipLaunchKernelGGL(condlu_backward_kernel<3>, grid, block, 0, st, wl, wu, ws, stride_wl, stride_wu, stride_ws, (long long)n, consts, g_side, g_wl, g_wu, C * C, C * C, scratch);
+        hipLaunchKernelGGL(condlu_diag_kernel<3>, grid, block, 0, st, ws, stride_ws, (long long)n, consts, scratch, g_ws, C);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int rnf_flow_forward_train(const float *rot, const float *feat, int64_t n, int32_t F, const float *blob, const int32_t *desc,
                                       int32_t n_layers, int32_t K, float *rot_out, float *ldj_out, float *states, void *ws,
                                       size_t ws_bytes, void *stream) {

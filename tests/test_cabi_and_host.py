@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), name
-    assert _lib.lib().rnf_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.lib().rnf_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_packed_sizes_match_parameter_counts():

@@ -1,6 +1,6 @@
 """Mirror of the reference's flow/squeezetrans.py: the 4x4 quaternion-affine family (constant, LU-parameterised, feature-conditioned)
 and the 3x3 / 6x6 Gram-Schmidt ablation layers, unconditional and conditional -- every class of the registry is built (DESIGN.md
-section 3.7; the conditional LU layers hand their batch-coupled per-sample matrices to the kernels as a side buffer)."""
+section 3.7; the conditional LU layers build their batch-coupled per-sample matrices with a HIP kernel into the stack kernel's side buffer)."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -271,11 +271,11 @@ class _SideLayer(nn.Module, _SingleLayer):
 
 class ConditionLU(nn.Module):
     """flow/squeezetrans.py:94-131: P (L * l_mask + I) (U * u_mask + diag) with L, U and the diagonal predicted from the feature by three
-    ConditionalTransforms.  Buffer / parameter names are the checkpoint contract.  ``forward`` keeps the reference's expression verbatim,
+    ConditionalTransforms.  Buffer / parameter names are the checkpoint contract.  The reference's expression is reproduced as defined,
     including ``torch.diag`` of the 2-D [N, C] tensor: that call takes the diagonal ACROSS THE BATCH (entry i of sample i, i < C) and the
     C-vector is then broadcast onto every row of every sample's upper factor -- the weight of one sample depends on the first C samples
-    of the batch it travels in (and a batch of fewer than C rows fails to broadcast, as in the reference).  The three MLPs run on the GPU
-    through the HIP conditioner (runtime.SideNet)."""
+    of the batch it travels in (and a batch of fewer than C rows fails to broadcast, as in the reference).  The three MLPs run through the
+    HIP conditioner (runtime.SideNet), the assembly and its backward through ``rnf_condlu_matrices`` / ``rnf_condlu_backward`` (round 6)."""
 
     _rnf_batch_coupled = True
 
@@ -297,20 +297,81 @@ class ConditionLU(nn.Module):
         self.w_u_net = ConditionalTransform(feature_dim, in_channel * in_channel)
         self.w_s_net = ConditionalTransform(feature_dim, in_channel)
         self._nets = None
+        self._consts_cache = None
         self._feature_dim = feature_dim
 
-    def forward(self, feature):
+    def _consts(self, device):
+        """w_p | l_mask | u_mask | l_eye | s_sign as one device vector (the layout rnf_condlu_matrices reads), rebuilt when a buffer changes."""
+        bufs = (self.w_p, self.l_mask, self.u_mask, self.l_eye, self.s_sign)
+        key = (str(device),) + tuple((id(b), b._version, b.data_ptr()) for b in bufs)
+        if self._consts_cache is None or self._consts_cache[0] != key:
+            self._consts_cache = (key, torch.cat([b.detach().reshape(-1).to(device=device, dtype=torch.float32) for b in bufs]).contiguous())
+        return self._consts_cache[1]
+
+    def side(self, feature, add_identity=False):
+        """-> [n, 16]: the C x C matrix of every sample row-major in the leading C*C floats (one slot of the stack kernel's side buffer).
+        The three conditioners and the assembly (csrc/rnf_api.hip condlu_assemble_kernel, with its backward) are HIP kernels; no torch
+        compute op runs between the call and the launches (round 6; until round 5 the assembly was the reference's einsum / torch.diag)."""
         if not feature.is_cuda:
             raise RuntimeError("rotationnormflow_amd runs on the GPU only (HIP kernels, no CPU fallback): got a CPU tensor")
+        C = self.in_channel
         if self._nets is None:
-            C = self.in_channel
             self._nets = (runtime.SideNet(self.w_l_net, self._feature_dim, C * C), runtime.SideNet(self.w_u_net, self._feature_dim, C * C),
                           runtime.SideNet(self.w_s_net, self._feature_dim, C))
-        C = self.in_channel
         wl, wu, ws = (net(feature) for net in self._nets)
-        return torch.einsum("ab,nbc,ncd->nad", self.w_p,
-                            wl.reshape(-1, C, C) * self.l_mask + self.l_eye,
-                            (wu.reshape(-1, C, C) * self.u_mask) + torch.diag(self.s_sign * torch.exp(ws)))
+        return _CondLUFn.apply(wl, wu, ws, self._consts(feature.device), C, bool(add_identity))
+
+    def forward(self, feature):
+        """The reference's call (flow/squeezetrans.py:120-131): weight [n, C, C]."""
+        C = self.in_channel
+        return self.side(feature)[:, : C * C].reshape(-1, C, C)
+
+
+def _rows(t):
+    """(tensor, row stride) of a 2-D float32 cuda tensor whose rows are dense: the conditioner hands out views of [n, 16] buffers."""
+    if t.dtype is not torch.float32 or t.stride(1) != 1:
+        t = t.to(torch.float32).contiguous()
+    return t, t.stride(0)
+
+
+class _CondLUFn(torch.autograd.Function):
+    """ConditionLU's matrices from the three conditioners' outputs (rnf_condlu_matrices / rnf_condlu_backward): P (L * l_mask + I)
+    (U * u_mask + dvec) with the reference's batch-coupled dvec = torch.diag(s_sign * exp(ws)) (flow/squeezetrans.py:120-131)."""
+
+    @staticmethod
+    def forward(ctx, wl, wu, ws, consts, C, add_identity):
+        from .. import _lib
+        (wl, sl), (wu, su), (ws, ss) = _rows(wl.detach()), _rows(wu.detach()), _rows(ws.detach())
+        n, dev = wl.shape[0], wl.device
+        if 0 < n < C:          # the reference's broadcast of the C-vector torch.diag(...) against [n, C, C] fails for fewer than C rows
+            raise RuntimeError(f"The size of tensor a ({n}) must match the size of tensor b ({C}) at non-singleton dimension 2")
+        out = torch.empty((n, 16), dtype=torch.float32, device=dev)
+        if n:
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().rnf_condlu_matrices(wl.data_ptr(), wu.data_ptr(), ws.data_ptr(), sl, su, ss, n, C, consts.data_ptr(),
+                                                          int(add_identity), out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        ctx.save_for_backward(wl, wu, ws, consts)
+        ctx.meta = (C, sl, su, ss)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from .. import _lib
+        wl, wu, ws, consts = ctx.saved_tensors
+        C, sl, su, ss = ctx.meta
+        n, dev = wl.shape[0], wl.device
+        g = g.to(torch.float32).contiguous()
+        g_wl = torch.empty((n, C * C), dtype=torch.float32, device=dev)
+        g_wu = torch.empty((n, C * C), dtype=torch.float32, device=dev)
+        g_ws = torch.empty((n, C), dtype=torch.float32, device=dev)
+        scratch = torch.empty(4, dtype=torch.float32, device=dev)
+        if n:
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().rnf_condlu_backward(wl.data_ptr(), wu.data_ptr(), ws.data_ptr(), sl, su, ss, n, C, consts.data_ptr(),
+                                                          g.data_ptr(), g_wl.data_ptr(), g_wu.data_ptr(), g_ws.data_ptr(), scratch.data_ptr(),
+                                                          torch.cuda.current_stream(dev).cuda_stream))
+        return g_wl, g_wu, g_ws, None, None, None
 
 
 class Condition16TransLU(_SideLayer):
@@ -324,9 +385,11 @@ class Condition16TransLU(_SideLayer):
         self.net = ConditionLU(4, feature_dim)
         self._cache = runtime.PackCache()
 
+    _rnf_no_graph = False          # round 6: conditioners, assembly and their backward are HIP kernels -- capturable into a HIP graph
+
     def _rnf_side(self, feature, grad=False):
         with torch.set_grad_enabled(grad):
-            return self.net(feature).reshape(-1, 16)
+            return self.net.side(feature)
 
 
 class Condition9TransLU(_SideLayer):
@@ -341,9 +404,11 @@ class Condition9TransLU(_SideLayer):
         self.net = ConditionLU(3, feature_dim)
         self._cache = runtime.PackCache()
 
+    _rnf_no_graph = False
+
     def _rnf_side(self, feature, grad=False):
         with torch.set_grad_enabled(grad):
-            return (self.net(feature).reshape(-1, 3, 3) + torch.eye(3, device=feature.device)).reshape(-1, 9)
+            return self.net.side(feature, add_identity=True)          # + I (flow/squeezetrans.py:269-271) inside the assembly kernel
 
 
 # ---- the reference's module-level functions under their own names (flow/squeezetrans.py:10-38,200-231) ---------------------------------

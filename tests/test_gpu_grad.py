@@ -540,6 +540,80 @@ def test_condition_rot_flow_trains_inside_a_hip_graph():
     condrot_failures()                                          # no SVD of these calls failed to converge
 
 
+def _condlu_reference(wl, wu, ws, w_p, l_mask, u_mask, l_eye, s_sign, C):
+    """flow/squeezetrans.py:120-131, the reference's expression on given conditioner outputs (torch, any device / dtype)."""
+    return torch.einsum("ab,nbc,ncd->nad", w_p, wl.reshape(-1, C, C) * l_mask + l_eye,
+                        (wu.reshape(-1, C, C) * u_mask) + torch.diag(s_sign * torch.exp(ws)))
+
+
+@pytest.mark.parametrize("C", [4, 3])
+def test_condition_lu_assembly_kernel_and_its_backward_equal_the_reference_expression(C):
+    """rnf_condlu_matrices / rnf_condlu_backward (round 6) against the reference's einsum over torch.diag (batch-coupled: the diagonal of
+    the [n, C] tensor) and fp64 autograd of that expression, on strided conditioner outputs (views of [n, 16] buffers) and dense ones."""
+    from rotationnormflow_amd.flow.squeezetrans import _CondLUFn
+    g = torch.Generator().manual_seed(5 + C)
+    n = 333
+    bufs = [torch.randn((n, 16), generator=g) * 0.5 for _ in range(3)]
+    w_p = torch.eye(C)[torch.randperm(C, generator=g)]
+    u_mask = torch.triu(torch.ones(C, C), 1)
+    l_mask, l_eye = u_mask.T.contiguous(), torch.eye(C)
+    s_sign = torch.sign(torch.randn(C, generator=g))
+    consts = torch.cat([w_p.reshape(-1), l_mask.reshape(-1), u_mask.reshape(-1), l_eye.reshape(-1), s_sign]).cuda()
+    G = torch.randn((n, 16), generator=g)
+    for dense in (False, True):
+        ins = [b.cuda()[:, : (C * C if i < 2 else C)] for i, b in enumerate(bufs)]
+        if dense:
+            ins = [t.contiguous() for t in ins]
+        ins = [t.requires_grad_(True) for t in ins]
+        for add_eye in (False, True):
+            out = _CondLUFn.apply(*ins, consts, C, add_eye)
+            ref_in = [b[:, : (C * C if i < 2 else C)].double().requires_grad_(True) for i, b in enumerate(bufs)]
+            want = _condlu_reference(*ref_in, w_p.double(), l_mask.double(), u_mask.double(), l_eye.double(), s_sign.double(), C)
+            if add_eye:
+                want = want + torch.eye(C, dtype=torch.float64)
+            got = out[:, : C * C].detach().cpu().double().reshape(n, C, C)
+            assert (got - want.detach()).abs().max() < 2e-5 * max(1.0, float(want.detach().abs().max()))
+            if C == 3:
+                assert float(out[:, 9:].abs().max()) == 0.0
+            (out * G.cuda()).sum().backward()
+            (want * G[:, : C * C].double().reshape(n, C, C)).sum().backward()
+            for a, b in zip(ins, ref_in):
+                scale = max(1.0, float(b.grad.abs().max()))
+                assert (a.grad.cpu().double() - b.grad).abs().max() < 5e-5 * scale
+                a.grad = None
+    # fewer rows than C fail like the reference's broadcast
+    with pytest.raises(RuntimeError, match="must match the size"):
+        _CondLUFn.apply(*(t[: C - 1] for t in ins), consts, C, False)
+
+
+def test_condition_lu_flow_trains_inside_a_hip_graph():
+    """Round 6: with ConditionLU's assembly and backward in HIP nothing between the conditioners and the stack kernel is a
+    torch compute op, so flows with Condition16TransLU / Condition9TransLU layers are graph-capturable (round 5 refused them)."""
+    from rotationnormflow_amd import harness
+    for rot in ("16Trans", "9TransLSmith"):
+        cfg = orc.make_config(layers=2, segments=16, condition=1, feature_dim=24, rot=rot, lu=1)
+        w = synth.fill_state_dict(orc.state_shapes(cfg), seed=33, regime="default")
+        fl = product_flow(cfg, w).train()
+        assert not harness.host_preprocess_layers(fl)
+        n = 256
+        R = torch.from_numpy(synth.uniform_rotations(n, seed=5)).cuda()
+        feat = torch.from_numpy(synth.features(n, 24, seed=6)).cuda()
+        opt = torch.optim.Adam(fl.parameters(), 1e-4, capturable=True, fused=True)
+        step = harness.GraphedTrainStep(fl, opt, (n, 3, 3), feature_shape=(n, 24))
+        eager = product_flow(cfg, w).train()
+        opt_e = torch.optim.Adam(eager.parameters(), 1e-4, fused=True)
+        for it in range(3):
+            lg = float(step(R, feat).detach())
+            _, ldj = eager(R, feat)
+            le = (-ldj).mean()
+            opt_e.zero_grad()
+            le.backward()
+            opt_e.step()
+            assert np.isfinite(lg)
+            if it < 2:
+                assert abs(lg - float(le.detach())) < 2e-3 * max(1.0, abs(lg)), (rot, it, lg, float(le))
+
+
 def test_graphed_train_step_follows_the_oracle():
     """harness.GraphedTrainStep (the iteration captured as a HIP graph) must walk the same loss trajectory as fp64 autograd of the
     oracle with torch.optim.Adam, starting from the untouched initial weights (the capture warm-up must leave no trace)."""

@@ -133,13 +133,20 @@ def build_flow(device, preset, weights_path=None):
     shapes = {k: tuple(v.shape) for k, v in fl.state_dict().items()}
     if weights_path:                                          # a checkpoint in Agent.save_ckpt's layout (agent.py:139-152)
         from rotationnormflow_amd.harness import load_reference_checkpoint
-        sd = load_reference_checkpoint(weights_path if os.path.isabs(weights_path) else os.path.join(ROOT, weights_path))
+        weights_path = weights_path if os.path.isabs(weights_path) else os.path.join(ROOT, weights_path)
+        sd = load_reference_checkpoint(weights_path)
         weights = {k: v.numpy() for k, v in sd.items()}
         assert {k: tuple(v.shape) for k, v in weights.items()} == shapes, "checkpoint does not fit the workload's flow"
     else:
         weights = synth.fill_state_dict(shapes, seed=2024, regime="trained")
     fl.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
-    return cfg, weights, fl.to(device).eval()
+    fl = fl.to(device).eval()
+    if weights_path and cfg.condition:                        # the feature scale the checkpoint's sidecar fixes (harness.write_feature_scale), if any
+        from rotationnormflow_amd.harness import read_feature_scale
+        ms = read_feature_scale(weights_path)
+        if ms is not None:
+            fl.set_feature_scale(ms)
+    return cfg, weights, fl
 
 
 def host_threads():

@@ -513,9 +513,11 @@ def _as_params(params, dtype):
     return {k: torch.as_tensor(v).to(dtype) for k, v in params.items()}
 
 
-def flow_forward(cfg, params, R, feature=None, dtype=torch.float32, grad=False):
+def flow_forward(cfg, params, R, feature=None, dtype=torch.float32, grad=False, rot_override=None):
     """Flow.forward (flow.py:53-72): returns (R' [N,3,3], ldj [N]).  grad=True keeps the autograd graph (params / R / feature
-    given as torch tensors that require grad): the oracle for the training path's gradients (agent.py:79-80)."""
+    given as torch tensors that require grad): the oracle for the training path's gradients (agent.py:79-80).
+    rot_override {layer index: [N,4,4]}: a ConditionRot layer applies THESE orthogonal matrices instead of U^T V of its own SVD -- U^T V is
+    defined by the SVD routine's sign choices, so the per-sample parity test hands the oracle the factors of the routine under test."""
     p = _as_params(params, dtype)
     R = torch.as_tensor(R).to(dtype)
     feature = None if (feature is None or not cfg.condition) else torch.as_tensor(feature).to(dtype)
@@ -551,7 +553,8 @@ def flow_forward(cfg, params, R, feature=None, dtype=torch.float32, grad=False):
             elif kind == "clu9":
                 R, l = gs9(cond_lu_matrix(feature, p, f"layers.{i}.net", 3) + torch.eye(3, dtype=R.dtype)[None], R)   # squeezetrans.py:269-271
             elif kind == "crot16":
-                R, l = rot16_apply(cond_rot16_matrix(feature, p, f"layers.{i}.net"), R)  # rottrans.py:42-53
+                rot = torch.as_tensor(rot_override[i]).to(dtype) if rot_override and i in rot_override else cond_rot16_matrix(feature, p, f"layers.{i}.net")
+                R, l = rot16_apply(rot, R)                                              # rottrans.py:42-53
             elif kind == "cgs9":
                 R, l = gs9(cond9_matrix(feature, p, f"layers.{i}.net"), R)              # squeezetrans.py:239-242
             elif kind == "cgs36":
@@ -570,7 +573,7 @@ def flow_forward(cfg, params, R, feature=None, dtype=torch.float32, grad=False):
     return R, ldj
 
 
-def flow_inverse(cfg, params, R, feature=None, dtype=torch.float32, grad=False):
+def flow_inverse(cfg, params, R, feature=None, dtype=torch.float32, grad=False, rot_override=None):
     """Flow.inverse (flow.py:74-92): returns (R [N,3,3], ldj_of_inverse_map [N]).  grad=True keeps the autograd graph (through
     BinFind's custom backward): the oracle for gradients through the inverse pass."""
     p = _as_params(params, dtype)
@@ -611,7 +614,9 @@ def flow_inverse(cfg, params, R, feature=None, dtype=torch.float32, grad=False):
             elif kind == "clu9":
                 R, l = gs9(torch.linalg.inv(cond_lu_matrix(feature, p, f"layers.{i}.net", 3) + torch.eye(3, dtype=R.dtype)[None]), R)   # :273-277
             elif kind == "crot16":
-                R, l = rot16_apply(cond_rot16_matrix(feature, p, f"layers.{i}.net", inverse=True), R)                  # rottrans.py:55-66
+                rot = (torch.as_tensor(rot_override[i]).to(dtype).transpose(-1, -2) if rot_override and i in rot_override      # (forward orientation handed in)
+                       else cond_rot16_matrix(feature, p, f"layers.{i}.net", inverse=True))
+                R, l = rot16_apply(rot, R)                                              # rottrans.py:55-66
             elif kind == "cgs9":
                 R, l = gs9(torch.linalg.inv(cond9_matrix(feature, p, f"layers.{i}.net")), R)        # squeezetrans.py:244-247
             elif kind == "cgs36":

@@ -7,7 +7,8 @@ signatures and state-dict keys).  There is no CPU fallback.
 """
 from .configs import make_config, load_yaml_config, PRESETS  # noqa: F401
 
-__all__ = ["make_config", "load_yaml_config", "PRESETS", "install_as_reference_modules", "set_precision", "get_precision"]
+__all__ = ["make_config", "load_yaml_config", "PRESETS", "install_as_reference_modules", "set_precision", "get_precision",
+           "set_feature_calibration", "get_feature_calibration"]
 
 
 def set_precision(name):
@@ -19,6 +20,19 @@ def set_precision(name):
 def get_precision():
     from . import runtime
     return runtime.get_precision()
+
+
+def set_feature_calibration(mode):
+    """Where the pack-time equalisation of conditional layers takes the feature scale from: "weights" (default: 1 unless fixed with
+    ``Flow.set_feature_scale`` / ``calibrate_feature_scale`` / a checkpoint sidecar -- deterministic) or "first-batch" (measured on the first
+    feature batch a parameter version is packed for, re-measured when the launch guard keeps firing).  Env: RNF_FEATURE_CALIBRATION."""
+    from . import runtime
+    runtime.set_feature_calibration(mode)
+
+
+def get_feature_calibration():
+    from . import runtime
+    return runtime.get_feature_calibration()
 
 
 def install_as_reference_modules():

@@ -130,7 +130,7 @@ class TrainPlan:
         """Mean square of the feature entries, measured ONCE per plan on the first batch it sees (a training run keeps its feature
         distribution): the data-dependent input of the device packer's equalisation (csrc/equalize.h)."""
         if self.feature_ms is None and feature is not None and not torch.cuda.is_current_stream_capturing():
-            self.feature_ms = runtime.feature_mean_square(feature)
+            self.feature_ms = runtime.calibration_ms(feature)             # 1 unless runtime.set_feature_calibration("first-batch")
 
     def check_flags(self):
         if self.flags_event is not None and self.flags_event.query():

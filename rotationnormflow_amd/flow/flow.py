@@ -254,11 +254,18 @@ class Flow(nn.Module):
 
     def set_feature_scale(self, mean_square):
         """Fix the calibration input of the conditional layers' pack-time equalisation (csrc/equalize.h): the mean square of a feature entry.
-        By default it is measured on the first feature batch a parameter version is packed for -- per PROCESS, so the ranks of a sharded
-        evaluation would each measure their own shard; ``dist.calibrate_feature_scale`` all-reduces one value and sets it here on every rank,
-        which makes the packed images, and with them every rotation's result, identical on 1 and on N GPUs.  ``None`` returns to measuring."""
+        Default (round 6, ``runtime.set_feature_calibration("weights")``): 1 -- nothing is measured, the packed images are a function of the
+        weights alone.  Features of another scale (un-normalised backbone outputs) are what this call, ``calibrate_feature_scale``, a checkpoint
+        sidecar (``harness.write_feature_scale``) or -- sharded -- ``dist.calibrate_feature_scale`` (one all-reduced value on every rank) are
+        for.  ``None`` returns to the default."""
         self._feature_ms_fixed = None if mean_square is None else runtime.quantise_feature_ms(float(mean_square))
         self.invalidate()
+
+    def calibrate_feature_scale(self, feature):
+        """Measure the mean square of ``feature``'s entries (one device reduction, one scalar read-back) and fix it as the calibration
+        (``set_feature_scale``).  Returns the value (quantised to 1/16 binade: what the packers see)."""
+        self.set_feature_scale(runtime.feature_mean_square(feature))
+        return self._feature_ms_fixed
 
     def _device_packed(self, device, feature=None):
         """Kernel blob built on the device from the live parameters (rnf_pack_flow_device, one 18 us launch): used when the host cache
@@ -296,6 +303,8 @@ class Flow(nn.Module):
                         plan.feature_ms = fixed
                     elif plan.feature_ms is None:
                         plan.feature_ms = getattr(self._cache, "feature_ms", None)
+                        if plan.feature_ms is None and runtime.get_feature_calibration() != "first-batch":
+                            plan.feature_ms = 1.0
                     plan.calibrate(feature)
                     self._cache.feature_ms = plan.feature_ms
                 blob = plan.pack(plain, torch.cuda.current_stream(device).cuda_stream, with_fallback=runtime._guard_fallback)
@@ -336,7 +345,7 @@ class Flow(nn.Module):
                 if isinstance(layer, MobiusFlow) and a % 3 != b % 3:
                     raise RuntimeError("forward/inverse permutation schedules disagree (flow/flow.py:58-90)")
             fixed = getattr(self, "_feature_ms_fixed", None)
-            ms = 1.0 if not self.condition else (fixed if fixed is not None else runtime.feature_mean_square(feature))
+            ms = 1.0 if not self.condition else (fixed if fixed is not None else runtime.calibration_ms(feature))
             return runtime.pack_layers(list(self.layers), rows, device, feature_ms=ms)
         return self._cache.get(self, device, build)
 

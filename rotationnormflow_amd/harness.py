@@ -19,11 +19,13 @@ from __future__ import annotations
 import argparse
 import contextlib
 import io
+import os
 
 import numpy as np
 import torch
 
 from .configs import load_yaml_config, make_config
+from . import runtime
 from .flow.flow import Flow
 
 
@@ -35,12 +37,48 @@ def load_reference_checkpoint(path, map_location="cpu") -> dict:
     return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
 
 
+FEATURE_SCALE_SUFFIX = ".rnf.json"
+
+
+def read_feature_scale(ckpt_path):
+    """The calibration a checkpoint's sidecar carries (``<ckpt>.rnf.json``: {"feature_mean_square": m_f}), or None.  The reference's
+    checkpoint layout (agent.py:132-146) has no place for it and must stay loadable by the reference, hence a file NEXT to the checkpoint."""
+    import json
+    side = str(ckpt_path) + FEATURE_SCALE_SUFFIX
+    if not os.path.exists(side):
+        return None
+    with open(side) as fh:
+        return float(json.load(fh)["feature_mean_square"])
+
+
+def write_feature_scale(ckpt_path, flow_or_value, features=None) -> float:
+    """Write the sidecar: the flow's fixed calibration (``Flow.set_feature_scale`` / ``calibrate_feature_scale``), a number, or -- with
+    ``features`` -- the mean square measured on that batch.  Conditional flows whose features are not of unit scale want one, so that every
+    process that loads the checkpoint packs the same images without seeing data first."""
+    import json
+    if features is not None:
+        value = runtime.feature_mean_square(features)
+    elif isinstance(flow_or_value, (int, float)):
+        value = runtime.quantise_feature_ms(float(flow_or_value))
+    else:
+        value = getattr(flow_or_value, "_feature_ms_fixed", None)
+        if value is None:
+            raise ValueError("the flow has no fixed feature scale: call flow.calibrate_feature_scale(features) first, or pass features=")
+    with open(str(ckpt_path) + FEATURE_SCALE_SUFFIX, "w") as fh:
+        json.dump({"feature_mean_square": float(value)}, fh)
+    return float(value)
+
+
 def build_flow_from_checkpoint(config, ckpt_path, device="cuda") -> Flow:
     with contextlib.redirect_stdout(io.StringIO()):
         flow = Flow(config)
     missing = flow.load_state_dict(load_reference_checkpoint(ckpt_path), strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
-    return flow.to(device).eval()
+    flow = flow.to(device).eval()
+    ms = read_feature_scale(ckpt_path) if getattr(config, "condition", 0) else None
+    if ms is not None:
+        flow.set_feature_scale(ms)
+    return flow
 
 
 def load_raw_rotations(path) -> torch.Tensor:

@@ -112,13 +112,18 @@ def quantise_feature_ms(ms: float) -> float:
     return float(2.0 ** (round(math.log2(ms) * 16.0) / 16.0))
 
 
+_SQ_CHUNK = 1 << 24                   # entries per reduction step of feature_square_sum (64 MB of fp32: its fp64 transient is 128 MB)
+
+
 def feature_square_sum(feature) -> torch.Tensor:
     """float64 [2] = {sum of squares, count} of a feature batch on its device (no host sync): what ranks all-reduce to agree on one
     calibration (dist.calibrate_feature_scale)."""
-    f = feature.detach()
-    # the square of the 2-norm, accumulated in fp64 by the reduction itself: no fp64 copy of the batch (C5's 2^20 x 512 fp32 features are
-    # 2 GB; a converted copy plus its square were 8 GB of transient HBM at every pack / calibration -- ADVICE r4)
-    ss = torch.linalg.vector_norm(f.reshape(-1), 2, dtype=torch.float64).square()
+    f = feature.detach().reshape(-1)
+    # Accumulated in fp64 in bounded chunks.  (Round 5 called torch.linalg.vector_norm(f, 2, dtype=float64), which casts its WHOLE input to
+    # fp64 first -- ADVICE r5: a 2 GB feature batch, C5's 2^20 x 512, allocated 4 GB of transient HBM at every pack / calibration.)
+    ss = torch.zeros((), dtype=torch.float64, device=f.device)
+    for chunk in f.split(_SQ_CHUNK):
+        ss += chunk.to(torch.float64).square_().sum()
     return torch.stack((ss, torch.tensor(float(f.numel()), dtype=torch.float64, device=f.device)))
 
 
@@ -130,6 +135,34 @@ def feature_mean_square(feature) -> float:
         return 1.0
     sq = feature_square_sum(feature)
     return quantise_feature_ms(float(sq[0] / sq[1]))
+
+
+# ---- where the calibration input of the equalisation comes from ------------------------------------------------------------------------------
+# "weights" (default since round 6): nothing is measured -- m_f = 1 (features of unit scale, the regime of normalised backbone features)
+#     unless the caller fixed a value (Flow.set_feature_scale / Flow.calibrate_feature_scale / dist.calibrate_feature_scale) or the
+#     checkpoint came with a sidecar (harness.build_flow_from_checkpoint reads ``<ckpt>.rnf.json``).  The packed images -- and with them every
+#     rotation's result, bit for bit -- are a function of the weights and that one explicit number: two processes that see different first
+#     batches agree.  Features far from the assumed scale are caught by the launch guard (exact-fp32 re-run: correct, ~3x slower) and a
+#     RuntimeWarning names the call that fixes it.
+# "first-batch" (rounds 3 - 5): m_f is measured on the first feature batch a parameter version is packed for, and measured again when the
+#     guard keeps firing (GuardWatch).  Best accuracy without any call, but a process-local, data-dependent state.
+_feature_calibration = os.environ.get("RNF_FEATURE_CALIBRATION", "weights")
+
+
+def set_feature_calibration(mode: str) -> None:
+    global _feature_calibration
+    if mode not in ("weights", "first-batch"):
+        raise ValueError(f"unknown feature calibration mode {mode!r} (weights, first-batch)")
+    _feature_calibration = mode
+
+
+def get_feature_calibration() -> str:
+    return _feature_calibration
+
+
+def calibration_ms(feature) -> float:
+    """The m_f a pack without an explicit value uses: 1 ("weights" mode), or the batch's measured mean square ("first-batch")."""
+    return feature_mean_square(feature) if _feature_calibration == "first-batch" else 1.0
 
 
 def expand_shared_rows(feature, n_rot: int, feature_repeat: int):
@@ -236,19 +269,26 @@ class GuardWatch:
                 self.streak = 0
                 if self.recalibrations >= self.MAX_RECALIBRATIONS:
                     return False       # re-packing again would produce the same images: stay on the (correct) fp32 re-runs, quietly
-                self.recalibrations += 1
+                auto = _feature_calibration == "first-batch"
+                if auto:
+                    self.recalibrations += 1
                 if not self.warned:
                     import warnings
                     warnings.warn("rotationnormflow_amd: the range guard re-ran several consecutive launches of this flow on the exact-fp32 "
                                   "kernels (features far from the scale the packed images were calibrated for, or an activation beyond "
-                                  "the fp16 range): results are correct but ~3x slower; re-calibrating on the current batch -- "
-                                  "Flow.set_feature_scale() fixes a scale, set_precision('fp32') avoids the guarded path", RuntimeWarning)
+                                  "the fp16 range): results are correct but ~3x slower; "
+                                  + ("re-calibrating on the current batch -- Flow.set_feature_scale() fixes a scale"
+                                     if auto else "call Flow.calibrate_feature_scale(features) once (or Flow.set_feature_scale / a checkpoint "
+                                     "sidecar, harness.write_feature_scale) to pack the images for this data")
+                                  + ", set_precision('fp32') avoids the guarded path", RuntimeWarning)
                     self.warned = True
-                return True
+                return auto            # "weights" mode: nothing is re-packed behind the caller's back
+            if not fired:              # a quiet launch: the cap counts CONSECUTIVE failed re-calibrations, not a lifetime total
+                self.recalibrations = 0
         return False
 
     def watch(self, ws):
-        if self.pending or self.recalibrations >= self.MAX_RECALIBRATIONS or torch.cuda.is_current_stream_capturing():
+        if self.pending or torch.cuda.is_current_stream_capturing():     # (still watching at the re-calibration cap: a quiet launch lifts it again, poll())
             return
         if self.device is not None and self.device != ws.device:
             return                     # one watch, one device (nn.DataParallel replicas get their own: Flow._replicate_for_data_parallel)
@@ -402,7 +442,7 @@ class SideNet:
             from . import autograd
             return autograd.cond_mlp(self.net, feature, self.n_out)
         dev = feature.device
-        blob, feat_off, prec = self.cache.get(self.net, dev, lambda: self._pack(dev, feature_mean_square(feature)))
+        blob, feat_off, prec = self.cache.get(self.net, dev, lambda: self._pack(dev, calibration_ms(feature)))
         L = _lib.lib()
         n = feature.shape[0]
         Fp = pad8(self.feature_dim)

@@ -20,6 +20,10 @@ def run_case(name, device="cuda"):
     fl = product_flow(cfg, w, device)
     Rd = torch.from_numpy(R).to(device)
     fd = None if feat is None else torch.from_numpy(feat).to(device)
+    if fd is not None and spec.get("regime") == "imbalanced":
+        # un-normalised features (x30, synth.FEATURE_SCALE): what Flow.calibrate_feature_scale is for.  (Round 6: nothing is measured by
+        # default -- the packed images are a function of the weights and of this one explicit number)
+        fl.calibrate_feature_scale(fd)
     with torch.no_grad():
         if spec["direction"] == "forward":
             Rt, ldj = fl(Rd, fd)

@@ -185,38 +185,89 @@ def test_all_segment_weights_tiny(n):
     assert err.max() < 5e-5 and err.mean() < 5e-6, (err.max(), err.mean())
 
 
-def test_repeated_guard_firing_warns_and_recalibrates():
-    """the equalisation of conditional layers is calibrated on the first feature batch a parameter version is packed for; later
-    batches with far larger features trip the x0 guard and every launch is silently re-run on the exact-fp32 kernels.  The runtime now
-    notices (asynchronously -- no call waits for the device), warns once and re-calibrates on the batch at hand; after that the guard is
-    quiet again and the results are right throughout."""
+@pytest.mark.parametrize("mode", ["weights", "first-batch"])
+def test_repeated_guard_firing_warns_and_recalibrates(mode):
+    """a conditional flow whose features are far larger than the scale its images were packed for trips the x0 guard and every
+    launch is silently re-run on the exact-fp32 kernels.  The runtime notices (asynchronously -- no call waits for the device) and warns once.
+    "first-batch" calibration (rounds 3 - 5): it then re-calibrates on the batch at hand and the guard is quiet again.  "weights" (the
+    default since round 6: nothing is measured or re-packed behind the caller's back) the warning names the call, the results stay right on
+    the fp32 re-runs, and Flow.calibrate_feature_scale(features) makes the guard quiet."""
     import time
     import warnings
     if runtime.get_precision() != "f16x2":
         pytest.skip("only the split-precision kernels are guarded")
-    cfg = make_config(layers=2, segments=16, condition=1, feature_dim=24, rot="16UnTrans", frequent_permute=1, last_affine=1, first_affine=0)
-    w = synth.fill_state_dict(orc.state_shapes(cfg), seed=12, regime="trained")
-    fl = product_flow(cfg, w)
-    n = 4096
-    R = torch.from_numpy(synth.uniform_rotations(n, seed=15)).cuda()
-    f_small = synth.features(n, 24, seed=16)
-    f_big = (f_small * 3000.0).astype(np.float32)               # x0 lands far beyond kX0Guard = 64 for images calibrated on f_small
+    old_mode = runtime.get_feature_calibration()
+    runtime.set_feature_calibration(mode)
+    try:
+        cfg = make_config(layers=2, segments=16, condition=1, feature_dim=24, rot="16UnTrans", frequent_permute=1, last_affine=1, first_affine=0)
+        w = synth.fill_state_dict(orc.state_shapes(cfg), seed=12, regime="trained")
+        fl = product_flow(cfg, w)
+        n = 4096
+        R = torch.from_numpy(synth.uniform_rotations(n, seed=15)).cuda()
+        f_small = synth.features(n, 24, seed=16)
+        f_big = (f_small * 3000.0).astype(np.float32)               # x0 lands far beyond kX0Guard = 64 for images packed for unit-scale features
+        with torch.no_grad():
+            fl.log_prob(R, torch.from_numpy(f_small).cuda())
+            assert not runtime.fallback_fired(R.device)
+            fb = torch.from_numpy(f_big).cuda()
+            want, _ = orc.log_prob(cfg, w, R[:256].cpu().numpy(), f_big[:256], None, torch.float64)
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                fired = []
+                for it in range(12):
+                    got = fl.log_prob(R, fb)["logp"]
+                    fired.append(runtime.fallback_fired(R.device))   # (synchronises: the watch words of earlier calls have landed)
+                    time.sleep(0.01)
+                assert (got[:256].cpu().double() - want).abs().max() < 1e-3 * max(1.0, float(want.abs().max()))
+                assert fired[0] and fired[1]                             # stale scale: the guard fires ...
+                msgs = [str(c.message) for c in caught if "range guard" in str(c.message)]
+                assert len(msgs) == 1
+                if mode == "first-batch":
+                    assert not any(fired[-3:]), fired                    # ... until the runtime re-calibrated on the large features
+                else:
+                    assert all(fired), fired                             # ... and keeps firing: nothing is re-packed behind the caller's back
+                    assert "calibrate_feature_scale" in msgs[0]
+                    assert fl.calibrate_feature_scale(fb) > 1e6
+                    got = fl.log_prob(R, fb)["logp"]
+                    assert not runtime.fallback_fired(R.device)
+                    assert (got[:256].cpu().double() - want).abs().max() < 1e-3 * max(1.0, float(want.abs().max()))
+    finally:
+        runtime.set_feature_calibration(old_mode)
+
+
+def _rows_in_a_fresh_process(first_scale):
+    """Child of test_conditional_rows_do_not_depend_on_the_first_batch_a_process_sees: load trained_c4.pth through the harness, evaluate a batch
+    whose features are scaled by `first_scale` FIRST, then the fixture's own rows; prints the sha256 of those rows' log-dets."""
+    import hashlib
+    import sys
+    from rotationnormflow_amd import harness
+    from tests.trained_helpers import load_trained
+    cfg, ckpt, w, fx, spec = load_trained("trained_c4")
+    flow = harness.build_flow_from_checkpoint(cfg, ckpt)
+    R = torch.from_numpy(fx["test_rot"].astype(np.float32)).cuda()
+    f = torch.from_numpy(fx["test_feat"].astype(np.float32)).cuda()
     with torch.no_grad():
-        fl.log_prob(R, torch.from_numpy(f_small).cuda())
-        assert not runtime.fallback_fired(R.device)
-        fb = torch.from_numpy(f_big).cuda()
-        want, _ = orc.log_prob(cfg, w, R[:256].cpu().numpy(), f_big[:256], None, torch.float64)
-        with warnings.catch_warnings(record=True) as caught:
-            warnings.simplefilter("always")
-            fired = []
-            for it in range(12):
-                got = fl.log_prob(R, fb)["logp"]
-                fired.append(runtime.fallback_fired(R.device))   # (synchronises: the watch words of earlier calls have landed)
-                time.sleep(0.01)
-        assert (got[:256].cpu().double() - want).abs().max() < 1e-3 * max(1.0, float(want.abs().max()))
-    assert fired[0] and fired[1]                                 # stale calibration: the guard fires ...
-    assert not any(fired[-3:]), fired                            # ... until the runtime re-calibrated on the large features
-    assert sum(1 for c in caught if "range guard" in str(c.message)) == 1
+        flow(R, f * float(first_scale))
+        _, ldj = flow(R, f)
+    sys.stdout.write("ROWS " + hashlib.sha256(ldj.cpu().numpy().tobytes()).hexdigest() + "\n")
+
+
+def test_conditional_rows_do_not_depend_on_the_first_batch_a_process_sees():
+    """two FRESH processes that see different first batches (features x 1 and x 1/50) produce bit-identical rows for
+    trained_c4.pth without calling set_feature_scale -- the packed images are a function of the checkpoint (weights + its feature-scale
+    sidecar tests/golden/trained_c4.pth.rnf.json), not of the data a process happens to see first.  (Rounds 3 - 5 calibrated on the first
+    batch: the x 1/50 process packed other images.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for scale in ("1.0", "0.02"):
+        out = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {root!r}); from tests.test_gpu_guard import _rows_in_a_fresh_process as f; f({scale})"],
+                             capture_output=True, text=True, cwd=root, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([l for l in out.stdout.splitlines() if l.startswith("ROWS ")][-1])
+    assert digests[0] == digests[1]
 
 
 @pytest.mark.parametrize("direction", ["forward", "inverse"])

@@ -104,7 +104,7 @@ def test_forward_matches_reference_golden(name, precision):
     p99_32 = float(np.quantile(np.abs(ldj - fx["ldj32"].astype(np.float64)), 0.99))
     p99_ref = float(np.quantile(noise, 0.99))
     if precision == "f16x2":
-        assert frac >= 0.985 and excess <= noise.max() + 1e-5, (frac, excess)
+        assert frac >= 0.99 and excess <= noise.max() + 1e-5, (frac, excess)       # (round 6: 0.985 -> 0.99; measured minimum 0.991, c4_imbal)
         assert p99_32 <= p99_ref + 1e-5, (p99_32, p99_ref)
     else:
         assert frac >= 0.88 and excess <= 2 * noise.max() + 1e-5, (frac, excess)
@@ -145,6 +145,73 @@ def test_inverse_matches_reference_golden(name):
     assert rerr.max() <= 2.0 * cell + (2.0 if "imbal" in name else 1.0) * rnoise.max()
     assert err.max() <= 6 * cell + noise.max()
     assert np.mean(rerr > 0.5 * cell) <= max(0.01, np.mean(rnoise > 0.5 * cell)) + 0.005
+
+
+def _device_rotations(fl, fd):
+    """{layer index: [n,4,4] fp64} -- U^T V of every ConditionRot layer as the DEVICE SVD routine (csrc/svd4_lapack.h) produced it for these
+    features: the very matrices the stack kernel applied (build_side_buffer calls the same entry on the same inputs)."""
+    from rotationnormflow_amd.flow.rottrans import ConditionRot
+    out = {}
+    for i, layer in enumerate(fl.layers):
+        if isinstance(layer, ConditionRot):
+            out[i] = layer._rnf_side(fd.to(torch.float32), grad=False).reshape(-1, 4, 4).cpu().double()
+    return out
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if n.startswith("crot16")])
+def test_condition_rot_every_sample_against_the_oracle_on_the_same_svd_factors(name):
+    """Round 6: the percentile gates of the crot16 fixtures compare two SVD ROUTINES (the device restatement of LAPACK vs the
+    reference's torch.svd) and leave 5 - 10 % of the samples unbounded.  Here the fp64 oracle applies the device routine's own U^T V
+    (rot_override), so every other operation of every sample -- conditioners, quaternion maps, Moebius layers, bisection -- is gated at fp32
+    rounding with NO sample exempt: a wrong sign or transposition in any of them would be an O(1) error."""
+    from tests.helpers import load_case
+    fl, Rt, ldj, fx, spec, (Rd, fd) = run_case(name)
+    cfg, w, R, feat, _, _ = load_case(name)
+    rots = _device_rotations(fl, fd)
+    assert rots and all(float((r @ r.transpose(-1, -2) - torch.eye(4, dtype=torch.float64)).abs().max()) < 1e-5 for r in rots.values())
+    fn = orc.flow_forward if spec["direction"] == "forward" else orc.flow_inverse
+    want_R, want_l = fn(cfg, w, R, feat, dtype=torch.float64, rot_override=rots)
+    err = np.abs(ldj - want_l.numpy())
+    rerr = np.abs(Rt - want_R.numpy()).reshape(len(ldj), -1).max(1)
+    if spec["direction"] == "forward":
+        assert err.max() < 1e-4 and err.mean() < 1e-5, (err.max(), err.mean())
+        assert rerr.max() < 1e-4 and rerr.mean() < 5e-6, (rerr.max(), rerr.mean())
+        assert abs(ldj.mean() - want_l.numpy().mean()) < 1e-5
+    else:       # the bisection grid: every sample within 2 cells (+ fp32 rounding), the log-det within 6 cells' worth of slope
+        cell = np.pi / 2 ** 14
+        assert rerr.max() <= 2.0 * cell + 1e-4, rerr.max() / cell
+        assert err.max() <= 6 * cell + 1e-4 and err.mean() <= 0.5 * cell, (err.max() / cell, err.mean() / cell)
+        assert np.mean(rerr > 0.5 * cell) <= 0.02
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if n.startswith("clu16")])
+def test_condition_lu_every_sample_relative_to_its_condition_number(name):
+    """Round 6: Condition16TransLU's per-sample matrices are close to singular for a few samples (log-dets down to -30), so
+    the fixture gates trim the worst 1 %.  Here NO sample is exempt: its error is bounded by the amplification its own matrices allow,
+    |ldj - ldj64| <= c * sum_layers cond(M_layer) * 2^-23 + 2e-5 with cond from the fp64 oracle's matrices (log|det M| - 4 log|M q| moves by
+    ~ cond(M) times the relative rounding of M's entries, which come out of an fp32 conditioner)."""
+    from tests.helpers import load_case
+    fl, Rt, ldj, fx, spec, (Rd, fd) = run_case(name)
+    cfg, w, R, feat, _, _ = load_case(name)
+    p = {k: torch.from_numpy(np.asarray(v)).double() for k, v in w.items()}
+    f64 = torch.from_numpy(feat).double()
+    kappa = np.zeros(len(ldj))
+    for i, kind in enumerate(orc.layer_kinds(cfg)):
+        if kind == "clu16":
+            M = orc.cond_lu_matrix(f64, p, f"layers.{i}.net", 4)
+            kappa += torch.linalg.cond(M).numpy()
+    assert kappa.min() >= 1.0
+    err = np.abs(ldj - fx["ldj64"])
+    # c: measured (profiles/r6/clu16_cond_stats.txt, worst sample of 512, (err - 2e-5) / (cond 2^-23)): forward 3.7 - 10.1 for the build, 4.5 -
+    # 11.6 for the REFERENCE's own fp32 run; inverse pass (the per-sample matrix is inverted first: one more factor of the conditioning) 35 - 40
+    # against the reference's 21.  Gates at ~1.5x the larger of the two.
+    c = 64.0 if spec["direction"] == "inverse" else 16.0
+    bound = c * kappa * 2.0 ** -23 + 2e-5
+    worst = float(np.max(err / bound))
+    assert worst <= 1.0, (worst, int(np.argmax(err / bound)), float(kappa.max()), float(err.max()))
+    # ... and the reference's own fp32 run needs the same kind of slack: the bound is not looser than the reference's arithmetic by more than ~4x
+    noise = np.abs(fx["ldj32"].astype(np.float64) - fx["ldj64"])
+    assert np.max(noise / bound) > 0.25
 
 
 @pytest.mark.parametrize("name", ["c2_default", "c2_trained"])
@@ -253,7 +320,8 @@ def test_shared_feature_rows_equal_materialised_repeat_and_the_oracle(direction,
         # the inverse lands on the bisection grid (cells of pi / 2^14): the row form adds G to x0 in another order than the tile form (one more
         # fc_first matrix step instead of the accumulator start), and a root within rounding of a cell boundary may take the other cell
         cell = np.pi / 2 ** 14
-        assert dR.max().item() <= 2.0 * cell and dl.max().item() <= 6 * cell and (dR > 0.5 * cell).float().mean().item() <= 0.01
+        # (3 cells: two arithmetics that each flip a cell in consecutive layers -- 2.5 observed on one of 4500 samples)
+        assert dR.max().item() <= 3.0 * cell and dl.max().item() <= 6 * cell and (dR > 0.5 * cell).float().mean().item() <= 0.01
         assert dR.median().item() < 2e-6 and dl.median().item() < 5e-6
     frep_n = np.repeat(fn, Q, axis=0)
     run = orc.flow_forward if direction == "forward" else orc.flow_inverse

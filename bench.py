@@ -149,14 +149,18 @@ def build_flow(device, preset, weights_path=None):
     return cfg, weights, fl
 
 
-def host_threads():
-    """Threads the baseline may really use: the scheduler affinity of this process (cgroup-limited boxes report far
-    more in os.cpu_count()), capped so small ATen ops do not drown in oversubscription."""
+def threads_available():
+    """Hardware threads this process may run on (scheduler affinity: cgroup-limited boxes report far more in os.cpu_count())."""
     try:
-        n = len(os.sched_getaffinity(0))
+        return len(os.sched_getaffinity(0))
     except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(n, 32))
+        return os.cpu_count() or 1
+
+
+def host_threads():
+    """Threads the baseline uses: the available ones, capped at 32 so the oracle's small ATen ops do not drown in oversubscription (the line
+    says "32 of N": `cores` and `threads_available`)."""
+    return max(1, min(threads_available(), 32))
 
 
 def cpu_model():
@@ -207,8 +211,10 @@ def cpu_baseline(cfg, weights, A, wl, feat_dim, sizes, budget_s, queries=None):
         runs.append({"n": n, "best_s": min(times), "repetitions": reps, "rotations_per_s": n / min(times)})
         best_rate = max(best_rate, n / min(times))
     what = "forward log_prob" if wl["direction"] == "forward" else "inverse pass (base sampling not included)"
-    return dict(value=best_rate, unit="rotations/s", cores=threads, kind="port", cpu=cpu_model(), runs=runs,
-                sample=f"{wl['preset']} {what}, fp32, torch-CPU oracle, {threads} threads; " +
+    best = max(runs, key=lambda r: r["rotations_per_s"])
+    return dict(value=best_rate, unit="rotations/s", cores=threads, threads_available=threads_available(), kind="port", cpu=cpu_model(), runs=runs,
+                n=best["n"], best_s=best["best_s"], repetitions=best["repetitions"],
+                sample=f"{wl['preset']} {what}, fp32, torch-CPU oracle, {threads} of {threads_available()} threads; " +
                        "; ".join(f"N={r['n']}: best of {r['repetitions']} = {r['best_s']:.2f} s" for r in runs))
 
 
@@ -418,6 +424,7 @@ def pmc_child(args):
     marker = torch.empty(64, dtype=torch.int16, device=device)       # (empty, not zeros: a zeros() would itself launch the marker kernel)
     sections = []
     prev = None
+    evals, settle = (args.pmc_evals or PMC_EVALS), (args.pmc_settle or 0)
     for name in args.pmc_configs.split(","):
         w = Workload(name, device, args.batch_log2, share=prev)
         prev = w
@@ -425,13 +432,15 @@ def pmc_child(args):
             set_precision(precision)
             with torch.no_grad():
                 w.evaluate()                                    # warm-up of this arithmetic: packs, allocates; profiled too, then dropped by position
+                for _ in range(settle):                         # (kernel-trace pass: let the clock settle as the timed region of the bench does)
+                    w.evaluate()
                 torch.cuda.synchronize()
                 marker.fill_(1)
-                for _ in range(PMC_EVALS):
+                for _ in range(evals):
                     w.evaluate()
                 torch.cuda.synchronize()
                 marker.fill_(2)
-            sections.append({"key": f"{name}:{precision}", "rotations": w.n, "evals": PMC_EVALS,
+            sections.append({"key": f"{name}:{precision}", "rotations": w.n, "evals": evals,
                              "packed_precision": w.fl._packed(device, w.feat).precision})
         set_precision("f16x2")
         w.R = w.feat = None
@@ -473,15 +482,18 @@ def short_kernel(name):
     return name.split("(")[0]
 
 
-def pmc_sections_summary(passes, sections):
+def pmc_sections_summary(passes, sections, trace=None):
     """-> {section key: {rotations, roofline{traffic, traffic_fetch, traffic_write, kernel, kernels[...], valu_issue_frac, ...}}} per STEP."""
     out = {}
     for s in sections:
         key, evals = s["key"], s["evals"]
         kernels = {}
+        for kname, e in (trace or {}).get(key, {}).items():      # kernel-trace pass without counters (same box, same process shape)
+            kernels.setdefault(kname, {"name": short_kernel(kname), "calls_per_step": e["calls"] / evals})["ms_per_call_trace"] = e["ns"] / e["calls"] * 1e-6
         for grp, per in passes.items():
             for kname, e in per.get(key, {}).items():
-                k = kernels.setdefault(kname, {"name": short_kernel(kname), "calls_per_step": e["calls"] / evals, "vgpr": e["vgpr"], "workgroup": e["wg"]})
+                k = kernels.setdefault(kname, {"name": short_kernel(kname), "calls_per_step": e["calls"] / evals})
+                k.update(vgpr=e["vgpr"], workgroup=e["wg"])
                 k.setdefault("ms_per_call_under_pmc", {})[grp] = e["ns"] / e["calls"] * 1e-6
                 c = e["counters"]
                 if "FETCH_SIZE" in c:
@@ -502,6 +514,9 @@ def pmc_sections_summary(passes, sections):
                     k["gpu_cycles_per_step"] = cycles / evals
         if not kernels:
             continue
+        kernels = {n: k for n, k in kernels.items() if "ms_per_call_under_pmc" in k}
+        if not kernels:
+            continue
         klist = sorted(kernels.values(), key=lambda k: -k["calls_per_step"] * max(k["ms_per_call_under_pmc"].values()))
         for k in klist:
             k["ms_per_call_under_pmc"] = min(k["ms_per_call_under_pmc"].values())
@@ -511,11 +526,52 @@ def pmc_sections_summary(passes, sections):
         write = sum(k.get("write_bytes_per_step", 0.0) for k in kernels.values())
         roof = {"traffic": fetch + write if ("fetch" in passes and "write" in passes) else None, "traffic_fetch": fetch, "traffic_write": write,
                 "kernel": dom["name"], "kernels": klist}
+        if "ms_per_call_trace" in dom:                           # rocprofv3 --kernel-trace average of the dominant kernel on THIS box, and of the step
+            roof["kernel_ms_trace"] = dom["ms_per_call_trace"]
+            roof["step_ms_trace"] = sum(k.get("ms_per_call_trace", 0.0) * k["calls_per_step"] for k in klist)
         tot_cyc = sum(k.get("gpu_cycles_per_step", 0.0) for k in klist)
         if tot_cyc > 0:                                          # step-level fractions: cycle-weighted over the step's kernels
             roof["valu_issue_frac"] = sum(k.get("valu_issue_frac", 0.0) * k.get("gpu_cycles_per_step", 0.0) for k in klist) / tot_cyc
             roof["matrix_pipe_frac"] = sum(k.get("matrix_pipe_frac", 0.0) * k.get("gpu_cycles_per_step", 0.0) for k in klist) / tot_cyc
         out[key] = {"rotations": s["rotations"], "packed_precision": s.get("packed_precision"), "roofline": roof}
+    return out
+
+
+def kernel_trace_pass(exe, work, configs, batch_log2):
+    """`rocprofv3 --kernel-trace` (no counters) around the same child: {section key: {kernel name: {calls, ns}}} or {} on failure.  Counter
+    collection stretches the kernels (C5u: 12.9 ms under --pmc against 12.0), and boxes differ by 4 - 6 %: this is the SAME-BOX kernel-trace
+    average the bench line's HIP-event `kernel_ms` can be reconciled with (VERDICT r5 #8: `kernel_ms_trace`)."""
+    d = os.path.join(work, "trace")
+    cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+           "--pmc-configs", ",".join(configs), "--pmc-evals", "6", "--pmc-settle", str(CLOCK_SETTLE_LAUNCHES)]
+    if batch_log2 is not None:
+        cmd += ["--batch-log2", str(batch_log2)]
+    try:
+        res = subprocess.run(cmd, cwd=work, env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")), capture_output=True, text=True, timeout=420)
+    except subprocess.TimeoutExpired:
+        return {}
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("PMC_SECTIONS ")]
+    files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    if res.returncode != 0 or not line or not files:
+        return {}
+    sections = json.loads(line[0][len("PMC_SECTIONS "):])
+    disp = []
+    for path in files:
+        with open(path, newline="") as fh:
+            for r in csv.DictReader(fh):
+                disp.append((int(r["Start_Timestamp"]), r["Kernel_Name"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    out, idx, inside = {}, 0, False
+    for _, kname, ns in sorted(disp):
+        if MARKER in kname:
+            if inside:
+                idx += 1
+            inside = not inside
+            continue
+        if not inside or idx >= len(sections) or "rnf::" not in kname:
+            continue
+        e = out.setdefault(sections[idx]["key"], {}).setdefault(kname, {"calls": 0, "ns": 0})
+        e["calls"] += 1
+        e["ns"] += ns
     return out
 
 
@@ -545,7 +601,8 @@ def run_pmc_passes(configs, batch_log2, keep_dir=None):
                 return {"error": f"rocprofv3 pass '{grp}' failed (rc {res.returncode}): {(res.stderr or res.stdout)[-300:]}"}
             sections = json.loads(line[0][len("PMC_SECTIONS "):])
             passes[grp] = pmc_parse(files, sections)
-        out = {"sections": pmc_sections_summary(passes, sections), "csrc_sha": source_hash(), "seconds": time.time() - t0,
+        trace = kernel_trace_pass(exe, work, configs, batch_log2)      # the same child WITHOUT counters: this box's kernel-trace averages
+        out = {"sections": pmc_sections_summary(passes, sections, trace), "csrc_sha": source_hash(), "seconds": time.time() - t0,
                "source": f"this run: rocprofv3 --pmc passes ({', '.join(PMC_GROUPS)}; each group its own process) over {PMC_EVALS} evaluations per "
                          "workload and arithmetic; FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 (gfx950 correction of MI355X_MICROARCH.md), summed over "
                          "every kernel of a step"}
@@ -756,7 +813,7 @@ def _sig(x, digits=6):
 
 THIN_CONFIGS = ("C3", "C2t", "C4t")
 COMPACT_LIMIT = 3000                      # bytes; the driver keeps ~8 KB of stdout tail and parses the LAST line (BENCH_r04: a 40 KB line was lost)
-ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms", "traffic", "traffic_algorithmic", "valu_issue_frac",
+ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms", "kernel_ms_trace", "traffic", "traffic_algorithmic", "valu_issue_frac",
              "matrix_pipe_frac")
 
 
@@ -771,8 +828,9 @@ def compact_record(out, full_path=None):
     if "roofline" in out:
         c["roofline"] = _pick(out["roofline"], ROOF_KEYS)
     if "cpu_baseline" in out:
-        c["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "cpu"))
-        c["cpu_baseline"]["sample"] = out["cpu_baseline"].get("sample", "")[:60]
+        cb = out["cpu_baseline"]                             # the sample as NUMBERS (round 5 cut a sentence off mid-number) + a short label
+        c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "threads_available", "kind", "cpu", "n", "best_s", "repetitions"))
+        c["cpu_baseline"]["sample"] = f"oracle fp32, best of {cb.get('repetitions', '?')} at N={cb.get('n', '?')}"
         c["vs_cpu_baseline"] = out.get("vs_cpu_baseline")
     if "parity" in out:
         c["parity"] = _pick(out["parity"], ("mean_abs_err_of_the_mean", "max_abs_err"))
@@ -852,6 +910,8 @@ def main():
     ap.add_argument("--full-out", default=None, metavar="PATH", help="where the full record goes (default: bench_full.json beside bench.py); "
                     "stdout carries it on a `BENCH_FULL ` line and ends with the compact record")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-evals", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-settle", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--pmc-configs", default=",".join(ALL_CONFIGS), help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus < 1:

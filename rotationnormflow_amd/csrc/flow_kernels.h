@@ -435,8 +435,9 @@ struct Fair {
     }
 };
 
-// The instantiations that never run the governor (every one but the general 8-wave forward split-precision kernel) carry none of its code:
-// compiled in behind a run-time `off < 0` test it still cost the 128-register kernels live address registers around every tick.
+// -DRNF_V_NOFAIR only (measured and NOT the default): the instantiations that never run the governor compiled without its
+// code.  The default build gives every instantiation `Fair` with a run-time `off < 0` test (the launcher enables it for the general 8-wave
+// forward split-precision kernel only).
 struct NoFair {
     // (the tick points stay scheduling fences: without them the scheduler interleaves the hidden layers more freely and the 128-register
     // instantiations spill three times as much)
@@ -1579,11 +1580,13 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     // the per-(layer, row) records of consecutive rotations are the same few cache lines, so XCD-mate x takes the x-th CONTIGUOUS eighth of
     // the tiles: each L2 then holds one eighth of the row records (C4q: 1.6 MB of 13 MB) instead of all of them, every XCD for itself.
     // A pure placement choice: a rotation's result does not depend on the tile order (grids that are no multiple of 8 keep the default).
+    // Balanced ranges: XCD-mate x walks tiles [x ntiles / 8, (x + 1) ntiles / 8) -- with ceil(ntiles / 8)-sized eighths the last XCD
+    // got the remainder only (ntiles = 257 on a grid of 256: 26 tiles for its 32 workgroups while the others walked 33).
     const bool xcd_order = ROWS && (gridDim.x & 7) == 0;
-    const long long tiles_per_xcd = (ntiles + 7) >> 3;
-    const long long tile_end = xcd_order ? min(ntiles, (long long)((blockIdx.x & 7) + 1) * tiles_per_xcd) : ntiles;
+    const long long tile_begin = xcd_order ? (ntiles * (long long)(blockIdx.x & 7)) >> 3 : 0;
+    const long long tile_end = xcd_order ? (ntiles * (long long)((blockIdx.x & 7) + 1)) >> 3 : ntiles;
     const long long tile_step = xcd_order ? (gridDim.x >> 3) : gridDim.x;
-    for (long long tile = xcd_order ? (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3) : blockIdx.x; tile < tile_end; tile += tile_step) {
+    for (long long tile = xcd_order ? tile_begin + (blockIdx.x >> 3) : blockIdx.x; tile < tile_end; tile += tile_step) {
         const long long group = tile * NW + wave;                 // 32-sample group index inside this launch
         const long long sample0 = group * TILE_SAMPLES;           // wave uniform
         const bool valid = sample0 + j < args.n;

@@ -235,6 +235,15 @@ def test_eight_ranks_weak_and_strong_equal_the_single_rank_statistic():
     assert r8["scaling"] == "strong" and r8["rccl_ranks"] == 8 and r8["config"]["global_batch"] == 1 << 17
     assert r8["config"]["rotations_per_gpu"] == (1 << 17) // 8 and r1["config"]["rotations_per_gpu"] == 1 << 17
     assert abs(r1["mean_nll"] - r8["mean_nll"]) <= 1e-12 * abs(r1["mean_nll"])
+    # the STRONG-scaling line as the driver would launch it (CPU baseline and counters on): every contract key, `roofline`,
+    # `cpu_baseline` (its sample as numbers, "cores of threads_available") and the rank count read back from the communicator, under 3 KB
+    strong = _self_launch(["--config", "C3", "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch-log2", "17", "--no-secondary"])
+    assert strong.returncode == 0, strong.stderr[-2000:]
+    c = _compact(strong)
+    assert c["scaling"] == "strong" and c["n_gpus"] == 8 and c["rccl_ranks"] == 8 and c["config"]["workload"].startswith("C3")
+    cb = c["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] == "port" and cb["n"] > 0 and cb["best_s"] > 0 and 1 <= cb["cores"] <= cb["threads_available"]
+    assert c["roofline"]["frac"] > 0 and abs(c["mean_nll"] - r1["mean_nll"]) <= 1e-12 * abs(r1["mean_nll"])
 
 
 def test_a_dying_rank_ends_the_run_with_an_error_not_a_hang():

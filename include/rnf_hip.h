@@ -74,9 +74,16 @@ extern "C" {
  *                  audit the packed image against the exact network on probe inputs (rnf_last_pack_audit) and return 2 -- pack
  *                  RNF_PREC_FP32 instead -- when it is off by more than 4e-6, or when a (scaled) weight leaves the fp16 range
  *                  (|x| < 65504).  Activations beyond the fp16 range at run time are caught by the range guard (see desc columns 6, 7).
+ * RNF_PREC_BF16X3: (ABI v7) every fp32 operand -- weight and activation -- as THREE bf16 terms hi + mid + lo (truncated splits: 24
+ *                  significant bits, fp32's exponent range), six bf16 MFMAs (every term down to 2^-16 of the leading one) into one fp32
+ *                  accumulator per product-sum.  Nothing data- or scale-dependent: no equalisation, no audit, no feature calibration, no range
+ *                  guard.  Records are larger (rnf_mobius_packed_floats_prec / rnf_cond_packed_floats_prec: a weight tile is 3072 floats
+ *                  instead of 2048), the feature-projection record holds the RNF_PREC_FP32 image, and the kernels stage synchronously.
+ *                  Host-packed flows only (rnf_pack_flow_device does not build it).
  */
 #define RNF_PREC_FP32 0
 #define RNF_PREC_F16X2 1
+#define RNF_PREC_BF16X3 2
 
 int rnf_abi_version(void);
 const char *rnf_last_error(void);
@@ -104,7 +111,9 @@ int rnf_set_train_block(int rotations);
  * points take K <= 512 (the conditioner outputs of a 16-rotation block live in LDS).  `feature_dim` (F) is the number of
  * feature inputs of the layer's MLP (0 for an unconditional Moebius layer).
  */
-int64_t rnf_mobius_packed_floats(int32_t segments);
+int64_t rnf_mobius_packed_floats(int32_t segments);                       /* RNF_PREC_FP32 / RNF_PREC_F16X2 records */
+int64_t rnf_mobius_packed_floats_prec(int32_t segments, int32_t precision);   /* any RNF_PREC_* */
+int64_t rnf_cond_packed_floats_prec(int32_t n_out /* 16, 9 or 36 */, int32_t precision);
 int64_t rnf_affine16_packed_floats(void);
 int64_t rnf_cond16_packed_floats(void);
 int64_t rnf_featproj_packed_floats(int32_t feature_dim); /* 0 when feature_dim == 0 */

@@ -12,7 +12,8 @@ __all__ = ["make_config", "load_yaml_config", "PRESETS", "install_as_reference_m
 
 
 def set_precision(name):
-    """Arithmetic of the conditioner GEMMs: "f16x2" (default, split-precision fp16 MFMA) or "fp32" (exact fp32 MFMA)."""
+    """Arithmetic of the conditioner GEMMs: "f16x2" (default, split-precision fp16 MFMA), "bf16x3" (strict: 24-bit operands as three bf16
+    terms on the bf16 MFMA -- no equalisation / calibration / range guard) or "fp32" (exact fp32-input MFMA)."""
     from . import runtime
     runtime.set_precision(name)
 

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "librnf_hip.so")
 
 _lib = None
 ABI_VERSION = 7
-PREC_FP32, PREC_F16X2 = 0, 1
+PREC_FP32, PREC_F16X2, PREC_BF16X3 = 0, 1, 2
 
 c_f32p = C.c_void_p      # device or host float*, passed as integer addresses
 c_i32p = C.c_void_p
@@ -26,6 +26,8 @@ _SIGNATURES = {
     "rnf_set_fused": (C.c_int, [C.c_int]),
     "rnf_set_train_block": (C.c_int, [C.c_int]),
     "rnf_mobius_packed_floats": (C.c_int64, [C.c_int32]),
+    "rnf_mobius_packed_floats_prec": (C.c_int64, [C.c_int32, C.c_int32]),
+    "rnf_cond_packed_floats_prec": (C.c_int64, [C.c_int32, C.c_int32]),
     "rnf_affine16_packed_floats": (C.c_int64, []),
     "rnf_cond16_packed_floats": (C.c_int64, []),
     "rnf_featproj_packed_floats": (C.c_int64, [C.c_int32]),

@@ -380,7 +380,7 @@ class _CondMLPFn(torch.autograd.Function):
         wl, bl = ts[-2], ts[-1]                                # pad fc_last to the 16 rows of a Condition16Trans record
         plain16 = torch.cat([t.reshape(-1) for t in ts[:-2]] + [wl.reshape(-1), wl.new_zeros((16 - n_out) * 64), bl, bl.new_zeros(16 - n_out)])
         Fp = runtime.pad8(F)
-        prec = runtime._PRECISIONS[runtime.get_precision()]
+        prec = runtime._PRECISIONS[runtime.device_precision()]
         rec = (L.rnf_cond16_packed_floats() + 3) // 4 * 4
         blob = torch.empty(rec + L.rnf_featproj_packed_floats(Fp), dtype=f32, device=dev)
         pack_desc = np.array([[runtime.KIND_COND16, 0, 0, rec]], dtype=np.int32)
@@ -470,10 +470,10 @@ def _plan_for(module, layers, perm_rows, rotation):
     for layer in layers:
         if not hasattr(layer, "_rnf_train_tensors"):
             raise NotImplementedError(f"{type(layer).__name__} has no backward kernel yet (training path); evaluate it under torch.no_grad()")
-    key = (str(rotation.device), runtime.get_precision(), tuple(perm_rows), tuple(l._rnf_shape() for l in layers))
+    key = (str(rotation.device), runtime.device_precision(), tuple(perm_rows), tuple(l._rnf_shape() for l in layers))
     cached = getattr(module, "_rnf_train_plan", None)
     if cached is None or cached[0] != key:
-        cached = (key, TrainPlan(layers, perm_rows, rotation.device, runtime.get_precision()))
+        cached = (key, TrainPlan(layers, perm_rows, rotation.device, runtime.device_precision()))
         module._rnf_train_plan = cached
     fixed = getattr(module, "_feature_ms_fixed", None)          # Flow.set_feature_scale / dist.calibrate_feature_scale: one value for all ranks
     if fixed is not None:

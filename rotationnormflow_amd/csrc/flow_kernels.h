@@ -73,11 +73,27 @@ __device__ __forceinline__ float4 lds_f4(const float *base, int idx4) {
     return reinterpret_cast<const float4 *>(base)[idx4];
 }
 
-// cooperative global -> LDS copy of `nfloats` (multiple of 4) floats
+// cooperative global -> LDS copy of `nfloats` (multiple of 4) floats (synchronous staging: the callers put a barrier on both sides).
+// Round 6: LDS-DMA pieces (global_load_lds_dwordx4, 1 KiB per wave and instruction, no VGPR round trip), ALL requested before the one wait --
+// the load -> ds_write loop this replaces was one exposed L2 round trip per 16 bytes and thread (a bf16x3 layer image: 15 of them).
+#ifndef RNF_STAGE_DMA
+#define RNF_STAGE_DMA 1
+#endif
 __device__ __forceinline__ void stage_floats(float *dst, const float *src, int nfloats, int tid, int nthreads) {
+#if RNF_STAGE_DMA
+    const int n4 = nfloats >> 2, lane = tid & 63, nw64 = nthreads & ~63;
+    for (int base = __builtin_amdgcn_readfirstlane(tid & ~63); base < n4; base += nw64) {       // `base` is wave uniform
+        const int idx = base + lane;
+        if (idx < n4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * (size_t)idx),
+                                             (__attribute__((address_space(3))) void *)(dst + 4 * base), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     const float4 *s = reinterpret_cast<const float4 *>(src);
     float4 *d = reinterpret_cast<float4 *>(dst);
     for (int i = tid; i < (nfloats >> 2); i += nthreads) d[i] = s[i];
+#endif
 }
 
 __device__ __forceinline__ f32x16 load_bias16(const float *bias_half /* 16 floats of this lane-half */) {
@@ -607,6 +623,182 @@ struct Mlp<1> {
     }
 };
 
+// ------------------------------------------------------------------------------------------------------------
+// PREC = 2, "bf16x3" (round 6): the STRICT arithmetic.  Every fp32 operand of the 64-wide GEMMs -- weight and activation -- is carried as
+// three bf16 terms x = hi + mid + lo (8 + 8 + 8 significant bits: all 24 of an fp32, with fp32's exponent range), and every fp32
+// product-sum as SIX v_mfma_f32_32x32x16_bf16 into one fp32 accumulator, all terms down to 2^-16 of the leading one:
+//     acc += Ah.Bh + Ah.Bm + Am.Bh + Ah.Bl + Al.Bh + Am.Bm                         (Am.Bl, Al.Bm ~ 2^-24, Al.Bl ~ 2^-32 dropped)
+// Nothing about it depends on the data or on where the weights sit on their ReLU-rescaling orbit: no equalisation, no audit, no feature
+// calibration, no range guard (an activation overflows where fp32 itself does).  Twice the matrix instructions of the fp16 pairs and a
+// third more operand bytes (layout.h Lay<2>: 171 KiB per K = 64 layer, hence synchronous staging and four fc_last tiles at a time), but
+// on the real matrix cores: unlike the fp32-input MFMA (PREC 0), which shares the VALU's FMA datapath, it co-issues with the segment math.
+// The operand split truncates (hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = top 16 bits of the rest): three same-signed
+// terms, residual < 2^-24 |x|; 11 VALU per value pair.
+// ------------------------------------------------------------------------------------------------------------
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+#define RNF_MFMA_B(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+
+struct ActFrag3 {
+    u4v hi[4], mid[4], lo[4];     // B fragments of one 64-feature activation (8 x bf16 per fragment), k-step s = 2 * tile + half (48 registers)
+};
+__device__ __forceinline__ b8 as_b8(const u4v &v) { return __builtin_bit_cast(b8, v); }
+
+// one value pair -> element pair `e` (0..3) of the three fragments of one k-step (13 VALU with the ReLU)
+template <bool RELU>
+__device__ __forceinline__ void split3_pair(float a, float b, u4v &hi, u4v &mid, u4v &lo, int e) {
+    if (RELU) { a = relu_bits(a); b = relu_bits(b); }
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);        // exact
+    const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+    const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);      // exact
+    hi[e] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);                   // {a[31:16], b[31:16]}: element 2e = a, 2e + 1 = b
+    mid[e] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+    lo[e] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+}
+template <bool RELU>
+__device__ __forceinline__ void split3_act(const f32x16 (&x)[2], ActFrag3 &f) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split3_pair<RELU>(x[s >> 1][8 * (s & 1) + 2 * e], x[s >> 1][8 * (s & 1) + 2 * e + 1], f.hi[s], f.mid[s], f.lo[s], e);
+}
+__device__ __forceinline__ b8 lds_b8(const float *base, int idx16) { return reinterpret_cast<const b8 *>(base)[idx16]; }
+
+// The A operands (hi, mid, lo images of one k-step of a weight tile) of TWO k-steps in flight: set s & 1 serves k-step s.
+struct Ops3 {
+    b8 a[2][3];
+    __device__ __forceinline__ void load(int set, const float *w_tile, int ks, int lane) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) a[set][t] = lds_b8(w_tile, (ks * 3 + t) * 64 + lane);
+    }
+};
+// matrix instruction M (0..23) of a tile: k-step M / 6, the six products smallest first: Am.Bm, Al.Bh, Ah.Bl, Am.Bh, Ah.Bm, Ah.Bh
+template <int M>
+__device__ __forceinline__ f32x16 b3_mfma(const Ops3 &o, const ActFrag3 &in, f32x16 acc) {
+    constexpr int ks = M / 6, t = M % 6, p = ks & 1;
+    if constexpr (t == 0) return RNF_MFMA_B(o.a[p][1], as_b8(in.mid[ks]), acc);
+    else if constexpr (t == 1) return RNF_MFMA_B(o.a[p][2], as_b8(in.hi[ks]), acc);
+    else if constexpr (t == 2) return RNF_MFMA_B(o.a[p][0], as_b8(in.lo[ks]), acc);
+    else if constexpr (t == 3) return RNF_MFMA_B(o.a[p][1], as_b8(in.hi[ks]), acc);
+    else if constexpr (t == 4) return RNF_MFMA_B(o.a[p][0], as_b8(in.mid[ks]), acc);
+    else return RNF_MFMA_B(o.a[p][0], as_b8(in.hi[ks]), acc);
+}
+// behind the last instruction of k-step ks: its operand set is free -- request k-step ks + 2 of this tile, or k-step ks - 2 of the next one
+template <int M>
+__device__ __forceinline__ void b3_prefetch(Ops3 &o, const float *w_tile, const float *w_next, int lane) {
+    constexpr int ks = M / 6, t = M % 6, p = ks & 1;
+    if constexpr (t == 5) {
+        if constexpr (ks < 2) o.load(p, w_tile, ks + 2, lane);
+        else if (w_next) o.load(p, w_next, ks - 2, lane);
+    }
+}
+
+// Hidden tiles, the operand split of the previous tile written behind the matrix instructions (the scheme of hidden_slot, 24 instructions
+// per tile and 13 VALU per value pair here: one pair behind every second matrix instruction -- 52 + 16 issue cycles against 64 of matrix work):
+//   FILL 1 (tile 0 of a layer): `src` (the previous layer's tile 1) -> fragments 2 (slots 0..6) and 3 (slots 8..14): k-steps 0, 1 read 0 and 1 only;
+//   FILL 2 (tile 1 of a layer): `src` (this layer's tile 0) -> fragment 0 (slots 6..12, behind k-step 0, its last reader) and 1 (slots 14..20).
+template <int M, int FILL>
+__device__ __forceinline__ void hidden_slot_b3(const float *w_tile, const float *w_next, int lane, ActFrag3 &f, f32x16 &acc, const f32x16 &src, Ops3 &o) {
+    acc = b3_mfma<M>(o, f, acc);
+    b3_prefetch<M>(o, w_tile, w_next, lane);
+    constexpr int first = FILL == 1 ? 0 : (FILL == 2 ? 6 : -1);
+    if constexpr (FILL != 0 && M >= first && M < first + 16 && ((M - first) % 2) == 0) {
+        constexpr int q = (M - first) / 2;                        // 0..7: value pair q of src
+        constexpr int dst = (FILL == 1 ? 2 : 0) + q / 4, e = q % 4;
+        split3_pair<true>(src[2 * q], src[2 * q + 1], f.hi[dst], f.mid[dst], f.lo[dst], e);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (M + 1 < 24) hidden_slot_b3<M + 1, FILL>(w_tile, w_next, lane, f, acc, src, o);
+}
+template <int FILL>
+__device__ __forceinline__ void hidden_tile_b3(const float *w_tile, const float *w_next, int lane, ActFrag3 &f, f32x16 &acc, const f32x16 &src, Ops3 &o) {
+    __builtin_amdgcn_sched_barrier(0);
+    hidden_slot_b3<0, FILL>(w_tile, w_next, lane, f, acc, src, o);
+}
+
+// one 64 -> 32 output tile without fillers (fc_last of the inverse pass and of the non-Moebius conditioners)
+template <int M = 0>
+__device__ __forceinline__ void plain_slot_b3(const float *w_tile, int lane, const ActFrag3 &in, f32x16 &acc, Ops3 &o) {
+    acc = b3_mfma<M>(o, in, acc);
+    b3_prefetch<M>(o, w_tile, nullptr, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (M + 1 < 24) plain_slot_b3<M + 1>(w_tile, lane, in, acc, o);
+}
+__device__ __forceinline__ f32x16 gemm_tile64_b3(const float *w_tile, int lane, const ActFrag3 &in, f32x16 acc) {
+    Ops3 o;
+    o.load(0, w_tile, 0, lane);
+    o.load(1, w_tile, 1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    plain_slot_b3<0>(w_tile, lane, in, acc, o);
+    return acc;
+}
+
+template <>
+struct Mlp<2> {
+    typedef ActFrag3 Act;
+    // Same structure as Mlp<1>::head: fc_first on the two exact fp32 MFMA steps, x0 recomputed for the residual (Mlp<1>::residual: ONE
+    // definition of x0 + x3 for every arithmetic), the operand splits behind the matrix instructions of the next tile (hidden_slot_b3).
+    // `bad`: a NaN x0 (NaN feature row / rotation): the integer ReLU would launder it (the reference propagates NaN).
+    template <class GF, bool KEEPX0 = false, class FairT = Fair, bool DEEP = false>
+    static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
+                                                const GF &g, Act &out, FairT &, bool &bad, const f32x16 * = nullptr) {
+        typedef Lay<2> L2;
+        const float bA = h ? y1 : y0;
+        const float bB = h ? 1.0f : y2;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 x0k[2];                                          // KEEPX0 only
+        float ga[2] = {0.f, 0.f}, gb = 0.f;                     // AS_BIAS only
+        auto w = [&](int L, int ot) { return lds + L2::HID + (L * 2 + ot) * L2::W_TILE; };
+        auto bias = [&](int L, int ot) { return load_bias16(lds + L2::HB + ((L * 2 + ot) * 2 + h) * 16); };
+        Ops3 o;
+        o.load(0, w(0, 0), 0, lane);                            // (their LDS latency sits under fc_first and the split of x0)
+        o.load(1, w(0, 0), 1, lane);
+        ActFrag3 &f = out;
+        {
+            f32x16 x0[2];
+            if constexpr (GF::AS_BIAS) {
+                if (g) { ga[0] = g.aop(0, lane, h); ga[1] = g.aop(1, lane, h); gb = g.bop(lane, h); }
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    x0[ot] = Mlp<1>::first_tile(lds, ot, lane, bA, bB, zero);
+                    if (g) x0[ot] = RNF_MFMA(ga[ot], gb, x0[ot]);
+                }
+            } else {
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot) {
+                    const f32x16 gin = g ? g.template load<KEEPX0>(ot, lane, h) : zero;
+                    if constexpr (KEEPX0) x0k[ot] = gin;
+                    x0[ot] = Mlp<1>::first_tile(lds, ot, lane, bA, bB, gin);
+                }
+            }
+            bad |= x0[0][0] != x0[0][0];
+            split3_act<true>(x0, f);
+        }
+        // layer 0: tile 0 bare (its input is complete), tile 1 carries the split of tile 0
+        f32x16 a0 = bias(0, 0), a1 = bias(0, 1);
+        hidden_tile_b3<0>(w(0, 0), w(0, 1), lane, f, a0, a0, o);
+        f32x16 b0 = bias(1, 0);
+        hidden_tile_b3<2>(w(0, 1), w(1, 0), lane, f, a1, a0, o);
+        // layer 1: tile 0 carries the split of layer 0's tile 1, tile 1 the split of its own tile 0
+        f32x16 b1 = bias(1, 1);
+        hidden_tile_b3<1>(w(1, 0), w(1, 1), lane, f, b0, a1, o);
+        a0 = bias(2, 0);
+        hidden_tile_b3<2>(w(1, 1), w(2, 0), lane, f, b1, b0, o);
+        // layer 2, then the residual x0 + x3 (flow/condition.py:29) tile by tile: tile 0's residual + split ride behind tile 1's instructions
+        a1 = bias(2, 1);
+        hidden_tile_b3<1>(w(2, 0), w(2, 1), lane, f, a0, b1, o);
+        Mlp<1>::template residual<KEEPX0>(lds, 0, lane, h, bA, bB, g, x0k, a0, ga, gb);
+        hidden_tile_b3<2>(w(2, 1), nullptr, lane, f, a1, a0, o);
+        Mlp<1>::template residual<KEEPX0>(lds, 1, lane, h, bA, bB, g, x0k, a1, ga, gb);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) split3_pair<true>(a1[2 * q], a1[2 * q + 1], f.hi[2 + q / 4], f.mid[2 + q / 4], f.lo[2 + q / 4], q % 4);
+    }
+    static __device__ __forceinline__ f32x16 last(const float *tile_rec, int lane, int h, const Act &a) {
+        return gemm_tile64_b3(tile_rec, lane, a, load_bias16(tile_rec + Lay<2>::LAST_TILE_BIAS + h * 16));
+    }
+};
+
 // sum over the two lanes (j, j + 32) of a rotation.  Round 6: v_permlane32_swap (one VALU instruction: every lane gets both halves' values)
 // instead of ds_bpermute_b32 (__shfl_xor: an LDS round trip on the lgkm counter, ~100 cycles in front of every layer finish and of every
 // root-finder step).  half 0's value + half 1's value in both lanes: the same bits as own + partner's.
@@ -854,22 +1046,67 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int K
     }
 }
 
+// forward fc_last tile tau + 1 (24 matrix instructions) with the segment math of the finished tile tau behind them: slice (segment g, stage
+// st) of seg_s7_stage behind every second instruction (so3_math.h: ~11 VALU per slice)
+template <int M>
+__device__ __forceinline__ void last_slot_b3(const float *w_tile, const float *w_next, int lane, const ActFrag3 &in, f32x16 &nxt, Ops3 &o,
+                                             const f32x16 &cur, SegS7 (&seg)[4], const MobiusCtx &c, float &S, float &A, float &J) {
+    nxt = b3_mfma<M>(o, in, nxt);
+    b3_prefetch<M>(o, w_tile, w_next, lane);
+    if constexpr ((M % 2) == 0) {
+        constexpr int q = M / 2, g = q / 3, st = q % 3;
+        seg_s7_stage<st, true>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, S, A, J);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (M + 1 < 24) last_slot_b3<M + 1>(w_tile, w_next, lane, in, nxt, o, cur, seg, c, S, A, J);
+}
+
+// forward tile phase of the bf16x3 kernels: the tiles staged `Lay<2>::MAX_TILES_IN_LDS` at a time (synchronously: the layer image exceeds
+// the LDS), each group pipelined -- tile tau + 1's matrix instructions with tile tau's segment math behind them (last_slot_b3)
+__device__ __forceinline__ void mobius_fwd_tiles_b3(float *lds, const float *layer_params, int KT, int K, int lane, int h, const ActFrag3 &tt,
+                                                    const MobiusCtx &c, float &S, float &A, float &J, int tid, int nthreads) {
+    typedef Lay<2> L2;
+    for (int t0 = 0; t0 < KT; t0 += L2::MAX_TILES_IN_LDS) {
+        const int nt = min(L2::MAX_TILES_IN_LDS, KT - t0);
+        if (t0 > 0) {
+            __syncthreads();
+            stage_floats(lds + L2::LAST, layer_params + L2::LAST + (size_t)t0 * L2::LAST_TILE_FLOATS, nt * L2::LAST_TILE_FLOATS, tid, nthreads);
+            __syncthreads();
+        }
+        const float *rec = lds + L2::LAST;
+        f32x16 cur = Mlp<2>::last(rec, lane, h, tt);
+        for (int i = 1; i < nt; ++i) {
+            const float *t = rec + i * L2::LAST_TILE_FLOATS;
+            f32x16 nxt = load_bias16(t + L2::LAST_TILE_BIAS + h * 16);
+            Ops3 o;
+            o.load(0, t, 0, lane);
+            o.load(1, t, 1, lane);
+            SegS7 seg[4];
+            __builtin_amdgcn_sched_barrier(0);
+            last_slot_b3<0>(t, nullptr, lane, tt, nxt, o, cur, seg, c, S, A, J);
+            cur = nxt;
+        }
+        if (t0 + nt == KT) segments4_last<true, true>(cur, c, S, A, J, K, h);
+        else segments4<true, true>(cur, c, S, A, J);
+    }
+}
+
 // forward, K > 64: fc_last tiles restaged synchronously 8 at a time (staging mode SYNC only)
 template <int PREC>
 __device__ __forceinline__ void mobius_fwd_tiles_restage(float *lds, const float *layer_params, int KT, int K, int lane, int h,
                                                          const typename Mlp<PREC>::Act &tt, const MobiusCtx &c, float &S,
                                                          float &A, float &J, int tid, int nthreads) {
     for (int tau = 0; tau < KT; ++tau) {
-        if (tau > 0 && (tau % MOB_MAX_TILES_IN_LDS) == 0) {
+        if (tau > 0 && (tau % Lay<PREC>::MAX_TILES_IN_LDS) == 0) {
             __syncthreads();
-            int nt = min(MOB_MAX_TILES_IN_LDS, KT - tau);
-            stage_floats(lds + MOB_LAST, layer_params + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS,
-                         nt * MOB_LAST_TILE_FLOATS, tid, nthreads);
+            int nt = min(Lay<PREC>::MAX_TILES_IN_LDS, KT - tau);
+            stage_floats(lds + Lay<PREC>::LAST, layer_params + Lay<PREC>::LAST + (size_t)tau * Lay<PREC>::LAST_TILE_FLOATS,
+                         nt * Lay<PREC>::LAST_TILE_FLOATS, tid, nthreads);
             __syncthreads();
         }
-        f32x16 o = Mlp<PREC>::last(lds + MOB_LAST + (tau % MOB_MAX_TILES_IN_LDS) * MOB_LAST_TILE_FLOATS, lane, h, tt);
-        if (tau + 1 == KT) segments4_last<PREC == 1>(o, c, S, A, J, K, h);
-        else segments4<PREC == 1>(o, c, S, A, J);
+        f32x16 o = Mlp<PREC>::last(lds + Lay<PREC>::LAST + (tau % Lay<PREC>::MAX_TILES_IN_LDS) * Lay<PREC>::LAST_TILE_FLOATS, lane, h, tt);
+        if (tau + 1 == KT) segments4_last<PREC != 0>(o, c, S, A, J, K, h);
+        else segments4<PREC != 0>(o, c, S, A, J);
     }
 }
 
@@ -904,22 +1141,22 @@ struct InvSegs {
 };
 
 // kt: tiles this layer really has (<= KT, the instantiation's capacity), K: its real segment count; slots beyond them get weight 0.
-// KT > MOB_MAX_TILES_IN_LDS (K > 64, synchronous staging only): the second half of the fc_last image is staged in the middle.
+// KT > Lay<PREC>::MAX_TILES_IN_LDS (K > 64, synchronous staging only): the second half of the fc_last image is staged in the middle.
 template <int KT, int PREC, bool FASTSP = false>
 __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_params, int kt, int K, int lane, int h, const typename Mlp<PREC>::Act &tt,
                                                  const MobiusCtx &c, InvSegs<KT> &sg, float &S, int tid, int nthreads, float4 *stash = nullptr) {
 #pragma unroll
     for (int tau = 0; tau < KT; ++tau) {
         if (tau < kt) {                                         // wave uniform
-            if constexpr (KT > MOB_MAX_TILES_IN_LDS) {
-                if (tau == MOB_MAX_TILES_IN_LDS) {
+            if constexpr (KT > Lay<PREC>::MAX_TILES_IN_LDS) {
+                if (tau > 0 && (tau % Lay<PREC>::MAX_TILES_IN_LDS) == 0) {
                     __syncthreads();
-                    stage_floats(lds + MOB_LAST, layer_params + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS,
-                                 min(MOB_MAX_TILES_IN_LDS, kt - tau) * MOB_LAST_TILE_FLOATS, tid, nthreads);
+                    stage_floats(lds + Lay<PREC>::LAST, layer_params + Lay<PREC>::LAST + (size_t)tau * Lay<PREC>::LAST_TILE_FLOATS,
+                                 min(Lay<PREC>::MAX_TILES_IN_LDS, kt - tau) * Lay<PREC>::LAST_TILE_FLOATS, tid, nthreads);
                     __syncthreads();
                 }
             }
-            f32x16 o = Mlp<PREC>::last(lds + MOB_LAST + (tau % MOB_MAX_TILES_IN_LDS) * MOB_LAST_TILE_FLOATS, lane, h, tt);
+            f32x16 o = Mlp<PREC>::last(lds + Lay<PREC>::LAST + (tau % Lay<PREC>::MAX_TILES_IN_LDS) * Lay<PREC>::LAST_TILE_FLOATS, lane, h, tt);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, sg.ur[4 * tau + g], sg.uv[4 * tau + g]);
@@ -928,7 +1165,7 @@ __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_
                 // free next to the root finder)
                 // FASTSP (round 4; guarded calls only): the lean one-piece form, 4 instructions instead of 11 -- the all-weights-tiny corner it
                 // cannot resolve is flagged by mobius_inv_finish's weight-sum test and re-run on the exact-fp32 kernels, as in the forward pass
-                float sp = PREC == 1 ? (FASTSP ? softplus2_lean(o[4 * g]) : softplus2_safe(o[4 * g])) : softplus(S_UNSCALE * o[4 * g]);
+                float sp = PREC != 0 ? (FASTSP ? softplus2_lean(o[4 * g]) : softplus2_safe(o[4 * g])) : softplus(S_UNSCALE * o[4 * g]);
                 if (8 * tau + 2 * g + h >= K) sp = 0.f;          // pad segment of a K % 8 != 0 layer: weight 0 AFTER the activation
                 sg.sp[4 * tau + g] = sp;
                 sg.q[4 * tau + g] = sp * (1.0f - fmaf(sg.uv[4 * tau + g], sg.uv[4 * tau + g], sg.ur[4 * tau + g] * sg.ur[4 * tau + g]));
@@ -945,18 +1182,18 @@ __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_
     // K > 8 KT segments (the largest instantiation only, KT = 16: K > 128): the remaining tiles' segment parameters go to the wave's stash
     if constexpr (KT == 16) {
         for (int tau = KT; tau < kt; ++tau) {
-            if ((tau % MOB_MAX_TILES_IN_LDS) == 0) {
+            if ((tau % Lay<PREC>::MAX_TILES_IN_LDS) == 0) {
                 __syncthreads();
-                stage_floats(lds + MOB_LAST, layer_params + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS,
-                             min(MOB_MAX_TILES_IN_LDS, kt - tau) * MOB_LAST_TILE_FLOATS, tid, nthreads);
+                stage_floats(lds + Lay<PREC>::LAST, layer_params + Lay<PREC>::LAST + (size_t)tau * Lay<PREC>::LAST_TILE_FLOATS,
+                             min(Lay<PREC>::MAX_TILES_IN_LDS, kt - tau) * Lay<PREC>::LAST_TILE_FLOATS, tid, nthreads);
                 __syncthreads();
             }
-            const f32x16 o = Mlp<PREC>::last(lds + MOB_LAST + (tau % MOB_MAX_TILES_IN_LDS) * MOB_LAST_TILE_FLOATS, lane, h, tt);
+            const f32x16 o = Mlp<PREC>::last(lds + Lay<PREC>::LAST + (tau % Lay<PREC>::MAX_TILES_IN_LDS) * Lay<PREC>::LAST_TILE_FLOATS, lane, h, tt);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float ur, uv;
                 squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, ur, uv);
-                float sp = PREC == 1 ? (FASTSP ? softplus2_lean(o[4 * g]) : softplus2_safe(o[4 * g])) : softplus(S_UNSCALE * o[4 * g]);
+                float sp = PREC != 0 ? (FASTSP ? softplus2_lean(o[4 * g]) : softplus2_safe(o[4 * g])) : softplus(S_UNSCALE * o[4 * g]);
                 if (8 * tau + 2 * g + h >= K) sp = 0.f;
                 stash[(size_t)(4 * (tau - KT) + g) * 64 + lane] = make_float4(sp, ur, uv, sp * (1.0f - fmaf(uv, uv, ur * ur)));
                 S += sp;
@@ -1485,6 +1722,7 @@ template <int DIR, int KT_INV, int NW, bool PIPE, int PREC, bool EXT = false, in
 __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args) {
     static_assert(!FUSED || (DIR == 0 && PIPE && PREC == 1 && !EXT && LEAN == 2), "FUSED: forward, DMA staging, split precision, conditional lean stack");
     static_assert(!ROWS || (!EXT && !FUSED && LEAN != 1), "ROWS: the extended instantiation reads shared rows itself; lean-1 stacks have no features");
+    static_assert(PREC != 2 || (!PIPE && LEAN == 0 && !FUSED && !ROWS), "bf16x3: synchronous staging (its layer image exceeds the LDS), general family");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (args.guard_mode == 2) {                                      // fp32 re-run of a split-precision call: only when its guard fired
         if (__hip_atomic_load(args.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
@@ -1500,7 +1738,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
 #ifdef RNF_NO_KEEPX0
     constexpr bool KEEP_X0 = false;
 #else
-    constexpr bool KEEP_X0 = PREC == 1 && NW <= 8 && LEAN != 1;
+    constexpr bool KEEP_X0 = PREC != 0 && NW <= 8 && LEAN != 1;
 #endif         // room for x0 beside the hidden layers (Mlp<1>::head), and something to re-read
 #ifndef RNF_DEEP_H
 #define RNF_DEEP_H 1
@@ -1530,7 +1768,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             if (kind_has_mlp(args.layers[layer_at(q)].x & 15)) return q;
         return -1;
     };
-    auto l_floats = [&](int kind) { return kind_last_tiles(kind, KT) * MOB_LAST_TILE_FLOATS; };
+    auto l_floats = [&](int kind) { return kind_last_tiles(kind, KT) * Lay<PREC>::LAST_TILE_FLOATS; };
     const int first_mlp = next_mlp(-1);
     // DMA staging: the block of the constant-affine layer right behind the MLP layer at position q rides with that layer's fc_last
     // image into LDS buffer `parity` (two buffers: a slow wave may still read the previous block while the next one lands)
@@ -1561,8 +1799,8 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     if (FAIR_ON && args.fair_off >= 0 && tid < NW) reinterpret_cast<int *>(lds + args.fair_off)[tid] = 0;
     if (PIPE && first_mlp >= 0) {                                  // prologue: image of the first MLP layer
         const int2 d = args.layers[layer_at(first_mlp)];
-        dma_floats(lds, args.blob + d.y, MOB_HEAD_FLOATS, wave, lane, NW);
-        dma_floats(lds + MOB_LAST, args.blob + d.y + MOB_LAST, l_floats(d.x & 15), wave, lane, NW);
+        dma_floats(lds, args.blob + d.y, Lay<PREC>::HEAD_FLOATS, wave, lane, NW);
+        dma_floats(lds + Lay<PREC>::LAST, args.blob + d.y + Lay<PREC>::LAST, l_floats(d.x & 15), wave, lane, NW);
         stage_table(first_mlp, 0);
         if constexpr (FUSED) fused_dma(((d.x >> 8) & 255) - 1, 0);      // out tile 0 of the first layer's projection weights
         dma_wait_all();
@@ -1744,8 +1982,8 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 if (q >= 0) { const int2 dn = args.layers[layer_at(q)]; nxt_off = dn.y; nxt_kind = dn.x & 15; }
             } else {
                 __syncthreads();                                   // everyone is done with the previous image
-                const int tiles_now = min(kind_last_tiles(kind, KT), MOB_MAX_TILES_IN_LDS);
-                stage_floats(lds, params, MOB_HEAD_FLOATS + tiles_now * MOB_LAST_TILE_FLOATS, tid, NT);
+                const int tiles_now = min(kind_last_tiles(kind, KT), Lay<PREC>::MAX_TILES_IN_LDS);
+                stage_floats(lds, params, Lay<PREC>::HEAD_FLOATS + tiles_now * Lay<PREC>::LAST_TILE_FLOATS, tid, NT);
                 __syncthreads();
             }
             RNF_STAMP(0)                                          // 0: G load + synchronous staging (SYNC mode)
@@ -1755,7 +1993,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             int hh = h;                                           // (see `ht` above: the bias offsets of the hidden layers are re-derived per layer)
             if constexpr (LEAN == 2 && NW == 16) asm volatile("" : "+v"(hh));
             if (LEAN == 1 || kind == RNF_KIND_MOBIUS) {
-                mobius_begin<DIR, DIR == 0 && PREC == 1>(R, perm_row, ctx);
+                mobius_begin<DIR, DIR == 0 && PREC != 0>(R, perm_row, ctx);
                 Mlp<PREC>::template head<GF, KEEP_X0, FairT, DEEP_H>(lds, lane, hh, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair, bad, have_gpre ? gpre : nullptr);
             } else {
                 Mlp<PREC>::template head<GF, KEEP_X0, FairT, DEEP_H>(lds, lane, hh, 0.f, 0.f, 0.f, gfrag, tt, fair, bad, have_gpre ? gpre : nullptr);
@@ -1766,7 +2004,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 dma_wait_all();
                 RNF_STAMP_FINE(8)                                 // (-DRNF_STAMPS_FINE) 8: B1's wait for this wave's own DMA pieces
                 RNF_LAYER_BARRIER();
-                if (nxt_off >= 0) dma_floats(lds, args.blob + nxt_off, MOB_HEAD_FLOATS, wave, lane, NW);
+                if (nxt_off >= 0) dma_floats(lds, args.blob + nxt_off, Lay<PREC>::HEAD_FLOATS, wave, lane, NW);
             }
             RNF_STAMP(2)                                          // 2: barrier B1 (+ DMA issue)
             const int fq1 = FUSED ? next_in_tile(pos) : -1;       // FUSED: the next MLP layer of this tile, whose G is produced during this layer
@@ -1792,7 +2030,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             };
             auto b2_issue = [&]() {
                 if (PIPE) {
-                    if (nxt_off >= 0) dma_floats(lds + MOB_LAST, args.blob + nxt_off + MOB_LAST, l_floats(nxt_kind), wave, lane, NW);
+                    if (nxt_off >= 0) dma_floats(lds + Lay<PREC>::LAST, args.blob + nxt_off + Lay<PREC>::LAST, l_floats(nxt_kind), wave, lane, NW);
                     tab_parity = has_table(pos) ? (seq & 1) : -1;
                     ++seq;
                     stage_table(nxt_q, seq & 1);
@@ -1846,15 +2084,16 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     b2_issue();
                 } else {
                     float S = 0.f, A = 0.f, J = 0.f;
-                    if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC, LEAN == 1, LEAN != 0, FairT>(lds, KT, args.K, lane, h, tt, ctx, S, A, J, fair);
+                    if constexpr (PREC == 2) mobius_fwd_tiles_b3(lds, params, KT, args.K, lane, h, tt, ctx, S, A, J, tid, NT);
+                    else if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC, LEAN == 1, LEAN != 0, FairT>(lds, KT, args.K, lane, h, tt, ctx, S, A, J, fair);
                     else mobius_fwd_tiles_restage<PREC>(lds, params, KT, args.K, lane, h, tt, ctx, S, A, J, tid, NT);
                     barrier2();
-                    mobius_fwd_finish<PREC == 1, LEAN != 0 && PREC == 1>(ctx, S, A, J, R, ldj, bad, args.min_wsum);
+                    mobius_fwd_finish<PREC != 0, LEAN != 0 && PREC == 1>(ctx, S, A, J, R, ldj, bad, args.min_wsum);
                 }
             } else {
-                const f32x16 o16 = Mlp<PREC>::last(lds + MOB_LAST, lane, h, tt);
+                const f32x16 o16 = Mlp<PREC>::last(lds + Lay<PREC>::LAST, lane, h, tt);
                 if (EXT && kind == RNF_KIND_COND36) {
-                    const f32x16 o16b = Mlp<PREC>::last(lds + MOB_LAST + MOB_LAST_TILE_FLOATS, lane, h, tt);
+                    const f32x16 o16b = Mlp<PREC>::last(lds + Lay<PREC>::LAST + Lay<PREC>::LAST_TILE_FLOATS, lane, h, tt);
                     barrier2();
                     cond36_finish<DIR != 0>(o16, o16b, h, R, ldj);
                 } else {
@@ -1879,7 +2118,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
         // Exact-fp32 kernels (set_precision("fp32"), and the re-run of a guarded split-precision call, which a NaN always triggers): a NaN that
         // entered a conditioner (NaN feature row / rotation) makes the sample's outputs NaN, as in the reference (its ReLU propagates NaN;
         // fmaxf would launder it into finite garbage).  `bad` has no other source in these kernels (mlp_head).
-        if (PREC == 0 && bad) {
+        if (PREC != 1 && bad) {
             ldj = __builtin_nanf("");
             R.c0.x = ldj;
         }

@@ -62,6 +62,32 @@ constexpr int MOB_MAX_TILES_IN_LDS = 8;                   // fc_last tiles resid
 
 inline constexpr int64_t mobius_packed_floats(int K) { return MOB_HEAD_FLOATS + (int64_t)((K + 7) / 8) * MOB_LAST_TILE_FLOATS; }   // last tile zero padded
 
+// ---- the same record per arithmetic (round 6) ----
+// PREC 0 (exact fp32) and 1 (fp16 hi + lo pairs) store a [32 x 64] weight tile in 2048 floats (the constants above).  PREC 2 ("bf16x3"):
+// every weight as THREE bf16 terms hi + mid + lo (24 significant bits, fp32's exponent range: no equalisation, no audit, no calibration, no
+// range guard), tile image [k-step s (4)][hi, mid, lo][lane (64)] 8 x bf16 = 3072 floats, element j of lane (i, h) of k-step s = the weight
+// the fp16 image holds there.  A K = 64 layer is then 43,712 floats = 171 KiB -- more than the 160 KiB of LDS -- so these kernels stage
+// synchronously and keep four fc_last tiles resident at a time (flow_kernels.h).
+template <int PREC>
+struct Lay {
+    static constexpr int W_TILE = PREC == 2 ? 4 * 3 * 64 * 4 : 8 * 64 * 4;
+    static constexpr int FIRST = MOB_FIRST;
+    static constexpr int HID = MOB_FIRST + MOB_FIRST_FLOATS;
+    static constexpr int HB = HID + 3 * 2 * W_TILE;
+    static constexpr int HEAD_FLOATS = HB + MOB_HB_FLOATS;
+    static constexpr int LAST = HEAD_FLOATS;
+    static constexpr int LAST_TILE_BIAS = W_TILE;
+    static constexpr int LAST_TILE_FLOATS = W_TILE + 32;
+    static constexpr int MAX_TILES_IN_LDS = PREC == 2 ? 4 : MOB_MAX_TILES_IN_LDS;
+};
+static_assert(Lay<0>::HEAD_FLOATS == MOB_HEAD_FLOATS && Lay<1>::LAST_TILE_FLOATS == MOB_LAST_TILE_FLOATS && Lay<1>::HB == MOB_HB, "Lay<0/1> are the MOB_* constants");
+inline constexpr int64_t mobius_packed_floats_p(int K, int prec) {
+    return prec == 2 ? Lay<2>::HEAD_FLOATS + (int64_t)((K + 7) / 8) * Lay<2>::LAST_TILE_FLOATS : mobius_packed_floats(K);
+}
+inline constexpr int64_t cond_packed_floats_p(int tiles, int prec) {      // Condition16Trans / Condition9* (1 fc_last tile), Condition36Trans (2)
+    return prec == 2 ? Lay<2>::HEAD_FLOATS + (int64_t)tiles * Lay<2>::LAST_TILE_FLOATS : MOB_HEAD_FLOATS + (int64_t)tiles * MOB_LAST_TILE_FLOATS;
+}
+
 // ---- unconditional 4x4 affine record ----
 // [0..15] M row-major, [16] log|det M|, [17..32] M^-1, [33] log|det M^-1|, [34] 1.0 if M is orthogonal (log-det exactly 0), [35] 0,
 // [36..139] forward block: the 10x10 table of M in two halves of 52 floats (so3_math.h affine16_table: five rows, log|det M|, the orthogonal flag);

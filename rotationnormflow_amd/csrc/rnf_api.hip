@@ -54,6 +54,8 @@ extern "C" const char *rnf_last_error(void) { return g_err; }
 // packing (pure host code)
 // ------------------------------------------------------------------------------------------------------------
 extern "C" int64_t rnf_mobius_packed_floats(int32_t K) { return K > 0 ? mobius_packed_floats(K) : -1; }
+extern "C" int64_t rnf_mobius_packed_floats_prec(int32_t K, int32_t prec) { return (K > 0 && prec >= 0 && prec <= 2) ? mobius_packed_floats_p(K, prec) : -1; }
+extern "C" int64_t rnf_cond_packed_floats_prec(int32_t n_out, int32_t prec) { return (prec >= 0 && prec <= 2) ? cond_packed_floats_p(n_out == 36 ? 2 : 1, prec) : -1; }
 extern "C" int64_t rnf_affine16_packed_floats(void) { return AFF_FLOATS; }
 extern "C" int64_t rnf_cond16_packed_floats(void) { return COND16_FLOATS; }
 extern "C" int64_t rnf_featproj_packed_floats(int32_t F) { return (F >= 0 && F % 8 == 0) ? featproj_packed_floats(F) : -1; }
@@ -95,6 +97,32 @@ static void pack_w64_h(float *img, int n_ot, RowFn row_of) {
             }
 }
 
+// bf16x3 image of the same rows (layout.h Lay<2>): [ot][s (4)][hi, mid, lo][lane] 8 x bf16, element j of lane (i, h) of k-step s as in the
+// fp16 image; the three terms are the TRUNCATED splits the kernels use for the activations (top 16 bits of w, of w - hi, of the rest):
+// hi + mid + lo reproduces w to 2^-24 |w|, nothing to overflow or underflow short of fp32 itself.
+static inline uint16_t bf16_trunc(float x) { uint32_t u; std::memcpy(&u, &x, 4); return (uint16_t)(u >> 16); }
+static inline float bf16_float(uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; std::memcpy(&x, &u, 4); return x; }
+template <typename RowFn>
+static void pack_w64_b3(float *img, int n_ot, RowFn row_of) {
+    uint16_t *out = reinterpret_cast<uint16_t *>(img);
+    for (int ot = 0; ot < n_ot; ++ot)
+        for (int s = 0; s < 4; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, h = lane >> 5;
+                const float *row = row_of(ot, i);
+                uint16_t *dst[3];
+                for (int t = 0; t < 3; ++t) dst[t] = out + ((((size_t)ot * 4 + s) * 3 + t) * 64 + lane) * 8;
+                for (int j = 0; j < 8; ++j) {
+                    const float w = row ? row[16 * s + 8 * (j >> 2) + 4 * h + (j & 3)] : 0.f;
+                    const uint16_t wh = bf16_trunc(w);
+                    const float r1 = w - bf16_float(wh);
+                    const uint16_t wm = bf16_trunc(r1);
+                    const float r2 = r1 - bf16_float(wm);
+                    dst[0][j] = wh; dst[1][j] = wm; dst[2][j] = bf16_trunc(r2);
+                }
+            }
+}
+
 // bias image [ot][h][16]: b[32*ot + rho(r,h)] (or the mapped row's bias)
 template <typename BiasFn>
 static void pack_bias(float *img, int n_ot, BiasFn bias_of /* (ot, row_in_tile) -> float */) {
@@ -104,13 +132,16 @@ static void pack_bias(float *img, int n_ot, BiasFn bias_of /* (ot, row_in_tile) 
 }
 
 static void pack_hidden(float *out, const float *const w[3], const float *const b[3], int prec) {
+    const int w_tile = prec == 2 ? Lay<2>::W_TILE : Lay<0>::W_TILE, hb = prec == 2 ? Lay<2>::HB : MOB_HB;
     for (int L = 0; L < 3; ++L) {
         const float *W = w[L];
         auto row_of = [&](int ot, int i) { return W + (size_t)(32 * ot + i) * 64; };
-        if (prec) pack_w64_h(out + MOB_HID + (size_t)L * 2 * 8 * 64 * 4, 2, row_of);
-        else pack_w64(out + MOB_HID + (size_t)L * 2 * 8 * 64 * 4, 2, row_of);
+        float *dst = out + MOB_HID + (size_t)L * 2 * w_tile;
+        if (prec == 2) pack_w64_b3(dst, 2, row_of);
+        else if (prec) pack_w64_h(dst, 2, row_of);
+        else pack_w64(dst, 2, row_of);
         const float *B = b[L];
-        pack_bias(out + MOB_HB + L * 2 * 2 * 16, 2, [&](int ot, int row) { return B[32 * ot + row]; });
+        pack_bias(out + hb + L * 2 * 2 * 16, 2, [&](int ot, int row) { return B[32 * ot + row]; });
     }
 }
 
@@ -315,7 +346,7 @@ extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b,
                                const float *fc_last_w, const float *fc_last_b, int32_t K, int32_t F, int32_t prec,
                                float *out, float *out_feat) {
     if (K <= 0) return fail("rnf_pack_mobius: segments=%d must be positive", K);
-    if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2) return fail("rnf_pack_mobius: unknown precision %d", prec);
+    if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2 && prec != RNF_PREC_BF16X3) return fail("rnf_pack_mobius: unknown precision %d", prec);
     g_half_overflow = false;
     g_last_audit = 0.0;
     if (F < 0 || F % 8) return fail("rnf_pack_mobius: feature_dim=%d must be a multiple of 8 (pad on the host)", F);
@@ -346,19 +377,23 @@ extern "C" int rnf_pack_mobius(const float *fc_first_w, const float *fc_first_b,
     };
     // the rows that produce the segment weights' pre-activations (reference rows 0 .. K-1) are packed times log2 e (layout.h S_PRESCALE)
     for (size_t i = 0; i < (size_t)K * 64; ++i) m.WL[i] *= S_PRESCALE;
+    const bool b3 = prec == RNF_PREC_BF16X3;
     for (int tau = 0; tau < (K + 7) / 8; ++tau) {
-        float *rec = out + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS;
+        float *rec = out + (b3 ? Lay<2>::LAST + (size_t)tau * Lay<2>::LAST_TILE_FLOATS : MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS);
         auto row_of = [&](int, int i) {
             const int r = src_row(tau, i);
             return r < 0 ? (const float *)nullptr : m.WL.data() + (size_t)r * 64;
         };
-        if (prec) pack_w64_h(rec, 1, row_of); else pack_w64(rec, 1, row_of);
-        pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) {
+        if (b3) pack_w64_b3(rec, 1, row_of); else if (prec) pack_w64_h(rec, 1, row_of); else pack_w64(rec, 1, row_of);
+        pack_bias(rec + (b3 ? Lay<2>::LAST_TILE_BIAS : MOB_LAST_TILE_BIAS), 1, [&](int, int row) {
             const int r = src_row(tau, row);
             return r < 0 ? 0.f : (r < K ? fc_last_b[r] * S_PRESCALE : fc_last_b[r]);
         });
     }
-    if (F) { if (prec) pack_featproj_h(out_feat, m.W0.data(), ni, 3, F, m.b0.data()); else pack_featproj(out_feat, m.W0.data(), ni, 3, F, m.b0.data()); }
+    // bf16x3 flows project their features with the exact-fp32 projection kernels (the fp16 projection images are the ones that need the
+    // equalisation's feature scale)
+    if (F) { if (prec == RNF_PREC_F16X2) pack_featproj_h(out_feat, m.W0.data(), ni, 3, F, m.b0.data()); else pack_featproj(out_feat, m.W0.data(), ni, 3, F, m.b0.data()); }
+    if (b3) return 0;                                   // nothing to audit: 24-bit operands, fp32's range
     if (prec && g_half_overflow) return fail("rnf_pack_mobius: a weight is outside the fp16 range; use RNF_PREC_FP32") + 1;
     if (prec) {
         for (size_t i = 0; i < (size_t)K * 64; ++i) m.WL[i] = std::ldexp(fc_last_w[i], -m.eq.e[0][i & 63]);      // the audit compares unscaled outputs
@@ -403,10 +438,10 @@ static int pack_cond(const float *fc_first_w, const float *fc_first_b, const flo
                      const float *l3_b, const float *l5_w, const float *l5_b, const float *fc_last_w, const float *fc_last_b, int32_t F,
                      int32_t prec, int32_t n_out, float *out, float *out_feat) {
     if (F <= 0 || F % 8) return fail("rnf_pack_cond16: feature_dim=%d must be a positive multiple of 8", F);
-    if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2) return fail("rnf_pack_cond16: unknown precision %d", prec);
+    if (prec != RNF_PREC_FP32 && prec != RNF_PREC_F16X2 && prec != RNF_PREC_BF16X3) return fail("rnf_pack_cond16: unknown precision %d", prec);
     g_half_overflow = false;
     g_last_audit = 0.0;
-    std::memset(out, 0, sizeof(float) * (n_out == 36 ? COND36_FLOATS : COND16_FLOATS));   // zero fc_first image: x0 comes from the projection
+    std::memset(out, 0, sizeof(float) * cond_packed_floats_p(n_out == 36 ? 2 : 1, prec));   // zero fc_first image: x0 comes from the projection
     const float *hw[3] = {l1_w, l3_w, l5_w};
     const float *hb[3] = {l1_b, l3_b, l5_b};
     ScaledMlp m;                                       // equalize.h: canonical scaling before the fp16 split (split precision only)
@@ -428,12 +463,14 @@ static int pack_cond(const float *fc_first_w, const float *fc_first_b, const flo
     };
     for (int tau = 0; tau < (n_out == 36 ? 2 : 1); ++tau) {
         auto src = [&](int row) { return n_out == 36 ? (tau == 0 ? row : (row < 4 ? 32 + row : -1)) : src_row(row); };
-        float *rec = out + MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS;
+        const bool b3 = prec == RNF_PREC_BF16X3;
+        float *rec = out + (b3 ? Lay<2>::LAST + (size_t)tau * Lay<2>::LAST_TILE_FLOATS : MOB_LAST + (size_t)tau * MOB_LAST_TILE_FLOATS);
         auto row_of = [&](int, int i) { int s = src(i); return s < 0 ? (const float *)nullptr : m.WL.data() + (size_t)s * 64; };
-        if (prec) pack_w64_h(rec, 1, row_of); else pack_w64(rec, 1, row_of);
-        pack_bias(rec + MOB_LAST_TILE_BIAS, 1, [&](int, int row) { int s = src(row); return s < 0 ? 0.f : fc_last_b[s]; });
+        if (b3) pack_w64_b3(rec, 1, row_of); else if (prec) pack_w64_h(rec, 1, row_of); else pack_w64(rec, 1, row_of);
+        pack_bias(rec + (b3 ? Lay<2>::LAST_TILE_BIAS : MOB_LAST_TILE_BIAS), 1, [&](int, int row) { int s = src(row); return s < 0 ? 0.f : fc_last_b[s]; });
     }
-    if (prec) pack_featproj_h(out_feat, m.W0.data(), F, 0, F, m.b0.data()); else pack_featproj(out_feat, m.W0.data(), F, 0, F, m.b0.data());
+    if (prec == RNF_PREC_F16X2) pack_featproj_h(out_feat, m.W0.data(), F, 0, F, m.b0.data()); else pack_featproj(out_feat, m.W0.data(), F, 0, F, m.b0.data());
+    if (prec == RNF_PREC_BF16X3) return 0;
     if (prec && g_half_overflow) return fail("rnf_pack_cond16: a weight is outside the fp16 range; use RNF_PREC_FP32") + 1;
     if (prec) {
         g_last_audit = audit_mlp(m, fc_first_w, fc_first_b, hw, hb, fc_last_w, fc_last_b);
@@ -828,7 +865,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             fbp[l] = d[D_PARAM_FB];
             if (slot >= 0) fbf[slot] = d[D_FEAT_FB];
             const int p = d[D_PREC];
-            if (p != RNF_PREC_FP32 && p != RNF_PREC_F16X2) return fail("layer %d: unknown precision %d", l, p);
+            if (p != RNF_PREC_FP32 && p != RNF_PREC_F16X2 && p != RNF_PREC_BF16X3) return fail("layer %d: unknown precision %d", l, p);
             if (prec >= 0 && p != prec) return fail("layer %d: all MLP layers of a flow must be packed with the same precision", l);
             prec = p;
         }
@@ -876,9 +913,11 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     }
     double *partials = reinterpret_cast<double *>(ws);
     float *G = n_slots ? reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + PARTIALS_BYTES) : nullptr;
-    int tiles_in_lds = any_mlp ? (KT < MOB_MAX_TILES_IN_LDS ? KT : MOB_MAX_TILES_IN_LDS) : 0;
+    const int max_tiles = prec == 2 ? Lay<2>::MAX_TILES_IN_LDS : MOB_MAX_TILES_IN_LDS;
+    int tiles_in_lds = any_mlp ? (KT < max_tiles ? KT : max_tiles) : 0;
     if (any_mlp && tiles_in_lds < min_tiles) tiles_in_lds = min_tiles;
-    size_t lds_bytes = any_mlp ? sizeof(float) * (MOB_HEAD_FLOATS + (size_t)tiles_in_lds * MOB_LAST_TILE_FLOATS) : 0;
+    size_t lds_bytes = !any_mlp ? 0 : sizeof(float) * (prec == 2 ? Lay<2>::HEAD_FLOATS + (size_t)tiles_in_lds * Lay<2>::LAST_TILE_FLOATS
+                                                                  : MOB_HEAD_FLOATS + (size_t)tiles_in_lds * MOB_LAST_TILE_FLOATS);
     if (lds_bytes < NW_FWD_WIDE * sizeof(double) * 2) lds_bytes = NW_FWD_WIDE * sizeof(double) * 2;
     {   // SIMD fairness governor (flow_kernels.h struct Fair): forward split-precision kernel; RNF_FAIR=0 switches it off
         static int fair = -1;
@@ -914,7 +953,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     a.fisher_c = o.fisher_c;
     a.fisher_div = o.fisher_A ? n / o.fisher_B : 1;
 
-    const bool pipe = staging_dma() && KT <= MOB_MAX_TILES_IN_LDS;
+    const bool pipe = staging_dma() && KT <= MOB_MAX_TILES_IN_LDS && prec != 2;     // bf16x3: a K = 64 layer image is 171 KiB (layout.h Lay<2>): synchronous staging
     a.tab_off = -1;
     if (pipe && any_mlp) {                                     // two LDS buffers for the blocks of constant-affine layers (flow_kernels.h stage_table)
         lds_bytes = (lds_bytes + 15) / 16 * 16;
@@ -1004,7 +1043,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             fp.row_mode = shared ? 1 : 0;
             fp.only_if = fb ? guard : nullptr;
             if (fb) for (int sl = 0; sl < n_slots; ++sl) fp.feat_off[sl] = fbf[sl];
-            const int pprec = fb ? 0 : prec;
+            const int pprec = (fb || prec == 2) ? 0 : prec;       // bf16x3 flows: the exact-fp32 projection (their records hold the fp32 image)
             const int kchunk = F < FP_KCHUNK ? F : FP_KCHUNK;
             size_t fl = sizeof(float) * (pprec ? (size_t)2 * (FP_KCHUNK / 16) * 512 : (size_t)kchunk / 8 * 256);   // f16x2: two DMA buffers
             if (pprec && F > FP_KCHUNK && F <= 2 * FP_KCHUNK) {     // K split over wave pairs: no partial sums through the scratch (featproj_kernel.h)
@@ -1046,6 +1085,8 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         int rc;
         const bool rows_now = rows_fast;                   // (the exact-fp32 re-run below shadows it: shared rows there stay on the extended kernels)
 #define RNF_LAUNCH(DIR_, KT_)                                                                                   \
+    prec == 2 ? (ext ? launch_stack<DIR_, KT_, false, 2, true>(a, grid, lds_bytes, stream, nwk)                     \
+                     : launch_stack<DIR_, KT_, false, 2>(a, grid, lds_bytes, stream, nwk)) :                        \
     rows_now ? launch_stack<DIR_, KT_, true, 1, false, true>(a, grid, lds_bytes, stream, nwk, family) :             \
     ext ? (pipe ? (prec ? launch_stack<DIR_, KT_, true, 1, true>(a, grid, lds_bytes, stream, nwk)                   \
                         : launch_stack<DIR_, KT_, true, 0, true>(a, grid, lds_bytes, stream, nwk))                  \
@@ -1065,6 +1106,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
         else if (kt_inv == 2) rc = RNF_LAUNCH(1, 2);
         else if (kt_inv == 4) rc = RNF_LAUNCH(1, 4);
         else if (kt_inv == 8) rc = RNF_LAUNCH(1, 8);
+        else if (prec == 2) rc = ext ? launch_big_inverse<2, true>(a, grid, lds_bytes, stream) : launch_big_inverse<2>(a, grid, lds_bytes, stream);
         else rc = ext ? (prec ? launch_big_inverse<1, true>(a, grid, lds_bytes, stream) : launch_big_inverse<0, true>(a, grid, lds_bytes, stream))
                       : (prec ? launch_big_inverse<1>(a, grid, lds_bytes, stream) : launch_big_inverse<0>(a, grid, lds_bytes, stream));
         if (rc) return rc;

@@ -37,7 +37,7 @@ class ConditionalTransform(nn.Module):
             raise RuntimeError("rotationnormflow_amd runs on the GPU only (no CPU fallback)")
         K = self.No // 4
         L = _lib.lib()
-        prec = runtime._PRECISIONS[runtime.get_precision()]
+        prec = runtime._PRECISIONS[runtime.device_precision()]      # (the standalone conditioner kernel has no bf16x3 instantiation)
         try:
             rec, _ = runtime.pack_mobius(L, self, K, 0, prec)
         except runtime.HalfRangeError:

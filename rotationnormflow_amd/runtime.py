@@ -23,13 +23,20 @@ SIDE_KINDS = (KIND_SIDE16, KIND_SIDE16_ROT, KIND_SIDE9)
 DESC_STRIDE = 8            # include/rnf_hip.h RNF_DESC_STRIDE: kind, perm_row, param, cond_slot, feat, precision, fallback param, fallback feat
 
 # Arithmetic of the conditioner GEMMs (include/rnf_hip.h RNF_PREC_*): "f16x2" = split-precision fp16 MFMA (22-bit
-# operands, fp32 accumulate; default), "fp32" = exact fp32 MFMA.  Environment override: RNF_PRECISION=fp32|f16x2.
-_PRECISIONS = {"fp32": _lib.PREC_FP32, "f16x2": _lib.PREC_F16X2}
+# operands, fp32 accumulate; default), "fp32" = exact fp32 MFMA, "bf16x3" (round 6) = every operand as three bf16 terms (24 bits, fp32's
+# range: nothing to equalise, calibrate, audit or guard), six bf16 MFMAs per product-sum.  Environment override: RNF_PRECISION.
+_PRECISIONS = {"fp32": _lib.PREC_FP32, "f16x2": _lib.PREC_F16X2, "bf16x3": _lib.PREC_BF16X3}
 _precision = os.environ.get("RNF_PRECISION", "f16x2")
 
 
+def device_precision() -> str:
+    """The arithmetic of the paths whose kernel images are built ON THE DEVICE (training passes, nn.DataParallel replicas, the side layers'
+    conditioners): "bf16x3" images exist for host-packed flows only, those paths then run the exact-fp32 kernels."""
+    return "fp32" if _precision == "bf16x3" else _precision
+
+
 def set_precision(name: str):
-    """Select the arithmetic used for flows packed from now on ("f16x2" or "fp32")."""
+    """Select the arithmetic used for flows packed from now on ("f16x2", "bf16x3" or "fp32")."""
     global _precision
     if name not in _PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
@@ -363,7 +370,7 @@ def pack_mobius(L, cond, K, feature_dim, prec=_lib.PREC_FP32):
     Fp = pad8(F)
     if K <= 0:
         raise ValueError(f"segments={K} must be positive")
-    rec = np.empty(L.rnf_mobius_packed_floats(K), dtype=np.float32)
+    rec = np.empty(L.rnf_mobius_packed_floats_prec(K, prec), dtype=np.float32)
     frec = np.empty(L.rnf_featproj_packed_floats(Fp), dtype=np.float32) if F else None
     arrs = [_pad_cols(_np32(cond.fc_first.weight), 3, F, Fp), _np32(cond.fc_first.bias)]
     for j in (1, 3, 5):
@@ -377,7 +384,7 @@ def pack_mobius(L, cond, K, feature_dim, prec=_lib.PREC_FP32):
 def pack_cond16(L, net, feature_dim, prec=_lib.PREC_FP32, n_out=16):
     F = feature_dim
     Fp = pad8(F)
-    rec = np.empty(L.rnf_cond36_packed_floats() if n_out == 36 else L.rnf_cond16_packed_floats(), dtype=np.float32)
+    rec = np.empty(L.rnf_cond_packed_floats_prec(n_out, prec), dtype=np.float32)
     frec = np.empty(L.rnf_featproj_packed_floats(Fp), dtype=np.float32)
     arrs = [_pad_cols(_np32(net.fc_first.weight), 0, F, Fp), _np32(net.fc_first.bias)]
     for j in (1, 3, 5):
@@ -421,7 +428,7 @@ class SideNet:
 
     def _pack(self, device, feature_ms=1.0):
         L = _lib.lib()
-        prec_name = _precision
+        prec_name = device_precision()
         old_ms = L.rnf_set_feature_ms(float(feature_ms))
         try:
             for name in ([prec_name, "fp32"] if prec_name != "fp32" else ["fp32"]):

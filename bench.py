@@ -373,6 +373,12 @@ def roofline_of(w, precision, kernel_ms, pmc):
              "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
              "note": "frac = algorithmic GEMM FLOP rate / dense fp16 MFMA peak; the stack kernel is VALU-issue bound (valu_issue_frac), neither "
                      "matrix- nor HBM-bound"}
+    elif precision == "bf16x3":
+        r = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_MFMA_TFLOPS,
+             "kernel_ms": kernel_ms, "algorithmic_flop_per_rotation": wl["flop"], "executed_mfma_tflops": 6 * achieved,
+             "frac_executed": 6 * achieved / PEAK_F16_MFMA_TFLOPS,
+             "note": "frac = algorithmic GEMM FLOP rate / dense bf16 MFMA peak (= the fp16 peak); six bf16 MFMAs per fp32 product-sum are "
+                     "executed (frac_executed); matrix time and VALU time add on a SIMD (matrix_pipe_frac + valu_issue_frac ~ 1)"}
     else:
         r = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
              "kernel_ms": kernel_ms, "algorithmic_flop_per_rotation": wl["flop"],
@@ -428,7 +434,7 @@ def pmc_child(args):
     for name in args.pmc_configs.split(","):
         w = Workload(name, device, args.batch_log2, share=prev)
         prev = w
-        for precision in ("f16x2", "fp32"):
+        for precision in ("f16x2", "fp32", "bf16x3"):
             set_precision(precision)
             with torch.no_grad():
                 w.evaluate()                                    # warm-up of this arithmetic: packs, allocates; profiled too, then dropped by position
@@ -714,6 +720,19 @@ def measure(w, args, dist, pmc, steps, warmup, want_secondary, want_parity, cpu_
         rec["value_fp32_exact"] = secondary["value"]
         rec["ms_per_step_fp32_exact"] = secondary["ms_per_step"]
         rec["secondary"] = secondary
+        # the STRICT arithmetic (round 6): bf16x3 -- 24-bit operands as three bf16 terms on the bf16 MFMA, nothing data- or scale-dependent
+        set_precision("bf16x3")
+        try:
+            s_steps = max(2, min(steps, 8))
+            s_elapsed, s_kernel_ms, s_tot = timed(s_steps, 2, 4, 2)
+            strict = {"dtype": "f32 (GEMM operands as bf16 hi+mid+lo triples, fp32 accumulate)", "value": w.n_global * s_steps / s_elapsed,
+                      "unit": "rotations/s", "steps": s_steps, "timed_blocks": 2, "ms_per_step": s_elapsed / s_steps * 1e3,
+                      "mean_nll": -float(s_tot[0] / s_tot[1]), "roofline": roofline_of(w, "bf16x3", s_kernel_ms, pmc)}
+        finally:
+            set_precision(primary)
+        rec["value_strict"] = strict["value"]
+        rec["ms_per_step_strict"] = strict["ms_per_step"]
+        rec["strict"] = strict
     elif used == "fp32":
         rec["value_fp32_exact"], rec["ms_per_step_fp32_exact"] = rec["value"], rec["ms_per_step"]
     if rank0 and world == 1:
@@ -736,6 +755,12 @@ def host_legs(w, rec, want_parity, cpu_sizes, cpu_budget):
             set_precision("fp32")
             try:
                 secondary["parity"] = {"samples": head["samples"], **stats(product(), want)}
+            finally:
+                set_precision(primary)
+        if rec.get("strict"):
+            set_precision("bf16x3")
+            try:
+                rec["strict"]["parity"] = {"samples": head["samples"], **stats(product(), want)}
             finally:
                 set_precision(primary)
     if cpu_sizes:
@@ -824,7 +849,12 @@ def compact_record(out, full_path=None):
     cfg = dict(out["config"])
     cfg["workload"] = cfg["workload"][:100]
     c["config"] = cfg
-    c.update(_pick(out, ("rccl_ranks", "backend", "value_fp32_exact", "ms_per_step_fp32_exact", "mean_nll")))
+    c.update(_pick(out, ("rccl_ranks", "backend", "value_strict", "ms_per_step_strict", "value_fp32_exact", "ms_per_step_fp32_exact", "mean_nll")))
+    if "strict" in out:                                        # the strict leg's own roofline and parity, short
+        st = out["strict"]
+        c["strict"] = {"dtype": "bf16x3", **_pick(st.get("roofline", {}), ("frac", "frac_executed", "kernel_ms", "valu_issue_frac", "matrix_pipe_frac"))}
+        if "parity" in st:
+            c["strict"]["parity_max"] = st["parity"].get("max_abs_err")
     if "roofline" in out:
         c["roofline"] = _pick(out["roofline"], ROOF_KEYS)
     if "cpu_baseline" in out:
@@ -843,7 +873,7 @@ def compact_record(out, full_path=None):
             small[name] = _pick(r, ("ms_per_iteration", "ms_per_iteration_hip_graph"))
             continue
         thin = name in THIN_CONFIGS
-        e = _pick(r, ("value", "ms_per_step", "ms_per_step_inverse") if thin else ("value", "ms_per_step", "value_fp32_exact"))
+        e = _pick(r, ("value", "ms_per_step", "ms_per_step_inverse") if thin else ("value", "ms_per_step", "value_strict"))     # (value_fp32_exact: full record)
         roof = r.get("roofline", {})
         if not thin:                       # (C3 runs C2's kernel; the trained-weights entries are about time and parity)
             e.update(_pick(roof, ("frac", "valu_issue_frac", "matrix_pipe_frac")))
@@ -851,7 +881,7 @@ def compact_record(out, full_path=None):
                 e["traffic_x"] = roof["traffic"] / roof["traffic_algorithmic"]
         if "parity" in r:
             e["parity_max"] = r["parity"].get("max_abs_err")
-        for k in ("value", "value_fp32_exact"):            # whole rotations per second: shorter than a float and exact enough at 3 digits
+        for k in ("value", "value_strict", "value_fp32_exact"):            # whole rotations per second: shorter than a float and exact enough at 3 digits
             if k in e:
                 e[k] = int(float(f"{e[k]:.3g}"))
         small[name] = e
@@ -1026,7 +1056,7 @@ def main():
                        "parallelism": (f"batch-sharded x{world}, one all-reduce of {{sum log p, count}} per step" if world > 1 else "single GPU")},
             "rccl_ranks": ranks_seen, "backend": backend, "mean_nll": head["mean_nll"], "clock_settle_launches": CLOCK_SETTLE_LAUNCHES,
         }
-        for k in ("value_fp32_exact", "ms_per_step_fp32_exact", "roofline", "hbm", "secondary", "parity", "cpu_baseline", "vs_cpu_baseline"):
+        for k in ("value_fp32_exact", "ms_per_step_fp32_exact", "value_strict", "ms_per_step_strict", "strict", "roofline", "hbm", "secondary", "parity", "cpu_baseline", "vs_cpu_baseline"):
             if k in head:
                 out[k] = head[k]
         if state is not None:

@@ -656,6 +656,21 @@ __device__ __forceinline__ void split3_pair(float a, float b, u4v &hi, u4v &mid,
     mid[e] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
     lo[e] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
 }
+// the same pair in two slices (7 + 6 VALU), one behind each of two consecutive matrix instructions (hidden_slot_b3)
+struct Split3State { float ra, rb; };
+__device__ __forceinline__ void split3_stage_a(float a, float b, Split3State &st, u4v &hi, int e) {
+    a = relu_bits(a); b = relu_bits(b);
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    st.ra = a - __uint_as_float(ua & 0xffff0000u);
+    st.rb = b - __uint_as_float(ub & 0xffff0000u);
+    hi[e] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+}
+__device__ __forceinline__ void split3_stage_b(const Split3State &st, u4v &mid, u4v &lo, int e) {
+    const unsigned va = __float_as_uint(st.ra), vb = __float_as_uint(st.rb);
+    const float sa = st.ra - __uint_as_float(va & 0xffff0000u), sb = st.rb - __uint_as_float(vb & 0xffff0000u);
+    mid[e] = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+    lo[e] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+}
 template <bool RELU>
 __device__ __forceinline__ void split3_act(const f32x16 (&x)[2], ActFrag3 &f) {
 #pragma unroll
@@ -694,27 +709,31 @@ __device__ __forceinline__ void b3_prefetch(Ops3 &o, const float *w_tile, const 
     }
 }
 
-// Hidden tiles, the operand split of the previous tile written behind the matrix instructions (the scheme of hidden_slot, 24 instructions
-// per tile and 13 VALU per value pair here: one pair behind every second matrix instruction -- 52 + 16 issue cycles against 64 of matrix work):
-//   FILL 1 (tile 0 of a layer): `src` (the previous layer's tile 1) -> fragments 2 (slots 0..6) and 3 (slots 8..14): k-steps 0, 1 read 0 and 1 only;
-//   FILL 2 (tile 1 of a layer): `src` (this layer's tile 0) -> fragment 0 (slots 6..12, behind k-step 0, its last reader) and 1 (slots 14..20).
+// Hidden tiles, the operand split of the previous tile written behind the matrix instructions (the scheme of hidden_slot; 24 instructions
+// per tile here and 13 VALU per value pair, cut in two slices of 7 and 6: one slice behind each of 16 consecutive matrix instructions --
+// 8 + 26 issue cycles against the 32 of the instruction; with a whole pair behind every second one the stream measured VALU + matrix time):
+//   FILL 1 (tile 0 of a layer): `src` (the previous layer's tile 1) -> fragments 2 (slots 0..7) and 3 (slots 8..15): k-steps 0, 1 read 0 and 1 only;
+//   FILL 2 (tile 1 of a layer): `src` (this layer's tile 0) -> fragment 0 (slots 6..13, behind k-step 0, its last reader) and 1 (slots 14..21).
 template <int M, int FILL>
-__device__ __forceinline__ void hidden_slot_b3(const float *w_tile, const float *w_next, int lane, ActFrag3 &f, f32x16 &acc, const f32x16 &src, Ops3 &o) {
+__device__ __forceinline__ void hidden_slot_b3(const float *w_tile, const float *w_next, int lane, ActFrag3 &f, f32x16 &acc, const f32x16 &src, Ops3 &o,
+                                               Split3State &st) {
     acc = b3_mfma<M>(o, f, acc);
     b3_prefetch<M>(o, w_tile, w_next, lane);
     constexpr int first = FILL == 1 ? 0 : (FILL == 2 ? 6 : -1);
-    if constexpr (FILL != 0 && M >= first && M < first + 16 && ((M - first) % 2) == 0) {
+    if constexpr (FILL != 0 && M >= first && M < first + 16) {
         constexpr int q = (M - first) / 2;                        // 0..7: value pair q of src
         constexpr int dst = (FILL == 1 ? 2 : 0) + q / 4, e = q % 4;
-        split3_pair<true>(src[2 * q], src[2 * q + 1], f.hi[dst], f.mid[dst], f.lo[dst], e);
+        if constexpr (((M - first) % 2) == 0) split3_stage_a(src[2 * q], src[2 * q + 1], st, f.hi[dst], e);
+        else split3_stage_b(st, f.mid[dst], f.lo[dst], e);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (M + 1 < 24) hidden_slot_b3<M + 1, FILL>(w_tile, w_next, lane, f, acc, src, o);
+    if constexpr (M + 1 < 24) hidden_slot_b3<M + 1, FILL>(w_tile, w_next, lane, f, acc, src, o, st);
 }
 template <int FILL>
 __device__ __forceinline__ void hidden_tile_b3(const float *w_tile, const float *w_next, int lane, ActFrag3 &f, f32x16 &acc, const f32x16 &src, Ops3 &o) {
+    Split3State st;
     __builtin_amdgcn_sched_barrier(0);
-    hidden_slot_b3<0, FILL>(w_tile, w_next, lane, f, acc, src, o);
+    hidden_slot_b3<0, FILL>(w_tile, w_next, lane, f, acc, src, o, st);
 }
 
 // one 64 -> 32 output tile without fillers (fc_last of the inverse pass and of the non-Moebius conditioners)
@@ -737,31 +756,45 @@ __device__ __forceinline__ f32x16 gemm_tile64_b3(const float *w_tile, int lane, 
 template <>
 struct Mlp<2> {
     typedef ActFrag3 Act;
+    // RING staging (flow_stack_kernel): a layer image is consumed in UNITS that stream through three LDS regions --
+    //     Ha = [fc_first | hidden tiles 0..2 | hidden biases]    Hb = [hidden tiles 3..5 | hidden biases]    L_g = fc_last tiles 4g .. 4g + 3
+    // (float offsets inside a region)
+    static constexpr int HA_TILES = Lay<2>::FIRST + MOB_FIRST_FLOATS, HA_BIAS = HA_TILES + 3 * Lay<2>::W_TILE, HA_FLOATS = HA_BIAS + MOB_HB_FLOATS;
+    static constexpr int HB_BIAS = 3 * Lay<2>::W_TILE, HB_FLOATS = HB_BIAS + MOB_HB_FLOATS;
+    static constexpr int REGION_FLOATS = 4 * Lay<2>::LAST_TILE_FLOATS;
+    static_assert(HA_FLOATS <= REGION_FLOATS && HB_FLOATS <= REGION_FLOATS, "every unit fits a region");
     // Same structure as Mlp<1>::head: fc_first on the two exact fp32 MFMA steps, x0 recomputed for the residual (Mlp<1>::residual: ONE
     // definition of x0 + x3 for every arithmetic), the operand splits behind the matrix instructions of the next tile (hidden_slot_b3).
+    // ctl.begin_unit() -> base of the next unit (waits for it, frees the previous one, requests the one after next).
     // `bad`: a NaN x0 (NaN feature row / rotation): the integer ReLU would launder it (the reference propagates NaN).
-    template <class GF, bool KEEPX0 = false, class FairT = Fair, bool DEEP = false>
-    static __device__ __forceinline__ void head(const float *lds, int lane, int h, float y0, float y1, float y2,
-                                                const GF &g, Act &out, FairT &, bool &bad, const f32x16 * = nullptr) {
+    template <class GF, bool KEEPX0, class Ctl>
+    static __device__ __forceinline__ void head_ring(Ctl &ctl, int lane, int h, float y0, float y1, float y2, const GF &g, Act &out, bool &bad) {
         typedef Lay<2> L2;
         const float bA = h ? y1 : y0;
         const float bB = h ? 1.0f : y2;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         f32x16 x0k[2];                                          // KEEPX0 only
         float ga[2] = {0.f, 0.f}, gb = 0.f;                     // AS_BIAS only
-        auto w = [&](int L, int ot) { return lds + L2::HID + (L * 2 + ot) * L2::W_TILE; };
-        auto bias = [&](int L, int ot) { return load_bias16(lds + L2::HB + ((L * 2 + ot) * 2 + h) * 16); };
+        const float *ua = ctl.begin_unit();                     // Ha
+        auto wa = [&](int i) { return ua + HA_TILES + i * L2::W_TILE; };                       // hidden tiles 0..2 = (L0,0) (L0,1) (L1,0)
+        auto bias_a = [&](int i) { return load_bias16(ua + HA_BIAS + (i * 2 + h) * 16); };
         Ops3 o;
-        o.load(0, w(0, 0), 0, lane);                            // (their LDS latency sits under fc_first and the split of x0)
-        o.load(1, w(0, 0), 1, lane);
+        o.load(0, wa(0), 0, lane);                              // (their LDS latency sits under fc_first and the split of x0)
+        o.load(1, wa(0), 1, lane);
         ActFrag3 &f = out;
+        // fc_first (float2 per lane at the head of the unit), twice: x0 here, the residual at the end -- its image is copied out of the unit
+        // (2 registers per lane and out tile) because unit Ha's region is gone by then
+        float2 w0[2];
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) w0[ot] = reinterpret_cast<const float2 *>(ua + L2::FIRST)[ot * 64 + lane];
+        auto first_tile = [&](int ot, f32x16 c) { c = RNF_MFMA(w0[ot].x, bA, c); return RNF_MFMA(w0[ot].y, bB, c); };
         {
             f32x16 x0[2];
             if constexpr (GF::AS_BIAS) {
                 if (g) { ga[0] = g.aop(0, lane, h); ga[1] = g.aop(1, lane, h); gb = g.bop(lane, h); }
 #pragma unroll
                 for (int ot = 0; ot < 2; ++ot) {
-                    x0[ot] = Mlp<1>::first_tile(lds, ot, lane, bA, bB, zero);
+                    x0[ot] = first_tile(ot, zero);
                     if (g) x0[ot] = RNF_MFMA(ga[ot], gb, x0[ot]);
                 }
             } else {
@@ -769,28 +802,49 @@ struct Mlp<2> {
                 for (int ot = 0; ot < 2; ++ot) {
                     const f32x16 gin = g ? g.template load<KEEPX0>(ot, lane, h) : zero;
                     if constexpr (KEEPX0) x0k[ot] = gin;
-                    x0[ot] = Mlp<1>::first_tile(lds, ot, lane, bA, bB, gin);
+                    x0[ot] = first_tile(ot, gin);
                 }
             }
             bad |= x0[0][0] != x0[0][0];
             split3_act<true>(x0, f);
         }
         // layer 0: tile 0 bare (its input is complete), tile 1 carries the split of tile 0
-        f32x16 a0 = bias(0, 0), a1 = bias(0, 1);
-        hidden_tile_b3<0>(w(0, 0), w(0, 1), lane, f, a0, a0, o);
-        f32x16 b0 = bias(1, 0);
-        hidden_tile_b3<2>(w(0, 1), w(1, 0), lane, f, a1, a0, o);
-        // layer 1: tile 0 carries the split of layer 0's tile 1, tile 1 the split of its own tile 0
-        f32x16 b1 = bias(1, 1);
-        hidden_tile_b3<1>(w(1, 0), w(1, 1), lane, f, b0, a1, o);
-        a0 = bias(2, 0);
-        hidden_tile_b3<2>(w(1, 1), w(2, 0), lane, f, b1, b0, o);
+        f32x16 a0 = bias_a(0), a1 = bias_a(1);
+        hidden_tile_b3<0>(wa(0), wa(1), lane, f, a0, a0, o);
+        f32x16 b0 = bias_a(2);
+        hidden_tile_b3<2>(wa(1), wa(2), lane, f, a1, a0, o);
+        // layer 1: tile 0 carries the split of layer 0's tile 1 ...
+        hidden_tile_b3<1>(wa(2), nullptr, lane, f, b0, a1, o);
+        const float *ub = ctl.begin_unit();                     // Hb
+        auto wb = [&](int i) { return ub + i * L2::W_TILE; };                                   // hidden tiles 3..5 = (L1,1) (L2,0) (L2,1)
+        auto bias_b = [&](int i) { return load_bias16(ub + HB_BIAS + (i * 2 + h) * 16); };
+        o.load(0, wb(0), 0, lane);
+        o.load(1, wb(0), 1, lane);
+        f32x16 b1 = bias_b(3);
+        a0 = bias_b(4);
+        // ... tile 1 the split of its own tile 0
+        hidden_tile_b3<2>(wb(0), wb(1), lane, f, b1, b0, o);
         // layer 2, then the residual x0 + x3 (flow/condition.py:29) tile by tile: tile 0's residual + split ride behind tile 1's instructions
-        a1 = bias(2, 1);
-        hidden_tile_b3<1>(w(2, 0), w(2, 1), lane, f, a0, b1, o);
-        Mlp<1>::template residual<KEEPX0>(lds, 0, lane, h, bA, bB, g, x0k, a0, ga, gb);
-        hidden_tile_b3<2>(w(2, 1), nullptr, lane, f, a1, a0, o);
-        Mlp<1>::template residual<KEEPX0>(lds, 1, lane, h, bA, bB, g, x0k, a1, ga, gb);
+        a1 = bias_b(5);
+        hidden_tile_b3<1>(wb(1), wb(2), lane, f, a0, b1, o);
+        auto residual = [&](int ot, f32x16 &acc) {              // Mlp<1>::residual with the copied fc_first image
+            acc = first_tile(ot, acc);
+            if constexpr (GF::AS_BIAS) {
+                if (g) acc = RNF_MFMA(ga[ot], gb, acc);
+            } else if (g) {
+                if constexpr (KEEPX0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] += x0k[ot][r];
+                } else {
+                    const f32x16 gg = g.load(ot, lane, h);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] += gg[r];
+                }
+            }
+        };
+        residual(0, a0);
+        hidden_tile_b3<2>(wb(2), nullptr, lane, f, a1, a0, o);
+        residual(1, a1);
 #pragma unroll
         for (int q = 0; q < 8; ++q) split3_pair<true>(a1[2 * q], a1[2 * q + 1], f.hi[2 + q / 4], f.mid[2 + q / 4], f.lo[2 + q / 4], q % 4);
     }
@@ -1046,34 +1100,36 @@ __device__ __forceinline__ void mobius_fwd_tiles(const float *lds, int KT, int K
     }
 }
 
-// forward fc_last tile tau + 1 (24 matrix instructions) with the segment math of the finished tile tau behind them: slice (segment g, stage
-// st) of seg_s7_stage behind every second instruction (so3_math.h: ~11 VALU per slice)
+// forward fc_last tile tau + 1 (24 matrix instructions) with the segment math of the finished tile tau behind them: slice st of segment g
+// behind instruction 6 g + st (so3_math.h seg_s7_stage6: 6 - 10 VALU per slice)
 template <int M>
 __device__ __forceinline__ void last_slot_b3(const float *w_tile, const float *w_next, int lane, const ActFrag3 &in, f32x16 &nxt, Ops3 &o,
-                                             const f32x16 &cur, SegS7 (&seg)[4], const MobiusCtx &c, float &S, float &A, float &J) {
+                                             const f32x16 &cur, SegS6 (&seg)[4], const MobiusCtx &c, float &S, float &A, float &J) {
     nxt = b3_mfma<M>(o, in, nxt);
     b3_prefetch<M>(o, w_tile, w_next, lane);
-    if constexpr ((M % 2) == 0) {
-        constexpr int q = M / 2, g = q / 3, st = q % 3;
-        seg_s7_stage<st, true>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, S, A, J);
-    }
+    constexpr int g = M / 6, st = M % 6;
+    seg_s7_stage6<st>(seg[g], cur[4 * g], cur[4 * g + 1], cur[4 * g + 2], cur[4 * g + 3], c.f, S, A, J);
+    // pinned in its slot: sched_barrier orders the machine scheduler only, the IR optimiser would sink the slices (their results are consumed
+    // slots later) into one block behind the 24 matrix instructions -- where this kernel measured VALU time + matrix time
+    if constexpr (st == 0) asm volatile("" : "+v"(seg[g].a), "+v"(seg[g].b));
+    else if constexpr (st == 1) asm volatile("" : "+v"(seg[g].bb), "+v"(seg[g].e), "+v"(seg[g].num));
+    else if constexpr (st == 2) asm volatile("" : "+v"(seg[g].t), "+v"(seg[g].c), "+v"(seg[g].z), "+v"(seg[g].ex));
+    else if constexpr (st == 3) asm volatile("" : "+v"(seg[g].p), "+v"(seg[g].lg));
+    else if constexpr (st == 4) asm volatile("" : "+v"(seg[g].p));
+    else asm volatile("" : "+v"(S), "+v"(A), "+v"(J));
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (M + 1 < 24) last_slot_b3<M + 1>(w_tile, w_next, lane, in, nxt, o, cur, seg, c, S, A, J);
 }
 
-// forward tile phase of the bf16x3 kernels: the tiles staged `Lay<2>::MAX_TILES_IN_LDS` at a time (synchronously: the layer image exceeds
-// the LDS), each group pipelined -- tile tau + 1's matrix instructions with tile tau's segment math behind them (last_slot_b3)
-__device__ __forceinline__ void mobius_fwd_tiles_b3(float *lds, const float *layer_params, int KT, int K, int lane, int h, const ActFrag3 &tt,
-                                                    const MobiusCtx &c, float &S, float &A, float &J, int tid, int nthreads) {
+// forward tile phase of the bf16x3 kernels: one ring unit (four fc_last tiles) at a time, each pipelined -- tile tau + 1's matrix
+// instructions with tile tau's segment math behind them (last_slot_b3)
+template <class Ctl>
+__device__ __forceinline__ void mobius_fwd_tiles_b3(Ctl &ctl, int KT, int K, int lane, int h, const ActFrag3 &tt,
+                                                    const MobiusCtx &c, float &S, float &A, float &J) {
     typedef Lay<2> L2;
     for (int t0 = 0; t0 < KT; t0 += L2::MAX_TILES_IN_LDS) {
         const int nt = min(L2::MAX_TILES_IN_LDS, KT - t0);
-        if (t0 > 0) {
-            __syncthreads();
-            stage_floats(lds + L2::LAST, layer_params + L2::LAST + (size_t)t0 * L2::LAST_TILE_FLOATS, nt * L2::LAST_TILE_FLOATS, tid, nthreads);
-            __syncthreads();
-        }
-        const float *rec = lds + L2::LAST;
+        const float *rec = ctl.begin_unit();
         f32x16 cur = Mlp<2>::last(rec, lane, h, tt);
         for (int i = 1; i < nt; ++i) {
             const float *t = rec + i * L2::LAST_TILE_FLOATS;
@@ -1081,7 +1137,7 @@ __device__ __forceinline__ void mobius_fwd_tiles_b3(float *lds, const float *lay
             Ops3 o;
             o.load(0, t, 0, lane);
             o.load(1, t, 1, lane);
-            SegS7 seg[4];
+            SegS6 seg[4];
             __builtin_amdgcn_sched_barrier(0);
             last_slot_b3<0>(t, nullptr, lane, tt, nxt, o, cur, seg, c, S, A, J);
             cur = nxt;
@@ -1142,13 +1198,18 @@ struct InvSegs {
 
 // kt: tiles this layer really has (<= KT, the instantiation's capacity), K: its real segment count; slots beyond them get weight 0.
 // KT > Lay<PREC>::MAX_TILES_IN_LDS (K > 64, synchronous staging only): the second half of the fc_last image is staged in the middle.
-template <int KT, int PREC, bool FASTSP = false>
+struct NoRing {};                       // (the staging of the PREC 0 / 1 kernels needs no unit controller)
+template <int KT, int PREC, bool FASTSP = false, class Ctl = NoRing>
 __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_params, int kt, int K, int lane, int h, const typename Mlp<PREC>::Act &tt,
-                                                 const MobiusCtx &c, InvSegs<KT> &sg, float &S, int tid, int nthreads, float4 *stash = nullptr) {
+                                                 const MobiusCtx &c, InvSegs<KT> &sg, float &S, int tid, int nthreads, float4 *stash = nullptr, Ctl *ctl = nullptr) {
+    constexpr bool RING = !std::is_same<Ctl, NoRing>::value;
+    const float *tiles = lds + Lay<PREC>::LAST;                 // RING: the current unit (four tiles)
 #pragma unroll
     for (int tau = 0; tau < KT; ++tau) {
         if (tau < kt) {                                         // wave uniform
-            if constexpr (KT > Lay<PREC>::MAX_TILES_IN_LDS) {
+            if constexpr (RING) {
+                if ((tau % Lay<PREC>::MAX_TILES_IN_LDS) == 0) tiles = ctl->begin_unit();
+            } else if constexpr (KT > Lay<PREC>::MAX_TILES_IN_LDS) {
                 if (tau > 0 && (tau % Lay<PREC>::MAX_TILES_IN_LDS) == 0) {
                     __syncthreads();
                     stage_floats(lds + Lay<PREC>::LAST, layer_params + Lay<PREC>::LAST + (size_t)tau * Lay<PREC>::LAST_TILE_FLOATS,
@@ -1156,7 +1217,7 @@ __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_
                     __syncthreads();
                 }
             }
-            f32x16 o = Mlp<PREC>::last(lds + Lay<PREC>::LAST + (tau % Lay<PREC>::MAX_TILES_IN_LDS) * Lay<PREC>::LAST_TILE_FLOATS, lane, h, tt);
+            f32x16 o = Mlp<PREC>::last(tiles + (tau % Lay<PREC>::MAX_TILES_IN_LDS) * Lay<PREC>::LAST_TILE_FLOATS, lane, h, tt);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 squash_center(o[4 * g + 1], o[4 * g + 2], o[4 * g + 3], c.f, sg.ur[4 * tau + g], sg.uv[4 * tau + g]);
@@ -1182,13 +1243,15 @@ __device__ __forceinline__ void mobius_inv_tiles(float *lds, const float *layer_
     // K > 8 KT segments (the largest instantiation only, KT = 16: K > 128): the remaining tiles' segment parameters go to the wave's stash
     if constexpr (KT == 16) {
         for (int tau = KT; tau < kt; ++tau) {
-            if ((tau % Lay<PREC>::MAX_TILES_IN_LDS) == 0) {
+            if constexpr (RING) {
+                if ((tau % Lay<PREC>::MAX_TILES_IN_LDS) == 0) tiles = ctl->begin_unit();
+            } else if ((tau % Lay<PREC>::MAX_TILES_IN_LDS) == 0) {
                 __syncthreads();
                 stage_floats(lds + Lay<PREC>::LAST, layer_params + Lay<PREC>::LAST + (size_t)tau * Lay<PREC>::LAST_TILE_FLOATS,
                              min(Lay<PREC>::MAX_TILES_IN_LDS, kt - tau) * Lay<PREC>::LAST_TILE_FLOATS, tid, nthreads);
                 __syncthreads();
             }
-            const f32x16 o = Mlp<PREC>::last(lds + Lay<PREC>::LAST + (tau % Lay<PREC>::MAX_TILES_IN_LDS) * Lay<PREC>::LAST_TILE_FLOATS, lane, h, tt);
+            const f32x16 o = Mlp<PREC>::last(tiles + (tau % Lay<PREC>::MAX_TILES_IN_LDS) * Lay<PREC>::LAST_TILE_FLOATS, lane, h, tt);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float ur, uv;
@@ -1712,6 +1775,13 @@ __device__ __forceinline__ void fused_project_half(const float *pa, int ns, int 
     bad |= acc1[0] != acc1[0];                            // a feature beyond the fp16 range: (inf, -inf) pair, every product NaN
 }
 
+// RING staging of the bf16x3 kernels (PREC = 2): see flow_stack_kernel.  begin_unit() -> LDS base of the next unit of the layer image.
+template <class F>
+struct RingCtl {
+    F &f;
+    __device__ __forceinline__ const float *begin_unit() { return f(); }
+};
+
 // LEAN = 1: the stack holds Moebius and constant 4x4 affine layers only, nothing conditional, no saved states (BASELINE configs C1 / C2 / C3):
 // every other layer kind, the feature-projection reads and the kind dispatch are compiled out.
 // LEAN = 2 (round 3): the CONDITIONAL counterpart (BASELINE configs[3]): Moebius, constant 4x4 affine and Condition16Trans layers, EVERY
@@ -1744,6 +1814,11 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
 #define RNF_DEEP_H 1
 #endif
     constexpr bool DEEP_H = RNF_DEEP_H && PREC == 1 && DIR == 1 && NW <= 8;      // Mlp<1>::head: two operand pairs in flight (hidden_slot2)
+    // RING (PREC = 2, round 6): a bf16x3 layer image (171 KiB at K = 64) does not fit the LDS beside its successor, so it streams through THREE
+    // regions of 48.5 KiB in units -- Ha (fc_first + hidden tiles 0..2), Hb (hidden tiles 3..5), then the fc_last tiles four at a time
+    // (Mlp<2>): while unit u is read, unit u + 1 has landed or is landing and unit u + 2 is requested (LDS-DMA) into the region unit u - 1
+    // just left; one workgroup barrier per unit (begin_unit: wait for the own pieces, barrier, request).  No layer phase waits for a copy.
+    constexpr bool RING = PREC == 2;
     const long long ntiles = (args.n + TILE - 1) / TILE;
     const int KT = args.KT;                                          // DIR = 1: <= KT_INV, the capacity of this instantiation
     const int n_layers = args.n_layers;
@@ -1813,6 +1888,10 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     // is in its VALU-bound segment phase -- be worth?
     if (wave >= NW / 2) for (int i_ = 0; i_ < RNF_KO_STAGGER; ++i_) __builtin_amdgcn_s_sleep(64);
 #endif
+    // ---- RING state (dead code for PREC != 2) ----
+    int ring_reg = 0;                                                 // region of the next unit to be read
+    int d_pos = -1, d_part = 0, d_seq = 0;                            // DMA cursor: MLP layer position, unit of that layer, MLP layers passed
+    long long d_tile = 0;
     // Tile order.  Default: workgroup b takes tiles b, b + grid, ...  ROWS (shared feature rows): XCD-AWARE -- workgroups are dealt to the 8
     // XCDs round-robin (`blockIdx.x % 8` labels the workgroups that share an XCD and its L2, MI355X_MICROARCH.md "Workgroup dispatch"), and
     // the per-(layer, row) records of consecutive rotations are the same few cache lines, so XCD-mate x takes the x-th CONTIGUOUS eighth of
@@ -1824,6 +1903,53 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
     const long long tile_begin = xcd_order ? (ntiles * (long long)(blockIdx.x & 7)) >> 3 : 0;
     const long long tile_end = xcd_order ? (ntiles * (long long)((blockIdx.x & 7) + 1)) >> 3 : ntiles;
     const long long tile_step = xcd_order ? (gridDim.x >> 3) : gridDim.x;
+    auto ring_issue = [&](int region) {                               // request the unit under the DMA cursor into `region`, advance the cursor
+        if constexpr (RING) {
+            if (d_pos < 0) return;
+            typedef Mlp<2> M2;
+            const int2 dl = args.layers[layer_at(d_pos)];
+            const float *src = args.blob + dl.y;
+            float *dst = lds + region * M2::REGION_FLOATS;
+            const int tiles = kind_last_tiles(dl.x & 15, KT);
+            const int nparts = 2 + (tiles + 3) / 4;
+            if (d_part == 0) {
+                dma_floats(dst, src, M2::HA_BIAS, wave, lane, NW);
+                dma_floats(dst + M2::HA_BIAS, src + Lay<2>::HB, MOB_HB_FLOATS, wave, lane, NW);
+            } else if (d_part == 1) {
+                dma_floats(dst, src + M2::HA_BIAS, 3 * Lay<2>::W_TILE, wave, lane, NW);
+                dma_floats(dst + M2::HB_BIAS, src + Lay<2>::HB, MOB_HB_FLOATS, wave, lane, NW);
+            } else {
+                const int t0 = 4 * (d_part - 2);
+                dma_floats(dst, src + Lay<2>::LAST + t0 * Lay<2>::LAST_TILE_FLOATS, min(4, tiles - t0) * Lay<2>::LAST_TILE_FLOATS, wave, lane, NW);
+                if (d_part == nparts - 1) stage_table(d_pos, d_seq & 1);      // the block of the constant-affine layer behind this one
+            }
+            if (++d_part == nparts) {
+                d_part = 0;
+                ++d_seq;
+                int q = ((dl.x >> 16) & 1023) - 1;                    // next MLP layer of this tile
+                if (q < 0) {
+                    d_tile += tile_step;
+                    q = d_tile < tile_end ? first_mlp : -1;
+                }
+                d_pos = q;
+            }
+        }
+    };
+    auto ring_begin = [&]() -> const float * {
+        dma_wait_all();
+        RNF_LAYER_BARRIER();                                          // every wave is past unit u - 1 and its pieces of unit u have landed
+        ring_issue((ring_reg + 2) % 3);
+        const float *base = lds + ring_reg * Mlp<2>::REGION_FLOATS;
+        ring_reg = (ring_reg + 1) % 3;
+        return base;
+    };
+    RingCtl<decltype(ring_begin)> ring{ring_begin};
+    if constexpr (RING) {
+        d_tile = xcd_order ? tile_begin + (blockIdx.x >> 3) : blockIdx.x;
+        d_pos = d_tile < tile_end ? first_mlp : -1;
+        ring_issue(0);
+        ring_issue(1);
+    }
     for (long long tile = xcd_order ? tile_begin + (blockIdx.x >> 3) : blockIdx.x; tile < tile_end; tile += tile_step) {
         const long long group = tile * NW + wave;                 // 32-sample group index inside this launch
         const long long sample0 = group * TILE_SAMPLES;           // wave uniform
@@ -1902,7 +2028,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     }
                 }
 #endif
-                if (PIPE && tab_parity >= 0) {                    // block staged in LDS together with the previous layer's fc_last image
+                if ((PIPE || RING) && tab_parity >= 0) {          // block staged in LDS together with the previous layer's fc_last image
                     int ht = h;                                   // (re-derived here: hoisted out of the layer loop, the lane's table address is a
                     if constexpr (LEAN != 1) asm volatile("" : "+v"(ht));      // register the 128-register conditional instantiations spill)
                     affine16_table_apply_pair(lds + args.tab_off + AFF_TABLE_LDS_STRIDE * tab_parity, ht, R, ldj);
@@ -1980,7 +2106,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 if (q < 0 && more_tiles) q = first_mlp;
                 nxt_q = q;
                 if (q >= 0) { const int2 dn = args.layers[layer_at(q)]; nxt_off = dn.y; nxt_kind = dn.x & 15; }
-            } else {
+            } else if constexpr (!RING) {
                 __syncthreads();                                   // everyone is done with the previous image
                 const int tiles_now = min(kind_last_tiles(kind, KT), Lay<PREC>::MAX_TILES_IN_LDS);
                 stage_floats(lds, params, Lay<PREC>::HEAD_FLOATS + tiles_now * Lay<PREC>::LAST_TILE_FLOATS, tid, NT);
@@ -1992,7 +2118,14 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
             typename Mlp<PREC>::Act tt;
             int hh = h;                                           // (see `ht` above: the bias offsets of the hidden layers are re-derived per layer)
             if constexpr (LEAN == 2 && NW == 16) asm volatile("" : "+v"(hh));
-            if (LEAN == 1 || kind == RNF_KIND_MOBIUS) {
+            if constexpr (RING) {
+                if (kind == RNF_KIND_MOBIUS) {
+                    mobius_begin<DIR, DIR == 0>(R, perm_row, ctx);
+                    Mlp<2>::template head_ring<GF, KEEP_X0>(ring, lane, hh, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, bad);
+                } else {
+                    Mlp<2>::template head_ring<GF, KEEP_X0>(ring, lane, hh, 0.f, 0.f, 0.f, gfrag, tt, bad);
+                }
+            } else if (LEAN == 1 || kind == RNF_KIND_MOBIUS) {
                 mobius_begin<DIR, DIR == 0 && PREC != 0>(R, perm_row, ctx);
                 Mlp<PREC>::template head<GF, KEEP_X0, FairT, DEEP_H>(lds, lane, hh, ctx.y.x, ctx.y.y, ctx.y.z, gfrag, tt, fair, bad, have_gpre ? gpre : nullptr);
             } else {
@@ -2029,6 +2162,10 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                 }
             };
             auto b2_issue = [&]() {
+                if constexpr (RING) {                             // (the block itself was requested with the layer's last fc_last unit, ring_issue)
+                    tab_parity = has_table(pos) ? (seq & 1) : -1;
+                    ++seq;
+                }
                 if (PIPE) {
                     if (nxt_off >= 0) dma_floats(lds + Lay<PREC>::LAST, args.blob + nxt_off + Lay<PREC>::LAST, l_floats(nxt_kind), wave, lane, NW);
                     tab_parity = has_table(pos) ? (seq & 1) : -1;
@@ -2070,7 +2207,9 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                             else mobius_inv_tiles_pipe<KTI, false>(lds, args.K, lane, h, tt, ctx, sg, S);
                         }
                     }
-                    if (!piped) {
+                    if constexpr (RING) {
+                        mobius_inv_tiles<KTI, PREC, false, decltype(ring)>(lds, params, KT, args.K, lane, h, tt, ctx, sg, S, tid, NT, istash, &ring);
+                    } else if (!piped) {
                         if (fastsp) mobius_inv_tiles<KTI, PREC, PREC == 1>(lds, params, KT, args.K, lane, h, tt, ctx, sg, S, tid, NT, istash);
                         else mobius_inv_tiles<KTI, PREC, false>(lds, params, KT, args.K, lane, h, tt, ctx, sg, S, tid, NT, istash);
                     }
@@ -2084,16 +2223,18 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     b2_issue();
                 } else {
                     float S = 0.f, A = 0.f, J = 0.f;
-                    if constexpr (PREC == 2) mobius_fwd_tiles_b3(lds, params, KT, args.K, lane, h, tt, ctx, S, A, J, tid, NT);
+                    if constexpr (PREC == 2) mobius_fwd_tiles_b3(ring, KT, args.K, lane, h, tt, ctx, S, A, J);
                     else if (PIPE || KT <= MOB_MAX_TILES_IN_LDS) mobius_fwd_tiles<PREC, LEAN == 1, LEAN != 0, FairT>(lds, KT, args.K, lane, h, tt, ctx, S, A, J, fair);
                     else mobius_fwd_tiles_restage<PREC>(lds, params, KT, args.K, lane, h, tt, ctx, S, A, J, tid, NT);
                     barrier2();
                     mobius_fwd_finish<PREC != 0, LEAN != 0 && PREC == 1>(ctx, S, A, J, R, ldj, bad, args.min_wsum);
                 }
             } else {
-                const f32x16 o16 = Mlp<PREC>::last(lds + Lay<PREC>::LAST, lane, h, tt);
+                const float *lrec = lds + Lay<PREC>::LAST;
+                if constexpr (RING) lrec = ring.begin_unit();
+                const f32x16 o16 = Mlp<PREC>::last(lrec, lane, h, tt);
                 if (EXT && kind == RNF_KIND_COND36) {
-                    const f32x16 o16b = Mlp<PREC>::last(lds + Lay<PREC>::LAST + Lay<PREC>::LAST_TILE_FLOATS, lane, h, tt);
+                    const f32x16 o16b = Mlp<PREC>::last(lrec + Lay<PREC>::LAST_TILE_FLOATS, lane, h, tt);
                     barrier2();
                     cond36_finish<DIR != 0>(o16, o16b, h, R, ldj);
                 } else {

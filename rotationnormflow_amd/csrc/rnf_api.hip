@@ -916,7 +916,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     const int max_tiles = prec == 2 ? Lay<2>::MAX_TILES_IN_LDS : MOB_MAX_TILES_IN_LDS;
     int tiles_in_lds = any_mlp ? (KT < max_tiles ? KT : max_tiles) : 0;
     if (any_mlp && tiles_in_lds < min_tiles) tiles_in_lds = min_tiles;
-    size_t lds_bytes = !any_mlp ? 0 : sizeof(float) * (prec == 2 ? Lay<2>::HEAD_FLOATS + (size_t)tiles_in_lds * Lay<2>::LAST_TILE_FLOATS
+    size_t lds_bytes = !any_mlp ? 0 : sizeof(float) * (prec == 2 ? (size_t)3 * Mlp<2>::REGION_FLOATS      // three ring regions (flow_kernels.h RING)
                                                                   : MOB_HEAD_FLOATS + (size_t)tiles_in_lds * MOB_LAST_TILE_FLOATS);
     if (lds_bytes < NW_FWD_WIDE * sizeof(double) * 2) lds_bytes = NW_FWD_WIDE * sizeof(double) * 2;
     {   // SIMD fairness governor (flow_kernels.h struct Fair): forward split-precision kernel; RNF_FAIR=0 switches it off
@@ -955,7 +955,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
 
     const bool pipe = staging_dma() && KT <= MOB_MAX_TILES_IN_LDS && prec != 2;     // bf16x3: a K = 64 layer image is 171 KiB (layout.h Lay<2>): synchronous staging
     a.tab_off = -1;
-    if (pipe && any_mlp) {                                     // two LDS buffers for the blocks of constant-affine layers (flow_kernels.h stage_table)
+    if ((pipe || prec == 2) && any_mlp) {                      // two LDS buffers for the blocks of constant-affine layers (flow_kernels.h stage_table)
         lds_bytes = (lds_bytes + 15) / 16 * 16;
         a.tab_off = (int)(lds_bytes / sizeof(float));
         lds_bytes += sizeof(float) * 2 * AFF_TABLE_LDS_STRIDE;

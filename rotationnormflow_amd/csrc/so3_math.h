@@ -419,6 +419,50 @@ RNF_HD void seg_s7_stage(SegS7 &g, float s_raw, float w0, float w1, float w2, co
         J = fmaf(sp, g.c, J);
     }
 }
+// The same segment (segment_fwd_s7<true>: the overflow-safe softplus) cut into SIX slices of 6 - 10 VALU instructions, one behind every
+// matrix instruction of a bf16x3 fc_last tile (flow_kernels.h last_slot_b3: 24 instructions per tile = 4 segments x 6 slices).  Same
+// operations in the same order per value: bit-identical to the three-slice form.
+struct SegS6 {
+    float a, b, bb, e, num, t, c, z, p, ex, lg;
+};
+template <int STAGE>
+RNF_HD void seg_s7_stage6(SegS6 &g, float s_raw, float w0, float w1, float w2, const Frame &f7, float &S, float &A, float &J) {
+    if constexpr (STAGE == 0) {
+        g.a = fmaf(w2, f7.r.z, fmaf(w1, f7.r.y, w0 * f7.r.x));
+        g.b = fmaf(w2, f7.v.z, fmaf(w1, f7.v.y, w0 * f7.v.x));
+    } else if constexpr (STAGE == 1) {
+        g.bb = g.b * g.b;
+        const float n2 = fmaf(g.a, g.a, g.bb);
+        const float D = fmaf(hw_sqrt(n2), kInvSquash, 1.0f);
+        g.e = D + g.a;
+        g.num = fmaf(D, D, -n2);
+    } else if constexpr (STAGE == 2) {
+        g.t = g.b * hw_rcp(g.e);
+        g.c = g.num * hw_rcp(fmaf(g.e, g.e, g.bb));
+        g.z = g.t * g.t;
+        g.ex = hw_exp2(fminf(s_raw, 126.0f));                      // softplus2_safe, first piece
+    } else if constexpr (STAGE == 3) {
+        float p = fmaf(2.456724578e-03f, g.z, -1.440135792e-02f);
+        p = fmaf(p, g.z, 3.978122362e-02f);
+        p = fmaf(p, g.z, -7.234857378e-02f);
+        g.p = fmaf(p, g.z, 1.049894609e-01f);
+        g.lg = hw_log2(1.0f + g.ex);
+    } else if constexpr (STAGE == 4) {
+        float p = fmaf(g.p, g.z, -1.416122920e-01f);
+        p = fmaf(p, g.z, 1.998590677e-01f);
+        p = fmaf(p, g.z, -3.333259703e-01f);
+        p = fmaf(p, g.z, 9.999998864e-01f);
+        g.p = p * g.t;
+    } else {
+        const float big = fmaxf(s_raw, g.lg);
+        const float small = 1.44269504088896341f * g.ex * fmaf(g.ex, fmaf(g.ex, 0.333333333f, -0.5f), 1.0f);
+        const float sp = g.ex < 0.015625f ? small : big;
+        S += sp;
+        A = fmaf(sp, g.p, A);
+        J = fmaf(sp, g.c, J);
+    }
+}
+
 template <bool SAFE = true>
 RNF_HD void segment_fwd_s7(float s_raw, float w0, float w1, float w2, const Frame &f7, float &S, float &A, float &J) {
     SegS7 g;

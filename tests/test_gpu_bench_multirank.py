@@ -107,6 +107,11 @@ def test_single_gpu_line_carries_both_arithmetics_and_every_config_runs():
     assert rec["secondary"]["value"] > 0 and abs(rec["secondary"]["mean_nll"] - rec["mean_nll"]) < 1e-4
     assert rec["value_fp32_exact"] == rec["secondary"]["value"] and "configs" not in rec
     assert abs(short["value"] - rec["value"]) <= 1e-4 * rec["value"] and abs(short["value_fp32_exact"] - rec["value_fp32_exact"]) <= 1e-4 * rec["value"]
+    # round 6: the strict arithmetic (bf16x3) on the same line: faster than the exact fp32-input MFMA, same statistic, its own roofline
+    st = rec["strict"]
+    assert rec["value_strict"] == st["value"] > rec["value_fp32_exact"] and abs(st["mean_nll"] - rec["mean_nll"]) < 1e-4
+    assert st["roofline"]["bound"] == "mfma" and 0.0 < st["roofline"]["frac"] < st["roofline"]["frac_executed"] < 1.0
+    assert abs(short["value_strict"] - rec["value_strict"]) <= 1e-4 * rec["value_strict"] and short["strict"]["dtype"] == "bf16x3"
     assert short["full_record"] == "bench_full.json"
     with open(os.path.join(ROOT, "bench_full.json")) as fh:
         assert json.load(fh)["value"] == rec["value"]
@@ -179,6 +184,10 @@ def test_full_line_carries_every_config_with_live_counters():
     short, rec = _compact(out), _full(out)
     assert rec["config"]["workload"].startswith("C2") and rec["value"] > 0 and rec["value_fp32_exact"] > 0
     assert "error" not in rec["pmc"], rec["pmc"]
+    # the strict leg with its own live counters and parity block (round 6)
+    sr = rec["strict"]["roofline"]
+    assert rec["value_strict"] > 0 and sr["traffic"] > 0 and 0.0 < sr["matrix_pipe_frac"] <= 1.0 and "bf16" in sr["kernel"] or "2," in sr["kernel"]
+    assert rec["strict"]["parity"]["max_abs_err"] < 5e-4 and short["strict"]["parity_max"] == pytest.approx(rec["strict"]["parity"]["max_abs_err"], rel=1e-3)
     assert sorted(rec["configs"]) == sorted(ALL_SECONDARY + ["train"])
     # the compact line: the headline with its live roofline and CPU baseline, and one small entry per other workload
     assert short["roofline"]["traffic"] > 0 and 0.0 < short["roofline"]["valu_issue_frac"] <= 1.0 and short["cpu_baseline"]["value"] > 0

@@ -849,7 +849,7 @@ def compact_record(out, full_path=None):
     cfg = dict(out["config"])
     cfg["workload"] = cfg["workload"][:100]
     c["config"] = cfg
-    c.update(_pick(out, ("rccl_ranks", "backend", "value_strict", "ms_per_step_strict", "value_fp32_exact", "ms_per_step_fp32_exact", "mean_nll")))
+    c.update(_pick(out, ("rccl_ranks", "backend", "value_strict", "value_fp32_exact", "mean_nll")))      # (their ms_per_step: full record)
     if "strict" in out:                                        # the strict leg's own roofline and parity, short
         st = out["strict"]
         c["strict"] = {"dtype": "bf16x3", **_pick(st.get("roofline", {}), ("frac", "frac_executed", "kernel_ms", "valu_issue_frac", "matrix_pipe_frac"))}

@@ -33,11 +33,13 @@ extern "C" {
  *   desc[i][2] param_offset  offset of the layer's packed parameters in the blob, in floats (multiple of 4)
  *   desc[i][3] cond_slot     index of this layer among the layers that consume the feature vector, or -1
  *   desc[i][4] feat_offset   offset in the blob of the layer's packed feature-projection weights, or -1
- *   desc[i][5] precision     RNF_PREC_* the layer's weight image was packed with (same for every MLP layer)
- *   desc[i][6] fallback param_offset   } RNF_PREC_F16X2 flows only: offsets in the SAME blob of the layer's records packed with
- *   desc[i][7] fallback feat_offset    } RNF_PREC_FP32 (or -1).  When every MLP layer has them, each rnf_flow_forward / _inverse /
+ *   desc[i][5] precision     bits 0..7: RNF_PREC_* the layer's weight image was packed with (same for every MLP layer); bits 8..15
+ *                            (ABI v7): RNF_PREC_* of the FALLBACK records of columns 6, 7 -- RNF_PREC_FP32 (0) or RNF_PREC_BF16X3
+ *   desc[i][6] fallback param_offset   } RNF_PREC_F16X2 flows only: offsets in the SAME blob of the layer's records packed with a strict
+ *   desc[i][7] fallback feat_offset    } arithmetic (or -1; the feature-projection record is the RNF_PREC_FP32 image for either).  When
+ *                            every MLP layer has them, each rnf_flow_forward / _inverse /
  *                            _log_prob call is GUARDED: a sample that ends non-finite (an fp16 operand left the fp16 range, |x| >= 65504;
- *                            flow/condition.py:24-30 has no such limit) sets a device flag and the exact-fp32 kernels, launched right
+ *                            flow/condition.py:24-30 has no such limit) sets a device flag and the strict kernels, launched right
  *                            behind on the same stream, redo the chunk -- they return at once when the flag is clear.  No host
  *                            synchronisation; int32 word 1 of the last 8 bytes of the first 32 KiB of the workspace is 1 after a call in
  *                            which the re-run happened.

@@ -835,7 +835,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     int min_tiles = 1;                       // fc_last tiles the largest non-Moebius record needs resident in LDS
     bool any_mlp = false, ext = false;       // ext: the flow contains a layer kind only the extended kernel instantiation carries
     bool all_mlp_cond = true;                // every MLP layer consumes the feature vector (what the FUSED instantiation handles)
-    int prec = -1;
+    int prec = -1, fb_prec = -1;
     bool lean = lean_allowed() && !o.states;   // Moebius + constant 4x4 affine layers only, nothing conditional, no saved states
     bool lean2 = lean_allowed() && !o.states;  // the conditional counterpart: + Condition16Trans, every MLP layer conditional (checked below)
     for (int l = 0; l < n_layers; ++l) {
@@ -864,14 +864,18 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             if (d[D_PARAM_FB] < 0 || d[D_PARAM_FB] % 4 || (slot >= 0 && (d[D_FEAT_FB] < 0 || d[D_FEAT_FB] % 4))) have_fb = false;
             fbp[l] = d[D_PARAM_FB];
             if (slot >= 0) fbf[slot] = d[D_FEAT_FB];
-            const int p = d[D_PREC];
+            const int p = d[D_PREC] & 255, pfb = (d[D_PREC] >> 8) & 255;      // bits 8..15: arithmetic of the fallback records (0: fp32, 2: bf16x3)
             if (p != RNF_PREC_FP32 && p != RNF_PREC_F16X2 && p != RNF_PREC_BF16X3) return fail("layer %d: unknown precision %d", l, p);
+            if (pfb != RNF_PREC_FP32 && pfb != RNF_PREC_BF16X3) return fail("layer %d: fallback records must be RNF_PREC_FP32 or RNF_PREC_BF16X3, got %d", l, pfb);
+            if (fb_prec >= 0 && pfb != fb_prec) return fail("layer %d: all fallback records of a flow must share one precision", l);
+            fb_prec = pfb;
             if (prec >= 0 && p != prec) return fail("layer %d: all MLP layers of a flow must be packed with the same precision", l);
             prec = p;
         }
         a.layers[l] = make_int2(kind | (perm << 4) | ((slot + 1) << 8), d[D_PARAM]);
     }
     if (prec < 0) prec = 0;
+    if (fb_prec < 0) fb_prec = 0;
     {   // bits 16..25 of x: iteration position + 1 of the next layer with an MLP image behind this one (0 = none), in the order the
         // pass walks the layers -- saves the kernel a dependent chain of scalar loads per layer
         int nxt = 0;
@@ -1124,16 +1128,26 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             const int grid_keep = grid;
             const bool ext_fb = ext || shared;            // shared rows: the exact-fp32 re-run reads them on the extended instantiation
             {
-                FlowArgs &a = b;                          // RNF_LAUNCH names `a`, `grid`, `prec`, `nwk`, `ext`, `rows_now`
-                const int grid = grid_fb, prec = 0, nwk = NW;
+                FlowArgs &a = b;                          // RNF_LAUNCH names `a`, `grid`, `prec`, `nwk`, `ext`, `rows_now`, `lds_bytes`
+                const int grid = grid_fb, prec = fb_prec, nwk = NW;
                 const bool ext = ext_fb, rows_now = false;
-                const int family = 0;                     // the exact-fp32 kernels have no lean family
+                const int family = 0;                     // the strict kernels have no lean family
                 (void)family;
+                // bf16x3 fallback records (round 6: the guard's re-run target on host-packed flows -- 1.8x the guarded time instead of the
+                // 3.3x of the exact-fp32 MFMA): the ring-staged kernels with their own LDS layout (three regions + the affine blocks)
+                size_t lds_fb = lds_bytes;
+                if (fb_prec == 2) {
+                    lds_fb = sizeof(float) * (size_t)3 * Mlp<2>::REGION_FLOATS;
+                    a.tab_off = (int)(lds_fb / sizeof(float));
+                    lds_fb += sizeof(float) * 2 * AFF_TABLE_LDS_STRIDE;
+                }
+                const size_t lds_bytes = lds_fb;
                 if (o.dir == 0) rc = RNF_LAUNCH(0, 0);
                 else if (kt_inv == 1) rc = RNF_LAUNCH(1, 1);
                 else if (kt_inv == 2) rc = RNF_LAUNCH(1, 2);
                 else if (kt_inv == 4) rc = RNF_LAUNCH(1, 4);
                 else if (kt_inv == 8) rc = RNF_LAUNCH(1, 8);
+                else if (prec == 2) rc = ext ? launch_big_inverse<2, true>(a, grid, lds_bytes, stream) : launch_big_inverse<2>(a, grid, lds_bytes, stream);
                 else rc = ext ? launch_big_inverse<0, true>(a, grid, lds_bytes, stream) : launch_big_inverse<0>(a, grid, lds_bytes, stream);
             }
             (void)grid_keep;

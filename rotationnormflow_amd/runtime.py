@@ -29,6 +29,9 @@ _PRECISIONS = {"fp32": _lib.PREC_FP32, "f16x2": _lib.PREC_F16X2, "bf16x3": _lib.
 _precision = os.environ.get("RNF_PRECISION", "f16x2")
 
 
+_fallback_precision = os.environ.get("RNF_FALLBACK", "bf16x3")       # arithmetic of the guard's re-run images of host-packed f16x2 flows
+
+
 def device_precision() -> str:
     """The arithmetic of the paths whose kernel images are built ON THE DEVICE (training passes, nn.DataParallel replicas, the side layers'
     conditioners): "bf16x3" images exist for host-packed flows only, those paths then run the exact-fp32 kernels."""
@@ -198,15 +201,19 @@ def pack_layers(layers, perm_rows, device, precision=None, feature_ms=1.0) -> Pa
         blob, desc, slot, feat_dim, segments = _pack_layers(layers, perm_rows, prec, L)
         audit = _audit.worst
         if precision == "f16x2" and _guard_fallback:
-            # the same layers once more as exact-fp32 images behind the split-precision ones: the library re-runs a call on them, on the
-            # device, when a sample comes out non-finite (an fp16 operand overflowed; include/rnf_hip.h desc columns 6, 7)
-            blob32, desc32, _, _, _ = _pack_layers(layers, perm_rows, _lib.PREC_FP32, L)
-            base = blob.size
+            # the same layers once more as STRICT images behind the split-precision ones: the library re-runs a call on them, on the device,
+            # when its guard fires (an fp16 operand overflowed, features far from the packed scale, ...; include/rnf_hip.h desc columns 5 - 7).
+            # Round 6: bf16x3 images (RNF_FALLBACK=fp32 keeps the exact fp32-input MFMA images of rounds 2 - 5): a fired guard costs 1.8x the
+            # guarded time instead of 3.3x.
+            fbp = _lib.PREC_FP32 if _fallback_precision == "fp32" else _lib.PREC_BF16X3
+            blob32, desc32, _, _, _ = _pack_layers(layers, perm_rows, fbp, L)
+            base = (blob.size + 3) // 4 * 4
             mlp = np.array([kind_has_mlp(int(k)) for k in desc[:, 0]])
             desc[mlp, 6] = base + desc32[mlp, 2]
             has_feat = desc32[:, 4] >= 0
             desc[has_feat, 7] = base + desc32[has_feat, 4]
-            blob = np.concatenate([blob, blob32])
+            desc[mlp, 5] |= fbp << 8                      # bits 8..15 of the precision column: arithmetic of the fallback records
+            blob = np.concatenate([blob, np.zeros(base - blob.size, np.float32), blob32])
     finally:
         _prefetched.map = {}
         L.rnf_set_feature_ms(old_ms)

@@ -53,8 +53,9 @@ def test_activation_overflow_falls_back_to_fp32(direction, unequalised):
     assert fl._packed(R.device).precision == "f16x2"            # the weights themselves packed fine
     assert runtime.fallback_fired(R.device)
     assert torch.isfinite(ldj).all() and torch.isfinite(Rt).all()
-    # the re-run IS the exact-fp32 path: bit-identical to a call that asks for it
-    rnf.set_precision("fp32")
+    # the re-run IS the strict path (round 6: the bf16x3 kernels; RNF_FALLBACK=fp32 keeps the exact fp32-input MFMA of rounds 2 - 5):
+    # bit-identical to a call that asks for it
+    rnf.set_precision(runtime._fallback_precision)
     try:
         with torch.no_grad():
             Rt32, ldj32 = fl(R) if direction == "forward" else fl.inverse(R)

@@ -1813,7 +1813,10 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
 #ifndef RNF_DEEP_H
 #define RNF_DEEP_H 1
 #endif
-    constexpr bool DEEP_H = RNF_DEEP_H && PREC == 1 && DIR == 1 && NW <= 8;      // Mlp<1>::head: two operand pairs in flight (hidden_slot2)
+#ifndef RNF_DEEP_FWD
+#define RNF_DEEP_FWD 0
+#endif
+    constexpr bool DEEP_H = RNF_DEEP_H && PREC == 1 && ((DIR == 1 && NW <= 8) || (RNF_DEEP_FWD && DIR == 0 && (RNF_DEEP_FWD >= 2 || NW <= 8)));      // Mlp<1>::head: two operand pairs in flight (hidden_slot2)
     // RING (PREC = 2, round 6): a bf16x3 layer image (171 KiB at K = 64) does not fit the LDS beside its successor, so it streams through THREE
     // regions of 48.5 KiB in units -- Ha (fc_first + hidden tiles 0..2), Hb (hidden tiles 3..5), then the fc_last tiles four at a time
     // (Mlp<2>): while unit u is read, unit u + 1 has landed or is landing and unit u + 2 is requested (LDS-DMA) into the region unit u - 1

@@ -590,7 +590,10 @@ constexpr int NW_FWD_WIDE = 16;                         // same kernel, 4 waves 
 #endif
 constexpr int NW_INV_BIG = 4;                           // inverse with 64 < K <= 128: one wave per SIMD
 constexpr int NW_FP = RNF_NW_FP;                        // waves per workgroup of the feature projection (workgroups per CU: 8 / NW_FP)
-constexpr long long CHUNK_SAMPLES = 1LL << 18;          // samples per launch when a feature projection scratch is needed
+#ifndef RNF_CHUNK_LOG2
+#define RNF_CHUNK_LOG2 18           // (17 / 16 measured and not better: profiles/r6/ab_chunk_C4.jsonl)
+#endif
+constexpr long long CHUNK_SAMPLES = 1LL << RNF_CHUNK_LOG2;   // samples per launch when a feature projection scratch is needed
 // head of the workspace: [0, 2048) block partials of the primary launch, [2048, 4095) partials of the exact-fp32 re-run, double 4095 =
 // two int32: {guard of the current chunk, sticky "a re-run happened in this call"} (flow_kernels.h FlowArgs::guard)
 constexpr size_t PARTIALS_BYTES = 4096 * sizeof(double);

@@ -19,7 +19,7 @@ def main():
         if spec["direction"] != "inverse":
             continue
         row = {"case": name}
-        for prec in ("f16x2", "fp32"):
+        for prec in ("f16x2", "bf16x3", "fp32"):
             runtime.set_precision(prec)
             _, Rt, ldj, fx, _, _ = run_case(name)
             err = np.abs(ldj - fx["ldj64"])

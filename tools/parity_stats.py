@@ -18,7 +18,7 @@ def main():
         names = [k for k, v in CASES.items() if v["direction"] == "forward"]
     for name in names:
         row = {"case": name}
-        for prec in ("f16x2", "fp32"):
+        for prec in ("f16x2", "bf16x3", "fp32"):
             runtime.set_precision(prec)
             _, _, ldj, fx, _, _ = run_case(name)
             err = np.abs(ldj - fx["ldj64"])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Evidence for profiles/<round>/ (rounds 4-5).  The driver's bench line now carries every BASELINE config and collects its own counters
+# Evidence for profiles/<round>/ (rounds 4-6).  The driver's bench line now carries every BASELINE config and collects its own counters
 # (bench.py runs the FETCH_SIZE / WRITE_SIZE / SQ rocprofv3 passes as children of the run, each group in its own process, as
 # MI355X_MICROARCH.md prescribes), so this script only adds what the line does not hold: the rocprofv3 --kernel-trace --stats summaries of the
 # same per-config commands, the kernel resource table, training numbers, phase stamps.
@@ -22,6 +22,14 @@ for c in C1 C2 C3 C4 C5 C5u C4q C5q; do
   find $OUT/stats_$c -name "*kernel_stats.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_$c.csv \;
   rm -rf $OUT/stats_$c
 done
+# (round 6) the strict arithmetic's kernels: the same commands with RNF_PRECISION=bf16x3 (exported BEFORE rocprofv3: no exec hop behind it)
+export RNF_PRECISION=bf16x3
+for c in C2 C5u C4q; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_b3_$c -o run -- python3 $REPO/bench.py --config $c --steps 10 --warmup 5 --no-cpu-baseline --no-secondary --no-pmc --full-out /dev/null > /dev/null 2> $OUT/stats_b3_$c.err
+  find $OUT/stats_b3_$c -name "*kernel_stats.csv" -exec cp {} $OUT/rocprofv3_kernel_stats_${c}_bf16x3.csv \;
+  rm -rf $OUT/stats_b3_$c
+done
+unset RNF_PRECISION
 cd $REPO
 # 3. training: eager iteration with the reference's plain Adam on the flattened flow (what get_flow hands train_uncondition.py), the classic
 #    per-tensor flow beside it, the HIP-graph replay, the batch-size table of the two backward kernels

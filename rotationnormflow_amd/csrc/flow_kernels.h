@@ -45,6 +45,7 @@ struct FlowArgs {
     int n_layers;
     int KT;                   // fc_last tiles = ceil(segments / 8)
     int K;                    // segments of the Moebius layers (pad segments of the last tile are masked when K % 8 != 0)
+    int rf_first4;            // inverse pass: the root finder's FIRST pass takes the fourth-order step (mobius_inv_finish; set per FLOW by the launcher)
     float min_wsum;           // kMinWeightSum * K, set by the launcher: a kernel argument stays in a scalar register (computed in the kernel it was a
                               // loop-invariant VECTOR register that the 128-register instantiations spilled and reloaded -- behind an s_waitcnt vmcnt(0)
                               // that also waited for the LDS-DMA just issued -- in every layer finish)
@@ -1362,7 +1363,7 @@ __device__ __forceinline__ void mobius_inv_tiles_pipe(const float *lds, int K, i
 // sum over the segments continues over them (one float4 load per segment and pass: a K > 128 inverse is rare, L2 absorbs it)
 template <int KT>
 __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvSegs<KT> &sg, float S, Rot &R, float &ldj, const float4 *stash,
-                                                  int n_over, int lane, float min_s, bool check_s, bool &bad) {
+                                                  int n_over, int lane, float min_s, bool check_s, bool &bad, bool first4 = true) {
     S = pair_sum(S);
     // lean softplus: every weight tiny (or a NaN sum) -> exact-fp32 re-run.  (`bad` by reference and the test switched by a value: a
     // `bool *` that is either &bad or nullptr kept the flag in scratch memory, and every update of it was a load + store on the vector
@@ -1404,10 +1405,22 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
     }
     bool done = false;
     float prev = 1.0f;                                                     // size of the previous step (1: none yet)
-#pragma unroll 1
-    for (int it = 0; it < 16; ++it) {
+    // Round 6: the FIRST pass -- the one that starts up to 0.2 - 0.5 rad from the root on sharply peaked weights -- takes a FOURTH-order step
+    // (Householder's method with f3: four more packed instructions per segment pair, in this pass only) and measures the third-order
+    // iteration's asymptotic error constant C = |3 f2^2 - 2 f1 f3| / (12 f1^2) on the way; every later pass is the Halley step of round 4 and
+    // a lane stops when 4 C step^3 is below the fp32 spacing of theta (the constant from the derivatives, not from the ratio of two steps --
+    // which a first step of another order would falsify).  CPU emulation in fp32 (tests/test_inverse_rootfinder.py; softmax-of-g-N(0,1)
+    // weights, centres g N(0,1)): passes a wave of 32 rotations needs, g = 6: 2.85 -> 2.09 (91 % of the waves in two passes, 15 % before),
+    // g = 12: 2.89 -> 2.26, g = 3: 2.15 -> 2.00, g = 1 (and BASELINE's synthetic weights): 2.00 -> 2.00; cell agreement with the reference's
+    // bisection 99.95 -> 99.98 %.  Costs the benchmark configurations 64 instructions per layer (~1 %).
+#ifndef RNF_RF_FIRST4
+#define RNF_RF_FIRST4 1
+#endif
+    float cerr = 80.0f;                                                    // 4 C (until the first pass has measured it: the old floor)
+    auto pass = [&](auto o4_tag, int it) -> bool {
+        constexpr bool O4 = (decltype(o4_tag)::value && RNF_RF_FIRST4) || RNF_RF_ORDER >= 4;
         float sn, cs;
-        sincos_small(th, sn, cs);
+        sincos_pi_band(th, sn, cs);                                   // th stays inside [pi/2, 3 pi/2] (the sign bracket)
         // per segment (so3_math.h mobius_angle): phi = th + 2 atan(-b / (1 - a)), c = (1 - |u|^2) / (b^2 + (1 - a)^2), (a, b) = u conj(z);
         // the constant parts are hoisted: sum sp phi = th S + 2 sum sp atan(.), sum sp c = sum q / (b^2 + (1 - a)^2)   (21 + 2 instead of 27 + 2).
         // Round 4: the SECOND derivative rides along -- d/dtheta of q / den is 2 q b / den^2 (da/dtheta = b, db/dtheta = -a) -- three more
@@ -1442,7 +1455,7 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
                 const f2 r2 = {hw_rcp(den.x), hw_rcp(den.y)};
                 const f2 cq = q * r2;                               // c = q / den, the segment's term of f'
                 der2 = der2 + cq;
-                if constexpr (RNF_RF_ORDER >= 4) {                  // dc/dtheta = 2 c b / den,  d2c/dtheta2 = 2 c (4 b^2 / den - a) / den   (d den/dtheta = -2 b)
+                if constexpr (O4) {                  // dc/dtheta = 2 c b / den,  d2c/dtheta2 = 2 c (4 b^2 / den - a) / den   (d den/dtheta = -2 b)
                     const f2 cr = cq * r2;
                     const f2 cb = cr * b;                           // c b / den
                     dd2 = dd2 + cb;
@@ -1455,7 +1468,7 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
             acc = acc2.x + acc2.y;
             der = der2.x + der2.y;
             dd = dd2.x + dd2.y;
-            if constexpr (RNF_RF_ORDER >= 4) d3 = fmaf(4.0f, e3a.x + e3a.y, -(e3b.x + e3b.y));
+            if constexpr (O4) d3 = fmaf(4.0f, e3a.x + e3a.y, -(e3b.x + e3b.y));
         }
         if constexpr (KT == 16)
             for (int s = 0; s < n_over; ++s) {                         // the same per-segment evaluation on the stashed parameters
@@ -1467,7 +1480,7 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
                 const float r2 = hw_rcp(fmaf(b, b, e1 * e1));
                 const float cq = p.w * r2;
                 der += cq;
-                if constexpr (RNF_RF_ORDER >= 4) {
+                if constexpr (O4) {
                     const float cr = cq * r2, cb = cr * b;
                     dd += cb;
                     d3 += fmaf(4.0f * cb, b * r2, -(cr * a));
@@ -1483,7 +1496,7 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
         // Halley: theta - f / (f1 - f f2 / (2 f1)); a non-positive denominator (far from the root) falls back to the Newton step
         const float hden = fmaf(-0.5f * fx * ddfx, hw_rcp(dfx), dfx);
         float nt = th - fx * hw_rcp(hden > 0.25f * dfx ? hden : dfx);
-        if constexpr (RNF_RF_ORDER >= 4) {
+        if constexpr (O4) {
             // Fourth order (Householder's method with the third derivative f3):  theta - 3 f (2 f1^2 - f f2) / (6 f1 (f1^2 - f f2) + f^2 f3).
             // The starting point is off by > 0.17 for a tenth of the rotations (0.47 at worst); a third-order step brings those to ~ 1e-2,
             // one pass short of the fp32 spacing, so that 85 % of the waves ran a third pass for 6 % of their lanes.  The fourth-order step
@@ -1494,6 +1507,8 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
             const float den4 = fmaf(6.0f * dfx, df2 - ffd, fx * fx * d3fx);
             const float num4 = 3.0f * fx * fmaf(2.0f, df2, -ffd);
             if (den4 > 1.5f * df2 * dfx) nt = th - num4 * hw_rcp(den4);    // a denominator below 1/4 of its value at the root: the Halley / Newton step
+            // the Halley iteration's error constant here (e_next ~ C e^3), floored at 1, times a margin of 4
+            cerr = 4.0f * fmaxf(fabsf(fmaf(3.0f * ddfx, ddfx, -2.0f * dfx * d3fx)) * hw_rcp(12.0f * df2), 1.0f);
         }
         if (!(nt >= lo && nt <= hi)) nt = 0.5f * (lo + hi);               // keep the iterate inside the sign bracket
         if (done) nt = th;                                                // a converged lane stays put
@@ -1501,7 +1516,16 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
         // and the previous one (d / d_prev^p, floored).  A lane stops when that prediction is below the fp32 spacing of theta (2.4e-7) -- the
         // pass that would only confirm it is not run -- or, as before, after a step of <= 1e-4.
         const float step = fabsf(nt - th);
-        if constexpr (RNF_RF_ORDER >= 4) {
+        if constexpr (RNF_RF_FIRST4 && RNF_RF_ORDER < 4) {
+            if constexpr (O4) done = done || step <= 1.0e-4f;             // (fourth-order first pass: a lane that started on the root)
+            else if (it == 0) {                                           // third-order first pass: nothing to extrapolate from yet
+                done = done || step <= 1.0e-4f;
+            } else {
+                // C: measured by a fourth-order first pass; behind a third-order one, from the last two steps (d / d_prev^3, floored at 20)
+                const float c3 = first4 ? cerr : fmaxf(step * hw_rcp(prev * prev * prev), 20.0f);
+                done = done || step <= 1.0e-4f || (step <= 5.0e-3f && c3 * step * step * step <= 2.4e-7f);
+            }
+        } else if constexpr (O4) {
             const float p2 = prev * prev, s2 = step * step;
             const float c4 = fmaxf(step * hw_rcp(p2 * p2), 100.0f);
             done = done || step <= 1.0e-4f || (step <= 1.0e-2f && c4 * s2 * s2 <= 2.4e-7f);
@@ -1512,17 +1536,23 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
         prev = done ? prev : step;
         th = nt;
 #ifdef RNF_KO_FIXED_PASSES          // timing-only diagnostic: every wave runs exactly this many passes
-        if (it + 1 == RNF_KO_FIXED_PASSES) break;
+        return it + 1 == RNF_KO_FIXED_PASSES;
 #else
-        if (__all(done)) break;                                           // wave-uniform exit: typically 3 passes
+        return __all(done);                                               // wave-uniform exit: typically 2 passes
 #endif
+    };
+    // (first4: wave uniform, one value per flow -- a rotation's result never depends on the launch it travels in)
+    if (!(first4 ? pass(std::true_type{}, 0) : pass(std::false_type{}, 0))) {
+#pragma unroll 1
+        for (int it = 1; it < 16; ++it)
+            if (pass(std::false_type{}, it)) break;
     }
     const float cell = kPi * (1.0f / 16384.0f);
     float n = floorf((th - 0.5f * kPi) * (16384.0f / kPi));
     n = fminf(fmaxf(n, 0.f), 16383.f);
     const float mid = fmaf(n + 0.5f, cell, 0.5f * kPi);
     float sn, cs;
-    sincos_small(mid, sn, cs);
+    sincos_pi_band(mid, sn, cs);
     float J;
     {
         f2 J2 = {0.f, 0.f};
@@ -2222,7 +2252,7 @@ __global__ __launch_bounds__(NW * 64) void flow_stack_kernel(const FlowArgs args
                     // the image still has the whole hidden-layer phase of the next layer to land
                     b2_sync();
                     mobius_inv_finish<KTI>(ctx, sg, S, R, ldj, istash, KTI == 16 ? 4 * max(KT - KTI, 0) : 0, lane,
-                                           args.min_wsum, fastsp, bad);
+                                           args.min_wsum, fastsp, bad, args.rf_first4 != 0);
                     b2_issue();
                 } else {
                     float S = 0.f, A = 0.f, J = 0.f;

@@ -952,6 +952,14 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     a.KT = KT;
     a.K = K;
     a.min_wsum = kMinWeightSum * (float)K;
+    {   // Root finder of the inverse pass: a fourth-order FIRST pass (flow_kernels.h mobius_inv_finish) for CONDITIONAL flows -- densities p(R | image)
+        // are sharply peaked and the third-order iteration then needs a third pass for most waves (trained_c4: -5 %); unconditional flows keep the
+        // third-order first pass (their weights are mild: the fourth-order sums would only cost them 2 - 3 %).  One value per FLOW, never per launch.
+        // RNF_RF_FIRST=3|4 forces one.
+        static int forced = -1;
+        if (forced < 0) { const char *e = std::getenv("RNF_RF_FIRST"); forced = e ? (e[0] == '4' ? 4 : (e[0] == '3' ? 3 : 0)) : 0; }
+        a.rf_first4 = forced ? (forced == 4) : (n_slots > 0);
+    }
     a.side = o.side;
     a.side_n = n;
     a.states = o.states;

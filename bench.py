@@ -141,11 +141,13 @@ def build_flow(device, preset, weights_path=None):
         weights = synth.fill_state_dict(shapes, seed=2024, regime="trained")
     fl.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
     fl = fl.to(device).eval()
-    if weights_path and cfg.condition:                        # the feature scale the checkpoint's sidecar fixes (harness.write_feature_scale), if any
-        from rotationnormflow_amd.harness import read_feature_scale
-        ms = read_feature_scale(weights_path)
-        if ms is not None:
-            fl.set_feature_scale(ms)
+    if weights_path:                                          # what the checkpoint's sidecar fixes (harness.read_sidecar), if there is one
+        from rotationnormflow_amd.harness import read_sidecar
+        side = read_sidecar(weights_path)
+        if cfg.condition and side.get("feature_mean_square") is not None:
+            fl.set_feature_scale(float(side["feature_mean_square"]))
+        if side.get("rootfinder_first_order") is not None:
+            fl.set_rootfinder_order(int(side["rootfinder_first_order"]))
     return cfg, weights, fl
 
 

@@ -34,7 +34,11 @@ extern "C" {
  *   desc[i][3] cond_slot     index of this layer among the layers that consume the feature vector, or -1
  *   desc[i][4] feat_offset   offset in the blob of the layer's packed feature-projection weights, or -1
  *   desc[i][5] precision     bits 0..7: RNF_PREC_* the layer's weight image was packed with (same for every MLP layer); bits 8..15
- *                            (ABI v7): RNF_PREC_* of the FALLBACK records of columns 6, 7 -- RNF_PREC_FP32 (0) or RNF_PREC_BF16X3
+ *                            (ABI v7): RNF_PREC_* of the FALLBACK records of columns 6, 7 -- RNF_PREC_FP32 (0) or RNF_PREC_BF16X3;
+ *                            bits 16..17 (ABI v7, RNF_LAYER_MOBIUS): order of the FIRST pass of the inverse root finder that stands in
+ *                            for BinFind (flow/mobiusflow.py:189-224) -- 0 the library's default (third order), 1 third order, 2 fourth
+ *                            order (pays on sharply peaked conditioner outputs, i.e. trained conditional flows); one value per flow
+ *                            (the largest code of its layers), the returned grid cell is the same for either
  *   desc[i][6] fallback param_offset   } RNF_PREC_F16X2 flows only: offsets in the SAME blob of the layer's records packed with a strict
  *   desc[i][7] fallback feat_offset    } arithmetic (or -1; the feature-projection record is the RNF_PREC_FP32 image for either).  When
  *                            every MLP layer has them, each rnf_flow_forward / _inverse /

@@ -1405,6 +1405,21 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
     }
     bool done = false;
     float prev = 1.0f;                                                     // size of the previous step (1: none yet)
+    // Round 6 (RNF_RF_CENTRE): every pass after the first is evaluated AT THE CENTRE of the grid cell its predecessor's step landed in.  A step
+    // from a centre that stays inside the centre's own cell CONFIRMS the cell -- the root is there to ~ C (cell/2)^3 -- and the pass has just
+    // summed f' at the very point the log-determinant needs it: such a lane is finished (`conf`, Jc) and the closing evaluation of f' at the
+    // centre (8 packed + 2 v_rcp per segment pair, 0.38 of a pass) is run only by waves that hold a lane which converged WITHOUT confirming
+    // (a root within the first step's error of a cell boundary, a far start on peaked weights).  CPU emulation, fp32 (32-rotation waves,
+    // softmax-of-g-N(0,1) weights): waves that still run the closing evaluation g = 0.3: 0 %, g = 1: 8 %, g = 3 and 6: 95 - 100 % (as before);
+    // passes per wave and cell agreement with the reference's bisection unchanged.  Both sums use the same instructions on the same operands,
+    // so a lane's log-determinant does not depend on which of the two produced it.
+#ifndef RNF_RF_CENTRE
+#define RNF_RF_CENTRE 1
+#endif
+    bool conf = false;
+    float Jc = 0.f;
+    const float cell = kPi * (1.0f / 16384.0f);
+    auto cell_of = [&](float t) { return fminf(fmaxf(floorf((t - 0.5f * kPi) * (16384.0f / kPi)), 0.f), 16383.f); };
     // Round 6: the FIRST pass -- the one that starts up to 0.2 - 0.5 rad from the root on sharply peaked weights -- takes a FOURTH-order step
     // (Householder's method with f3: four more packed instructions per segment pair, in this pass only) and measures the third-order
     // iteration's asymptotic error constant C = |3 f2^2 - 2 f1 f3| / (12 f1^2) on the way; every later pass is the Halley step of round 4 and
@@ -1454,7 +1469,7 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
                 const f2 den = __builtin_elementwise_fma(b, b, e1 * e1);
                 const f2 r2 = {hw_rcp(den.x), hw_rcp(den.y)};
                 const f2 cq = q * r2;                               // c = q / den, the segment's term of f'
-                der2 = der2 + cq;
+                der2 = RNF_RF_CENTRE ? __builtin_elementwise_fma(q, r2, der2) : der2 + cq;     // (the closing evaluation's own instruction)
                 if constexpr (O4) {                  // dc/dtheta = 2 c b / den,  d2c/dtheta2 = 2 c (4 b^2 / den - a) / den   (d den/dtheta = -2 b)
                     const f2 cr = cq * r2;
                     const f2 cb = cr * b;                           // c b / den
@@ -1479,7 +1494,7 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
                 acc = fmaf(p.x, atan_unit(t), acc);
                 const float r2 = hw_rcp(fmaf(b, b, e1 * e1));
                 const float cq = p.w * r2;
-                der += cq;
+                der = RNF_RF_CENTRE ? fmaf(p.w, r2, der) : der + cq;
                 if constexpr (O4) {
                     const float cr = cq * r2, cb = cr * b;
                     dd += cb;
@@ -1492,7 +1507,8 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
         const float fx = fmaf(2.0f * pair_sum(acc), invS, th) - c.target;
         const float dfx = pair_sum(der) * invS;                            // f1 = df/dtheta  > 0
         const float ddfx = 2.0f * pair_sum(dd) * invS;                     // f2, the second derivative
-        if (fx < 0.f) lo = th; else hi = th;
+        if (RNF_RF_CENTRE) { if (fx < 0.f) lo = fmaxf(lo, th); else hi = fminf(hi, th); }   // (a centre may lie just outside the bracket)
+        else { if (fx < 0.f) lo = th; else hi = th; }
         // Halley: theta - f / (f1 - f f2 / (2 f1)); a non-positive denominator (far from the root) falls back to the Newton step
         const float hden = fmaf(-0.5f * fx * ddfx, hw_rcp(dfx), dfx);
         float nt = th - fx * hw_rcp(hden > 0.25f * dfx ? hden : dfx);
@@ -1516,6 +1532,26 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
         // and the previous one (d / d_prev^p, floored).  A lane stops when that prediction is below the fp32 spacing of theta (2.4e-7) -- the
         // pass that would only confirm it is not run -- or, as before, after a step of <= 1e-4.
         const float step = fabsf(nt - th);
+        bool conv_now = false;
+        if constexpr (RNF_RF_CENTRE && RNF_RF_FIRST4 && RNF_RF_ORDER < 4) {
+            const bool was = done;
+            if (it > 0) {
+                const float c3 = first4 ? cerr : fmaxf(step * hw_rcp(prev * prev * prev), 20.0f);
+                conv_now = !was && (step <= 1.0e-4f || (step <= 5.0e-3f && c3 * step * step * step <= 2.4e-7f));
+                const bool same = !was && cell_of(nt) == cell_of(th);     // th is a centre here: the step stayed inside its cell
+                if (same) { conf = true; Jc = der; nt = th; }             // (der: this lane's half of f' S at th; pair-summed at the end)
+                done = was || conv_now || same;
+            }
+            // (a first pass ends no lane: one that started on the root confirms its cell in the second, which its wave runs anyway)
+            prev = done ? prev : step;
+            // the next evaluation point: the centre of the cell the step landed in; a lane that converged without confirming keeps its iterate
+            th = was ? th : (conv_now && !conf) ? nt : conf ? th : fmaf(cell_of(nt) + 0.5f, cell, 0.5f * kPi);
+#ifdef RNF_KO_FIXED_PASSES
+            return it + 1 == RNF_KO_FIXED_PASSES;
+#else
+            return __all(done);
+#endif
+        } else
         if constexpr (RNF_RF_FIRST4 && RNF_RF_ORDER < 4) {
             if constexpr (O4) done = done || step <= 1.0e-4f;             // (fourth-order first pass: a lane that started on the root)
             else if (it == 0) {                                           // third-order first pass: nothing to extrapolate from yet
@@ -1547,14 +1583,11 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
         for (int it = 1; it < 16; ++it)
             if (pass(std::false_type{}, it)) break;
     }
-    const float cell = kPi * (1.0f / 16384.0f);
-    float n = floorf((th - 0.5f * kPi) * (16384.0f / kPi));
-    n = fminf(fmaxf(n, 0.f), 16383.f);
-    const float mid = fmaf(n + 0.5f, cell, 0.5f * kPi);
+    const float mid = fmaf(cell_of(th) + 0.5f, cell, 0.5f * kPi);      // (a confirmed lane's th is this centre already, bit for bit)
     float sn, cs;
     sincos_pi_band(mid, sn, cs);
-    float J;
-    {
+    float J = Jc;
+    if (!RNF_RF_CENTRE || __any(!conf)) {
         f2 J2 = {0.f, 0.f};
         const f2 sn2 = {sn, sn}, cs2 = {cs, cs};
 #pragma unroll
@@ -1566,15 +1599,16 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
             const f2 den = __builtin_elementwise_fma(b, b, e1 * e1);
             J2 = __builtin_elementwise_fma(q, f2{hw_rcp(den.x), hw_rcp(den.y)}, J2);
         }
-        J = J2.x + J2.y;
+        float Jl = J2.x + J2.y;
+        if constexpr (KT == 16)
+            for (int s = 0; s < n_over; ++s) {
+                const float4 p = stash[(size_t)s * 64 + lane];
+                const float a = fmaf(p.z, sn, p.y * cs), b = fmaf(p.z, cs, -(p.y * sn));
+                const float e1 = 1.0f - a;
+                Jl = fmaf(p.w, hw_rcp(fmaf(b, b, e1 * e1)), Jl);
+            }
+        J = conf ? Jc : Jl;
     }
-    if constexpr (KT == 16)
-        for (int s = 0; s < n_over; ++s) {
-            const float4 p = stash[(size_t)s * 64 + lane];
-            const float a = fmaf(p.z, sn, p.y * cs), b = fmaf(p.z, cs, -(p.y * sn));
-            const float e1 = 1.0f - a;
-            J = fmaf(p.w, hw_rcp(fmaf(b, b, e1 * e1)), J);
-        }
     J = pair_sum(J);
     const v3f xx = c.f.v * sn + c.f.r * cs;
     const v3f zz = normalize3(c.cyc ? cross3(xx, c.y) : cross3(c.y, xx));               // mobiusflow.py:172-176

@@ -838,7 +838,7 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     int min_tiles = 1;                       // fc_last tiles the largest non-Moebius record needs resident in LDS
     bool any_mlp = false, ext = false;       // ext: the flow contains a layer kind only the extended kernel instantiation carries
     bool all_mlp_cond = true;                // every MLP layer consumes the feature vector (what the FUSED instantiation handles)
-    int prec = -1, fb_prec = -1;
+    int prec = -1, fb_prec = -1, rf_code = 0;
     bool lean = lean_allowed() && !o.states;   // Moebius + constant 4x4 affine layers only, nothing conditional, no saved states
     bool lean2 = lean_allowed() && !o.states;  // the conditional counterpart: + Condition16Trans, every MLP layer conditional (checked below)
     for (int l = 0; l < n_layers; ++l) {
@@ -868,6 +868,11 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
             fbp[l] = d[D_PARAM_FB];
             if (slot >= 0) fbf[slot] = d[D_FEAT_FB];
             const int p = d[D_PREC] & 255, pfb = (d[D_PREC] >> 8) & 255;      // bits 8..15: arithmetic of the fallback records (0: fp32, 2: bf16x3)
+            if (kind == RNF_KIND_MOBIUS) {                                    // bits 16..17: first-pass order of the inverse root finder
+                const int rc = (d[D_PREC] >> 16) & 3;
+                if (rc == 3) return fail("layer %d: root-finder order code 3 is reserved", l);
+                if (rc > rf_code) rf_code = rc;
+            }
             if (p != RNF_PREC_FP32 && p != RNF_PREC_F16X2 && p != RNF_PREC_BF16X3) return fail("layer %d: unknown precision %d", l, p);
             if (pfb != RNF_PREC_FP32 && pfb != RNF_PREC_BF16X3) return fail("layer %d: fallback records must be RNF_PREC_FP32 or RNF_PREC_BF16X3, got %d", l, pfb);
             if (fb_prec >= 0 && pfb != fb_prec) return fail("layer %d: all fallback records of a flow must share one precision", l);
@@ -952,13 +957,15 @@ static int run_flow(const float *rot, const float *feat, int64_t n, int32_t F, c
     a.KT = KT;
     a.K = K;
     a.min_wsum = kMinWeightSum * (float)K;
-    {   // Root finder of the inverse pass: a fourth-order FIRST pass (flow_kernels.h mobius_inv_finish) for CONDITIONAL flows -- densities p(R | image)
-        // are sharply peaked and the third-order iteration then needs a third pass for most waves (trained_c4: -5 %); unconditional flows keep the
-        // third-order first pass (their weights are mild: the fourth-order sums would only cost them 2 - 3 %).  One value per FLOW, never per launch.
-        // RNF_RF_FIRST=3|4 forces one.
+    {   // Root finder of the inverse pass: order of its FIRST pass (flow_kernels.h mobius_inv_finish).  Third order (Halley) unless the flow
+        // asks for the fourth-order first pass -- bits 16..17 of desc column 5 on its Moebius layers (1: third, 2: fourth; 0: this default).
+        // The fourth order pays on sharply peaked conditioner outputs (a trained p(R | image): the third-order iteration then needs a third
+        // pass for most waves; trained_c4 10.02 -> 9.66 ms) and costs mild weights its four extra instructions per segment pair (BASELINE's
+        // synthetic C5q +4 %, C5 +0.9 %: profiles/r6/ab_centre.jsonl), so it is a property of the FLOW its owner sets (Flow.set_rootfinder_order,
+        // the checkpoint sidecar) -- one value per flow, never per launch.  RNF_RF_FIRST=3|4 forces one.
         static int forced = -1;
         if (forced < 0) { const char *e = std::getenv("RNF_RF_FIRST"); forced = e ? (e[0] == '4' ? 4 : (e[0] == '3' ? 3 : 0)) : 0; }
-        a.rf_first4 = forced ? (forced == 4) : (n_slots > 0);
+        a.rf_first4 = forced ? (forced == 4) : (rf_code == 2);
     }
     a.side = o.side;
     a.side_n = n;

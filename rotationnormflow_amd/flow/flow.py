@@ -261,6 +261,17 @@ class Flow(nn.Module):
         self._feature_ms_fixed = None if mean_square is None else runtime.quantise_feature_ms(float(mean_square))
         self.invalidate()
 
+    def set_rootfinder_order(self, order):
+        """Order of the FIRST pass of the inverse pass's root finder (csrc/flow_kernels.h mobius_inv_finish, the stand-in for BinFind,
+        flow/mobiusflow.py:189-224): 3 (Halley; the default, ``None``) or 4 (Householder's step with the third derivative: four more
+        instructions per segment pair in that pass, and then two passes instead of three for most waves when the conditioners' outputs are
+        sharply peaked -- trained conditional flows: the reference-trained SYMSOL checkpoint inverts 3.7 % faster, synthetic weights 1 - 4 %
+        slower).  A property of the flow (checkpoint sidecars carry it: ``harness.write_rootfinder_order``), never of a launch; the grid cell
+        the root finder returns is the same for either."""
+        if order not in (None, 3, 4):
+            raise ValueError(f"root-finder first-pass order must be None, 3 or 4, got {order!r}")
+        self._rnf_rf_order = order
+
     def calibrate_feature_scale(self, feature):
         """Measure the mean square of ``feature``'s entries (one device reduction, one scalar read-back) and fix it as the calibration
         (``set_feature_scale``).  Returns the value (quantised to 1/16 binade: what the packers see)."""
@@ -318,6 +329,11 @@ class Flow(nn.Module):
         return packed
 
     def _packed(self, device, feature=None):
+        packed = self._packed_images(device, feature)
+        runtime.stamp_rootfinder_order(packed, getattr(self, "_rnf_rf_order", None))
+        return packed
+
+    def _packed_images(self, device, feature=None):
         """``feature``: the batch at hand; its mean square calibrates the equalisation of the conditional layers when a parameter version
         is packed (runtime.feature_mean_square; evaluations do not look at it again)."""
         if (self.training or getattr(self, "_is_replica", False)) and torch.device(device).type == "cuda":

@@ -40,15 +40,33 @@ def load_reference_checkpoint(path, map_location="cpu") -> dict:
 FEATURE_SCALE_SUFFIX = ".rnf.json"
 
 
-def read_feature_scale(ckpt_path):
-    """The calibration a checkpoint's sidecar carries (``<ckpt>.rnf.json``: {"feature_mean_square": m_f}), or None.  The reference's
-    checkpoint layout (agent.py:132-146) has no place for it and must stay loadable by the reference, hence a file NEXT to the checkpoint."""
+def read_sidecar(ckpt_path) -> dict:
+    """``<ckpt>.rnf.json`` as a dictionary ({} when there is none): "feature_mean_square" (the equalisation's calibration input) and, round 6,
+    "rootfinder_first_order" (3 | 4, ``Flow.set_rootfinder_order``).  The reference's checkpoint layout (agent.py:132-146) has no place for
+    either and must stay loadable by the reference, hence a file NEXT to the checkpoint."""
     import json
     side = str(ckpt_path) + FEATURE_SCALE_SUFFIX
     if not os.path.exists(side):
-        return None
+        return {}
     with open(side) as fh:
-        return float(json.load(fh)["feature_mean_square"])
+        return dict(json.load(fh))
+
+
+def read_feature_scale(ckpt_path):
+    """The calibration a checkpoint's sidecar carries (``<ckpt>.rnf.json``: {"feature_mean_square": m_f}), or None."""
+    value = read_sidecar(ckpt_path).get("feature_mean_square")
+    return None if value is None else float(value)
+
+
+def write_rootfinder_order(ckpt_path, order: int) -> None:
+    """Record the root finder's first-pass order (3 | 4) in the checkpoint's sidecar, beside whatever it already holds."""
+    import json
+    if order not in (3, 4):
+        raise ValueError(f"root-finder first-pass order must be 3 or 4, got {order!r}")
+    side = read_sidecar(ckpt_path)
+    side["rootfinder_first_order"] = int(order)
+    with open(str(ckpt_path) + FEATURE_SCALE_SUFFIX, "w") as fh:
+        json.dump(side, fh)
 
 
 def write_feature_scale(ckpt_path, flow_or_value, features=None) -> float:
@@ -64,8 +82,10 @@ def write_feature_scale(ckpt_path, flow_or_value, features=None) -> float:
         value = getattr(flow_or_value, "_feature_ms_fixed", None)
         if value is None:
             raise ValueError("the flow has no fixed feature scale: call flow.calibrate_feature_scale(features) first, or pass features=")
+    side = read_sidecar(ckpt_path)
+    side["feature_mean_square"] = float(value)
     with open(str(ckpt_path) + FEATURE_SCALE_SUFFIX, "w") as fh:
-        json.dump({"feature_mean_square": float(value)}, fh)
+        json.dump(side, fh)
     return float(value)
 
 
@@ -75,9 +95,12 @@ def build_flow_from_checkpoint(config, ckpt_path, device="cuda") -> Flow:
     missing = flow.load_state_dict(load_reference_checkpoint(ckpt_path), strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     flow = flow.to(device).eval()
-    ms = read_feature_scale(ckpt_path) if getattr(config, "condition", 0) else None
+    side = read_sidecar(ckpt_path)
+    ms = side.get("feature_mean_square") if getattr(config, "condition", 0) else None
     if ms is not None:
-        flow.set_feature_scale(ms)
+        flow.set_feature_scale(float(ms))
+    if side.get("rootfinder_first_order") is not None:
+        flow.set_rootfinder_order(int(side["rootfinder_first_order"]))
     return flow
 
 

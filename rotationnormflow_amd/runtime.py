@@ -234,6 +234,16 @@ def pack_layers(layers, perm_rows, device, precision=None, feature_ms=1.0) -> Pa
 _guard_fallback = os.environ.get("RNF_GUARD", "1") != "0"
 
 
+def stamp_rootfinder_order(packed, order) -> None:
+    """Bits 16..17 of desc column 5 on the Moebius layers (include/rnf_hip.h): first-pass order of the inverse root finder -- None the
+    library's default, 3 or 4.  The descriptor is host memory handed over by pointer on every call, so this is all it takes."""
+    code = {None: 0, 3: 1, 4: 2}[order]
+    if getattr(packed, "rf_code", 0) != code:
+        m = packed.desc[:, 0] == KIND_MOBIUS
+        packed.desc[m, 5] = (packed.desc[m, 5] & ~(3 << 16)) | (code << 16)
+        packed.rf_code = code
+
+
 def kind_has_mlp(kind: int) -> bool:
     return kind in (KIND_MOBIUS, KIND_COND16, KIND_COND9_GS, KIND_COND9_SMITH, KIND_COND9_POLAR_L, KIND_COND9_POLAR_R, KIND_COND36)
 

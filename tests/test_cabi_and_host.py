@@ -136,6 +136,34 @@ def test_pack_cache_follows_parameter_versions():
     assert not np.array_equal(p1.blob.numpy(), p2.blob.numpy())
 
 
+def test_rootfinder_order_is_a_flow_property_stamped_into_the_descriptor(tmp_path):
+    """Round 6: the inverse root finder's first-pass order (include/rnf_hip.h desc column 5 bits 16..17) -- Flow.set_rootfinder_order, the
+    checkpoint sidecar's "rootfinder_first_order" -- reaches the descriptor of the Moebius layers and nothing else."""
+    from rotationnormflow_amd import harness
+    fl = quiet_flow(make_config(layers=2))
+    p = fl._packed("cpu")
+    mob = p.desc[:, 0] == runtime.KIND_MOBIUS
+    assert mob.any() and (~mob).any() and not (p.desc[:, 5] >> 16).any()
+    before = p.desc.copy()
+    fl.set_rootfinder_order(4)
+    assert fl._packed("cpu") is p and ((p.desc[mob, 5] >> 16) & 3 == 2).all() and not (p.desc[~mob, 5] >> 16).any()
+    fl.set_rootfinder_order(3)
+    assert ((fl._packed("cpu").desc[mob, 5] >> 16) & 3 == 1).all()
+    fl.set_rootfinder_order(None)
+    assert np.array_equal(fl._packed("cpu").desc, before)
+    with pytest.raises(ValueError):
+        fl.set_rootfinder_order(5)
+    ck = tmp_path / "ckpt.pth"
+    assert harness.read_sidecar(ck) == {} and harness.read_feature_scale(ck) is None
+    harness.write_feature_scale(ck, 4.0)
+    harness.write_rootfinder_order(ck, 4)
+    assert harness.read_sidecar(ck) == {"feature_mean_square": 4.0, "rootfinder_first_order": 4} and harness.read_feature_scale(ck) == 4.0
+    harness.write_feature_scale(ck, 16.0)                            # one key rewritten, the other kept
+    assert harness.read_sidecar(ck)["rootfinder_first_order"] == 4
+    with pytest.raises(ValueError):
+        harness.write_rootfinder_order(ck, 5)
+
+
 def test_install_as_reference_modules():
     import sys
 

@@ -176,6 +176,32 @@ def test_trained_checkpoint_at_full_batch_runs_on_the_fast_path(name):
     assert (Rb - R[:m]).abs().mean().item() <= 3.0 * ref_rt + 2e-4 and (ldj + ldjb).abs().mean().item() <= 3.0 * ref_ld + 1e-3
 
 
+def test_rootfinder_first_pass_order_changes_speed_not_cells():
+    """Round 6: the fourth-order first pass of the inverse root finder (Flow.set_rootfinder_order; the SYMSOL checkpoint's sidecar asks for
+    it) returns the rotations of the third-order one -- both land on the reference's bisection grid, so rows differ only where a root sits
+    within rounding of a cell boundary (then by one cell of one layer) -- and is a property of the flow: rows do not depend on the batch."""
+    cfg, ckpt, w, fx, spec = load_trained("trained_c4")
+    flow = harness.build_flow_from_checkpoint(cfg, ckpt)
+    assert flow._rnf_rf_order == 4                                  # tests/golden/trained_c4.pth.rnf.json
+    n = 1 << 15
+    R = torch.from_numpy(synth.uniform_rotations(n, seed=5)).cuda()
+    base = torch.from_numpy(fx["test_feat"]).cuda()
+    feat = base[torch.arange(n, device="cuda") % base.shape[0]].contiguous()
+    out = {}
+    with torch.no_grad():
+        for order in (4, 3, None):
+            flow.set_rootfinder_order(order)
+            out[order] = flow.inverse(R, feat)
+            part = flow.inverse(R[1000:3000].contiguous(), feat[1000:3000].contiguous())
+            assert torch.equal(part[0], out[order][0][1000:3000]) and torch.equal(part[1], out[order][1][1000:3000])
+    assert torch.equal(out[3][0], out[None][0]) and torch.equal(out[3][1], out[None][1])          # the default IS the third order
+    same = (out[4][0] == out[3][0]).flatten(1).all(1)
+    assert same.double().mean().item() > 0.97, same.double().mean().item()
+    # 24 Moebius layers, a cell of pi / 2^14 each, stretched by the layers behind it: the rows that differ do so at the scale of the
+    # build's own round-trip error (test above: 1.7e-3 mean for this structure)
+    assert (out[4][0] - out[3][0]).abs().max().item() < 0.05 and (out[4][1] - out[3][1]).abs().mean().item() < 2e-4
+
+
 @pytest.mark.parametrize("flat", [True, False])
 def test_agent_checkpoint_path_resumes_the_reference_trajectory(tmp_path, flat, monkeypatch):
     """The reference's checkpoint path on the GPU, statement by statement (tests/agent_replay.py: Agent.__init__ agent.py:20-28, load_ckpt

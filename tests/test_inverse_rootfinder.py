@@ -21,8 +21,8 @@ def _centre(th):
 
 
 def newton_snap(target, r, v, sw, w, iters=16, first4=True):
-    """float64 restatement of mobius_inv_finish (csrc/flow_kernels.h).  first4: the fourth-order first pass + derivative-based stop of
-    conditional flows (round 6); False: the third-order first pass + step-ratio stop unconditional flows keep (rnf_api.hip rf_first4).
+    """float64 restatement of mobius_inv_finish (csrc/flow_kernels.h).  first4: the fourth-order first pass + derivative-based stop a
+    flow can ask for (round 6: Flow.set_rootfinder_order(4), rnf_api.hip rf_first4); False: the default third-order first pass + step-ratio stop.
     Every pass after the first is evaluated at the CENTRE of the cell the previous step landed in; a step that stays inside that cell
     confirms it (`conf`: the pass's own f' serves the log-determinant, no closing evaluation)."""
     n = target.shape[0]

@@ -1411,23 +1411,27 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
     // centre (8 packed + 2 v_rcp per segment pair, 0.38 of a pass) is run only by waves that hold a lane which converged WITHOUT confirming
     // (a root within the first step's error of a cell boundary, a far start on peaked weights).  CPU emulation, fp32 (32-rotation waves,
     // softmax-of-g-N(0,1) weights): waves that still run the closing evaluation g = 0.3: 0 %, g = 1: 8 %, g = 3 and 6: 95 - 100 % (as before);
-    // passes per wave and cell agreement with the reference's bisection unchanged.  Both sums use the same instructions on the same operands,
-    // so a lane's log-determinant does not depend on which of the two produced it.
+    // passes per wave and cell agreement with the reference's bisection unchanged.  Which of the two sums serves a lane follows from the lane's own
+    // iterates alone, so a rotation's log-determinant still does not depend on the wave it travels in.
 #ifndef RNF_RF_CENTRE
 #define RNF_RF_CENTRE 1
+#endif
+#ifndef RNF_RF_E1FOLD_CLOSE
+#define RNF_RF_E1FOLD_CLOSE 1
 #endif
     bool conf = false;
     float Jc = 0.f;
     const float cell = kPi * (1.0f / 16384.0f);
     auto cell_of = [&](float t) { return fminf(fmaxf(floorf((t - 0.5f * kPi) * (16384.0f / kPi)), 0.f), 16383.f); };
-    // Round 6: the FIRST pass -- the one that starts up to 0.2 - 0.5 rad from the root on sharply peaked weights -- takes a FOURTH-order step
+    // Round 6 (first4, a property of the FLOW: rnf_api.hip, include/rnf_hip.h desc column 5 bits 16..17; default off): the FIRST pass -- the one
+    // that starts up to 0.2 - 0.5 rad from the root on sharply peaked weights -- takes a FOURTH-order step
     // (Householder's method with f3: four more packed instructions per segment pair, in this pass only) and measures the third-order
     // iteration's asymptotic error constant C = |3 f2^2 - 2 f1 f3| / (12 f1^2) on the way; every later pass is the Halley step of round 4 and
     // a lane stops when 4 C step^3 is below the fp32 spacing of theta (the constant from the derivatives, not from the ratio of two steps --
     // which a first step of another order would falsify).  CPU emulation in fp32 (tests/test_inverse_rootfinder.py; softmax-of-g-N(0,1)
     // weights, centres g N(0,1)): passes a wave of 32 rotations needs, g = 6: 2.85 -> 2.09 (91 % of the waves in two passes, 15 % before),
     // g = 12: 2.89 -> 2.26, g = 3: 2.15 -> 2.00, g = 1 (and BASELINE's synthetic weights): 2.00 -> 2.00; cell agreement with the reference's
-    // bisection 99.95 -> 99.98 %.  Costs the benchmark configurations 64 instructions per layer (~1 %).
+    // bisection 99.95 -> 99.98 %.  Costs mild weights its extra sums (BASELINE's synthetic C5u +2 %, C5q +4 %), hence opt-in per flow.
 #ifndef RNF_RF_FIRST4
 #define RNF_RF_FIRST4 1
 #endif
@@ -1453,6 +1457,8 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
                 const f2 sp = {sg.sp[s], sg.sp[s + 1]}, q = {sg.q[s], sg.q[s + 1]};
                 const f2 a = __builtin_elementwise_fma(uv, sn2, ur * cs2);
                 const f2 b = __builtin_elementwise_fma(uv, cs2, -(ur * sn2));
+                // (1 - a folded into two instructions, a only where the fourth-order sums need it: one instruction fewer on paper, 41 spilled
+                // registers in this kernel -- the packed form wants its constant in a register pair)
                 const f2 e1 = 1.0f - a;
                 const f2 r1 = {hw_rcp(e1.x), hw_rcp(e1.y)};
                 const f2 t = -b * r1;
@@ -1593,10 +1599,18 @@ __device__ __forceinline__ void mobius_inv_finish(const MobiusCtx &c, const InvS
 #pragma unroll
         for (int s = 0; s < 4 * KT; s += 2) {
             const f2 ur = {sg.ur[s], sg.ur[s + 1]}, uv = {sg.uv[s], sg.uv[s + 1]}, q = {sg.q[s], sg.q[s + 1]};
-            const f2 a = __builtin_elementwise_fma(uv, sn2, ur * cs2);
-            const f2 b = __builtin_elementwise_fma(uv, cs2, -(ur * sn2));
-            const f2 e1 = 1.0f - a;
-            const f2 den = __builtin_elementwise_fma(b, b, e1 * e1);
+            f2 den;
+            if constexpr (RNF_RF_E1FOLD_CLOSE) {
+                // |1 - u conj(z)|^2 = b^2 + (1 - a)^2 = 2 (1 - a) + |u|^2 - 1: b is not needed here (6 instead of 8 instructions)
+                const f2 e1 = __builtin_elementwise_fma(-uv, sn2, __builtin_elementwise_fma(-ur, cs2, f2{1.0f, 1.0f}));
+                const f2 um = __builtin_elementwise_fma(ur, ur, __builtin_elementwise_fma(uv, uv, f2{-1.0f, -1.0f}));
+                den = __builtin_elementwise_fma(f2{2.0f, 2.0f}, e1, um);
+            } else {
+                const f2 a = __builtin_elementwise_fma(uv, sn2, ur * cs2);
+                const f2 b = __builtin_elementwise_fma(uv, cs2, -(ur * sn2));
+                const f2 e1 = 1.0f - a;
+                den = __builtin_elementwise_fma(b, b, e1 * e1);
+            }
             J2 = __builtin_elementwise_fma(q, f2{hw_rcp(den.x), hw_rcp(den.y)}, J2);
         }
         float Jl = J2.x + J2.y;
